@@ -1,0 +1,123 @@
+"""Oracle PPO: GAE + clipped-surrogate minibatch updates, restating
+PPO_file/PPO_with_tricks.py:290-354 (Gaussian actor :79-108, critic :158-177, Agent :179-209).
+Test infrastructure (see oracle/__init__.py).
+
+Reference defect handled explicitly: PPO_with_tricks.py:302 `np.zeros(h, dtype=torch.float32)`
+raises TypeError as committed; the intent (float32 advantage array, as PPO.py:222 modulo
+precision) is what is restated here and what the golden generator patches in.
+"""
+import math
+
+import numpy as np
+
+from . import nn
+from .buffer import BufferForPPO
+from .nn import F32, MLP, Adam
+
+HALF_LOG_2PI = 0.5 * math.log(2 * math.pi)
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+def gae(td_delta, adv_dones, gamma, lmbda):
+    """Sequential reverse scan, PPO_with_tricks.py:308-311.  Under NumPy >= 2 the recurrence
+    runs in float32: `gamma*lmbda` is a Python float (weak scalar), `td_delta[i]` and
+    `adv_dones[i]` are float32 scalars, so every product/sum rounds to float32."""
+    T = td_delta.shape[0]
+    adv = np.zeros(T, dtype=F32)
+    g = 0
+    c = gamma * lmbda
+    for i in reversed(range(T)):
+        g = td_delta[i] + c * g * (1.0 - adv_dones[i])
+        adv[i] = g
+    return adv
+
+
+class PPO:
+    def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick):
+        self.trick = trick
+        act = "tanh" if trick.get("tanh") else "relu"
+        self.pi = MLP(["l1", "l2", "mean_layer"], hidden_act=act, out_act="tanh")   # mean = tanh(...) (:99)
+        self.v = MLP(["l1", "l2", "l3"], hidden_act=act)
+        self.actor = nn.copy_params(actor_p)
+        self.critic = nn.copy_params(critic_p)
+        eps = 1e-5 if trick.get("adam_eps") else 1e-8                               # :191-196
+        self.actor_opt = Adam(self.actor, actor_lr, eps=eps)
+        self.critic_opt = Adam(self.critic, critic_lr, eps=eps)
+        self.horizon = int(horizon)
+        self.buffer = BufferForPPO(horizon, obs_dim, act_dim)
+        self.actor_losses, self.critic_losses = [], []
+        self.adv_raw = self.v_target = None
+
+    def _dist(self, obs):
+        mean, acts = self.pi.forward({k: v for k, v in self.actor.items() if k != "log_std"}, obs)
+        log_std = np.clip(np.broadcast_to(self.actor["log_std"], mean.shape), -20, 2).astype(F32)   # :102
+        return mean, log_std, acts
+
+    def evaluate_action(self, obs):                      # :257-270: the mean
+        return self._dist(nn.f32(obs).reshape(1, -1))[0][0]
+
+    def select_action(self, obs, eps):                   # :234-255: a ~ N(mean,std); per-dim log-prob
+        mean, log_std, _ = self._dist(nn.f32(obs).reshape(1, -1))
+        std = np.exp(log_std)
+        a = mean + std * nn.f32(eps).reshape(1, -1)
+        logp = -((a - mean) ** 2) / (F32(2) * std * std) - log_std - F32(LOG_SQRT_2PI)
+        return a[0], logp[0]
+
+    def add(self, *a):
+        self.buffer.add(*a)
+
+    def learn_with(self, perms, minibatch_size, gamma, lmbda, clip_param, k_epochs, ent_coef):
+        obs, action, reward, nobs, done, logp_old, adv_dones = self.buffer.all()
+        T = self.horizon
+        vs = self.v.forward(self.critic, obs)[0]
+        vs_ = self.v.forward(self.critic, nobs)[0]
+        td = reward + F32(gamma) * (F32(1.0) - done) * vs_ - vs                      # :306
+        adv = gae(td.reshape(-1), adv_dones.reshape(-1), gamma, lmbda).reshape(-1, 1)
+        v_target = adv + vs                                                          # :313
+        self.adv_raw, self.v_target = adv.copy(), v_target.copy()
+        if self.trick.get("adv_norm"):                                               # :314-315
+            std = np.sqrt(np.sum((adv - adv.mean(dtype=F32)) ** 2, dtype=F32) / F32(T - 1))   # unbiased
+            adv = (adv - adv.mean(dtype=F32)) / (std + F32(1e-8))
+        body = {k: v for k, v in self.actor.items() if k != "log_std"}
+        for k in range(k_epochs):
+            perm = perms[k]
+            for s in range(0, T, minibatch_size):
+                ix = perm[s:s + minibatch_size]
+                mb = len(ix)
+                # ---- actor (:324-346)
+                body = {kk: vv for kk, vv in self.actor.items() if kk != "log_std"}
+                mean, acts = self.pi.forward(body, obs[ix])
+                raw = self.actor["log_std"]
+                log_std = np.clip(np.broadcast_to(raw, mean.shape), -20, 2).astype(F32)
+                std = np.exp(log_std)
+                var = std * std
+                a = action[ix]
+                logp = -((a - mean) ** 2) / (F32(2) * var) - log_std - F32(LOG_SQRT_2PI)
+                ent = (F32(0.5 + HALF_LOG_2PI) + log_std).sum(axis=1, keepdims=True)
+                ratio = np.exp(logp.sum(axis=1, keepdims=True) - logp_old[ix].sum(axis=1, keepdims=True))
+                A = adv[ix]
+                surr1 = ratio * A
+                surr2 = np.clip(ratio, 1 - clip_param, 1 + clip_param).astype(F32) * A
+                aloss = F32(-np.mean(np.minimum(surr1, surr2), dtype=F32) - F32(ent_coef) * np.mean(ent, dtype=F32))
+                # backward: d min / d ratio = A where surr1 <= surr2 (ties: both branches pass
+                # the clamp, half each, summing to A), else 0 (clamped branch has zero slope)
+                dratio = np.where(surr1 <= surr2, A, F32(0)) * F32(-1.0 / mb)
+                dlogp_sum = dratio * ratio
+                dmean = dlogp_sum * (a - mean) / var
+                inside = ((raw >= -20) & (raw <= 2)).astype(F32)
+                dls = dlogp_sum * ((a - mean) ** 2 / var - F32(1)) - F32(ent_coef / mb)
+                _, g = self.pi.backward(body, acts, dmean.astype(F32), need_dx=False)
+                g["log_std"] = (dls.sum(axis=0, keepdims=True) * inside).astype(F32)
+                g = {kk: g[kk] for kk in self.actor}
+                nn.clip_grad_norm(g, 0.5)
+                self.actor_opt.step(self.actor, g)
+                self.actor_losses.append(aloss)
+                # ---- critic (:349-351): mse(v_target[idx], V(obs[idx]))
+                v_s, vacts = self.v.forward(self.critic, obs[ix])
+                closs, dv = nn.mse(v_s, v_target[ix])
+                _, gc = self.v.backward(self.critic, vacts, dv, need_dx=False)
+                gc = {kk: gc[kk] for kk in self.critic}
+                nn.clip_grad_norm(gc, 0.5)
+                self.critic_opt.step(self.critic, gc)
+                self.critic_losses.append(closs)
+        self.buffer.clear()                                                          # :354

@@ -1,0 +1,142 @@
+"""Parity cases: dimensions, hyper-parameters and seeds.
+
+One definition, three consumers: `make_golden.py` drives the imported REFERENCE through a
+case and stores its outputs; `tests/test_oracle_golden.py` drives `oracle/` through the same
+case and compares with the stored outputs; `tests/test_gpu_parity.py` drives the HIP engine
+and compares with the oracle (live) and with the stored outputs.
+
+Inputs are regenerated from seeds by `synth.py` — fixtures hold outputs only.
+"""
+import numpy as np
+
+from . import synth
+
+H = 128  # the reference's hidden width (DQN.py:38, TD3.py:53, SAC.py:61 ...)
+
+
+def actor_layers(obs_dim, act_dim, head="l3", hidden=H):
+    return [("l1", hidden, obs_dim), ("l2", hidden, hidden), (head, act_dim, hidden)]
+
+
+def critic_layers(in_dim, twin=False, hidden=H):
+    ls = [("l1", hidden, in_dim), ("l2", hidden, hidden), ("l3", 1, hidden)]
+    if twin:
+        ls += [("l4", hidden, in_dim), ("l5", hidden, hidden), ("l6", 1, hidden)]
+    return ls
+
+
+CASES = {
+    # Buffer ring + sample (TD3_file/Buffer.py:11-61)
+    "buffer": dict(kind="buffer", obs_dim=5, act_dim=2, capacity=300, n_add=450, batch=64,
+                   table_seed=11, idx_seed=12),
+    # DQN.learn (DQN_file/DQN.py:104-128); SYN-D shape of SURVEY §8(d)
+    "dqn": dict(kind="dqn", obs_dim=8, n_actions=4, capacity=4096, n_table=1024, batch=256,
+                n_learn=5, gamma=0.99, tau=0.01, lr=1e-3, table_seed=123, param_seed=1000,
+                idx_seed=2000),
+    # DDPG_simple.learn (DDPG_file/DDPG_simple.py:137-156)
+    "ddpg": dict(kind="ddpg", obs_dim=8, act_dim=2, capacity=4096, n_table=1024, batch=256,
+                 n_learn=4, gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                 table_seed=123, param_seed=1100, idx_seed=2100),
+    # TD3.learn (TD3_file/TD3.py:189-233), all `realize` flags on, max_action 2 (Pendulum)
+    "td3": dict(kind="td3", obs_dim=8, act_dim=2, capacity=4096, n_table=1024, batch=256,
+                n_learn=4, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3,
+                policy_noise=0.2, noise_clip=0.5, max_action=2.0, policy_freq=2,
+                policy_noise_scale=1.0, table_seed=123, param_seed=1200, idx_seed=2200,
+                noise_seed=3200),
+    # TD3 with batch not a multiple of the 64-row tile and Pendulum's dims (config 2 shape)
+    "td3_pendulum": dict(kind="td3", obs_dim=3, act_dim=1, capacity=1000, n_table=700, batch=100,
+                         n_learn=3, gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                         policy_noise=0.1, noise_clip=0.5, max_action=2.0, policy_freq=2,
+                         policy_noise_scale=1.0, table_seed=124, param_seed=1210, idx_seed=2210,
+                         noise_seed=3210),
+    # SAC.learn + Alpha (SAC_file/SAC.py:222-260,154-169)
+    "sac": dict(kind="sac", obs_dim=8, act_dim=2, capacity=4096, n_table=1024, batch=256,
+                n_learn=3, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3,
+                table_seed=123, param_seed=1300, idx_seed=2300, noise_seed=3300),
+    # MADDPG_simple.learn (MADDPG_file/MADDPG_simple.py:165-186), heterogeneous agents
+    "maddpg": dict(kind="maddpg", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
+                   capacity=512, n_table=256, batch=64, n_learn=2, gamma=0.95, tau=0.01,
+                   actor_lr=1e-3, critic_lr=1e-3, table_seed=125, param_seed=1400, idx_seed=2400),
+    # PPO_with_tricks.learn (PPO_file/PPO_with_tricks.py:290-354), Gaussian actor, no tricks
+    "ppo": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
+                gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                trick=dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_scaling=False,
+                           orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
+                           Batch_ObsNorm=False),
+                table_seed=126, param_seed=1500, perm_seed=2500),
+    # PPO with adv_norm + tanh hidden activations + Adam eps 1e-5
+    "ppo_tricks": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
+                       gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                       trick=dict(adv_norm=True, ObsNorm=False, reward_norm=False,
+                                  reward_scaling=False, orthogonal_init=False, adam_eps=True,
+                                  lr_decay=False, tanh=True, Batch_ObsNorm=False),
+                       table_seed=127, param_seed=1510, perm_seed=2510),
+}
+
+
+def dqn_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_table"], c["obs_dim"], 1, n_discrete=c["n_actions"])
+    params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("l2", c["n_actions"], H)])
+    idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
+    return dict(table=tab, params=dict(Qnet=params), idx=idx)
+
+
+def ac_inputs(c, twin, gaussian=False):
+    """DDPG / TD3 / SAC inputs."""
+    O, A = c["obs_dim"], c["act_dim"]
+    tab = synth.transitions(c["table_seed"], c["n_table"], O, A)
+    actor = synth.mlp_params(c["param_seed"], actor_layers(O, A, head="mean_layer" if gaussian else "l3"))
+    if gaussian:
+        g = np.random.default_rng(c["param_seed"] + 7)
+        # reference initialises log_std to zeros (SAC.py:66); a non-zero value makes the
+        # fixture exercise d(loss)/d(log_std) with distinct per-dimension std
+        actor = dict([("log_std", g.uniform(-0.5, 0.3, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O + A, twin=twin))
+    idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
+    out = dict(table=tab, params=dict(actor=actor, critic=critic), idx=idx)
+    if "noise_seed" in c:
+        n_draw = 2 if gaussian else 1
+        out["noise"] = [[synth.normal(c["noise_seed"] + 10 * k + j, (c["batch"], A)) for j in range(n_draw)]
+                        for k in range(c["n_learn"])]
+    return out
+
+
+def maddpg_inputs(c):
+    dims = c["dims"]
+    ids = list(dims.keys())
+    total = sum(o + a for o, a in dims.values())
+    tabs = {}
+    for j, aid in enumerate(ids):
+        o, a = dims[aid]
+        tabs[aid] = synth.transitions(c["table_seed"] + 100 * j, c["n_table"], o, a)
+    params = {}
+    for j, aid in enumerate(ids):
+        o, a = dims[aid]
+        params[aid] = dict(actor=synth.mlp_params(c["param_seed"] + 10 * j, actor_layers(o, a)),
+                           critic=synth.mlp_params(c["param_seed"] + 10 * j + 1, critic_layers(total)))
+    # MADDPG_simple.learn re-samples once PER AGENT per learn call (MADDPG_simple.py:169)
+    idx = [[synth.indices(c["idx_seed"] + 10 * k + j, c["n_table"], c["batch"]) for j in range(len(ids))]
+           for k in range(c["n_learn"])]
+    return dict(tables=tabs, params=params, idx=idx, ids=ids)
+
+
+def ppo_inputs(c):
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    tab = synth.transitions(c["table_seed"], T, O, A)
+    g = np.random.default_rng(c["table_seed"] + 1)
+    tab["act"] = g.standard_normal((T, A)).astype(np.float32) * 0.7   # un-squashed Gaussian actions
+    tab["logp"] = (-0.5 * g.standard_normal((T, A)) ** 2 - 0.9).astype(np.float32)  # stored per dim
+    # adv_done = terminated or truncated (PPO_with_tricks.py:291-295)
+    tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
+    actor = synth.mlp_params(c["param_seed"], actor_layers(O, A, head="mean_layer"))
+    actor = dict([("log_std", g.uniform(-0.5, 0.3, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
+    perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
+    return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)
+
+
+def buffer_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_add"], c["obs_dim"], c["act_dim"])
+    size = min(c["n_add"], c["capacity"])
+    idx = synth.indices(c["idx_seed"], size, c["batch"])
+    return dict(table=tab, idx=idx)

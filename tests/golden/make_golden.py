@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Generate the golden OUTPUT vectors by running the imported FreeRL reference (PyTorch CPU)
+on the seeded synthetic cases of `cases.py`.
+
+Run by hand in the build container only:   python -m tests.golden.make_golden
+(`/root/reference` does not exist on the GPU box; the fixtures it writes, `*.npz` next to
+this file, are data: inputs are regenerated from seeds, the files hold reference outputs.)
+
+How the reference is driven (no reference code is copied — its classes are imported):
+  * parameters are overwritten with PCG64-drawn values (synth.mlp_params) through
+    `load_state_dict`, so the inputs do not depend on torch's init stream;
+  * the legacy-RNG draws the hot path makes are INJECTED: `np.random.choice` (sample indices,
+    DQN.py:97 ...), `torch.randn_like` (TD3.py:197), `_standard_normal` (Normal.rsample,
+    SAC.py:79) and `np.random.permutation` (PPO_with_tricks.py:320) are patched to return the
+    seeded arrays of `cases.py`;
+  * losses are captured by wrapping `agent.update_*` (learn() returns None).
+"""
+import contextlib
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests.golden import cases, synth  # noqa: E402
+from tests.golden._ref_import import import_reference  # noqa: E402
+
+CPU = torch.device("cpu")
+
+
+def t2n(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def load(module, params):
+    module.load_state_dict({k: torch.as_tensor(v) for k, v in params.items()})
+
+
+def adam_state(opt, module):
+    """exp_avg / exp_avg_sq keyed by parameter name, plus the step count."""
+    names = {id(p): n for n, p in module.named_parameters()}
+    m, v, step = {}, {}, 0
+    for group in opt.param_groups:
+        for p in group["params"]:
+            st = opt.state.get(p, None)
+            if st:
+                m[names[id(p)]] = st["exp_avg"].numpy().copy()
+                v[names[id(p)]] = st["exp_avg_sq"].numpy().copy()
+                step = int(st["step"])
+    return m, v, step
+
+
+@contextlib.contextmanager
+def inject(obj, name, fn):
+    old = getattr(obj, name)
+    setattr(obj, name, fn)
+    try:
+        yield
+    finally:
+        setattr(obj, name, old)
+
+
+def feeder(seq):
+    it = iter(seq)
+
+    def f(*a, **k):
+        return next(it)
+    return f
+
+
+def wrap_losses(agent, names):
+    rec = {n: [] for n in names}
+    for n in names:
+        orig = getattr(agent, n)
+
+        def w(loss, _orig=orig, _n=n):
+            rec[_n].append(np.float32(loss.item()))
+            return _orig(loss)
+        setattr(agent, n, w)
+    return rec
+
+
+def fill(policy, tab):
+    discrete = not getattr(policy, "is_continue", True)
+    for i in range(len(tab["rew"])):
+        a = tab["act"][i]
+        policy.add(tab["obs"][i], a[0] if discrete else a, float(tab["rew"][i]), tab["next_obs"][i],
+                   bool(tab["done"][i]))
+
+
+# ----------------------------------------------------------------------------- buffer
+def gen_buffer(out):
+    c = cases.CASES["buffer"]
+    inp = cases.buffer_inputs(c)
+    mod = import_reference("TD3_file", "TD3")
+    Buffer = mod._helpers["Buffer"].Buffer
+    buf = Buffer(c["capacity"], c["obs_dim"], c["act_dim"], CPU)
+    tab = inp["table"]
+    for i in range(c["n_add"]):
+        buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    o, a, r, no, d = buf.sample(inp["idx"])
+    out.update({"index": np.int64(buf._index), "size": np.int64(buf._size), "obs": o.numpy(),
+                "act": a.numpy(), "rew": r.numpy(), "next_obs": no.numpy(), "done": d.numpy()})
+
+
+# ----------------------------------------------------------------------------- DQN
+def gen_dqn(out):
+    c = cases.CASES["dqn"]
+    inp = cases.dqn_inputs(c)
+    mod = import_reference("DQN_file", "DQN")
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU)
+    load(pol.agent.Qnet, inp["params"]["Qnet"])
+    load(pol.agent.Qnet_target, inp["params"]["Qnet"])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    acts = np.array([pol.select_action(inp["table"]["obs"][i]) for i in range(32)], dtype=np.int64)
+    with torch.no_grad():
+        q0 = pol.agent.Qnet(torch.as_tensor(inp["table"]["obs"][:32])).numpy()
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    out["select_action"] = acts
+    out["q0"] = q0
+    synth.pack_digest("Qnet", t2n(pol.agent.Qnet.state_dict()), out)
+    synth.pack_digest("Qnet_target", t2n(pol.agent.Qnet_target.state_dict()), out)
+    m, v, step = adam_state(pol.agent.Qnet_optimizer, pol.agent.Qnet)
+    synth.pack_digest("Qnet_m", m, out)
+    synth.pack_digest("Qnet_v", v, out)
+    out["step"] = np.int64(step)
+
+
+# ----------------------------------------------------------------------------- DDPG / TD3
+def _ac_outputs(pol, out, rec, loss_names):
+    for n in loss_names:
+        out["loss_" + n.replace("update_", "")] = np.array(rec[n], dtype=np.float32)
+    for net in ("actor", "critic", "actor_target", "critic_target"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+    for net in ("actor", "critic"):
+        m, v, step = adam_state(getattr(pol.agent, net + "_optimizer"), getattr(pol.agent, net))
+        synth.pack_digest(net + "_m", m, out)
+        synth.pack_digest(net + "_v", v, out)
+        out[net + "_step"] = np.int64(step)
+
+
+def gen_ddpg(out):
+    c = cases.CASES["ddpg"]
+    inp = cases.ac_inputs(c, twin=False)
+    mod = import_reference("DDPG_file", "DDPG_simple")
+    pol = mod.DDPG([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU)
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    out["select_action"] = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(32)])
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
+
+
+def gen_td3(name, out):
+    c = cases.CASES[name]
+    inp = cases.ac_inputs(c, twin=True)
+    mod = import_reference("TD3_file", "TD3")
+    realize = {"clip_double": True, "policy_noise": True, "twin_delay": True}
+    pol = mod.TD3([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU,
+                  trick=None, realize=realize)
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    out["select_action"] = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(32)])
+    noises = [torch.as_tensor(n[0]) for n in inp["noise"]]
+    with inject(np.random, "choice", feeder(inp["idx"])), inject(torch, "randn_like", feeder(noises)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"], c["policy_noise"], c["noise_clip"], c["max_action"],
+                      c["policy_freq"], c["policy_noise_scale"])
+    _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
+    out["total_it"] = np.int64(pol.total_it)
+
+
+# ----------------------------------------------------------------------------- SAC
+def gen_sac(out):
+    c = cases.CASES["sac"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    mod = import_reference("SAC_file", "SAC")
+    trick = {"ObsNorm": False, "Batch_ObsNorm": False, "OUNoise": False, "GaussNoise": False}
+    pol = mod.SAC([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, trick=trick)
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    rec_a = wrap_losses(pol.alphas, ["update_alpha"])
+    out["evaluate_action"] = np.stack([pol.evaluate_action(inp["table"]["obs"][i]) for i in range(32)])
+    eps = [torch.as_tensor(e) for pair in inp["noise"] for e in pair]
+    import torch.distributions.normal as tdn
+    alphas = []
+    with inject(np.random, "choice", feeder(inp["idx"])), inject(tdn, "_standard_normal", feeder(eps)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            alphas.append(np.float32(pol.alphas.alpha.item()))
+    _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
+    out["loss_alpha"] = np.array(rec_a["update_alpha"], dtype=np.float32)
+    out["alpha"] = np.array(alphas, dtype=np.float32)
+    out["log_alpha"] = np.float32(pol.alphas.log_alpha.item())
+    # stochastic select_action with a known eps
+    sa_eps = [torch.as_tensor(synth.normal(c["noise_seed"] + 900 + i, (1, c["act_dim"]))) for i in range(8)]
+    with inject(tdn, "_standard_normal", feeder(sa_eps)):
+        out["select_action"] = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(8)])
+
+
+# ----------------------------------------------------------------------------- MADDPG
+def gen_maddpg(out):
+    c = cases.CASES["maddpg"]
+    inp = cases.maddpg_inputs(c)
+    ids = inp["ids"]
+    mod = import_reference("MADDPG_file", "MADDPG_simple")
+    pol = mod.MADDPG(copy.deepcopy(c["dims"]), True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU)
+    for aid in ids:
+        ag = pol.agents[aid]
+        for net in ("actor", "critic"):
+            load(getattr(ag, net), inp["params"][aid][net])
+            load(getattr(ag, net + "_target"), inp["params"][aid][net])
+    n = c["n_table"]
+    for i in range(n):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    acts = pol.select_action({a: inp["tables"][a]["obs"][0] for a in ids})
+    for a in ids:
+        out["select_action/" + a] = acts[a]
+    flat_idx = [ix for per_call in inp["idx"] for ix in per_call]
+    with inject(np.random, "choice", feeder(flat_idx)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    for a in ids:
+        ag = pol.agents[a]
+        out["loss_critic/" + a] = np.array(recs[a]["update_critic"], dtype=np.float32)
+        out["loss_actor/" + a] = np.array(recs[a]["update_actor"], dtype=np.float32)
+        for net in ("actor", "critic", "actor_target", "critic_target"):
+            synth.pack_digest(a + "/" + net, t2n(getattr(ag, net).state_dict()), out)
+
+
+# ----------------------------------------------------------------------------- PPO
+class _NpProxy(types.ModuleType):
+    """`np` as seen by PPO_with_tricks.py only: `np.zeros(h, dtype=torch.float32)` at
+    PPO_with_tricks.py:302 raises TypeError as committed; the proxy maps the
+    torch dtype to the NumPy one (the evident intent, and what PPO.py:222 does modulo
+    precision) and remembers the array so the raw GAE advantages can be read back."""
+
+    def __init__(self, perms):
+        super().__init__("np_proxy")
+        self._perms = iter(perms)
+        self.captured = []
+        rnd = types.SimpleNamespace(permutation=lambda n: next(self._perms))
+        self.random = rnd
+
+    def zeros(self, shape, dtype=float):
+        if dtype is torch.float32:
+            dtype = np.float32
+        arr = np.zeros(shape, dtype=dtype)
+        self.captured.append(arr)
+        return arr
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+def gen_ppo(name, out):
+    c = cases.CASES[name]
+    inp = cases.ppo_inputs(c)
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    pol = mod.PPO([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["horizon"], CPU,
+                  trick=dict(c["trick"]), beta=False)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+    out["evaluate_action"] = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    vt_chunks = []
+    orig_mse = mod.F.mse_loss
+
+    def mse(a, b, *args, **kw):
+        vt_chunks.append(a.detach().numpy().copy())
+        return orig_mse(a, b, *args, **kw)
+    proxy = _NpProxy(inp["perms"])
+    mod.np = proxy
+    with inject(mod.F, "mse_loss", mse):
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    mod.np = np
+    adv = proxy.captured[0]
+    assert adv.shape == (c["horizon"],)
+    out["adv_raw"] = adv.astype(np.float32)
+    # rebuild v_target from the first epoch's minibatches (every row appears exactly once)
+    n_mb = c["horizon"] // c["minibatch"]
+    vt = np.zeros(c["horizon"], np.float32)
+    for j in range(n_mb):
+        vt[inp["perms"][0][j * c["minibatch"]:(j + 1) * c["minibatch"]]] = vt_chunks[j].reshape(-1)
+    out["v_target"] = vt
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+        m, v, step = adam_state(getattr(pol.agent, net + "_optimizer"), getattr(pol.agent, net))
+        out[net + "_step"] = np.int64(step)
+    out["buffer_size_after"] = np.int64(len(pol.buffer))
+
+
+# ----------------------------------------------------------------------------- normalisers
+def gen_norm(out):
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    nz = mod._helpers["normalization"]
+    g = np.random.default_rng(77)
+    xs = g.standard_normal((6, 5)).astype(np.float32) * 2 + 1
+    norm = nz.Normalization(shape=5)
+    ys = [norm(x.copy()) for x in xs]
+    out["norm_y"] = np.stack(ys)
+    out["norm_mean"] = np.asarray(norm.running_ms.mean, dtype=np.float64)
+    out["norm_std"] = np.asarray(norm.running_ms.std, dtype=np.float64)
+    out["norm_eval"] = norm(xs[0].copy(), update=False)
+    bn = nz.Normalization_batch_size(shape=5, device=CPU)
+    xb = g.standard_normal((4, 16, 5)).astype(np.float32) + 0.5
+    yb = [bn(torch.as_tensor(x)).numpy() for x in xb]
+    out["bnorm_y"] = np.stack(yb)
+    out["bnorm_mean"] = bn.running_ms.mean.numpy()
+    out["bnorm_std"] = bn.running_ms.std.numpy()
+    rs = nz.RewardScaling(shape=1, gamma=0.99)
+    rr = g.standard_normal(8)
+    out["rscale_y"] = np.array([np.asarray(rs(r)).reshape(-1)[0] for r in rr], dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------- harness self-check
+def survey_known_answers():
+    """SURVEY.md §8(c) recorded `DQN.learn` losses for torch-seeded init + legacy-RNG indices.
+    If this harness does not reproduce them, the harness (not a kernel) is wrong."""
+    mod = import_reference("DQN_file", "DQN")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    pol = mod.DQN([8, 4], False, 1e-3, 4096, CPU)
+    tab = synth.transitions(123, 1024, 8, 1, n_discrete=4)
+    fill(pol, tab)
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    for _ in range(5):
+        pol.learn(256, 0.99, 0.01)
+    got = np.array(rec["update_Qnet"])
+    want = np.array([0.94327211, 1.04127622, 1.05781567, 1.11205149, 1.13564432], dtype=np.float32)
+    ok = np.allclose(got, want, rtol=1e-6)
+    print("survey known-answer DQN losses:", got, "OK" if ok else "MISMATCH vs %s" % want)
+    return ok
+
+
+def main():
+    gens = {
+        "buffer": gen_buffer, "dqn": gen_dqn, "ddpg": gen_ddpg,
+        "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
+        "sac": gen_sac, "maddpg": gen_maddpg,
+        "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
+        "norm": gen_norm,
+    }
+    torch.set_num_threads(1)
+    only = sys.argv[1:]
+    assert survey_known_answers()
+    for name, fn in gens.items():
+        if only and name not in only:
+            continue
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-14s -> %s (%d entries, %.1f KB)" % (name, os.path.basename(path), len(out), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

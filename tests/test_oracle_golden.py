@@ -1,0 +1,200 @@
+"""Pin the oracle: drive `oracle/` through every case of tests/golden/cases.py and compare with
+the outputs the imported REFERENCE produced on the same seeded inputs (tests/golden/*.npz,
+written by tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the reference is PyTorch-CPU fp32 (MKL sgemm), the oracle NumPy fp32 (OpenBLAS);
+reduction orders differ, so losses are compared at 2e-5 relative and parameters at
+rtol 2e-4 / atol 2e-6 after up to five Adam steps (Adam's m/sqrt(v) amplifies 1-ulp gradient
+differences on near-zero gradients)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import algos, normalization, ppo
+from oracle.buffer import Buffer
+from tests.golden import cases, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOSS_RTOL = 2e-5
+P_RTOL, P_ATOL = 2e-4, 2e-6
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def fill(policy, tab, discrete=False):
+    for i in range(len(tab["rew"])):
+        a = tab["act"][i]
+        policy.add(tab["obs"][i], a[0] if discrete else a, float(tab["rew"][i]), tab["next_obs"][i],
+                   bool(tab["done"][i]))
+
+
+def test_buffer_ring_and_sample_bit_exact():
+    c = cases.CASES["buffer"]
+    inp = cases.buffer_inputs(c)
+    fx = gold("buffer")
+    buf = Buffer(c["capacity"], c["obs_dim"], c["act_dim"])
+    tab = inp["table"]
+    for i in range(c["n_add"]):
+        buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    assert buf._index == int(fx["index"]) and buf._size == int(fx["size"])
+    for got, key in zip(buf.sample(inp["idx"]), ["obs", "act", "rew", "next_obs", "done"]):
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, fx[key])      # pure data movement: bit-exact
+
+
+def test_dqn_learn():
+    c = cases.CASES["dqn"]
+    inp = cases.dqn_inputs(c)
+    fx = gold("dqn")
+    pol = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+    fill(pol, inp["table"], discrete=True)
+    np.testing.assert_allclose(pol.q_values(inp["table"]["obs"][:32]), fx["q0"], rtol=1e-5, atol=1e-6)
+    acts = [pol.select_action(inp["table"]["obs"][i]) for i in range(32)]
+    np.testing.assert_array_equal(np.array(acts), fx["select_action"])
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_m", pol.opt.m, fx, P_RTOL, 1e-7)
+    synth.check_digest("Qnet_v", pol.opt.v, fx, P_RTOL, 1e-9)
+    assert pol.opt.t == int(fx["step"])
+
+
+def _check_ac(pol, fx):
+    synth.check_digest("actor", pol.actor, fx, P_RTOL, P_ATOL)
+    synth.check_digest("critic", pol.critic, fx, P_RTOL, P_ATOL)
+    synth.check_digest("actor_target", pol.actor_t, fx, P_RTOL, P_ATOL)
+    synth.check_digest("critic_target", pol.critic_t, fx, P_RTOL, P_ATOL)
+    synth.check_digest("critic_m", pol.critic_opt.m, fx, 5e-4, 1e-7)
+    synth.check_digest("critic_v", pol.critic_opt.v, fx, 5e-4, 1e-9)
+    assert pol.actor_opt.t == int(fx["actor_step"]) and pol.critic_opt.t == int(fx["critic_step"])
+
+
+def test_ddpg_learn():
+    c = cases.CASES["ddpg"]
+    inp = cases.ac_inputs(c, twin=False)
+    fx = gold("ddpg")
+    pol = algos.DDPG(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                     c["actor_lr"], c["critic_lr"], c["capacity"])
+    fill(pol, inp["table"])
+    sa = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(32)])
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=1e-5, atol=1e-6)
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=LOSS_RTOL, atol=1e-7)
+    _check_ac(pol, fx)
+
+
+@pytest.mark.parametrize("name", ["td3", "td3_pendulum"])
+def test_td3_learn(name):
+    c = cases.CASES[name]
+    inp = cases.ac_inputs(c, twin=True)
+    fx = gold(name)
+    pol = algos.TD3(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                    c["actor_lr"], c["critic_lr"], c["capacity"])
+    fill(pol, inp["table"])
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], inp["noise"][k][0], c["gamma"], c["tau"], c["policy_noise"],
+                       c["noise_clip"], c["max_action"], c["policy_freq"], c["policy_noise_scale"])
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=LOSS_RTOL, atol=1e-7)
+    assert pol.total_it == int(fx["total_it"])
+    _check_ac(pol, fx)
+
+
+def test_sac_learn():
+    c = cases.CASES["sac"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    fx = gold("sac")
+    pol = algos.SAC(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                    c["actor_lr"], c["critic_lr"], c["capacity"])
+    fill(pol, inp["table"])
+    ev = np.stack([pol.evaluate_action(inp["table"]["obs"][i]) for i in range(32)])
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], inp["noise"][k][0], inp["noise"][k][1], c["gamma"], c["tau"])
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(np.array(pol.alpha_losses), fx["loss_alpha"], rtol=5e-5)
+    np.testing.assert_allclose(np.array(pol.alphas), fx["alpha"], rtol=1e-6)
+    np.testing.assert_allclose(pol.alpha_p["log_alpha"], fx["log_alpha"], rtol=1e-6)
+    _check_ac(pol, fx)
+    sa = np.stack([pol.select_action(inp["table"]["obs"][i], synth.normal(c["noise_seed"] + 900 + i, (1, c["act_dim"])))
+                   for i in range(8)])
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=2e-5, atol=2e-6)
+
+
+def test_maddpg_learn():
+    c = cases.CASES["maddpg"]
+    inp = cases.maddpg_inputs(c)
+    fx = gold("maddpg")
+    ids = inp["ids"]
+    pol = algos.MADDPG(inp["params"], c["dims"], c["actor_lr"], c["critic_lr"], c["capacity"])
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    acts = pol.select_action({a: inp["tables"][a]["obs"][0] for a in ids})
+    for a in ids:
+        np.testing.assert_allclose(acts[a], fx["select_action/" + a], rtol=1e-5, atol=1e-6)
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    for a in ids:
+        np.testing.assert_allclose(np.array(pol.critic_losses[a]), fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(np.array(pol.actor_losses[a]), fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=1e-7)
+        synth.check_digest(a + "/actor", pol.actor[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic", pol.critic[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/actor_target", pol.actor_t[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
+
+
+@pytest.mark.parametrize("name", ["ppo", "ppo_tricks"])
+def test_ppo_learn(name):
+    c = cases.CASES[name]
+    inp = cases.ppo_inputs(c)
+    fx = gold(name)
+    pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                  c["actor_lr"], c["critic_lr"], c["horizon"], c["trick"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(pol.adv_raw.reshape(-1), fx["adv_raw"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(pol.v_target.reshape(-1), fx["v_target"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
+    synth.check_digest("actor", pol.actor, fx, 1e-3, 1e-5)
+    synth.check_digest("critic", pol.critic, fx, 1e-3, 1e-5)
+    assert pol.actor_opt.t == int(fx["actor_step"]) and pol.critic_opt.t == int(fx["critic_step"])
+    assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
+
+
+def test_normalizers():
+    fx = gold("norm")
+    g = np.random.default_rng(77)
+    xs = g.standard_normal((6, 5)).astype(np.float32) * 2 + 1
+    norm = normalization.Normalization(shape=5)
+    ys = np.stack([norm(x.copy()) for x in xs])
+    np.testing.assert_allclose(ys, fx["norm_y"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(norm.running_ms.mean, fx["norm_mean"], rtol=1e-12)
+    np.testing.assert_allclose(norm.running_ms.std, fx["norm_std"], rtol=1e-12)
+    np.testing.assert_allclose(norm(xs[0].copy(), update=False), fx["norm_eval"], rtol=1e-12)
+    bn = normalization.NormalizationBatch(shape=5)
+    xb = g.standard_normal((4, 16, 5)).astype(np.float32) + 0.5
+    yb = np.stack([bn(x) for x in xb])
+    np.testing.assert_allclose(yb, fx["bnorm_y"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(bn.running_ms.mean, fx["bnorm_mean"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(bn.running_ms.std, fx["bnorm_std"], rtol=1e-5, atol=1e-7)
+    rs = normalization.RewardScaling(shape=1, gamma=0.99)
+    rr = g.standard_normal(8)
+    got = np.array([np.asarray(rs(r)).reshape(-1)[0] for r in rr])
+    np.testing.assert_allclose(got, fx["rscale_y"], rtol=1e-12)
