@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — learner updates/s of the fused replay-sample + batched-update hot path.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): TD3.learn()
+(TD3_file/TD3.py:189-233, all `realize` flags on, policy_freq 2) with replay capacity 1e6
+(filled) and batch 256, at the north_star's synthetic shape obs_dim 8 / act_dim 2, hidden 128.
+One "step" = one pass of the hot path over one batch for EVERY learner resident on the GPU:
+index draw (device Philox, without replacement) -> record gather from the HBM ring -> target
+forward -> twin-critic forward/backward -> clip -> Adam [-> actor forward/backward -> clip ->
+Adam -> soft updates on every 2nd step].  Learners are independent seeds: P per
+GPU in one launch, sharded over ranks with no data-path collective (scaling "weak"); the only
+collective is the RCCL all-reduce of the metric vector.
+
+Contract: W untimed warmup steps, then exactly K timed steps between barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OBS, ACT, BATCH, CAP, HIDDEN = 8, 2, 256, 1_000_000, 128
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def td3_kwargs(k):
+    return dict(gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1),
+                use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0)
+
+
+def make_engine(N, Engine, learners, device_id, seed):
+    e = Engine(N.ALGO_TD3, OBS, ACT, CAP, n_learners=learners, twin_critic=True, batch_max=BATCH, hidden=HIDDEN,
+               device_id=device_id, seed=seed)
+    rng = np.random.default_rng(seed)
+    # random-init weights of the reference architecture: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    def init(net, dims):
+        parts = []
+        for out_d, in_d in dims:
+            b = 1.0 / np.sqrt(in_d)
+            parts += [rng.uniform(-b, b, out_d * in_d), rng.uniform(-b, b, out_d)]
+        return np.concatenate(parts).astype(np.float32)
+    a_dims = [(HIDDEN, OBS), (HIDDEN, HIDDEN), (ACT, HIDDEN)]
+    c_dims = [(HIDDEN, OBS + ACT), (HIDDEN, HIDDEN), (1, HIDDEN)] * 2
+    for p in range(learners):
+        fa, fc = init(0, a_dims), init(1, c_dims)
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(0, fa, kind, learner=p)
+            e.set_params(1, fc, kind, learner=p)
+    e.fill_synthetic(CAP, seed=seed + 17)
+    e.sync()
+    return e
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (NumPy port of TD3.learn, incl. the reference's np.random.choice over the full
+    1e6-row buffer) timed on ONE host core: a bounded sample of the same workload."""
+    from oracle import algos
+    from tests.golden import cases, synth
+    try:
+        import threadpoolctl
+        ctx = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        ctx = None
+    actor = synth.mlp_params(1, cases.actor_layers(OBS, ACT))
+    critic = synth.mlp_params(2, cases.critic_layers(OBS + ACT, twin=True))
+    pol = algos.TD3(actor, critic, OBS, ACT, 1e-3, 1e-3, CAP)
+    g = np.random.default_rng(3)
+    b = pol.buffer
+    b.obs[:] = g.standard_normal((CAP, OBS)); b.next_obs[:] = g.standard_normal((CAP, OBS))
+    b.actions[:] = g.uniform(-1, 1, (CAP, ACT)); b.rewards[:] = g.standard_normal(CAP)
+    b.dones[:] = g.random(CAP) < 0.05
+    b._size, b._index = CAP, 0
+    np.random.seed(0)
+    noise = g.standard_normal((BATCH, ACT)).astype(np.float32)
+    for _ in range(3):
+        pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
+        n += 1
+    dt = time.perf_counter() - t0
+    if ctx is not None:
+        ctx.unregister() if hasattr(ctx, "unregister") else None
+    return {"value": n / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "%d oracle TD3.learn() calls (1 learner, replay 1e6 full, batch 256, np.random.choice "
+                      "index draw included) in %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--learners", type=int, default=int(os.environ.get("FRL_BENCH_LEARNERS", "512")),
+                    help="independent learners (seeds) per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from freerl_amd import _native as N
+    from freerl_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or N.device_count() == 0:
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
+
+    P = args.learners
+    e = make_engine(N, Engine, P, local_rank, seed=1000 + rank)           # seeds sharded by rank
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e.sync()
+
+    for k in range(args.warmup):
+        e.learn(BATCH, **td3_kwargs(k))
+    barrier()
+    e.timer_start()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        e.learn(BATCH, **td3_kwargs(k))
+    kernel_ms = e.timer_stop()            # HIP events on the engine's stream around the K launches (synchronises)
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = e.stats()
+    assert np.all(np.isfinite(stats)), "non-finite losses"
+
+    metrics = torch.tensor([dt, float(P * args.steps), kernel_ms], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = metrics.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)                    # the metric all-reduce (RCCL over xGMI)
+        dt_max, total_updates, kernel_ms = float(tmax[0]), float(metrics[1]), float(tmax[2])
+    else:
+        dt_max, total_updates = dt, float(P * args.steps)
+
+    if rank == 0:
+        fl_a, by_a = e.learn_work(BATCH, True)
+        fl_c, by_c = e.learn_work(BATCH, False)
+        n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
+        flops = (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps      # per launch, all P learners
+        abytes = (by_a * n_act + by_c * (args.steps - n_act)) / args.steps
+        launch_s = kernel_ms * 1e-3 / args.steps
+        achieved = flops / launch_s / 1e12
+        lds, rc = e.lds_bytes()
+        # single-learner latency (P = 1): the reference-compatible drop-in case
+        e.close()
+        e1 = make_engine(N, Engine, 1, local_rank, seed=7)
+        for k in range(10):
+            e1.learn(BATCH, **td3_kwargs(k))
+        e1.sync()
+        t1 = time.perf_counter()
+        n1 = 200
+        for k in range(n1):
+            e1.learn(BATCH, **td3_kwargs(k))
+        e1.sync()
+        single = n1 / (time.perf_counter() - t1)
+        e1.close()
+        traffic = None
+        pf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(pf):
+            try:
+                traffic = json.load(open(pf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "learner_updates_per_sec", "value": total_updates / dt_max, "unit": "updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TD3.learn() (BASELINE configs[1] algorithm; north_star synthetic shape): obs_dim 8, "
+                                   "act_dim 2, batch 256, replay 1e6 rows filled, hidden 128, policy_freq 2, "
+                                   "device-drawn indices/noise",
+                       "learners_per_gpu": P, "updates_per_step": P * world, "row_chunk": rc, "lds_bytes": lds,
+                       "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world},
+            "env_steps_per_sec": None,
+            "single_learner_updates_per_sec": single,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "ac_update_kernel", "avg_launch_ms": launch_s * 1e3,
+                         "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
+                         "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS},
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+"""ctypes binding of the C ABI declared in include/freerl_hip.h.
+
+There is NO CPU fallback: if `libfreerl_hip.so` is missing or no HIP device is visible, the
+product raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfreerl_hip.so")
+HEADER = os.path.join(ROOT, "include", "freerl_hip.h")
+
+FRL_MAX_AGENTS = 8
+FRL_STAT_COUNT = 8
+
+# enum frl_algo
+ALGO_REPLAY_ONLY, ALGO_DQN, ALGO_DDPG, ALGO_TD3, ALGO_SAC, ALGO_MADDPG, ALGO_PPO = -1, 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+PARAM_ONLINE, PARAM_TARGET, PARAM_ADAM_M, PARAM_ADAM_V, PARAM_GRAD = 0, 1, 2, 3, 4
+ACT_RAW, ACT_ARGMAX, ACT_TANHHEAD, ACT_SAC_SAMPLE, ACT_PPO_SAMPLE = 0, 1, 2, 3, 4
+STAT_CRITIC_LOSS, STAT_ACTOR_LOSS, STAT_ALPHA_LOSS, STAT_ALPHA, STAT_CRITIC_GNORM, STAT_ACTOR_GNORM, STAT_ENTROPY = range(7)
+
+
+class FrlError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("algo", C.c_int), ("n_learners", C.c_int), ("n_agents", C.c_int),
+                ("obs_dim", C.c_int * FRL_MAX_AGENTS), ("act_dim", C.c_int * FRL_MAX_AGENTS),
+                ("discrete", C.c_int), ("hidden", C.c_int), ("hidden_act", C.c_int), ("twin_critic", C.c_int),
+                ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("device_id", C.c_int),
+                ("seed", C.c_uint64)]
+
+
+class RecordLayout(C.Structure):
+    _fields_ = [("n_agents", C.c_int), ("width", C.c_int), ("stride", C.c_int),
+                ("obs_off", C.c_int * FRL_MAX_AGENTS), ("obs_dim", C.c_int * FRL_MAX_AGENTS),
+                ("act_off", C.c_int * FRL_MAX_AGENTS), ("act_dim", C.c_int * FRL_MAX_AGENTS),
+                ("rew_off", C.c_int), ("done_off", C.c_int), ("next_obs_off", C.c_int * FRL_MAX_AGENTS),
+                ("extra_off", C.c_int), ("extra", C.c_int)]
+
+
+class LearnArgs(C.Structure):
+    _fields_ = [("batch", C.c_int), ("do_actor", C.c_int), ("use_policy_noise", C.c_int),
+                ("gamma", C.c_float), ("tau", C.c_float), ("actor_lr", C.c_float), ("critic_lr", C.c_float),
+                ("alpha_lr", C.c_float), ("adam_eps", C.c_float), ("critic_weight_decay", C.c_float),
+                ("clip_norm", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
+                ("max_action", C.c_float), ("policy_noise_scale", C.c_float), ("target_entropy", C.c_float),
+                ("idx", C.POINTER(C.c_int64)), ("noise", C.POINTER(C.c_float)), ("stats_out", C.POINTER(C.c_float))]
+
+
+class PpoArgs(C.Structure):
+    _fields_ = [("horizon", C.c_int), ("minibatch", C.c_int), ("k_epochs", C.c_int), ("adv_norm", C.c_int),
+                ("gamma", C.c_float), ("lmbda", C.c_float), ("clip", C.c_float), ("ent_coef", C.c_float),
+                ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("adam_eps", C.c_float), ("clip_norm", C.c_float),
+                ("perms", C.POINTER(C.c_int64)), ("loss_trace_out", C.POINTER(C.c_float)),
+                ("adv_out", C.POINTER(C.c_float)), ("vtarget_out", C.POINTER(C.c_float))]
+
+
+_P = C.POINTER
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_fp, _ip, _i64p = _P(C.c_float), _P(C.c_int), _P(C.c_int64)
+
+# name -> (restype, argtypes); every symbol include/freerl_hip.h declares
+SIGNATURES = {
+    "frl_last_error": (C.c_char_p, []),
+    "frl_version": (_i, []),
+    "frl_device_count": (_i, [_ip]),
+    "frl_create": (_i, [_P(Config), _P(_vp)]),
+    "frl_destroy": (_i, [_vp]),
+    "frl_sync": (_i, [_vp]),
+    "frl_lds_bytes": (_i, [_vp, _ip, _ip]),
+    "frl_record_layout_get": (_i, [_vp, _P(RecordLayout)]),
+    "frl_buffer_add": (_i, [_vp, _i, _fp]),
+    "frl_buffer_add_batch": (_i, [_vp, _i, _ip, _fp]),
+    "frl_buffer_flush": (_i, [_vp]),
+    "frl_buffer_cursor_get": (_i, [_vp, _i, _ip, _ip]),
+    "frl_buffer_cursor_set": (_i, [_vp, _i, _i, _i]),
+    "frl_buffer_sample": (_i, [_vp, _i, _i64p, _i, _i, _ip, _ip, _P(_vp)]),
+    "frl_buffer_read": (_i, [_vp, _i, _i, _i, _fp]),
+    "frl_buffer_fill_synthetic": (_i, [_vp, _i, C.c_uint64]),
+    "frl_net_count": (_i, [_vp, _ip]),
+    "frl_net_num_params": (_i, [_vp, _i, _ip]),
+    "frl_params_get": (_i, [_vp, _i, _i, _i, _fp]),
+    "frl_params_set": (_i, [_vp, _i, _i, _i, _fp]),
+    "frl_opt_step_get": (_i, [_vp, _i, _i, _ip]),
+    "frl_opt_step_set": (_i, [_vp, _i, _i, _i]),
+    "frl_alpha_get": (_i, [_vp, _i, _fp, _ip]),
+    "frl_alpha_set": (_i, [_vp, _i, _fp, _i]),
+    "frl_act": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "frl_learn": (_i, [_vp, _P(LearnArgs)]),
+    "frl_stats_get": (_i, [_vp, _fp]),
+    "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
+    "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
+    "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "frl_timer_start": (_i, [_vp]),
+    "frl_timer_stop": (_i, [_vp, _fp]),
+}
+
+_lib = None
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))] + \
+           [os.path.join(CSRC, "device", f) for f in sorted(os.listdir(os.path.join(CSRC, "device")))] + [HEADER]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force=False, verbose=False):
+    """Compile libfreerl_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-Wno-pass-failed", "-o", LIB_PATH, os.path.join(CSRC, "frl_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise FrlError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises FrlError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FrlError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the engine has no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FrlError("freerl_hip error %d: %s" % (rc, lib().frl_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().frl_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

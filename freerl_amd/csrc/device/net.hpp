@@ -1,0 +1,273 @@
+// Layer / MLP / optimiser building blocks of the fused update kernels.
+//
+// Activations of one row-chunk (rc rows) are LDS resident:
+//     xin  [rc][xp]   first-layer input (zero padded to the layer's k_pad)
+//     h1,h2[rc][hp]   hidden activations, overwritten IN PLACE by their deltas on the way back
+//     outb [rc][op]   head output / head delta
+// Pitches are (width + 4) floats: 16-byte aligned rows and conflict-light MFMA operand reads.
+// Weight gradients are accumulated in the learner's global `grad` block (one owner per
+// element, plain read-modify-write), parameters/Adam state/targets are streamed once per step.
+#pragma once
+#include "../frl_desc.h"
+#include "rng.hpp"
+#include "tile.hpp"
+
+namespace frl {
+
+struct Lds {
+    float* xin; int xp;
+    float* h1; float* h2; int hp;
+    float* outb; int op;
+    float* y;          // [batch_pad] TD targets / v_targets
+    float* abuf;       // [rc][ap] actions produced by the actor(s)
+    float* dabuf;      // [rc][ap] d loss / d action (or eps staging)
+    int ap;
+    float* red;        // [8] reduction scratch
+    int rc;
+};
+
+// Carve the dynamic LDS region; must mirror lds_bytes() in the host code.
+__device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int kin_pad_max, int out_pad_max,
+                                         int batch_pad, int act_pad) {
+    Lds S;
+    S.rc = rc;
+    S.xp = kin_pad_max + 4;
+    S.hp = hidden + 4;
+    S.op = out_pad_max + 4;
+    S.ap = act_pad + 4;
+    float* p = smem;
+    S.xin = p; p += rc * S.xp;
+    S.h1 = p; p += rc * S.hp;
+    S.h2 = p; p += rc * S.hp;
+    S.outb = p; p += rc * S.op;
+    S.abuf = p; p += rc * S.ap;
+    S.dabuf = p; p += rc * S.ap;
+    S.y = p; p += batch_pad;
+    S.red = p; p += 8;
+    return S;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative from the activation OUTPUT
+__device__ __forceinline__ float act_grad(float h, int act) {
+    if (act == ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    if (act == ACT_TANH) return 1.f - h * h;
+    return 1.f;
+}
+
+// Y[rc][n_pad] = act(X[rc][k_pad] * W^T + b)
+__device__ __forceinline__ void linear_fwd(const LayerDesc& L, const float* __restrict__ theta, const float* X,
+                                           int ldx, float* Y, int ldy, int act, int rc) {
+    const float* W = theta + L.w_off;
+    const float* b = theta + L.b_off;
+    const int kpad = L.k_pad;
+    for_tile_blocks(rc / 16, L.n_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+        f32x4 acc[BM][BN];
+        acc_zero(acc);
+        mma_nt<BM, BN>(acc, X, ldx, mt0 * 16, W, kpad, nt0 * 16, kpad);
+        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16,
+                              [&](int r, int c, float v) { Y[r * ldy + c] = act_apply(v + b[c], act); });
+    });
+}
+
+// dX[rc][k tiles ct0..ct1) = (dY[rc][n_pad] * W) (.) act'(H)   written in place over H (pitch ldh).
+// act_prev == ACT_NONE: plain store (used for d/d(first-layer input)).
+__device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, const float* __restrict__ theta, const float* dY,
+                                              int ldy, float* H, int ldh, int act_prev, int rc, int ct0, int ct1) {
+    const float* W = theta + L.w_off;
+    const int kpad = L.k_pad, npad = L.n_pad;
+    for_tile_blocks(rc / 16, ct1 - ct0, [&](auto bm, auto bn, int mt0, int nt0) {
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+        f32x4 acc[BM][BN];
+        acc_zero(acc);
+        mma_nn<BM, BN>(acc, dY, ldy, mt0 * 16, W, kpad, (ct0 + nt0) * 16, npad);
+        tile_epilogue<BM, BN>(acc, mt0 * 16, (ct0 + nt0) * 16, [&](int r, int c, float v) {
+            float* h = H + r * ldh + c;
+            *h = (act_prev == ACT_NONE) ? v : v * act_grad(*h, act_prev);
+        });
+    });
+}
+
+// G.W[n_pad][k_pad] (=|+=) dY^T * X ;  G.b (=|+=) column sums of dY
+__device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, float* __restrict__ G, const float* dY, int ldy,
+                                              const float* X, int ldx, int rc, bool first) {
+    float* GW = G + L.w_off;
+    const int kpad = L.k_pad;
+    for_tile_blocks(L.n_pad / 16, L.k_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
+        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+        f32x4 acc[BM][BN];
+        acc_zero(acc);
+        mma_tn<BM, BN>(acc, dY, ldy, mt0 * 16, X, ldx, nt0 * 16, rc);
+        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c, float v) {
+            float* g = GW + (size_t)r * kpad + c;
+            *g = first ? v : (*g + v);
+        });
+    });
+    float* Gb = G + L.b_off;
+    for (int n = threadIdx.x; n < L.n_pad; n += kWG) {
+        float s = 0.f;
+        for (int r = 0; r < rc; ++r) s += dY[r * ldy + n];
+        Gb[n] = first ? s : (Gb[n] + s);
+    }
+}
+
+// Forward of layers [l0, l0+nl) of net N: xin -> h1 [-> h2] -> outb.  Ends with a barrier.
+__device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, const float* __restrict__ theta,
+                                        const Lds& S, int out_act) {
+    const float* in = S.xin;
+    int ldin = S.xp;
+    for (int i = 0; i < nl; ++i) {
+        const bool last = (i == nl - 1);
+        float* out = last ? S.outb : (i == 0 ? S.h1 : S.h2);
+        const int ldo = last ? S.op : S.hp;
+        linear_fwd(N.L[l0 + i], theta, in, ldin, out, ldo, last ? out_act : N.hidden_act, S.rc);
+        __syncthreads();
+        in = out;
+        ldin = ldo;
+    }
+}
+
+// Backward of layers [l0, l0+nl): head delta in outb (zero in padded columns and invalid rows).
+// G != nullptr accumulates weight/bias gradients (first: overwrite).  want_dx0 leaves
+// d loss / d xin in xin for column tiles [ct0, ct1).  Ends with a barrier.
+__device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, const float* __restrict__ theta,
+                                        float* __restrict__ G, const Lds& S, bool first, bool want_dx0, int ct0,
+                                        int ct1) {
+    for (int i = nl - 1; i >= 0; --i) {
+        const bool last = (i == nl - 1);
+        const float* D = last ? S.outb : (i == 0 ? S.h1 : S.h2);
+        const int ldd = last ? S.op : S.hp;
+        float* X = (i == 0) ? S.xin : (i == 1 ? S.h1 : S.h2);
+        const int ldx = (i == 0) ? S.xp : S.hp;
+        const LayerDesc& L = N.L[l0 + i];
+        if (G) {
+            linear_bwd_dw(L, G, D, ldd, X, ldx, S.rc, first);
+            __syncthreads();
+        }
+        if (i > 0) {
+            linear_bwd_dx(L, theta, D, ldd, X, ldx, N.hidden_act, S.rc, 0, L.k_pad / 16);
+            __syncthreads();
+        } else if (want_dx0) {
+            linear_bwd_dx(L, theta, D, ldd, X, ldx, ACT_NONE, S.rc, ct0, ct1);
+            __syncthreads();
+        }
+    }
+}
+
+// X[r][dst0 + c] = ring[idx[r0 + r]][src0 + c] for r < nvalid, c < ncols; 0 for r >= nvalid
+__device__ __forceinline__ void gather_cols(float* X, int ldx, int rc, int nvalid, const int* __restrict__ idx,
+                                            const float* __restrict__ ring, int stride, int src0, int ncols,
+                                            int dst0) {
+    const int total = rc * ncols;
+    for (int e = threadIdx.x; e < total; e += kWG) {
+        const int r = e / ncols, c = e - r * ncols;
+        float v = 0.f;
+        if (r < nvalid) v = ring[(size_t)idx[r] * stride + src0 + c];
+        X[r * ldx + dst0 + c] = v;
+    }
+}
+__device__ __forceinline__ void zero_cols(float* X, int ldx, int rc, int c0, int c1) {
+    const int w = c1 - c0;
+    if (w <= 0) return;
+    for (int e = threadIdx.x; e < rc * w; e += kWG) {
+        const int r = e / w, c = e - r * w;
+        X[r * ldx + c0 + c] = 0.f;
+    }
+}
+
+// beta^t in double by repeated squaring (torch computes `beta ** step` in Python floats)
+__device__ __forceinline__ double powi_d(double b, int t) {
+    double r = 1.0;
+    while (t > 0) {
+        if (t & 1) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
+// Global-norm clip + Adam (+ optional soft target update) over one net's parameter block.
+// torch semantics: clip_grad_norm_(params, clip) then optim.Adam.step() (single-tensor order),
+// then theta_t <- theta_t*(1-tau) + theta*tau.  Returns the pre-clip gradient norm.
+__device__ __forceinline__ float adam_net(int size, float* __restrict__ theta, float* __restrict__ m,
+                                          float* __restrict__ v, const float* __restrict__ g,
+                                          float* __restrict__ target, float lr, float eps, float b1, float b2,
+                                          float wd, float clip_norm, int t_new, float tau, float* red) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < size; i += kWG) {
+        const float x = g[i];
+        ss += x * x;
+    }
+    const float total = sqrtf(block_sum(ss, red));
+    float coef = 1.f;
+    if (clip_norm > 0.f) coef = fminf(clip_norm / (total + 1e-6f), 1.f);
+    const double bc1 = 1.0 - powi_d((double)b1, t_new);
+    const double bc2 = 1.0 - powi_d((double)b2, t_new);
+    const float step = (float)((double)lr / bc1);
+    const float bc2s = (float)sqrt(bc2);
+    const float w1 = 1.f - b1, w2 = 1.f - b2, tk = 1.f - tau;
+    for (int i = threadIdx.x; i < size; i += kWG) {
+        float gi = g[i] * coef;
+        float th = theta[i];
+        if (wd != 0.f) gi += wd * th;
+        float mi = m[i];
+        mi = mi + (gi - mi) * w1;
+        const float vi = v[i] * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        th = th - step * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] = th;
+        if (target) target[i] = target[i] * tk + th * tau;
+    }
+    return total;
+}
+
+__device__ __forceinline__ void soft_update_net(int size, float* __restrict__ target, const float* __restrict__ theta,
+                                                float tau) {
+    const float tk = 1.f - tau;
+    for (int i = threadIdx.x; i < size; i += kWG) target[i] = target[i] * tk + theta[i] * tau;
+}
+
+// Draw `batch` distinct row indices in [0,size) into idx (global, this learner's slice) using
+// `lidx` (LDS int[batch]) for the duplicate check: rejection keeps the draw uniform over
+// subsets, like np.random.choice(size, batch, replace=False) (DQN.py:97).
+__device__ __forceinline__ void draw_indices(int* __restrict__ idx, int* lidx, int batch, int size,
+                                             unsigned long long counter, unsigned stream, unsigned long long key) {
+    for (int i = threadIdx.x; i < batch; i += kWG)
+        lidx[i] = (int)uniform_index(philox4x32_10(counter, stream, (unsigned)i, key), (unsigned)size);
+    __syncthreads();
+    for (unsigned round = 1; round < 64; ++round) {
+        int dup = 0;
+        for (int i = threadIdx.x; i < batch; i += kWG) {
+            const int mine = lidx[i];
+            bool d = false;
+            for (int j = 0; j < i; ++j) d |= (lidx[j] == mine);
+            if (d) dup = 1;
+        }
+        // redraw AFTER everyone has finished comparing against the old values
+        const int any = __syncthreads_or(dup);
+        if (!any) break;
+        for (int i = threadIdx.x; i < batch; i += kWG) {
+            const int mine = lidx[i];
+            bool d = false;
+            for (int j = 0; j < i; ++j) d |= (lidx[j] == mine);
+            if (d) lidx[i] = -1 - i;          // mark; distinct negative so marks never collide
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < batch; i += kWG)
+            if (lidx[i] < 0)
+                lidx[i] = (int)uniform_index(philox4x32_10(counter, stream + round * 0x10000u, (unsigned)i, key),
+                                             (unsigned)size);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < batch; i += kWG) idx[i] = lidx[i];
+    __syncthreads();
+}
+
+}  // namespace frl

@@ -1,0 +1,815 @@
+// Host side of the C ABI (include/freerl_hip.h): engine construction, the replay ring's pinned
+// staging, parameter import/export, kernel launches.  Compiled with hipcc for gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/freerl_hip.h"
+#include "frl_desc.h"
+
+#include "kernels_replay.hip"
+#include "kernels_update.hip"
+#include "kernels_act.hip"
+#include "kernels_ppo.hip"
+
+using namespace frl;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(FRL_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static inline int pad16(int x) { return (x + 15) / 16 * 16; }
+static inline int pad32(int x) { return (x + 31) / 32 * 32; }
+
+struct frl_engine {
+    frl_config cfg;
+    EngineDesc h;                 // host mirror of the device descriptor
+    EngineDesc* d = nullptr;      // device copy
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_stage = nullptr;
+    int lds_bytes = 0;
+    // replay cursors (host authoritative, reference semantics Buffer.py:23-24,36-38)
+    std::vector<int> index, size;
+    // pinned staging of not-yet-flushed adds
+    float* stage_rows = nullptr;          // [stage_cap][width] pinned
+    long long* stage_slots = nullptr;     // [stage_cap] pinned
+    float* d_stage_rows = nullptr;
+    long long* d_stage_slots = nullptr;
+    int stage_cap = 0, stage_n = 0;
+    bool stage_inflight = false;
+    std::vector<int> staged_per_learner;  // rows staged since the last flush (a flush may not hold one ring row twice)
+    // pinned scratch for idx / noise uploads
+    int* h_idx = nullptr;
+    long long* h_idx64 = nullptr;
+    long long* d_idx64 = nullptr;
+    float* h_noise = nullptr;
+    size_t idx_count = 0, noise_count = 0;
+    unsigned long long rng_counter = 0;
+    // act scratch (device)
+    float* d_act_in = nullptr;
+    float* d_act_eps = nullptr;
+    float* d_act_out = nullptr;
+    float* d_act_logp = nullptr;
+    size_t act_in_cap = 0, act_out_cap = 0;
+    // ppo scratch
+    float* d_ppo = nullptr;
+    size_t ppo_cap = 0;
+    int* d_perm = nullptr;
+    size_t perm_cap = 0;
+    bool has_nets = false;
+};
+
+// ------------------------------------------------------------------------------ descriptors
+static int build_net(NetDesc& N, const std::vector<std::pair<int, int>>& layers /* (out,in) */, int heads,
+                     int hidden_act, int out_act, int extra_n) {
+    memset(&N, 0, sizeof N);
+    N.n_layers = (int)layers.size();
+    N.heads = heads;
+    N.hidden_act = hidden_act;
+    N.out_act = out_act;
+    int off = 0, np = 0;
+    for (int i = 0; i < N.n_layers; ++i) {
+        LayerDesc& L = N.L[i];
+        L.n = layers[i].first;
+        L.k = layers[i].second;
+        L.n_pad = pad16(L.n);
+        L.k_pad = pad16(L.k);
+        L.w_off = off;
+        off += L.n_pad * L.k_pad;
+        L.b_off = off;
+        off += L.n_pad;
+        np += L.n * L.k + L.n;
+    }
+    N.extra_off = -1;
+    N.extra_n = extra_n;
+    if (extra_n > 0) {
+        N.extra_off = off;
+        off += pad16(extra_n);
+        np += extra_n;
+    }
+    N.size = pad32(off);
+    N.n_params = np;
+    return 0;
+}
+
+static void build_record(RecordDesc& R, const frl_config& c) {
+    memset(&R, 0, sizeof R);
+    R.n_agents = c.n_agents;
+    int off = 0;
+    for (int j = 0; j < c.n_agents; ++j) { R.obs_off[j] = off; R.obs_dim[j] = c.obs_dim[j]; off += c.obs_dim[j]; }
+    R.obs_total = off;
+    for (int j = 0; j < c.n_agents; ++j) {
+        R.act_off[j] = off;
+        R.act_dim[j] = c.discrete ? 1 : c.act_dim[j];
+        off += R.act_dim[j];
+    }
+    R.act_total = off - R.obs_total;
+    R.rew_off = off; off += c.n_agents;
+    R.done_off = off; off += c.n_agents;
+    for (int j = 0; j < c.n_agents; ++j) { R.nobs_off[j] = off; off += c.obs_dim[j]; }
+    R.extra_off = off;
+    R.extra = c.extra_cols;
+    off += c.extra_cols;
+    R.width = off;
+    R.stride = pad32(off);
+}
+
+static int lds_bytes_for(const EngineDesc& h, int rc) {
+    const int xp = h.lds_kin_pad + 4, hp = h.hidden + 4, op = h.lds_out_pad + 4, ap = h.lds_act_pad + 4;
+    const long long fl = (long long)rc * (xp + 2 * hp + op + 2 * ap) + h.lds_batch_pad + 8;
+    return (int)(fl * 4);
+}
+
+// --------------------------------------------------------------------------------- lifetime
+extern "C" const char* frl_last_error(void) { return g_err.c_str(); }
+extern "C" int frl_version(void) { return 100; }
+
+extern "C" int frl_device_count(int* n_out) {
+    if (!n_out) return fail(FRL_ERR_INVALID, "n_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; return fail(FRL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n_out = n;
+    return FRL_OK;
+}
+
+extern "C" int frl_destroy(frl_engine* e) {
+    if (!e) return FRL_OK;
+    hipSetDevice(e->cfg.device_id);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    float* dev[] = {e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
+                    e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo};
+    for (float* p : dev) if (p) hipFree(p);
+    if (e->h.idx) hipFree(e->h.idx);
+    if (e->h.steps) hipFree(e->h.steps);
+    if (e->d_stage_slots) hipFree(e->d_stage_slots);
+    if (e->d_idx64) hipFree(e->d_idx64);
+    if (e->d_perm) hipFree(e->d_perm);
+    if (e->d) hipFree(e->d);
+    if (e->stage_rows) hipHostFree(e->stage_rows);
+    if (e->stage_slots) hipHostFree(e->stage_slots);
+    if (e->h_idx) hipHostFree(e->h_idx);
+    if (e->h_idx64) hipHostFree(e->h_idx64);
+    if (e->h_noise) hipHostFree(e->h_noise);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->ev_stage) hipEventDestroy(e->ev_stage);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return FRL_OK;
+}
+
+template <class T>
+static hipError_t dalloc_zero(T** p, size_t count, hipStream_t s) {
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(*p, 0, count * sizeof(T), s);
+}
+
+extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
+    if (!cfg || !out) return fail(FRL_ERR_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    const frl_config& c = *cfg;
+    if (c.n_learners < 1) return fail(FRL_ERR_INVALID, "n_learners must be >= 1");
+    if (c.n_agents < 1 || c.n_agents > FRL_MAX_AGENTS) return fail(FRL_ERR_INVALID, "n_agents out of range");
+    if (c.algo != FRL_ALGO_MADDPG && c.n_agents != 1) return fail(FRL_ERR_INVALID, "n_agents > 1 needs FRL_ALGO_MADDPG");
+    if (c.capacity < 1) return fail(FRL_ERR_INVALID, "capacity must be >= 1");
+    if (c.algo < FRL_ALGO_REPLAY_ONLY || c.algo > FRL_ALGO_PPO) return fail(FRL_ERR_INVALID, "unknown algo %d", c.algo);
+    for (int j = 0; j < c.n_agents; ++j)
+        if (c.obs_dim[j] < 1 || c.act_dim[j] < 1) return fail(FRL_ERR_INVALID, "obs_dim/act_dim must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FRL_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (c.device_id < 0 || c.device_id >= ndev) return fail(FRL_ERR_INVALID, "device_id %d of %d", c.device_id, ndev);
+    HIP_TRY(hipSetDevice(c.device_id));
+
+    frl_engine* e = new frl_engine();
+    e->cfg = c;
+    EngineDesc& h = e->h;
+    memset(&h, 0, sizeof h);
+    h.algo = c.algo;
+    h.P = c.n_learners;
+    h.n_agents = c.n_agents;
+    h.hidden = c.hidden > 0 ? c.hidden : 128;
+    if (h.hidden % 16) { delete e; return fail(FRL_ERR_INVALID, "hidden must be a multiple of 16"); }
+    h.capacity = c.capacity;
+    h.batch_max = c.batch_max > 0 ? c.batch_max : 256;
+    h.seed = c.seed;
+    h.n_discrete = (c.algo == FRL_ALGO_DQN) ? c.act_dim[0] : 0;
+    build_record(h.rec, c);
+    const RecordDesc& R = h.rec;
+    const int H = h.hidden;
+    const int hact = c.hidden_act == FRL_ACT_TANH ? ACT_TANH : ACT_RELU;
+    e->has_nets = c.algo != FRL_ALGO_REPLAY_ONLY;
+    if (c.algo == FRL_ALGO_DQN) {
+        h.n_nets = 1;
+        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);   // MLP, DQN.py:32-45
+    } else if (c.algo == FRL_ALGO_PPO) {
+        h.n_nets = 2;
+        build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, hact, ACT_TANH, c.act_dim[0]);
+        build_net(h.net[1], {{H, c.obs_dim[0]}, {H, H}, {1, H}}, 1, hact, ACT_NONE, 0);
+    } else if (e->has_nets) {
+        h.n_nets = 2 * c.n_agents;
+        const int cin = R.obs_total + R.act_total;
+        const int heads = c.twin_critic ? 2 : 1;
+        for (int j = 0; j < c.n_agents; ++j) {
+            const bool sac = c.algo == FRL_ALGO_SAC;
+            build_net(h.net[2 * j], {{H, c.obs_dim[j]}, {H, H}, {c.act_dim[j], H}}, 1, ACT_RELU,
+                      sac ? ACT_NONE : ACT_TANH, sac ? c.act_dim[j] : 0);
+            std::vector<std::pair<int, int>> ls;
+            for (int hd = 0; hd < heads; ++hd) { ls.push_back({H, cin}); ls.push_back({H, H}); ls.push_back({1, H}); }
+            build_net(h.net[2 * j + 1], ls, heads, ACT_RELU, ACT_NONE, 0);
+        }
+    }
+    int off = 0, kin = 16, outp = 16;
+    for (int i = 0; i < h.n_nets; ++i) {
+        h.net_off[i] = off;
+        off += h.net[i].size;
+        const int nl = h.net[i].n_layers / h.net[i].heads;
+        for (int hd = 0; hd < h.net[i].heads; ++hd) {
+            kin = std::max(kin, h.net[i].L[hd * nl].k_pad);
+            outp = std::max(outp, h.net[i].L[hd * nl + nl - 1].n_pad);
+        }
+    }
+    h.learner_stride = pad32(off);
+    h.act_max = 1;
+    for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);
+    h.lds_kin_pad = kin;
+    h.lds_out_pad = outp;
+    h.lds_batch_pad = pad32(h.batch_max);
+    h.lds_act_pad = pad16(std::max(R.act_total, 1));
+    h.rc = 64;
+    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;
+    if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
+    e->lds_bytes = lds_bytes_for(h, h.rc);
+
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            int rc_ = fail(FRL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));                   \
+            frl_destroy(e);                                                                        \
+            return rc_;                                                                            \
+        }                                                                                          \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&e->ev0));
+    CREATE_TRY(hipEventCreate(&e->ev1));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming));
+    const size_t P = h.P;
+    CREATE_TRY(dalloc_zero(&h.replay, P * (size_t)h.capacity * R.stride, e->stream));
+    if (e->has_nets) {
+        const size_t ls = h.learner_stride;
+        CREATE_TRY(dalloc_zero(&h.theta, P * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.target, P * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.m, P * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.v, P * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.grad, P * ls, e->stream));
+        e->idx_count = P * h.n_agents * h.batch_max;
+        e->noise_count = P * h.n_agents * 2 * (size_t)h.batch_max * h.act_max;
+        CREATE_TRY(dalloc_zero(&h.idx, e->idx_count, e->stream));
+        CREATE_TRY(dalloc_zero(&h.noise, e->noise_count, e->stream));
+        CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
+        CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
+        CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
+        CREATE_TRY(hipHostMalloc((void**)&e->h_idx, e->idx_count * sizeof(int)));
+        CREATE_TRY(hipHostMalloc((void**)&e->h_noise, e->noise_count * sizeof(float)));
+    }
+    e->stage_cap = 4096;
+    CREATE_TRY(hipHostMalloc((void**)&e->stage_rows, (size_t)e->stage_cap * R.width * sizeof(float)));
+    CREATE_TRY(hipHostMalloc((void**)&e->stage_slots, (size_t)e->stage_cap * sizeof(long long)));
+    CREATE_TRY(hipMalloc((void**)&e->d_stage_rows, (size_t)e->stage_cap * R.width * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->d_stage_slots, (size_t)e->stage_cap * sizeof(long long)));
+    CREATE_TRY(hipHostMalloc((void**)&e->h_idx64, (size_t)h.batch_max * 16 * sizeof(long long)));
+    CREATE_TRY(hipMalloc((void**)&e->d_idx64, (size_t)h.batch_max * 16 * sizeof(long long)));
+    CREATE_TRY(hipMalloc((void**)&e->d, sizeof(EngineDesc)));
+    CREATE_TRY(hipMemcpyAsync(e->d, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+    e->index.assign(P, 0);
+    e->size.assign(P, 0);
+    e->staged_per_learner.assign(P, 0);
+    if (e->lds_bytes > 64 * 1024) {
+        CREATE_TRY(hipFuncSetAttribute((const void*)dqn_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    }
+    CREATE_TRY(hipStreamSynchronize(e->stream));
+    *out = e;
+    return FRL_OK;
+}
+
+#define ENG(e)                                                  \
+    if (!(e)) return fail(FRL_ERR_INVALID, "engine is NULL");   \
+    HIP_TRY(hipSetDevice((e)->cfg.device_id))
+
+extern "C" int frl_sync(frl_engine* e) {
+    ENG(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FRL_OK;
+}
+
+extern "C" int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* rc_out) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    if (bytes_out) *bytes_out = e->lds_bytes;
+    if (rc_out) *rc_out = e->h.rc;
+    return FRL_OK;
+}
+
+// ----------------------------------------------------------------------------------- replay
+extern "C" int frl_record_layout_get(const frl_engine* e, frl_record_layout* out) {
+    if (!e || !out) return fail(FRL_ERR_INVALID, "NULL argument");
+    const RecordDesc& R = e->h.rec;
+    memset(out, 0, sizeof *out);
+    out->n_agents = R.n_agents;
+    out->width = R.width;
+    out->stride = R.stride;
+    for (int j = 0; j < R.n_agents; ++j) {
+        out->obs_off[j] = R.obs_off[j]; out->obs_dim[j] = R.obs_dim[j];
+        out->act_off[j] = R.act_off[j]; out->act_dim[j] = R.act_dim[j];
+        out->next_obs_off[j] = R.nobs_off[j];
+    }
+    out->rew_off = R.rew_off;
+    out->done_off = R.done_off;
+    out->extra_off = R.extra_off;
+    out->extra = R.extra;
+    return FRL_OK;
+}
+
+static int flush_stage(frl_engine* e) {
+    if (e->stage_n == 0) return FRL_OK;
+    const RecordDesc& R = e->h.rec;
+    const int n = e->stage_n;
+    HIP_TRY(hipMemcpyAsync(e->d_stage_rows, e->stage_rows, (size_t)n * R.width * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_stage_slots, e->stage_slots, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+    const int per_row = (R.width + 3) / 4;
+    const long long total = (long long)n * per_row;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(replay_scatter_kernel, dim3(blocks), dim3(256), 0, e->stream, e->h.replay, e->d_stage_rows,
+                       e->d_stage_slots, n, R.width, R.stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_stage, e->stream));
+    e->stage_inflight = true;
+    e->stage_n = 0;
+    std::fill(e->staged_per_learner.begin(), e->staged_per_learner.end(), 0);
+    return FRL_OK;
+}
+
+static int stage_one(frl_engine* e, int learner, const float* record) {
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner %d out of range", learner);
+    // one scatter launch writes its rows in no particular order: never stage the same ring row twice
+    if (e->stage_n == e->stage_cap || e->staged_per_learner[learner] >= e->h.capacity) { int rc = flush_stage(e); if (rc) return rc; }
+    if (e->stage_inflight) {     // the pinned area may still be read by the previous flush's copy
+        HIP_TRY(hipEventSynchronize(e->ev_stage));
+        e->stage_inflight = false;
+    }
+    const RecordDesc& R = e->h.rec;
+    memcpy(e->stage_rows + (size_t)e->stage_n * R.width, record, (size_t)R.width * sizeof(float));
+    int& ix = e->index[learner];
+    e->stage_slots[e->stage_n] = (long long)learner * e->h.capacity + ix;
+    e->stage_n++;
+    e->staged_per_learner[learner]++;
+    ix = (ix + 1) % e->h.capacity;                        // Buffer.py:36
+    if (e->size[learner] < e->h.capacity) e->size[learner]++;   // Buffer.py:37-38
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_add(frl_engine* e, int learner, const float* record) {
+    ENG(e);
+    if (!record) return fail(FRL_ERR_INVALID, "record is NULL");
+    return stage_one(e, learner, record);
+}
+
+extern "C" int frl_buffer_add_batch(frl_engine* e, int n, const int* learners, const float* records) {
+    ENG(e);
+    if (n < 0 || (n > 0 && !records)) return fail(FRL_ERR_INVALID, "bad batch");
+    const int w = e->h.rec.width;
+    for (int i = 0; i < n; ++i) {
+        int rc = stage_one(e, learners ? learners[i] : 0, records + (size_t)i * w);
+        if (rc) return rc;
+    }
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_flush(frl_engine* e) {
+    ENG(e);
+    return flush_stage(e);
+}
+
+extern "C" int frl_buffer_cursor_get(const frl_engine* e, int learner, int* index_out, int* size_out) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
+    if (index_out) *index_out = e->index[learner];
+    if (size_out) *size_out = e->size[learner];
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_cursor_set(frl_engine* e, int learner, int index, int size) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
+    if (index < 0 || index >= e->h.capacity || size < 0 || size > e->h.capacity)
+        return fail(FRL_ERR_INVALID, "cursor (%d,%d) outside capacity %d", index, size, e->h.capacity);
+    e->index[learner] = index;
+    e->size[learner] = size;
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_sample(frl_engine* e, int learner, const int64_t* idx, int batch, int n_fields,
+                                 const int* col0, const int* ncols, float* const* out_device) {
+    ENG(e);
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
+    if (batch < 0 || batch > e->h.batch_max * 16) return fail(FRL_ERR_INVALID, "batch %d exceeds 16*batch_max", batch);
+    if (n_fields < 1 || n_fields > 8 || !idx || !col0 || !ncols || !out_device) return fail(FRL_ERR_INVALID, "bad field list");
+    if (batch == 0) return FRL_OK;
+    const RecordDesc& R = e->h.rec;
+    GatherFields F;
+    memset(&F, 0, sizeof F);
+    F.n_fields = n_fields;
+    for (int f = 0; f < n_fields; ++f) {
+        if (col0[f] < 0 || ncols[f] < 1 || col0[f] + ncols[f] > R.width) return fail(FRL_ERR_INVALID, "field %d outside the record", f);
+        F.col0[f] = col0[f]; F.ncols[f] = ncols[f]; F.out[f] = out_device[f];
+    }
+    for (int i = 0; i < batch; ++i)     // NumPy fancy indexing semantics: negative wraps, out of range raises
+        if (idx[i] < -(int64_t)e->h.capacity || idx[i] >= e->h.capacity) return fail(FRL_ERR_INVALID, "index %lld out of range", (long long)idx[i]);
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));            // h_idx64 reuse
+    for (int i = 0; i < batch; ++i) e->h_idx64[i] = idx[i] < 0 ? idx[i] + e->h.capacity : idx[i];
+    HIP_TRY(hipMemcpyAsync(e->d_idx64, e->h_idx64, (size_t)batch * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+    const float* ring = e->h.replay + (size_t)learner * e->h.capacity * R.stride;
+    const int threads = 256, groups_per_block = threads / 16;
+    hipLaunchKernelGGL(replay_gather_kernel, dim3((batch + groups_per_block - 1) / groups_per_block), dim3(threads), 0,
+                       e->stream, ring, e->d_idx64, batch, R.stride, F);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));            // outputs are consumed on the caller's stream
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_read(frl_engine* e, int learner, int row0, int n, float* out_host) {
+    ENG(e);
+    if (learner < 0 || learner >= e->h.P || row0 < 0 || n < 0 || row0 + n > e->h.capacity || !out_host)
+        return fail(FRL_ERR_INVALID, "bad read range");
+    if (n == 0) return FRL_OK;
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    const RecordDesc& R = e->h.rec;
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)n * R.width * sizeof(float)));
+    const long long total = (long long)n * R.width;
+    hipLaunchKernelGGL(replay_read_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream,
+                       e->h.replay, (long long)learner * e->h.capacity + row0, n, R.width, R.stride, tmp);
+    hipError_t err = hipMemcpyAsync(out_host, tmp, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    hipFree(tmp);
+    if (err != hipSuccess) return fail(FRL_ERR_HIP, "frl_buffer_read: %s", hipGetErrorString(err));
+    return FRL_OK;
+}
+
+extern "C" int frl_buffer_fill_synthetic(frl_engine* e, int rows, uint64_t seed) {
+    ENG(e);
+    if (rows < 0 || rows > e->h.capacity) return fail(FRL_ERR_INVALID, "rows out of range");
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    const RecordDesc& R = e->h.rec;
+    for (int p = 0; p < e->h.P; ++p) {
+        float* ring = e->h.replay + (size_t)p * e->h.capacity * R.stride;
+        hipLaunchKernelGGL(replay_fill_kernel, dim3(std::min((rows + 255) / 256, 2048)), dim3(256), 0, e->stream, ring,
+                           (long long)rows, R, e->h.n_discrete, seed + 0x632BE59BD9B4E019ull * (p + 1));
+        e->index[p] = rows % e->h.capacity;
+        e->size[p] = rows;
+    }
+    HIP_TRY(hipGetLastError());
+    return FRL_OK;
+}
+
+// ------------------------------------------------------------------------------- parameters
+extern "C" int frl_net_count(const frl_engine* e, int* n_out) {
+    if (!e || !n_out) return fail(FRL_ERR_INVALID, "NULL argument");
+    *n_out = e->h.n_nets;
+    return FRL_OK;
+}
+
+extern "C" int frl_net_num_params(const frl_engine* e, int net, int* n_out) {
+    if (!e || !n_out) return fail(FRL_ERR_INVALID, "NULL argument");
+    if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
+    *n_out = e->h.net[net].n_params;
+    return FRL_OK;
+}
+
+static float* kind_ptr(frl_engine* e, int kind) {
+    switch (kind) {
+        case FRL_PARAM_ONLINE: return e->h.theta;
+        case FRL_PARAM_TARGET: return e->h.target;
+        case FRL_PARAM_ADAM_M: return e->h.m;
+        case FRL_PARAM_ADAM_V: return e->h.v;
+        case FRL_PARAM_GRAD: return e->h.grad;
+    }
+    return nullptr;
+}
+
+static int params_xfer(frl_engine* e, int learner, int net, int kind, float* host, bool to_device) {
+    ENG(e);
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
+    if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
+    float* base = kind_ptr(e, kind);
+    if (!base || !host) return fail(FRL_ERR_INVALID, "bad kind / NULL buffer");
+    const NetDesc& N = e->h.net[net];
+    float* dev = base + (size_t)learner * e->h.learner_stride + e->h.net_off[net];
+    std::vector<float> blk(N.size, 0.f);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!to_device) HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (int i = 0; i < N.n_layers; ++i) {
+        const LayerDesc& L = N.L[i];
+        for (int r = 0; r < L.n; ++r)
+            for (int c = 0; c < L.k; ++c) {
+                float& d = blk[L.w_off + (size_t)r * L.k_pad + c];
+                if (to_device) d = host[o]; else host[o] = d;
+                ++o;
+            }
+        for (int r = 0; r < L.n; ++r) {
+            float& d = blk[L.b_off + r];
+            if (to_device) d = host[o]; else host[o] = d;
+            ++o;
+        }
+    }
+    for (int j = 0; j < N.extra_n; ++j) {
+        float& d = blk[N.extra_off + j];
+        if (to_device) d = host[o]; else host[o] = d;
+        ++o;
+    }
+    if (to_device) HIP_TRY(hipMemcpy(dev, blk.data(), (size_t)N.size * sizeof(float), hipMemcpyHostToDevice));
+    return FRL_OK;
+}
+
+extern "C" int frl_params_get(frl_engine* e, int learner, int net, int kind, float* out_host) {
+    return params_xfer(e, learner, net, kind, out_host, false);
+}
+extern "C" int frl_params_set(frl_engine* e, int learner, int net, int kind, const float* in_host) {
+    return params_xfer(e, learner, net, kind, const_cast<float*>(in_host), true);
+}
+
+extern "C" int frl_opt_step_get(frl_engine* e, int learner, int net, int* t_out) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || net < 0 || net > kMaxNets || !t_out) return fail(FRL_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(t_out, e->h.steps + (size_t)learner * (kMaxNets + 1) + net, sizeof(int), hipMemcpyDeviceToHost));
+    return FRL_OK;
+}
+extern "C" int frl_opt_step_set(frl_engine* e, int learner, int net, int t) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || net < 0 || net > kMaxNets) return fail(FRL_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->h.steps + (size_t)learner * (kMaxNets + 1) + net, &t, sizeof(int), hipMemcpyHostToDevice));
+    return FRL_OK;
+}
+
+extern "C" int frl_alpha_get(frl_engine* e, int learner, float* vals4_out, int* step_out) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || !vals4_out) return fail(FRL_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(vals4_out, e->h.alpha + (size_t)learner * 4, 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (step_out) return frl_opt_step_get(e, learner, kMaxNets, step_out);
+    return FRL_OK;
+}
+extern "C" int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int step) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || !vals4) return fail(FRL_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->h.alpha + (size_t)learner * 4, vals4, 4 * sizeof(float), hipMemcpyHostToDevice));
+    return frl_opt_step_set(e, learner, kMaxNets, step);
+}
+
+// -------------------------------------------------------------------------------------- act
+static int launch_act(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim,
+                      const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev) {
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
+    const NetDesc& N = e->h.net[net];
+    if (head < 0 || head >= N.heads) return fail(FRL_ERR_INVALID, "head out of range");
+    const int nl = N.n_layers / N.heads;
+    if (in_dim != N.L[head * nl].k) return fail(FRL_ERR_INVALID, "in_dim %d != layer input %d", in_dim, N.L[head * nl].k);
+    if ((mode == FRL_ACT_SAC_SAMPLE || mode == FRL_ACT_PPO_SAMPLE) && N.extra_n == 0) return fail(FRL_ERR_INVALID, "net has no log_std");
+    if (n_rows < 1) return fail(FRL_ERR_INVALID, "n_rows must be >= 1");
+    ActArgs a;
+    a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
+    a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
+    dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
+    hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
+    HIP_TRY(hipGetLastError());
+    return FRL_OK;
+}
+
+extern "C" int frl_act_device(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim,
+                              const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev) {
+    ENG(e);
+    if (!in_dev || !out_dev) return fail(FRL_ERR_INVALID, "NULL device buffer");
+    return launch_act(e, net, mode, head, use_target, n_rows, in_dim, in_dev, eps_dev, out_dev, logp_dev);
+}
+
+extern "C" int frl_act(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim,
+                       const float* in_host, const float* eps_host, float* out_host, float* logp_host) {
+    ENG(e);
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
+    if (!in_host || !out_host || n_rows < 1) return fail(FRL_ERR_INVALID, "bad argument");
+    const NetDesc& N = e->h.net[net];
+    const int nl = N.n_layers / N.heads;
+    if (head < 0 || head >= N.heads) return fail(FRL_ERR_INVALID, "head out of range");
+    const int nout = N.L[head * nl + nl - 1].n;
+    const size_t rows = (size_t)e->h.P * n_rows;
+    const size_t in_n = rows * in_dim, out_n = rows * nout;
+    if (in_n > e->act_in_cap) {
+        if (e->d_act_in) hipFree(e->d_act_in);
+        e->d_act_in = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->d_act_in, in_n * sizeof(float)));
+        e->act_in_cap = in_n;
+    }
+    if (out_n > e->act_out_cap) {
+        for (float** p : {&e->d_act_eps, &e->d_act_out, &e->d_act_logp}) { if (*p) hipFree(*p); *p = nullptr; }
+        HIP_TRY(hipMalloc((void**)&e->d_act_eps, out_n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->d_act_out, out_n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->d_act_logp, out_n * sizeof(float)));
+        e->act_out_cap = out_n;
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_act_in, in_host, in_n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (eps_host) HIP_TRY(hipMemcpyAsync(e->d_act_eps, eps_host, out_n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = launch_act(e, net, mode, head, use_target, n_rows, in_dim, e->d_act_in, eps_host ? e->d_act_eps : nullptr,
+                        e->d_act_out, logp_host ? e->d_act_logp : nullptr);
+    if (rc) return rc;
+    const size_t got = (mode == FRL_ACT_ARGMAX) ? rows : out_n;
+    HIP_TRY(hipMemcpyAsync(out_host, e->d_act_out, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (logp_host) HIP_TRY(hipMemcpyAsync(logp_host, e->d_act_logp, out_n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FRL_OK;
+}
+
+// ------------------------------------------------------------------------------------ learn
+static int upload_idx_noise(frl_engine* e, const int64_t* idx, const float* noise, int batch, int n_sets_per_learner) {
+    const EngineDesc& h = e->h;
+    if (idx || noise) HIP_TRY(hipStreamSynchronize(e->stream));    // pinned scratch reuse
+    if (idx) {
+        for (int p = 0; p < h.P; ++p)
+            for (int a = 0; a < n_sets_per_learner; ++a) {
+                const int64_t* src = idx + ((size_t)p * n_sets_per_learner + a) * batch;
+                int* dst = e->h_idx + ((size_t)p * h.n_agents + a) * h.batch_max;
+                const int sz = e->size[p];
+                for (int i = 0; i < batch; ++i) {
+                    int64_t v = src[i];
+                    if (v < 0) v += h.capacity;
+                    if (v < 0 || v >= h.capacity) return fail(FRL_ERR_INVALID, "sample index %lld out of range", (long long)src[i]);
+                    (void)sz;
+                    dst[i] = (int)v;
+                }
+            }
+        HIP_TRY(hipMemcpyAsync(h.idx, e->h_idx, e->idx_count * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    if (noise) {
+        // host [P][n_agents][2][batch][act_max] -> device [P][n_agents][2][batch_max][act_max]
+        const int am = h.act_max;
+        for (size_t s = 0; s < (size_t)h.P * h.n_agents * 2; ++s)
+            memcpy(e->h_noise + s * h.batch_max * am, noise + s * batch * am, (size_t)batch * am * sizeof(float));
+        HIP_TRY(hipMemcpyAsync(h.noise, e->h_noise, e->noise_count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    }
+    return FRL_OK;
+}
+
+extern "C" int frl_stats_get(frl_engine* e, float* out_host) {
+    ENG(e);
+    if (!e->has_nets || !out_host) return fail(FRL_ERR_INVALID, "bad argument");
+    HIP_TRY(hipMemcpyAsync(out_host, e->h.stats, (size_t)e->h.P * e->h.n_agents * ST_COUNT * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FRL_OK;
+}
+
+extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
+    ENG(e);
+    if (!args) return fail(FRL_ERR_INVALID, "args is NULL");
+    const EngineDesc& h = e->h;
+    if (!(h.algo == ALGO_DQN || h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC || h.algo == ALGO_MADDPG))
+        return fail(FRL_ERR_STATE, "frl_learn: engine algo %d has no off-policy learn (PPO: frl_ppo_learn)", h.algo);
+    if (args->batch < 1 || args->batch > h.batch_max) return fail(FRL_ERR_INVALID, "batch %d outside [1,%d]", args->batch, h.batch_max);
+    int min_size = h.capacity;
+    for (int p = 0; p < h.P; ++p) min_size = std::min(min_size, e->size[p]);
+    if (min_size < args->batch) return fail(FRL_ERR_STATE, "a ring holds %d rows < batch %d", min_size, args->batch);
+    const bool dev_rng = (args->idx == nullptr);
+    if (dev_rng && min_size < 2 * args->batch)
+        return fail(FRL_ERR_STATE, "device index draw needs len(buffer) >= 2*batch (have %d); pass idx", min_size);
+    const bool needs_noise = (h.algo == ALGO_SAC) || (h.algo == ALGO_TD3 && args->use_policy_noise);
+    if (!dev_rng && needs_noise && !args->noise) return fail(FRL_ERR_INVALID, "idx given without noise: both or neither");
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    rc = upload_idx_noise(e, args->idx, needs_noise ? args->noise : nullptr, args->batch, h.n_agents);
+    if (rc) return rc;
+    LearnArgs a;
+    memset(&a, 0, sizeof a);
+    a.batch = args->batch;
+    a.size = min_size;
+    a.device_rng = dev_rng ? 1 : 0;
+    a.do_actor = (h.algo == ALGO_TD3) ? (args->do_actor ? 1 : 0) : 1;
+    a.gamma = args->gamma; a.tau = args->tau;
+    a.actor_lr = args->actor_lr; a.critic_lr = args->critic_lr; a.alpha_lr = args->alpha_lr;
+    a.adam_eps = args->adam_eps > 0 ? args->adam_eps : 1e-8f;
+    a.beta1 = 0.9f; a.beta2 = 0.999f;
+    a.critic_wd = args->critic_weight_decay;
+    a.clip_norm = args->clip_norm;
+    a.policy_noise = args->policy_noise; a.noise_clip = args->noise_clip;
+    a.max_action = args->max_action != 0.f ? args->max_action : 1.f;
+    a.policy_noise_scale = args->policy_noise_scale;
+    a.use_policy_noise = (h.algo == ALGO_TD3 && args->use_policy_noise) ? 1 : 0;
+    a.target_entropy = args->target_entropy;
+    a.rng_counter = e->rng_counter++;
+    if (h.algo == ALGO_DQN) {
+        hipLaunchKernelGGL(dqn_update_kernel, dim3(h.P), dim3(256), e->lds_bytes, e->stream, e->d, a);
+    } else {
+        hipLaunchKernelGGL(ac_update_kernel, dim3(h.P * h.n_agents), dim3(256), e->lds_bytes, e->stream, e->d, a);
+        if (h.algo == ALGO_MADDPG)
+            hipLaunchKernelGGL(soft_update_kernel, dim3(h.P * h.n_nets), dim3(256), 0, e->stream, e->d, a.tau);
+    }
+    HIP_TRY(hipGetLastError());
+    if (args->stats_out) return frl_stats_get(e, args->stats_out);
+    return FRL_OK;
+}
+
+// Algorithmic work of one launch (DESIGN.md "Roofline"): flops = 2*B*sum(in*out) per forward
+// pass, x2 more per backward pass that needs both dX and dW, x1 for dX-only passes; bytes =
+// gathered records + 24 B per trained parameter (theta, m, v read+write) + 8 B per
+// soft-updated target parameter.
+extern "C" int frl_learn_work(const frl_engine* e, int batch, int do_actor, double* flops_out, double* bytes_out) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    const EngineDesc& h = e->h;
+    auto macs = [](const NetDesc& N, int l0, int nl) { double s = 0; for (int i = l0; i < l0 + nl; ++i) s += (double)N.L[i].n * N.L[i].k; return s; };
+    double fl = 0, by = 0;
+    const double B = batch;
+    const RecordDesc& R = h.rec;
+    if (h.algo == ALGO_DQN) {
+        const NetDesc& N = h.net[0];
+        const double m = macs(N, 0, N.n_layers);
+        fl = 2 * B * m * (1 + 1 + 2);                  // target fwd, online fwd, bwd (dX+dW)
+        by = 4 * B * (2 * R.obs_total + R.act_total + 2) + 24.0 * N.n_params + 8.0 * N.n_params;
+    } else if (h.algo == ALGO_PPO) {
+        fl = 0; by = 0;
+    } else {
+        const int n = h.n_agents;
+        for (int ag = 0; ag < n; ++ag) {
+            const NetDesc& NC = h.net[2 * ag + 1];
+            const NetDesc& NA = h.net[2 * ag];
+            const int ql = NC.n_layers / NC.heads;
+            double f = 0;
+            for (int j = 0; j < n; ++j) f += macs(h.net[2 * j], 0, h.net[2 * j].n_layers);   // target actors fwd
+            f += macs(NC, 0, NC.n_layers);                      // target critic heads fwd
+            f += 3 * macs(NC, 0, NC.n_layers);                  // critic fwd + bwd
+            double bytes = 4 * B * n * (2.0 * R.obs_total / n + R.act_total / (double)n + 2) + 24.0 * NC.n_params;
+            if (do_actor) {
+                const int nq = (h.algo == ALGO_SAC) ? NC.heads : 1;
+                f += macs(NA, 0, NA.n_layers) * 3;              // actor fwd + bwd
+                f += nq * 2 * macs(NC, 0, ql);                  // Q(s, pi(s)) fwd + dX-only bwd
+                bytes += 24.0 * NA.n_params + 8.0 * (NA.n_params + NC.n_params);
+            }
+            fl += 2 * B * f;
+            by += bytes;
+        }
+    }
+    if (flops_out) *flops_out = fl * h.P;
+    if (bytes_out) *bytes_out = by * h.P;
+    return FRL_OK;
+}
+
+// ----------------------------------------------------------------------------------- timing
+extern "C" int frl_timer_start(frl_engine* e) {
+    ENG(e);
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    return FRL_OK;
+}
+extern "C" int frl_timer_stop(frl_engine* e, float* ms_out) {
+    ENG(e);
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (ms_out) *ms_out = ms;
+    return FRL_OK;
+}
+
+#include "frl_api_ppo.inc"

@@ -1,0 +1,99 @@
+// Descriptors shared by host code and kernels (plain structs; no device code here).
+#pragma once
+#include <stdint.h>
+
+namespace frl {
+
+constexpr int kMaxLayers = 6;     // twin critic = 2 x 3 layers in ONE net (one optimiser, one clip norm)
+constexpr int kMaxAgents = 8;
+constexpr int kMaxNets = 2 * kMaxAgents;
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum Algo : int { ALGO_DQN = 0, ALGO_DDPG = 1, ALGO_TD3 = 2, ALGO_SAC = 3, ALGO_MADDPG = 4, ALGO_PPO = 5 };
+
+// One nn.Linear in the engine-internal layout: W[n_pad][k_pad] row-major, zero padded, then b[n_pad].
+struct LayerDesc {
+    int n, k;            // logical out / in features
+    int n_pad, k_pad;    // padded to multiples of 16
+    int w_off, b_off;    // float offsets inside the net's parameter block
+};
+
+// A net = the unit one optimiser (and one clip_grad_norm_) covers.
+struct NetDesc {
+    int n_layers;
+    int size;            // floats per learner (multiple of 32)
+    int n_params;        // logical parameter count (unpadded), for the algorithmic-bytes figure
+    int hidden_act;      // Act after every layer but the head(s)
+    int out_act;         // Act after the head
+    int extra_off;       // state-independent log_std [extra_n] (Gaussian actors), else -1
+    int extra_n;
+    int heads;           // 1, or 2 for a twin critic (layers [0,n_layers/2) and [n_layers/2,n_layers))
+    LayerDesc L[kMaxLayers];
+};
+
+// Replay record (one transition of ALL agents, 128-byte aligned stride):
+//   [ obs_0..obs_{n-1} | act_0..act_{n-1} | rew_0..rew_{n-1} | done_0..done_{n-1} | next_obs_0.. | extra ]
+struct RecordDesc {
+    int n_agents;
+    int stride;          // floats, multiple of 32 (128 B)
+    int width;           // floats actually used
+    int obs_total, act_total, extra;
+    int obs_off[kMaxAgents], obs_dim[kMaxAgents];
+    int act_off[kMaxAgents], act_dim[kMaxAgents];    // act_dim = A' (1 for discrete)
+    int rew_off, done_off;
+    int nobs_off[kMaxAgents];
+    int extra_off;
+};
+
+// Per-learner statistics slots written by the update kernels.
+enum Stat : int {
+    ST_CRITIC_LOSS = 0, ST_ACTOR_LOSS = 1, ST_ALPHA_LOSS = 2, ST_ALPHA = 3, ST_CRITIC_GNORM = 4,
+    ST_ACTOR_GNORM = 5, ST_ENTROPY = 6, ST_COUNT = 8
+};
+
+struct EngineDesc {
+    int algo, P, n_agents, hidden, rc;       // rc = batch rows per LDS chunk (multiple of 16)
+    int capacity;                            // ring rows per learner
+    int batch_max;
+    int n_nets;
+    int learner_stride;                      // floats per learner in theta/target/m/v/grad
+    int net_off[kMaxNets];
+    NetDesc net[kMaxNets];                   // MADDPG: net 2i = actor_i, 2i+1 = critic_i; else 0 actor/Q, 1 critic
+    RecordDesc rec;
+    // device pointers
+    float* theta;
+    float* target;
+    float* m;
+    float* v;
+    float* grad;
+    float* replay;        // [P][capacity][rec.stride]
+    int* idx;             // [P][n_agents][batch_max] sampled row indices
+    float* noise;         // [P][2][batch_max][act_max] standard-normal draws (TD3 policy noise, SAC eps', eps)
+    float* stats;         // [P][n_agents][ST_COUNT]
+    int* steps;           // [P][kMaxNets + 1] Adam step counters (+1: SAC alpha)
+    float* alpha;         // [P][4]: log_alpha, m, v, alpha (SAC)
+    unsigned long long seed;
+    int act_max;          // max act_dim over agents (row pitch of `noise`)
+    // LDS carve parameters (must match between host lds_bytes() and device carve_lds())
+    int lds_kin_pad, lds_out_pad, lds_batch_pad, lds_act_pad;
+    int n_discrete;       // DQN: number of discrete actions (0 otherwise)
+};
+
+// Hyper-parameters of one learn() call (passed by value to the kernels).
+struct LearnArgs {
+    int batch;
+    int size;             // rows currently valid in every ring (for device-side index draws)
+    int device_rng;       // 1: draw indices / noise on the device (Philox); 0: use desc.idx / desc.noise as uploaded
+    int do_actor;         // TD3: total_it % policy_freq == 0; others 1
+    float gamma, tau;
+    float actor_lr, critic_lr, alpha_lr;
+    float adam_eps, beta1, beta2;
+    float critic_wd;      // DDPG.py supplement weight_decay (L2-in-grad), 0 otherwise
+    float clip_norm;      // 0.5, or <= 0 for no clipping (DQN)
+    float policy_noise, noise_clip, max_action, policy_noise_scale;   // TD3
+    int use_policy_noise;
+    float target_entropy; // SAC
+    unsigned long long rng_counter;   // device_rng: Philox counter of this call (host increments)
+};
+
+}  // namespace frl

@@ -1,0 +1,86 @@
+// Batched policy / value forward: select_action, evaluate_action and the PPO value pass.
+// DQN.py:70-84 (argmax), TD3.py:163-170 (tanh actor), SAC.py:192-204 (tanh-Gaussian sample /
+// tanh(mean)), PPO_with_tricks.py:234-270 (Gaussian sample + per-dimension log-prob / mean).
+// grid = (row chunks, learners); rows may be one observation (the reference's per-step call)
+// or a whole vectorised-env batch staged by the env pool.
+#include <hip/hip_runtime.h>
+
+#include "device/net.hpp"
+
+namespace frl {
+
+enum ActMode : int {
+    ACTM_RAW = 0,        // head output as is (Q values, V(s), Gaussian mean before squashing)
+    ACTM_ARGMAX = 1,     // DQN greedy action (index as float)
+    ACTM_TANH = 2,       // tanh(head): deterministic actors, SAC/PPO evaluate_action
+    ACTM_SAC_SAMPLE = 3, // tanh(mean + std*eps)
+    ACTM_PPO_SAMPLE = 4  // a = tanh(head) + std*eps ; logp per dimension
+};
+
+struct ActArgs {
+    int net;             // net index
+    int use_target;
+    int mode;
+    int n_rows;          // rows per learner
+    int head;            // critic head (0/1) for ACTM_RAW on twin critics
+    int in_dim;          // logical input width (obs dim, or obs+act for critics)
+    const float* in;     // [P][n_rows][in_dim] dense
+    const float* eps;    // [P][n_rows][out_dim] standard normal draws, or nullptr
+    float* out;          // [P][n_rows][out_dim]   (ARGMAX: out_dim = 1)
+    float* out_logp;     // [P][n_rows][out_dim] (PPO sample) or nullptr
+};
+
+__global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.y, r0 = blockIdx.x * D.rc;
+    const NetDesc& N = D.net[a.net];
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const int rc = D.rc, nv = min(rc, a.n_rows - r0);
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
+    const float* theta = (a.use_target ? D.target : D.theta) + off;
+    const int nl = N.n_layers / N.heads, l0 = a.head * nl;
+    const int K = a.in_dim, kpad = N.L[l0].k_pad;
+    const float* in = a.in + ((size_t)p * a.n_rows + r0) * K;
+    for (int e = threadIdx.x; e < rc * kpad; e += kWG) {
+        const int r = e / kpad, c = e - r * kpad;
+        S.xin[r * S.xp + c] = (r < nv && c < K) ? in[(size_t)r * K + c] : 0.f;
+    }
+    __syncthreads();
+    const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;
+    mlp_fwd(N, l0, nl, theta, S, out_act);
+    const int nout = N.L[l0 + nl - 1].n;
+    if (a.mode == ACTM_ARGMAX) {
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            int best = 0;
+            float mx = S.outb[r * S.op];
+            for (int j = 1; j < nout; ++j) {       // first maximum wins, like torch.argmax
+                const float v = S.outb[r * S.op + j];
+                if (v > mx) { mx = v; best = j; }
+            }
+            a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < nv * nout; e += kWG) {
+        const int r = e / nout, c = e - r * nout;
+        const size_t o = ((size_t)p * a.n_rows + r0 + r) * nout + c;
+        float v = S.outb[r * S.op + c];
+        if (a.mode == ACTM_SAC_SAMPLE || a.mode == ACTM_PPO_SAMPLE) {
+            const float ls = fminf(fmaxf(theta[N.extra_off + c], -20.f), 2.f);
+            const float sd = expf(ls);
+            const float eps = a.eps ? a.eps[o] : 0.f;
+            const float u = v + sd * eps;
+            if (a.mode == ACTM_SAC_SAMPLE) {
+                v = tanhf(u);
+            } else {
+                const float du = u - v;
+                if (a.out_logp) a.out_logp[o] = -(du * du) / (2.f * sd * sd) - ls - 0.91893853320467274178f;
+                v = u;
+            }
+        }
+        a.out[o] = v;
+    }
+}
+
+}  // namespace frl

@@ -1,0 +1,286 @@
+// PPO on-policy update: value pass -> wave-scan GAE (+ advantage normalisation) -> ONE persistent
+// launch running all K_epochs x (horizon / minibatch) clipped-surrogate actor and MSE critic
+// steps of a learner (PPO_file/PPO_with_tricks.py:290-354).  The reference does the GAE
+// recurrence as a sequential host loop (:308-311) after a device->host copy and launches a few
+// hundred tiny kernels per minibatch; here the rollout never leaves HBM.
+#include <hip/hip_runtime.h>
+
+#include "device/net.hpp"
+
+namespace frl {
+
+struct PpoArgs {
+    int horizon, minibatch, k_epochs, adv_norm;
+    float gamma, lmbda, clip, ent_coef;
+    float actor_lr, critic_lr, adam_eps, beta1, beta2, clip_norm;
+    // device scratch, per learner blocks of `horizon` floats
+    float* td;        // [P][T] td_delta, then (after GAE) unused
+    float* vs;        // [P][T] V(s)
+    float* adv_raw;   // [P][T] GAE advantages before normalisation
+    float* adv;       // [P][T] advantages used by the surrogate
+    float* vtarget;   // [P][T]
+    float* trace;     // [P][k_epochs * n_mb][2] per-minibatch (actor, critic) losses
+    const int* perm;  // [P][k_epochs][T]
+};
+
+// ---- td_delta = r + gamma*(1-done)*V(s') - V(s) for every stored row (PPO_with_tricks.py:304-306)
+__global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.y, r0 = blockIdx.x * D.rc, rc = D.rc, T = a.horizon;
+    const int nv = min(rc, T - r0);
+    const NetDesc& N = D.net[1];
+    const RecordDesc& R = D.rec;
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const float* theta = D.theta + (size_t)p * D.learner_stride + D.net_off[1];
+    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    const int O = R.obs_dim[0], kpad = N.L[0].k_pad;
+    float v0 = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int src = pass == 0 ? R.obs_off[0] : R.nobs_off[0];
+        for (int e = threadIdx.x; e < rc * kpad; e += kWG) {
+            const int r = e / kpad, c = e - r * kpad;
+            S.xin[r * S.xp + c] = (r < nv && c < O) ? ring[(size_t)(r0 + r) * R.stride + src + c] : 0.f;
+        }
+        __syncthreads();
+        mlp_fwd(N, 0, N.n_layers, theta, S, ACT_NONE);
+        if (threadIdx.x < nv) {
+            const float v = S.outb[threadIdx.x * S.op];
+            if (pass == 0) {
+                v0 = v;
+            } else {
+                const float* rec = ring + (size_t)(r0 + threadIdx.x) * R.stride;
+                const size_t o = (size_t)p * T + r0 + threadIdx.x;
+                a.vs[o] = v0;
+                a.td[o] = rec[R.rew_off] + a.gamma * (1.f - rec[R.done_off]) * v - v0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- GAE: A_t = delta_t + gamma*lambda*(1-adv_done_t)*A_{t+1}, reverse scan over the horizon.
+// Affine maps m_t(x) = delta_t + g_t*x compose associatively; each thread folds a contiguous
+// segment, a wave-shuffle suffix scan + 4 wave totals in LDS give every segment its incoming
+// value, and the segment is replayed.  One workgroup per sequence.
+struct Affine { float a, b; };
+__device__ __forceinline__ Affine compose(Affine f, Affine g) { return Affine{f.a * g.a, f.a * g.b + f.b}; }   // f(g(x))
+
+__device__ __forceinline__ void gae_scan(const float* __restrict__ delta, const float* __restrict__ ring, int stride,
+                                         int adv_done_col, int T, float c, float* __restrict__ adv, float* lds) {
+    const int t = threadIdx.x, L = (T + kWG - 1) / kWG;
+    const int s0 = min(t * L, T), s1 = min(s0 + L, T);
+    Affine f{1.f, 0.f};
+    for (int i = s1 - 1; i >= s0; --i) {
+        const float g = c * (1.f - ring[(size_t)i * stride + adv_done_col]);
+        f = Affine{g * f.a, delta[i] + g * f.b};
+    }
+    // inclusive suffix scan inside the wave
+    const int lane = t & 63, w = t >> 6;
+    Affine s = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Affine o{__shfl_down(s.a, off, 64), __shfl_down(s.b, off, 64)};
+        if (lane + off < 64) s = compose(s, o);
+    }
+    if (lane == 0) { lds[2 * w] = s.a; lds[2 * w + 1] = s.b; }
+    __syncthreads();
+    float right = 0.f;                                    // A just right of this wave's last segment
+    for (int ww = kWaves - 1; ww > w; --ww) right = lds[2 * ww] * right + lds[2 * ww + 1];
+    const float mine = s.a * right + s.b;                 // A at the start of my segment
+    float x = __shfl_down(mine, 1, 64);                   // A at the start of the next segment
+    if (lane == 63) x = right;
+    for (int i = s1 - 1; i >= s0; --i) {
+        const float g = c * (1.f - ring[(size_t)i * stride + adv_done_col]);
+        x = delta[i] + g * x;
+        adv[i] = x;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void ppo_gae_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
+    __shared__ float lds[16];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.x, T = a.horizon;
+    const RecordDesc& R = D.rec;
+    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    float* adv_raw = a.adv_raw + (size_t)p * T;
+    float* adv = a.adv + (size_t)p * T;
+    const float* vs = a.vs + (size_t)p * T;
+    float* vt = a.vtarget + (size_t)p * T;
+    const int adv_done_col = R.extra_off + R.extra - 1;   // last extra column (PPO_file/Buffer.py:282)
+    gae_scan(a.td + (size_t)p * T, ring, R.stride, adv_done_col, T, a.gamma * a.lmbda, adv_raw, lds);
+    // v_target = adv + V(s) (:313); optional (adv - mean)/(std + 1e-8), unbiased std (:314-315)
+    float s1 = 0.f;
+    for (int i = threadIdx.x; i < T; i += kWG) {
+        const float x = adv_raw[i];
+        vt[i] = x + vs[i];
+        s1 += x;
+    }
+    if (!a.adv_norm) {
+        for (int i = threadIdx.x; i < T; i += kWG) adv[i] = adv_raw[i];
+        return;
+    }
+    const float mean = block_sum(s1, lds + 8) / (float)T;
+    float s2 = 0.f;
+    for (int i = threadIdx.x; i < T; i += kWG) {
+        const float d = adv_raw[i] - mean;
+        s2 += d * d;
+    }
+    const float sd = sqrtf(block_sum(s2, lds + 8) / (float)(T - 1));
+    for (int i = threadIdx.x; i < T; i += kWG) adv[i] = (adv_raw[i] - mean) / (sd + 1e-8f);
+}
+
+// stand-alone K3 entry (frl_gae): adv_done given as a dense array
+__global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict__ delta, const float* __restrict__ adv_done,
+                                                         int T, float c, float* __restrict__ adv) {
+    __shared__ float lds[16];
+    const size_t o = (size_t)blockIdx.x * T;
+    gae_scan(delta + o, adv_done + o, 1, 0, T, c, adv + o, lds);
+}
+
+// ---- all minibatch updates of one learner in one launch
+__global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.x, T = a.horizon, mb = a.minibatch, rc = D.rc;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    const RecordDesc& R = D.rec;
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const size_t offA = (size_t)p * D.learner_stride + D.net_off[0], offC = (size_t)p * D.learner_stride + D.net_off[1];
+    float* thA = D.theta + offA;
+    float* thC = D.theta + offC;
+    float* gA = D.grad + offA;
+    float* gC = D.grad + offC;
+    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    const float* adv = a.adv + (size_t)p * T;
+    const float* vt = a.vtarget + (size_t)p * T;
+    const int O = R.obs_dim[0], A = R.act_dim[0], logp_col = R.extra_off;
+    const int napad = NA.L[NA.n_layers - 1].n_pad, ncpad = NC.L[NC.n_layers - 1].n_pad;
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    int tA = steps[0], tC = steps[1];
+    const int n_mb = (T + mb - 1) / mb;
+    float* trace = a.trace + (size_t)p * a.k_epochs * n_mb * 2;
+    constexpr float kHalfLog2PiPlusHalf = 1.41893853320467274178f;   // 0.5 + 0.5*log(2*pi)
+    constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+
+    for (int k = 0; k < a.k_epochs; ++k) {
+        const int* perm = a.perm + ((size_t)p * a.k_epochs + k) * T;
+        for (int s = 0; s < T; s += mb) {
+            const int m = min(mb, T - s);
+            const float invm = 1.f / (float)m;
+            const int* idx = perm + s;
+            // ---------------- actor: clipped surrogate + entropy bonus (:324-346)
+            float lossp = 0.f, gls = 0.f, ent = 0.f;
+            if (threadIdx.x < A) {
+                const float ls = fminf(fmaxf(thA[NA.extra_off + threadIdx.x], -20.f), 2.f);
+                ent = kHalfLog2PiPlusHalf + ls;
+            }
+            const float ent_sum = block_sum(ent, S.red);          // same for every row
+            for (int r0 = 0; r0 < m; r0 += rc) {
+                const int nv = min(rc, m - r0);
+                gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
+                zero_cols(S.xin, S.xp, rc, O, NA.L[0].k_pad);
+                __syncthreads();
+                mlp_fwd(NA, 0, NA.n_layers, thA, S, ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                // per-row ratio and d loss / d sum(logp)
+                if (threadIdx.x < rc) {
+                    const int r = threadIdx.x;
+                    float coef = 0.f;
+                    if (r < nv) {
+                        const float* rec = ring + (size_t)idx[r0 + r] * R.stride;
+                        float lp_now = 0.f, lp_old = 0.f;
+                        for (int c = 0; c < A; ++c) {
+                            const float mean = S.outb[r * S.op + c];
+                            const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
+                            const float sd = expf(ls);
+                            const float d = rec[R.act_off[0] + c] - mean;
+                            lp_now += -(d * d) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                            lp_old += rec[logp_col + c];
+                        }
+                        const float ratio = expf(lp_now - lp_old);
+                        const float Ar = adv[idx[r0 + r]];
+                        const float s1 = ratio * Ar;
+                        const float s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
+                        lossp += -fminf(s1, s2);
+                        coef = (s1 <= s2 ? Ar : 0.f) * (-invm) * ratio;   // d loss / d sum_c logp_now
+                    }
+                    S.dabuf[r * S.ap] = coef;
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < rc * napad; e += kWG) {
+                    const int r = e / napad, c = e - r * napad;
+                    float d = 0.f, dl = 0.f;
+                    if (r < nv && c < A) {
+                        const float coef = S.dabuf[r * S.ap];
+                        const float mean = S.outb[r * S.op + c];
+                        const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
+                        const float var = expf(2.f * ls);
+                        const float dm = ring[(size_t)idx[r0 + r] * R.stride + R.act_off[0] + c] - mean;
+                        d = coef * dm / var * (1.f - mean * mean);        // through mean = tanh(z)
+                        dl = coef * (dm * dm / var - 1.f);
+                    }
+                    S.outb[r * S.op + c] = d;
+                    if (c < A) S.abuf[r * S.ap + c] = dl;
+                }
+                __syncthreads();
+                if (threadIdx.x < A)
+                    for (int r = 0; r < rc; ++r) gls += S.abuf[r * S.ap + threadIdx.x];
+                mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+            }
+            if (threadIdx.x < A) {
+                const float raw = thA[NA.extra_off + threadIdx.x];
+                gA[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? (gls - a.ent_coef) : 0.f;
+            }
+            const float aloss = block_sum(lossp, S.red) * invm - a.ent_coef * ent_sum;
+            __syncthreads();
+            ++tA;
+            adam_net(NA.size, thA, D.m + offA, D.v + offA, gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+                     a.clip_norm, tA, 0.f, S.red);
+            __syncthreads();
+            // ---------------- critic: mse(v_target[idx], V(obs[idx])) (:349-351)
+            float closs_p = 0.f;
+            for (int r0 = 0; r0 < m; r0 += rc) {
+                const int nv = min(rc, m - r0);
+                gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
+                zero_cols(S.xin, S.xp, rc, O, NC.L[0].k_pad);
+                __syncthreads();
+                mlp_fwd(NC, 0, NC.n_layers, thC, S, ACT_NONE);
+                for (int e = threadIdx.x; e < rc * ncpad; e += kWG) {
+                    const int r = e / ncpad, c = e - r * ncpad;
+                    float d = 0.f;
+                    if (c == 0 && r < nv) {
+                        const float diff = S.outb[r * S.op] - vt[idx[r0 + r]];
+                        d = 2.f * diff * invm;
+                        closs_p += diff * diff;
+                    }
+                    S.outb[r * S.op + c] = d;
+                }
+                __syncthreads();
+                mlp_bwd(NC, 0, NC.n_layers, thC, gC, S, r0 == 0, false, 0, 0);
+            }
+            const float closs = block_sum(closs_p, S.red) * invm;
+            __syncthreads();
+            ++tC;
+            adam_net(NC.size, thC, D.m + offC, D.v + offC, gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+                     a.clip_norm, tC, 0.f, S.red);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int j = k * n_mb + s / mb;
+                trace[2 * j] = aloss;
+                trace[2 * j + 1] = closs;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        steps[0] = tA;
+        steps[1] = tC;
+        float* st = D.stats + (size_t)p * D.n_agents * ST_COUNT;
+        const int j = a.k_epochs * n_mb - 1;
+        st[ST_ACTOR_LOSS] = trace[2 * j];
+        st[ST_CRITIC_LOSS] = trace[2 * j + 1];
+    }
+}
+
+}  // namespace frl

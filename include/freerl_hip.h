@@ -1,0 +1,208 @@
+/* freerl_hip.h — C ABI of the MI355X-native replay-sample + batched-update engine.
+ *
+ * FreeRL (the reference) is pure Python and has NO plugin / FFI interface: its
+ * boundary for this path is the duck-typed class surface `Buffer.add / Buffer.sample /
+ * Agent.update_* / <ALGO>.select_action / <ALGO>.learn`.  This header is what a ctypes (or
+ * cffi / pybind) binding on the reference side binds in order to keep that surface and run it
+ * on hand-written HIP kernels; `freerl_amd/` is exactly such a binding and INTEGRATION.md shows
+ * the stub.  Each entry point names the reference interface it replaces (paths relative to
+ * the FreeRL tree).
+ *
+ * Conventions: opaque handle, `int` status (0 = FRL_OK), no exceptions or torch types across
+ * the boundary, plain pointers + sizes, caller-allocated output buffers.  One engine = one HIP
+ * stream; an engine is thread-compatible (one thread at a time).  "host" pointers are ordinary
+ * process memory, "device" pointers are HIP device memory on the engine's GPU.
+ *
+ * An engine holds P independent learners ("population": seeds / env-instance sets on this
+ * GPU); P = 1 is the reference-compatible single learner.  Every call below
+ * that takes [P][...] arrays processes all learners in ONE kernel launch.
+ */
+#ifndef FREERL_HIP_H
+#define FREERL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRL_MAX_AGENTS 8
+#define FRL_STAT_COUNT 8
+
+enum frl_status { FRL_OK = 0, FRL_ERR_INVALID = 1, FRL_ERR_HIP = 2, FRL_ERR_NO_DEVICE = 3, FRL_ERR_STATE = 4 };
+
+enum frl_algo {
+    FRL_ALGO_REPLAY_ONLY = -1, /* stand-alone Buffer.py replacement, no networks */
+    FRL_ALGO_DQN = 0,          /* DQN_file/DQN.py:62-138 */
+    FRL_ALGO_DDPG = 1,         /* DDPG_file/DDPG_simple.py:100-179, DDPG.py */
+    FRL_ALGO_TD3 = 2,          /* TD3_file/TD3.py:150-256 */
+    FRL_ALGO_SAC = 3,          /* SAC_file/SAC.py:171-282 */
+    FRL_ALGO_MADDPG = 4,       /* MADDPG_file/MADDPG_simple.py:107-210 */
+    FRL_ALGO_PPO = 5           /* PPO_file/PPO_with_tricks.py:211-374, PPO.py */
+};
+
+enum frl_activation { FRL_ACT_NONE = 0, FRL_ACT_RELU = 1, FRL_ACT_TANH = 2 };
+
+/* which copy of a net's parameters frl_params_get/set addresses */
+enum frl_param_kind { FRL_PARAM_ONLINE = 0, FRL_PARAM_TARGET = 1, FRL_PARAM_ADAM_M = 2, FRL_PARAM_ADAM_V = 3, FRL_PARAM_GRAD = 4 };
+
+/* frl_act modes */
+enum frl_act_mode {
+    FRL_ACT_RAW = 0,        /* head output: Q values (DQN.py:83), V(s) (PPO_with_tricks.py:304-305), Gaussian mean */
+    FRL_ACT_ARGMAX = 1,     /* DQN.select_action, DQN.py:70-84 */
+    FRL_ACT_TANHHEAD = 2,   /* TD3/DDPG/MADDPG select_action (TD3.py:163-170), SAC/PPO evaluate_action */
+    FRL_ACT_SAC_SAMPLE = 3, /* SAC.select_action, SAC.py:192-198: tanh(mean + std*eps) */
+    FRL_ACT_PPO_SAMPLE = 4  /* PPO.select_action, PPO_with_tricks.py:234-255: a = mean + std*eps, per-dim log-prob */
+};
+
+/* per-(learner, agent) statistics written by frl_learn; index into stats[.][FRL_STAT_COUNT] */
+enum frl_stat {
+    FRL_STAT_CRITIC_LOSS = 0, FRL_STAT_ACTOR_LOSS = 1, FRL_STAT_ALPHA_LOSS = 2, FRL_STAT_ALPHA = 3,
+    FRL_STAT_CRITIC_GNORM = 4, FRL_STAT_ACTOR_GNORM = 5, FRL_STAT_ENTROPY = 6
+};
+
+typedef struct frl_engine frl_engine;
+
+/* Constructor arguments; mirrors `<ALGO>(dim_info, is_continue, lrs, buffer_size, device, ...)`
+ * (DQN.py:63-68, TD3.py:151-161, SAC.py:172-190, MADDPG_simple.py:108-120, PPO_with_tricks.py:212-232). */
+typedef struct frl_config {
+    int algo;                     /* enum frl_algo */
+    int n_learners;               /* P >= 1 */
+    int n_agents;                 /* 1, or the MADDPG agent count (<= FRL_MAX_AGENTS) */
+    int obs_dim[FRL_MAX_AGENTS];
+    int act_dim[FRL_MAX_AGENTS];  /* continuous: action width; discrete (DQN): number of actions */
+    int discrete;                 /* 1: actions are stored as ONE float index (Buffer.py:3-9 act_dim vs action_dim) */
+    int hidden;                   /* 128 = the reference's hard-coded width (DQN.py:38, TD3.py:53 ...) */
+    int hidden_act;               /* FRL_ACT_RELU, or FRL_ACT_TANH for PPO trick['tanh'] */
+    int twin_critic;              /* Critic_TD3 / SAC Critic: l1..l6 in one module */
+    int capacity;                 /* replay rows per learner (PPO: horizon) */
+    int batch_max;                /* largest batch / minibatch a learn call will use */
+    int extra_cols;               /* extra record columns (PPO: act_dim log-probs + 1 adv_done) */
+    int device_id;
+    uint64_t seed;                /* device Philox key (fast path only) */
+} frl_config;
+
+/* Column layout of one replay record (all agents of one transition, fp32):
+ * [obs_0..|act_0..|rew_0..|done_0..|next_obs_0..|extra] — see DESIGN.md "Data layout". */
+typedef struct frl_record_layout {
+    int n_agents, width, stride;
+    int obs_off[FRL_MAX_AGENTS], obs_dim[FRL_MAX_AGENTS];
+    int act_off[FRL_MAX_AGENTS], act_dim[FRL_MAX_AGENTS];
+    int rew_off, done_off;
+    int next_obs_off[FRL_MAX_AGENTS];
+    int extra_off, extra;
+} frl_record_layout;
+
+/* Arguments of one learn() call: `<ALGO>.learn(batch_size, gamma, tau, ...)`
+ * (DQN.py:104, DDPG_simple.py:137, TD3.py:189, SAC.py:222, MADDPG_simple.py:165). */
+typedef struct frl_learn_args {
+    int batch;                 /* min(len(buffer), batch_size) is the caller's job (DQN.py:95-96) */
+    int do_actor;              /* TD3: total_it % policy_freq == 0 (TD3.py:224); else 1 */
+    int use_policy_noise;      /* TD3 realize['policy_noise'] */
+    float gamma, tau;
+    float actor_lr, critic_lr; /* DQN: critic_lr = Qnet_lr */
+    float alpha_lr;            /* SAC Alpha, 1e-4 (SAC.py:155) */
+    float adam_eps;            /* 1e-8; 1e-5 with PPO trick['adam_eps'] */
+    float critic_weight_decay; /* DDPG.py:131-134 supplement; 0 otherwise */
+    float clip_norm;           /* clip_grad_norm_ max_norm 0.5 (TD3.py:140); <= 0: none (DQN.py:56-59) */
+    float policy_noise, noise_clip, max_action, policy_noise_scale;   /* TD3.py:196-198 */
+    float target_entropy;      /* SAC: -act_dim (SAC.py:160) */
+    const int64_t* idx;        /* host [P][n_agents][batch] rows drawn by the caller (np.random.choice,
+                                  DQN.py:97) for bit-identical sampling; NULL: drawn on the device */
+    const float* noise;        /* host [P][n_agents][2][batch][act_max] N(0,1) draws the reference takes
+                                  from torch's generator (TD3.py:197 slot 0; SAC.py:227 slot 0, :244 slot 1);
+                                  NULL: drawn on the device */
+    float* stats_out;          /* host [P][n_agents][FRL_STAT_COUNT] or NULL (NULL: call is asynchronous) */
+} frl_learn_args;
+
+/* ---------------------------------------------------------------- library / engine lifetime */
+const char* frl_last_error(void);          /* message of the last failing call on this thread */
+int frl_version(void);
+int frl_device_count(int* n_out);
+int frl_create(const frl_config* cfg, frl_engine** out);
+int frl_destroy(frl_engine* e);
+int frl_sync(frl_engine* e);               /* wait for the engine's stream */
+int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* row_chunk_out);
+
+/* ---------------------------------------------------------------- replay ring (Buffer.py)
+ * Replaces class Buffer (TD3_file/Buffer.py:11-61 = DQN_file/Buffer.py:12-62) and
+ * Buffer_for_PPO (PPO_file/Buffer.py:266-323). */
+int frl_record_layout_get(const frl_engine* e, frl_record_layout* out);
+/* Buffer.add (Buffer.py:28-38): one record (host, `width` floats) appended at the learner's cursor;
+ * staged in pinned memory and pushed by the next flush / sample / learn. */
+int frl_buffer_add(frl_engine* e, int learner, const float* record);
+/* vectorised add: record i goes to learner learners[i] (NULL: all to learner 0 in order) */
+int frl_buffer_add_batch(frl_engine* e, int n, const int* learners, const float* records);
+int frl_buffer_flush(frl_engine* e);
+/* Buffer._index / Buffer._size / __len__ / clear (Buffer.py:23-24,60-61; PPO Buffer.py:303-306) */
+int frl_buffer_cursor_get(const frl_engine* e, int learner, int* index_out, int* size_out);
+int frl_buffer_cursor_set(frl_engine* e, int learner, int index, int size);
+/* Buffer.sample(indices) (Buffer.py:40-57): gather rows `idx` (host int64[B]) of one learner into
+ * n_fields dense DEVICE tensors out[f][B][ncols[f]] = record[:, col0[f] : col0[f]+ncols[f]] — one launch. */
+int frl_buffer_sample(frl_engine* e, int learner, const int64_t* idx, int batch, int n_fields, const int* col0,
+                      const int* ncols, float* const* out_device);
+/* read `n` whole records starting at ring row `row0` into host memory [n][width] (Buffer_for_PPO.all, views) */
+int frl_buffer_read(frl_engine* e, int learner, int row0, int n, float* out_host);
+/* synthetic fill of the first `rows` rows of every learner's ring (bench only) */
+int frl_buffer_fill_synthetic(frl_engine* e, int rows, uint64_t seed);
+
+/* ---------------------------------------------------------------- parameters (state_dict)
+ * Nets: DQN 0 = Qnet; DDPG/TD3/SAC/PPO 0 = actor, 1 = critic; MADDPG 2i = actor_i, 2i+1 = critic_i.
+ * Flat layout = the reference state_dict tensors in layer order (l1.weight[out][in], l1.bias, l2...,
+ * twin critic l1..l6), then log_std for Gaussian actors (DQN.py:131-138, SAC.py:274-282). */
+int frl_net_count(const frl_engine* e, int* n_out);
+int frl_net_num_params(const frl_engine* e, int net, int* n_out);
+int frl_params_get(frl_engine* e, int learner, int net, int kind, float* out_host);
+int frl_params_set(frl_engine* e, int learner, int net, int kind, const float* in_host);
+int frl_opt_step_get(frl_engine* e, int learner, int net, int* t_out);   /* Adam step count */
+int frl_opt_step_set(frl_engine* e, int learner, int net, int t);
+/* SAC Alpha (SAC.py:154-169): vals = {log_alpha, exp_avg, exp_avg_sq, alpha} */
+int frl_alpha_get(frl_engine* e, int learner, float* vals4_out, int* step_out);
+int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int step);
+
+/* ---------------------------------------------------------------- forward (select_action)
+ * in_host [P][n_rows][in_dim], eps_host [P][n_rows][out_dim] or NULL, out_host [P][n_rows][out_dim]
+ * (ARGMAX: [P][n_rows] indices as float), logp_host like out or NULL.  Synchronous. */
+int frl_act(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim, const float* in_host,
+            const float* eps_host, float* out_host, float* logp_host);
+/* same with DEVICE pointers, asynchronous on the engine stream (vectorised env pool path) */
+int frl_act_device(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim,
+                   const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev);
+
+/* ---------------------------------------------------------------- learn (the hot path) */
+int frl_learn(frl_engine* e, const frl_learn_args* args);
+int frl_stats_get(frl_engine* e, float* out_host);          /* [P][n_agents][FRL_STAT_COUNT] */
+/* algorithmic work of one frl_learn launch (for the roofline figure): flops and HBM bytes */
+int frl_learn_work(const frl_engine* e, int batch, int do_actor, double* flops_out, double* bytes_out);
+
+/* ---------------------------------------------------------------- PPO (PPO_file/PPO_with_tricks.py)
+ * `PPO.learn(minibatch_size, gamma, lmbda, clip_param, K_epochs, entropy_coefficient)` (:290-354):
+ * value pass over the stored horizon, GAE scan, v_target, optional advantage normalisation, then
+ * K_epochs x ceil(horizon/minibatch) actor + critic steps — three launches in total. */
+typedef struct frl_ppo_args {
+    int horizon;               /* rows 0..horizon-1 of the ring, in time order (Buffer_for_PPO.all, Buffer.py:312-323) */
+    int minibatch, k_epochs;
+    int adv_norm;              /* trick['adv_norm'] (:314-315) */
+    float gamma, lmbda, clip, ent_coef;
+    float actor_lr, critic_lr; /* per call so that PPO.lr_decay (:357-363) is the caller's arithmetic */
+    float adam_eps;            /* 1e-5 with trick['adam_eps'] (:191-196) */
+    float clip_norm;           /* 0.5 */
+    const int64_t* perms;      /* host [P][k_epochs][horizon] np.random.permutation draws (:320), or NULL */
+    float* loss_trace_out;     /* host [P][k_epochs*n_mb][2] (actor, critic) losses or NULL */
+    float* adv_out;            /* host [P][horizon] raw GAE advantages or NULL */
+    float* vtarget_out;        /* host [P][horizon] or NULL */
+} frl_ppo_args;
+int frl_ppo_learn(frl_engine* e, const frl_ppo_args* args);
+/* stand-alone GAE scan (K3) on device arrays [n_seq][horizon]: replaces the host loop at
+ * PPO_with_tricks.py:308-311 / PPO.py:229-231 */
+int frl_gae(frl_engine* e, const float* td_delta_dev, const float* adv_done_dev, int n_seq, int horizon,
+            float gamma, float lmbda, float* adv_out_dev);
+
+/* ---------------------------------------------------------------- timing on the engine stream */
+int frl_timer_start(frl_engine* e);
+int frl_timer_stop(frl_engine* e, float* ms_out);           /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREERL_HIP_H */

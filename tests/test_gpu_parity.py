@@ -1,0 +1,440 @@
+"""GPU parity: the HIP engine (through the C ABI) against the oracle run live on the same seeded
+inputs, and against the golden outputs of the reference (tests/golden/*.npz).
+
+Tolerances (fp32, different reduction orders: MFMA k-permuted fma chains vs BLAS):
+  * per-call losses: 1e-4 relative — the bar BASELINE.json's north_star states ("TD-loss curve
+    matching reference seed=0 to 1e-4 rel-tol"); observed ~1e-6;
+  * parameters after n Adam steps: rtol 5e-4 / atol 5e-6 (Adam's m/sqrt(v) turns 1-ulp gradient
+    differences on near-zero gradients into visible parameter differences of order lr*1e-3);
+  * Buffer.sample: bit-exact (pure data movement).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden import cases, synth
+from tests.hip_helpers import flat_params, records, rel_err, unflat_params
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOSS_RTOL = 1e-4
+P_RTOL, P_ATOL = 5e-4, 5e-6
+REPORT = {}
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def N():
+    from freerl_amd import _native
+    assert _native.device_count() > 0, "no HIP device: the engine has no CPU fallback"
+    return _native
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def note(key, val):
+    REPORT[key] = float(val)
+
+
+def assert_params_close(got, want, label):
+    worst = 0.0
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=P_RTOL, atol=P_ATOL, err_msg="%s %s" % (label, k))
+        worst = max(worst, rel_err(got[k], want[k]))
+    note("param_relerr/" + label, worst)
+
+
+# ------------------------------------------------------------------------------------ buffer
+def test_buffer_add_wrap_sample_bit_exact(N):
+    import torch
+    from freerl_amd.engine import Engine
+    c = cases.CASES["buffer"]
+    inp = cases.buffer_inputs(c)
+    fx = gold("buffer")
+    e = Engine(N.ALGO_REPLAY_ONLY, c["obs_dim"], c["act_dim"], c["capacity"], batch_max=c["batch"])
+    recs = records([inp["table"]])
+    for i in range(c["n_add"]):                      # one by one: exercises the pinned staging + wrap
+        e.add(0, recs[i])
+    assert e.cursor(0) == (int(fx["index"]), int(fx["size"]))
+    lay = e.layout
+    O, A = c["obs_dim"], c["act_dim"]
+    fields = [(lay.obs_off[0], O), (lay.act_off[0], A), (lay.rew_off, 1), (lay.next_obs_off[0], O), (lay.done_off, 1)]
+    outs = [torch.empty((c["batch"], w), dtype=torch.float32, device="cuda") for _, w in fields]
+    e.sample_into(0, inp["idx"], fields, [t.data_ptr() for t in outs])
+    for t, key in zip(outs, ["obs", "act", "rew", "next_obs", "done"]):
+        np.testing.assert_array_equal(t.cpu().numpy(), fx[key])
+    # whole-record read-back equals what the ring must hold after the wrap
+    rows = e.read_rows(0, 0, c["capacity"])
+    expect = np.zeros_like(rows)
+    for i in range(c["n_add"]):
+        expect[i % c["capacity"]] = recs[i]
+    np.testing.assert_array_equal(rows, expect)
+    e.close()
+
+
+def test_buffer_empty_ragged_and_errors(N):
+    import torch
+    from freerl_amd.engine import Engine
+    e = Engine(N.ALGO_REPLAY_ONLY, 3, 1, 8, batch_max=8)
+    assert e.cursor(0) == (0, 0)
+    out = torch.empty((0, 3), dtype=torch.float32, device="cuda")
+    e.sample_into(0, np.zeros(0, np.int64), [(0, 3)], [out.data_ptr()])        # empty sample is a no-op
+    recs = np.arange(3 * e.width, dtype=np.float32).reshape(3, e.width)
+    e.add_batch(recs)
+    got = torch.empty((4, 3), dtype=torch.float32, device="cuda")
+    e.sample_into(0, np.array([2, 0, -8, 1]), [(0, 3)], [got.data_ptr()])      # -8 wraps like NumPy indexing
+    np.testing.assert_array_equal(got.cpu().numpy(), recs[[2, 0, 0, 1], :3])
+    with pytest.raises(N.FrlError):
+        e.sample_into(0, np.array([8]), [(0, 3)], [got.data_ptr()])            # IndexError in the reference
+    with pytest.raises(N.FrlError):
+        e.learn(4, gamma=0.99, tau=0.01)                                       # replay-only engine
+    e.close()
+
+
+# --------------------------------------------------------------------------------------- DQN
+def test_dqn_learn_matches_oracle_and_reference(N):
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    c = cases.CASES["dqn"]
+    inp = cases.dqn_inputs(c)
+    fx = gold("dqn")
+    names = ["l1", "l2"]
+    e = Engine(N.ALGO_DQN, c["obs_dim"], c["n_actions"], c["capacity"], discrete=True, batch_max=c["batch"])
+    flat = flat_params(inp["params"]["Qnet"], names)
+    e.set_params(0, flat, N.PARAM_ONLINE)
+    e.set_params(0, flat, N.PARAM_TARGET)
+    e.add_batch(records([inp["table"]]))
+    orc = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    q0 = e.act(0, N.ACT_RAW, tab["obs"][:32], out_dim=c["n_actions"])[0]
+    np.testing.assert_allclose(q0, fx["q0"], rtol=1e-5, atol=1e-6)
+    greedy = e.act(0, N.ACT_ARGMAX, tab["obs"][:32])[0, :, 0].astype(np.int64)
+    np.testing.assert_array_equal(greedy, fx["select_action"])
+    losses = []
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], critic_lr=c["lr"], clip_norm=0.0,
+                     idx=inp["idx"][k], want_stats=True)
+        losses.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        orc.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    np.testing.assert_allclose(losses, np.array(orc.losses), rtol=LOSS_RTOL)
+    np.testing.assert_allclose(losses, fx["loss"], rtol=LOSS_RTOL)
+    note("loss_relerr/dqn", rel_err(losses, fx["loss"], 1e-6))
+    got = unflat_params(e.get_params(0, N.PARAM_ONLINE), orc.q, names)
+    assert_params_close(got, orc.q, "dqn/Qnet")
+    got_t = unflat_params(e.get_params(0, N.PARAM_TARGET), orc.q_t, names)
+    assert_params_close(got_t, orc.q_t, "dqn/Qnet_target")
+    synth.check_digest("Qnet", got, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    got_m = unflat_params(e.get_params(0, N.PARAM_ADAM_M), orc.q, names)
+    for k in got_m:
+        np.testing.assert_allclose(got_m[k], orc.opt.m[k], rtol=1e-3, atol=1e-7)
+    assert e.opt_step(0) == int(fx["step"])
+    e.close()
+
+
+# ------------------------------------------------------------------------- DDPG / TD3 / SAC
+AC_NAMES = ["l1", "l2", "l3"]
+TWIN_NAMES = ["l1", "l2", "l3", "l4", "l5", "l6"]
+
+
+def _setup_ac(N, algo, c, inp, twin, actor_names, actor_extra=None, n_learners=1):
+    from freerl_amd.engine import Engine
+    e = Engine(algo, c["obs_dim"], c["act_dim"], c["capacity"], twin_critic=twin, batch_max=c["batch"],
+               n_learners=n_learners)
+    fa = flat_params(inp["params"]["actor"], actor_names, actor_extra)
+    fc = flat_params(inp["params"]["critic"], TWIN_NAMES if twin else AC_NAMES)
+    for p in range(n_learners):
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(0, fa, kind, learner=p)
+            e.set_params(1, fc, kind, learner=p)
+    recs = records([inp["table"]])
+    for p in range(n_learners):
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+    return e
+
+
+def _fill_oracle(orc, tab):
+    for i in range(len(tab["rew"])):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+
+
+def _check_ac_params(N, e, orc, twin, actor_names, label, actor_extra=None, learner=0):
+    cn = TWIN_NAMES if twin else AC_NAMES
+    online = None
+    for kind, oa, oc, tag in ((N.PARAM_ONLINE, orc.actor, orc.critic, ""), (N.PARAM_TARGET, orc.actor_t, orc.critic_t, "_target")):
+        ga = unflat_params(e.get_params(0, kind, learner=learner), oa, actor_names, actor_extra)
+        gc = unflat_params(e.get_params(1, kind, learner=learner), oc, cn)
+        assert_params_close(ga, oa, "%s/actor%s" % (label, tag))
+        assert_params_close(gc, oc, "%s/critic%s" % (label, tag))
+        if online is None:
+            online = (ga, gc)
+    return online
+
+
+def test_ddpg_learn(N):
+    from oracle import algos
+    c = cases.CASES["ddpg"]
+    inp = cases.ac_inputs(c, twin=False)
+    fx = gold("ddpg")
+    e = _setup_ac(N, N.ALGO_DDPG, c, inp, False, AC_NAMES)
+    orc = algos.DDPG(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                     c["critic_lr"], c["capacity"])
+    _fill_oracle(orc, inp["table"])
+    sa = e.act(0, N.ACT_TANHHEAD, inp["table"]["obs"][:32], out_dim=c["act_dim"])[0]
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=1e-5, atol=1e-6)
+    cl, al = [], []
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     idx=inp["idx"][k], want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS]); al.append(st[0, 0, N.STAT_ACTOR_LOSS])
+        orc.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=LOSS_RTOL, atol=1e-6)
+    np.testing.assert_allclose(cl, np.array(orc.critic_losses), rtol=LOSS_RTOL)
+    note("loss_relerr/ddpg_critic", rel_err(cl, fx["loss_critic"], 1e-6))
+    _check_ac_params(N, e, orc, False, AC_NAMES, "ddpg")
+    assert e.opt_step(0) == int(fx["actor_step"]) and e.opt_step(1) == int(fx["critic_step"])
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["td3", "td3_pendulum"])
+def test_td3_learn(N, name):
+    from oracle import algos
+    c = cases.CASES[name]
+    inp = cases.ac_inputs(c, twin=True)
+    fx = gold(name)
+    e = _setup_ac(N, N.ALGO_TD3, c, inp, True, AC_NAMES)
+    orc = algos.TD3(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                    c["critic_lr"], c["capacity"])
+    _fill_oracle(orc, inp["table"])
+    cl, al = [], []
+    for k in range(c["n_learn"]):
+        total_it = k + 1
+        do_actor = total_it % c["policy_freq"] == 0
+        nz = np.zeros((1, 1, 2, c["batch"], c["act_dim"]), np.float32)
+        nz[0, 0, 0] = inp["noise"][k][0]
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     do_actor=do_actor, use_policy_noise=True, policy_noise=c["policy_noise"],
+                     noise_clip=c["noise_clip"], max_action=c["max_action"], policy_noise_scale=c["policy_noise_scale"],
+                     idx=inp["idx"][k], noise=nz, want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        if do_actor:
+            al.append(st[0, 0, N.STAT_ACTOR_LOSS])
+        orc.learn_with(inp["idx"][k], inp["noise"][k][0], c["gamma"], c["tau"], c["policy_noise"], c["noise_clip"],
+                       c["max_action"], c["policy_freq"], c["policy_noise_scale"])
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=LOSS_RTOL, atol=1e-6)
+    note("loss_relerr/%s_critic" % name, rel_err(cl, fx["loss_critic"], 1e-6))
+    note("loss_relerr/%s_actor" % name, rel_err(al, fx["loss_actor"], 1e-6))
+    ga, gc = _check_ac_params(N, e, orc, True, AC_NAMES, name)
+    synth.check_digest("actor", ga, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    synth.check_digest("critic", gc, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    assert e.opt_step(0) == int(fx["actor_step"]) and e.opt_step(1) == int(fx["critic_step"])
+    e.close()
+
+
+def test_sac_learn(N):
+    from oracle import algos
+    c = cases.CASES["sac"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    fx = gold("sac")
+    an = ["l1", "l2", "mean_layer"]
+    e = _setup_ac(N, N.ALGO_SAC, c, inp, True, an, "log_std")
+    e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)        # Alpha(alpha=0.01) (SAC.py:188)
+    orc = algos.SAC(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                    c["critic_lr"], c["capacity"])
+    _fill_oracle(orc, inp["table"])
+    ev = e.act(0, N.ACT_TANHHEAD, inp["table"]["obs"][:32], out_dim=c["act_dim"])[0]
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    cl, al, ll, alphas = [], [], [], []
+    for k in range(c["n_learn"]):
+        nz = np.stack([inp["noise"][k][0], inp["noise"][k][1]])[None, None]
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     alpha_lr=1e-4, target_entropy=-float(c["act_dim"]), idx=inp["idx"][k], noise=nz, want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS]); al.append(st[0, 0, N.STAT_ACTOR_LOSS])
+        ll.append(st[0, 0, N.STAT_ALPHA_LOSS]); alphas.append(st[0, 0, N.STAT_ALPHA])
+        orc.learn_with(inp["idx"][k], inp["noise"][k][0], inp["noise"][k][1], c["gamma"], c["tau"])
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=LOSS_RTOL, atol=2e-6)
+    np.testing.assert_allclose(ll, fx["loss_alpha"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(alphas, fx["alpha"], rtol=1e-5)
+    note("loss_relerr/sac_critic", rel_err(cl, fx["loss_critic"], 1e-6))
+    note("loss_relerr/sac_actor", rel_err(al, fx["loss_actor"], 1e-6))
+    ga, gc = _check_ac_params(N, e, orc, True, an, "sac", "log_std")
+    synth.check_digest("actor", ga, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    synth.check_digest("critic", gc, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    # stochastic select_action on the UPDATED actor with the reference's eps (generated after learn)
+    eps = np.stack([synth.normal(c["noise_seed"] + 900 + i, (1, c["act_dim"]))[0] for i in range(8)])
+    sa = e.act(0, N.ACT_SAC_SAMPLE, inp["table"]["obs"][:8], eps=eps, out_dim=c["act_dim"])[0]
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=5e-4, atol=5e-5)
+    vals, t = e.alpha_state()
+    np.testing.assert_allclose(vals[0], fx["log_alpha"], rtol=1e-5)
+    assert t == c["n_learn"]
+    e.close()
+
+
+def test_maddpg_learn(N):
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    c = cases.CASES["maddpg"]
+    inp = cases.maddpg_inputs(c)
+    fx = gold("maddpg")
+    ids = inp["ids"]
+    od = [c["dims"][a][0] for a in ids]
+    ad = [c["dims"][a][1] for a in ids]
+    e = Engine(N.ALGO_MADDPG, od, ad, c["capacity"], batch_max=c["batch"])
+    for j, a in enumerate(ids):
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(2 * j, flat_params(inp["params"][a]["actor"], AC_NAMES), kind)
+            e.set_params(2 * j + 1, flat_params(inp["params"][a]["critic"], AC_NAMES), kind)
+    e.add_batch(records([inp["tables"][a] for a in ids]))
+    orc = algos.MADDPG(inp["params"], c["dims"], c["actor_lr"], c["critic_lr"], c["capacity"])
+    for i in range(c["n_table"]):
+        orc.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    for j, a in enumerate(ids):
+        act = e.act(2 * j, N.ACT_TANHHEAD, inp["tables"][a]["obs"][:1], out_dim=ad[j])[0, 0]
+        np.testing.assert_allclose(act, fx["select_action/" + a], rtol=1e-5, atol=1e-6)
+    cl = {a: [] for a in ids}
+    al = {a: [] for a in ids}
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     idx=np.stack(inp["idx"][k])[None], want_stats=True)
+        for j, a in enumerate(ids):
+            cl[a].append(st[0, j, N.STAT_CRITIC_LOSS]); al[a].append(st[0, j, N.STAT_ACTOR_LOSS])
+        orc.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    for j, a in enumerate(ids):
+        np.testing.assert_allclose(cl[a], fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(al[a], fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=1e-6)
+        note("loss_relerr/maddpg_critic_" + a, rel_err(cl[a], fx["loss_critic/" + a], 1e-6))
+        for kind, oa, oc, tag in ((N.PARAM_ONLINE, orc.actor, orc.critic, ""), (N.PARAM_TARGET, orc.actor_t, orc.critic_t, "_t")):
+            assert_params_close(unflat_params(e.get_params(2 * j, kind), oa[a], AC_NAMES), oa[a], "maddpg/%s/actor%s" % (a, tag))
+            assert_params_close(unflat_params(e.get_params(2 * j + 1, kind), oc[a], AC_NAMES), oc[a], "maddpg/%s/critic%s" % (a, tag))
+    e.close()
+
+
+# --------------------------------------------------------------------------------------- PPO
+@pytest.mark.parametrize("name", ["ppo", "ppo_tricks"])
+def test_ppo_learn(N, name):
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    c = cases.CASES[name]
+    inp = cases.ppo_inputs(c)
+    fx = gold(name)
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    an = ["l1", "l2", "mean_layer"]
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=c["minibatch"], extra_cols=A + 1,
+               hidden_act=N.ACT_TANH if c["trick"]["tanh"] else N.ACT_RELU)
+    e.set_params(0, flat_params(inp["params"]["actor"], an, "log_std"))
+    e.set_params(1, flat_params(inp["params"]["critic"], AC_NAMES))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, c["actor_lr"], c["critic_lr"], T, c["trick"])
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = e.act(0, N.ACT_TANHHEAD, tab["obs"][:16], out_dim=A)[0]
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    out = e.ppo_learn(T, c["minibatch"], c["k_epochs"], gamma=c["gamma"], lmbda=c["lmbda"], clip=c["clip"],
+                      ent_coef=c["ent"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                      adam_eps=1e-5 if c["trick"]["adam_eps"] else 1e-8, adv_norm=c["trick"]["adv_norm"],
+                      perms=np.stack(inp["perms"])[None], want_trace=True, want_adv=True)
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    # GAE: wave-scan (affine composition) vs the reference's sequential fp32 recurrence
+    np.testing.assert_allclose(out["adv"][0], fx["adv_raw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["v_target"][0], fx["v_target"], rtol=1e-4, atol=1e-5)
+    note("gae_abs_err/" + name, float(np.max(np.abs(out["adv"][0] - fx["adv_raw"]))))
+    np.testing.assert_allclose(out["trace"][0, :, 0], fx["loss_actor"], rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(out["trace"][0, :, 1], fx["loss_critic"], rtol=2e-4)
+    note("loss_relerr/%s_critic" % name, rel_err(out["trace"][0, :, 1], fx["loss_critic"], 1e-6))
+    ga = unflat_params(e.get_params(0), orc.actor, an, "log_std")
+    gc = unflat_params(e.get_params(1), orc.critic, AC_NAMES)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
+    for k in orc.critic:
+        np.testing.assert_allclose(gc[k], orc.critic[k], rtol=2e-3, atol=2e-5, err_msg=k)
+    synth.check_digest("actor", ga, fx, 2e-3, 2e-5, "hip-vs-reference")
+    assert e.opt_step(0) == int(fx["actor_step"]) and e.opt_step(1) == int(fx["critic_step"])
+    assert e.cursor(0) == (0, 0)
+    e.close()
+
+
+# --------------------------------------------------------------- population / device RNG / scale
+def test_population_learners_are_independent(N):
+    """P = 3 learners with identical inputs but different sample indices each equal their own oracle."""
+    from oracle import algos
+    c = dict(cases.CASES["td3"])
+    inp = cases.ac_inputs(c, twin=True)
+    P = 3
+    e = _setup_ac(N, N.ALGO_TD3, c, inp, True, AC_NAMES, n_learners=P)
+    orcs = []
+    for p in range(P):
+        o = algos.TD3(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                      c["critic_lr"], c["capacity"])
+        _fill_oracle(o, inp["table"])
+        orcs.append(o)
+    for k in range(2):
+        idx = np.stack([synth.indices(7000 + 10 * k + p, c["n_table"], c["batch"]) for p in range(P)])[:, None]
+        nz = np.zeros((P, 1, 2, c["batch"], c["act_dim"]), np.float32)
+        for p in range(P):
+            nz[p, 0, 0] = synth.normal(8000 + 10 * k + p, (c["batch"], c["act_dim"]))
+        st = e.learn(c["batch"], gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1),
+                     use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=2.0, idx=idx, noise=nz,
+                     want_stats=True)
+        for p in range(P):
+            cl, _ = orcs[p].learn_with(idx[p, 0], nz[p, 0, 0], 0.99, 0.005, 0.2, 0.5, 2.0, 2, 1.0)
+            np.testing.assert_allclose(st[p, 0, N.STAT_CRITIC_LOSS], cl, rtol=LOSS_RTOL)
+    for p in range(P):
+        _check_ac_params(N, e, orcs[p], True, AC_NAMES, "pop%d" % p, learner=p)
+    e.close()
+
+
+def test_full_size_device_rng_properties(N):
+    """BASELINE config-2 scale (replay 1e6 rows, batch 256), device-drawn indices and noise.
+    Size-independent properties: (1) bitwise determinism from the seed; (2) tau = 1 makes the
+    target nets equal the online nets; (3) the ring content survives the update untouched."""
+    from freerl_amd.engine import Engine
+    cap = 1_000_000
+
+    def run():
+        e = Engine(N.ALGO_TD3, 8, 2, cap, twin_critic=True, batch_max=256, seed=1234)
+        rng = np.random.default_rng(5)
+        for net in (0, 1):
+            flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
+            e.set_params(net, flat, N.PARAM_ONLINE)
+            e.set_params(net, flat, N.PARAM_TARGET)
+        e.fill_synthetic(cap, seed=99)
+        before = e.read_rows(0, 123456, 64)
+        stats = []
+        for k in range(4):
+            st = e.learn(256, gamma=0.99, tau=1.0, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1),
+                         use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, want_stats=True)
+            stats.append(st.copy())
+        after = e.read_rows(0, 123456, 64)
+        out = dict(stats=np.stack(stats), a=e.get_params(0), c=e.get_params(1), at=e.get_params(0, N.PARAM_TARGET),
+                   ct=e.get_params(1, N.PARAM_TARGET))
+        np.testing.assert_array_equal(before, after)
+        e.close()
+        return out
+    r1, r2 = run(), run()
+    assert np.all(np.isfinite(r1["stats"])) and np.all(r1["stats"][:, 0, 0, N.STAT_CRITIC_LOSS] > 0)
+    for k in ("stats", "a", "c"):
+        np.testing.assert_array_equal(r1[k], r2[k])
+    np.testing.assert_array_equal(r1["a"], r1["at"])
+    np.testing.assert_array_equal(r1["c"], r1["ct"])
