@@ -141,6 +141,13 @@ def main():
     stats = e.stats()
     assert np.all(np.isfinite(stats)), "non-finite losses"
 
+    # per-kernel durations of the launch chain (HIP events around every launch), outside the timed region
+    e.profile(True)
+    for k in range(args.steps):
+        e.learn(BATCH, **td3_kwargs(k))
+    prof = e.profile_read()
+    e.profile(False)
+
     metrics = torch.tensor([dt, float(P * args.steps), kernel_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = metrics.clone()
@@ -156,8 +163,12 @@ def main():
         n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
         flops = (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps      # per launch, all P learners
         abytes = (by_a * n_act + by_c * (args.steps - n_act)) / args.steps
-        launch_s = kernel_ms * 1e-3 / args.steps
-        achieved = flops / launch_s / 1e12
+        step_s = kernel_ms * 1e-3 / args.steps
+        kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
+        # dominant kernel: ac_critic_kernel (targets + twin-critic forward/backward of every row chunk)
+        launch_s = kern["grad_critic"]["avg_ms"] * 1e-3
+        achieved = fl_c / launch_s / 1e12
+        flops, abytes = fl_c, by_c
         lds, rc = e.lds_bytes()
         # single-learner latency (P = 1): the reference-compatible drop-in case
         e.close()
@@ -192,9 +203,13 @@ def main():
             "single_learner_updates_per_sec": single,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "ac_update_kernel", "avg_launch_ms": launch_s * 1e3,
+                         "kernel": "ac_critic_kernel", "avg_launch_ms": launch_s * 1e3,
                          "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
-                         "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS},
+                         "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS,
+                         "step_flops_avg": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps,
+                         "step_ms_avg": step_s * 1e3,
+                         "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
+                         "kernels": kern},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
         }
         print(json.dumps(line))

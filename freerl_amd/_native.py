@@ -101,6 +101,8 @@ SIGNATURES = {
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "frl_timer_start": (_i, [_vp]),
     "frl_timer_stop": (_i, [_vp, _fp]),
+    "frl_profile_enable": (_i, [_vp, _i]),
+    "frl_profile_read": (_i, [_vp, _P(C.c_double), _P(C.c_longlong)]),
 }
 
 _lib = None

@@ -77,7 +77,44 @@ struct frl_engine {
     int* d_perm = nullptr;
     size_t perm_cap = 0;
     bool has_nets = false;
+    // optional per-kernel timing (frl_profile_*): event pairs recorded around each launch
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev;      // pool, pairs
+    std::vector<int> prof_kind;           // kernel kind per recorded pair
+    size_t prof_used = 0;
+    double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+enum ProfKind { PK_DRAW = 0, PK_GRAD_CRITIC = 1, PK_ADAM_CRITIC = 2, PK_GRAD_ACTOR = 3, PK_ADAM_ACTOR = 4, PK_SOFT = 5, PK_PPO = 6 };
+
+static void prof_begin(frl_engine* e, int kind) {
+    if (!e->profile) return;
+    if (e->prof_used + 2 > e->prof_ev.size()) {
+        for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); e->prof_ev.push_back(ev); }
+    }
+    hipEventRecord(e->prof_ev[e->prof_used], e->stream);
+    e->prof_kind.push_back(kind);
+}
+static void prof_end(frl_engine* e) {
+    if (!e->profile) return;
+    hipEventRecord(e->prof_ev[e->prof_used + 1], e->stream);
+    e->prof_used += 2;
+}
+static void prof_collect(frl_engine* e) {
+    if (e->prof_used == 0) return;
+    hipStreamSynchronize(e->stream);
+    for (size_t i = 0; i < e->prof_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) == hipSuccess) {
+            const int k = e->prof_kind[i / 2];
+            e->prof_ms[k] += ms;
+            e->prof_n[k]++;
+        }
+    }
+    e->prof_used = 0;
+    e->prof_kind.clear();
+}
 
 // ------------------------------------------------------------------------------ descriptors
 static int build_net(NetDesc& N, const std::vector<std::pair<int, int>>& layers /* (out,in) */, int heads,
@@ -174,6 +211,10 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->ev_stage) hipEventDestroy(e->ev_stage);
+    for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
+    if (e->h.slab) hipFree(e->h.slab);
+    if (e->h.part) hipFree(e->h.part);
+    if (e->h.gsq) hipFree(e->h.gsq);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return FRL_OK;
@@ -258,10 +299,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.lds_out_pad = outp;
     h.lds_batch_pad = pad32(h.batch_max);
     h.lds_act_pad = pad16(std::max(R.act_total, 1));
+    // row chunk: the largest of {64,32,16} whose LDS footprint still lets 3 workgroups share a CU
+    // (12 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
     h.rc = 64;
-    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;
+    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 53 * 1024) h.rc /= 2;
     if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
     e->lds_bytes = lds_bytes_for(h, h.rc);
+    h.S = (h.batch_max + h.rc - 1) / h.rc;
 
 #define CREATE_TRY(expr)                                                                           \
     do {                                                                                           \
@@ -286,6 +330,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.m, P * ls, e->stream));
         CREATE_TRY(dalloc_zero(&h.v, P * ls, e->stream));
         CREATE_TRY(dalloc_zero(&h.grad, P * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.slab, P * (size_t)h.S * ls, e->stream));
+        CREATE_TRY(dalloc_zero(&h.part, P * (size_t)h.n_agents * h.S * 4, e->stream));
+        h.Gmax = 1;
+        for (int i = 0; i < h.n_nets; ++i) h.Gmax = std::max(h.Gmax, (h.net[i].size / 4 + 256 * kAdamVec - 1) / (256 * kAdamVec));
+        CREATE_TRY(dalloc_zero(&h.gsq, P * (size_t)h.n_agents * h.Gmax, e->stream));
         e->idx_count = P * h.n_agents * h.batch_max;
         e->noise_count = P * h.n_agents * 2 * (size_t)h.batch_max * h.act_max;
         CREATE_TRY(dalloc_zero(&h.idx, e->idx_count, e->stream));
@@ -309,8 +358,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->size.assign(P, 0);
     e->staged_per_learner.assign(P, 0);
     if (e->lds_bytes > 64 * 1024) {
-        CREATE_TRY(hipFuncSetAttribute((const void*)dqn_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-        CREATE_TRY(hipFuncSetAttribute((const void*)ac_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)dqn_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
     }
@@ -740,12 +790,45 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     a.use_policy_noise = (h.algo == ALGO_TD3 && args->use_policy_noise) ? 1 : 0;
     a.target_entropy = args->target_entropy;
     a.rng_counter = e->rng_counter++;
-    if (h.algo == ALGO_DQN) {
-        hipLaunchKernelGGL(dqn_update_kernel, dim3(h.P), dim3(256), e->lds_bytes, e->stream, e->d, a);
-    } else {
-        hipLaunchKernelGGL(ac_update_kernel, dim3(h.P * h.n_agents), dim3(256), e->lds_bytes, e->stream, e->d, a);
-        if (h.algo == ALGO_MADDPG)
-            hipLaunchKernelGGL(soft_update_kernel, dim3(h.P * h.n_nets), dim3(256), 0, e->stream, e->d, a.tau);
+    const int ns = (a.batch + h.rc - 1) / h.rc;
+    const int units = h.P * h.n_agents;
+    const dim3 grid_chunks(((units + 7) / 8) * 8 * ns), grid_units(units), blk(256);
+    const bool sac = h.algo == ALGO_SAC, maddpg = h.algo == ALGO_MADDPG;
+    if (dev_rng) {
+        prof_begin(e, PK_DRAW);
+        hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)a.batch * sizeof(int), e->stream, e->d, a, needs_noise ? 1 : 0);
+        prof_end(e);
+    }
+    AdamArgs ad;
+    memset(&ad, 0, sizeof ad);
+    ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
+    ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy;
+    prof_begin(e, PK_GRAD_CRITIC);
+    if (h.algo == ALGO_DQN) hipLaunchKernelGGL(dqn_grad_kernel, grid_chunks, blk, e->lds_bytes, e->stream, e->d, a, ns);
+    else hipLaunchKernelGGL(ac_critic_kernel, grid_chunks, blk, e->lds_bytes, e->stream, e->d, a, ns);
+    prof_end(e);
+    ad.which = 0; ad.lr = a.critic_lr; ad.wd = a.critic_wd;
+    ad.soft = (h.algo == ALGO_DQN) ? 1 : ((!maddpg && a.do_actor) ? 1 : 0);
+    ad.G = h.Gmax;
+    const dim3 grid_adam(units * h.Gmax);
+    prof_begin(e, PK_ADAM_CRITIC);
+    hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, e->stream, e->d, ad);
+    hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, e->stream, e->d, ad);
+    prof_end(e);
+    if (h.algo != ALGO_DQN && a.do_actor) {
+        prof_begin(e, PK_GRAD_ACTOR);
+        hipLaunchKernelGGL(ac_actor_kernel, grid_chunks, blk, e->lds_bytes, e->stream, e->d, a, ns);
+        prof_end(e);
+        ad.which = 1; ad.lr = a.actor_lr; ad.wd = 0.f; ad.soft = maddpg ? 0 : 1; ad.sac_alpha = sac ? 1 : 0;
+        prof_begin(e, PK_ADAM_ACTOR);
+        hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, e->stream, e->d, ad);
+        hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, e->stream, e->d, ad);
+        prof_end(e);
+    }
+    if (maddpg) {
+        prof_begin(e, PK_SOFT);
+        hipLaunchKernelGGL(soft_update_kernel, dim3(h.P * h.n_nets), blk, 0, e->stream, e->d, a.tau);
+        prof_end(e);
     }
     HIP_TRY(hipGetLastError());
     if (args->stats_out) return frl_stats_get(e, args->stats_out);
@@ -809,6 +892,20 @@ extern "C" int frl_timer_stop(frl_engine* e, float* ms_out) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     if (ms_out) *ms_out = ms;
+    return FRL_OK;
+}
+
+extern "C" int frl_profile_enable(frl_engine* e, int on) {
+    ENG(e);
+    prof_collect(e);
+    e->profile = on != 0;
+    if (on) { for (int k = 0; k < 8; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; } }
+    return FRL_OK;
+}
+extern "C" int frl_profile_read(frl_engine* e, double* ms_sum8, long long* count8) {
+    ENG(e);
+    prof_collect(e);
+    for (int k = 0; k < 8; ++k) { if (ms_sum8) ms_sum8[k] = e->prof_ms[k]; if (count8) count8[k] = e->prof_n[k]; }
     return FRL_OK;
 }
 

@@ -65,7 +65,12 @@ struct EngineDesc {
     float* target;
     float* m;
     float* v;
-    float* grad;
+    float* grad;          // reduced gradients (sum of the partial slabs)
+    float* slab;          // [P][S][learner_stride] per-row-chunk partial gradients
+    float* part;          // [P][n_agents][S][4] per-row-chunk partial sums {loss, entropy, -, -}
+    int S;                // row chunks per batch_max = ceil(batch_max / rc)
+    float* gsq;           // [P][n_agents][Gmax] per-workgroup sum of squared gradients (reduce -> adam)
+    int Gmax;             // workgroups per net in the reduce/adam launches
     float* replay;        // [P][capacity][rec.stride]
     int* idx;             // [P][n_agents][batch_max] sampled row indices
     float* noise;         // [P][2][batch_max][act_max] standard-normal draws (TD3 policy noise, SAC eps', eps)

@@ -1,14 +1,19 @@
-// Fused replay-sample + batched-update kernels: ONE launch = one learn() of every learner.
+// Replay-sample + batched-update kernels of the off-policy learners (DQN, DDPG, TD3, SAC, MADDPG).
 //
-// Replaces, per learner, the reference's ~60 (DQN) to ~700 (MADDPG) eager ATen launches per
-// learn() and the 5 H2D copies of Buffer.sample (TD3_file/Buffer.py:50-55):
-//   index draw (Philox, or host-supplied for parity) -> record gather from the HBM ring ->
-//   target forward -> TD target -> online forward -> MSE delta -> backward (MFMA) ->
-//   global-norm clip -> Adam -> soft target update.
-// One workgroup owns one (learner, agent): batch-row chunks stream through LDS, weight
-// gradients accumulate in the learner's global grad block, so no cross-workgroup traffic.
-// Population mode (P learners = independent seeds) fills the 256 CUs; P = 1 is the
-// reference-compatible single learner.
+// One learn() of every resident learner = a short chain of launches:
+//     [draw]  -> grad(critic) -> adam(critic) [-> grad(actor) -> adam(actor)] [-> soft update]
+// replacing, per learner, the reference's ~60 (DQN) to ~700 (MADDPG) eager ATen launches per
+// learn() and the 5 H2D copies of Buffer.sample (TD3_file/Buffer.py:50-55).
+//
+// Decomposition (chosen from rocprofv3 counters, profiles/README.md): the batch of one
+// (learner, agent) is split into row chunks of `rc` rows; ONE workgroup owns ONE chunk:
+// record gather from the HBM ring -> forward passes -> deltas -> backward (all MFMA), its weight
+// gradients written ONCE to its partial slab.  The chunks of a learner are placed on the same
+// XCD (block -> XCD is id % 8), so the weights they share are served by that XCD's L2 instead
+// of being re-fetched per chunk.  `adam_kernel` then sums the slabs in a fixed order
+// (deterministic), applies clip_grad_norm_, Adam and the soft target update while streaming
+// theta/m/v once.  P learners (independent seeds) x chunks fill the 256 CUs; P = 1 still
+// spreads one learner's batch over batch/rc CUs.
 #include <hip/hip_runtime.h>
 
 #include "device/net.hpp"
@@ -28,374 +33,469 @@ __device__ __forceinline__ Lds carve(const EngineDesc& D, float* smem) {
     return carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
 }
 
+// block id -> (unit, slice): the `ns` row chunks of unit u = learner*n_agents + agent sit on
+// blocks {8*ns*g + x + 8s}, i.e. all on XCD x and adjacent in dispatch order.
+struct UnitSlice { int unit, slice; };
+__device__ __forceinline__ UnitSlice unit_slice(int ns) {
+    const int group = 8 * ns, g = blockIdx.x / group, l = blockIdx.x - g * group;
+    return UnitSlice{g * 8 + (l & 7), l >> 3};
+}
+
 }  // namespace
 
-// ------------------------------------------------------------------------------------- DQN
-// DQN.learn (DQN_file/DQN.py:104-128): y = r + gamma * max_a Q_t(s',a) * (1-d);
-// loss = mean((Q(s)[a] - y)^2); Adam (no clipping, DQN.py:56-59); soft update.
-__global__ __launch_bounds__(256) void dqn_update_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+// ----------------------------------------------------------------------------------- draw
+// Device-side sampling: `batch` distinct rows per (learner, agent) (np.random.choice(size, B,
+// replace=False), DQN.py:97) and the N(0,1) draws of TD3.py:197 / SAC.py:227,244.
+__global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int want_noise) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
-    const int p = blockIdx.x;
-    const NetDesc& N = D.net[0];
-    const RecordDesc& R = D.rec;
-    const Lds S = carve(D, smem);
-    const int rc = D.rc, B = a.batch, nl = N.n_layers;
-    const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
-    float* theta = D.theta + base;
-    float* target = D.target + base;
-    float* grad = D.grad + base;
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    int* idx = D.idx + (size_t)p * D.n_agents * D.batch_max;
-    const int O = R.obs_dim[0], nA = N.L[nl - 1].n, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
-
-    const unsigned long long counter = a.rng_counter;
-    if (a.device_rng) {
-        draw_indices(idx, reinterpret_cast<int*>(S.y), B, a.size, counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (p + 1));
-    }
-    __syncthreads();
-
-    // ---- TD targets with the target net
-    for (int r0 = 0; r0 < B; r0 += rc) {
-        const int nv = min(rc, B - r0);
-        gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.nobs_off[0], O, 0);
-        zero_cols(S.xin, S.xp, rc, O, k0pad);
-        __syncthreads();
-        mlp_fwd(N, 0, nl, target, S, ACT_NONE);
-        for (int r = threadIdx.x; r < nv; r += kWG) {
-            float mx = S.outb[r * S.op];
-            for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
-            const float* rec = ring + (size_t)idx[r0 + r] * R.stride;
-            S.y[r0 + r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
+    const int n = D.n_agents, p = blockIdx.x / n, ag = blockIdx.x - p * n, B = a.batch;
+    int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max;
+    const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
+    draw_indices(idx, reinterpret_cast<int*>(smem), B, a.size, a.rng_counter, (unsigned)ag, key);
+    if (want_noise) {
+        const int am = D.act_max;
+        float* noise0 = D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am;
+        float* noise1 = noise0 + (size_t)D.batch_max * am;
+        for (int e = threadIdx.x; e < B * am; e += kWG) {
+            float n0, n1;
+            normal2(philox4x32_10(a.rng_counter, 0x4000u + (unsigned)ag, (unsigned)e, key), n0, n1);
+            noise0[e] = n0;
+            noise1[e] = n1;
         }
-        __syncthreads();
-    }
-    // ---- online forward, MSE delta on the taken action, backward
-    float lossp = 0.f;
-    for (int r0 = 0; r0 < B; r0 += rc) {
-        const int nv = min(rc, B - r0);
-        gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
-        zero_cols(S.xin, S.xp, rc, O, k0pad);
-        __syncthreads();
-        mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
-        for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-            const int r = e / npad, j = e - r * npad;
-            float d = 0.f;
-            if (r < nv) {
-                const int ar = (int)ring[(size_t)idx[r0 + r] * R.stride + R.act_off[0]];   // actions.long() (DQN.py:114)
-                if (j == ar) {
-                    const float diff = S.outb[r * S.op + j] - S.y[r0 + r];
-                    d = 2.f * diff / (float)B;
-                    lossp += diff * diff;
-                }
-            }
-            S.outb[r * S.op + j] = d;
-        }
-        __syncthreads();
-        mlp_bwd(N, 0, nl, theta, grad, S, r0 == 0, false, 0, 0);
-    }
-    const float loss = block_sum(lossp, S.red) / (float)B;
-    __syncthreads();
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t = steps[0] + 1;
-    const float gn = adam_net(N.size, theta, D.m + base, D.v + base, grad, target, a.critic_lr, a.adam_eps, a.beta1,
-                              a.beta2, 0.f, a.clip_norm, t, a.tau, S.red);
-    if (threadIdx.x == 0) {
-        steps[0] = t;
-        float* st = D.stats + (size_t)p * D.n_agents * ST_COUNT;
-        st[ST_CRITIC_LOSS] = loss;
-        st[ST_CRITIC_GNORM] = gn;
     }
 }
 
-// ------------------------------------------------------------------- DDPG / TD3 / SAC / MADDPG
-// One workgroup per (learner, agent).  DDPG_simple.py:137-156, TD3.py:189-233, SAC.py:222-260,
-// MADDPG_simple.py:165-186.  MADDPG's target nets are read by every agent's workgroup, so its
-// soft updates run in `soft_update_kernel` after this launch; the single-agent algorithms fold
-// them into the Adam pass.
-__global__ __launch_bounds__(256) void ac_update_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+// ------------------------------------------------------------------------------------- DQN
+// DQN.learn (DQN_file/DQN.py:104-118) for one row chunk: y = r + gamma*max_a Q_t(s',a)*(1-d);
+// delta = 2(Q(s)[a] - y)/B on the taken action; backward -> partial slab.
+__global__ __launch_bounds__(256) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
-    const int n = D.n_agents, p = blockIdx.x / n, ag = blockIdx.x - p * n;
+    const UnitSlice us = unit_slice(ns);
+    const int p = us.unit, sl = us.slice;
+    if (p >= D.P) return;
+    const NetDesc& N = D.net[0];
+    const RecordDesc& R = D.rec;
+    const Lds S = carve(D, smem);
+    const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
+    const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
+    const float* theta = D.theta + base;
+    const float* target = D.target + base;
+    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0];
+    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    const int* idx = D.idx + (size_t)p * D.n_agents * D.batch_max + r0;
+    const int O = R.obs_dim[0], nA = N.L[nl - 1].n, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
+
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
+    zero_cols(S.xin, S.xp, rc, O, k0pad);
+    __syncthreads();
+    mlp_fwd(N, 0, nl, target, S, ACT_NONE);
+    for (int r = threadIdx.x; r < nv; r += kWG) {
+        float mx = S.outb[r * S.op];
+        for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+        const float* rec = ring + (size_t)idx[r] * R.stride;
+        S.y[r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
+    }
+    __syncthreads();
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], O, 0);
+    zero_cols(S.xin, S.xp, rc, O, k0pad);
+    __syncthreads();
+    mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
+    float lossp = 0.f;
+    for (int e = threadIdx.x; e < rc * npad; e += kWG) {
+        const int r = e / npad, j = e - r * npad;
+        float d = 0.f;
+        if (r < nv) {
+            const int ar = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];   // actions.long() (DQN.py:114)
+            if (j == ar) {
+                const float diff = S.outb[r * S.op + j] - S.y[r];
+                d = 2.f * diff / (float)B;
+                lossp += diff * diff;
+            }
+        }
+        S.outb[r * S.op + j] = d;
+    }
+    __syncthreads();
+    mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);
+    const float ls = block_sum(lossp, S.red);
+    if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
+}
+
+// ------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: critic
+// TD target with the target nets, twin/single critic forward, MSE delta, backward -> slab.
+// DDPG_simple.py:139-149, TD3.py:193-213, SAC.py:226-238, MADDPG_simple.py:169-176.
+__global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const UnitSlice us = unit_slice(ns);
+    const int n = D.n_agents;
+    if (us.unit >= D.P * n) return;
+    const int p = us.unit / n, ag = us.unit - p * n, sl = us.slice;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NC = D.net[2 * ag + 1];
+    const Lds S = carve(D, smem);
+    const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
+    const bool sac = (D.algo == ALGO_SAC);
+    const size_t lbase = (size_t)p * D.learner_stride;
+    const float* thC = D.theta + lbase + D.net_off[2 * ag + 1];
+    const float* tgC = D.target + lbase + D.net_off[2 * ag + 1];
+    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag + 1];
+    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    const int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max + r0;
+    const int am = D.act_max;
+    const float* noise0 = D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am + (size_t)r0 * am;
+    const int heads = NC.heads, ql = NC.n_layers / heads;
+    const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
+    const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+    const float invB = 1.f / (float)B;
+
+    // ---- a' = actor_target_j(s'_j) for every agent j (MADDPG_simple.py:155; n = 1 otherwise)
+    float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
+    for (int j = 0; j < n; ++j) {
+        const NetDesc& NJ = D.net[2 * j];
+        const float* tgJ = D.target + lbase + D.net_off[2 * j];
+        const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
+        gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
+        zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
+        __syncthreads();
+        mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
+        if (sac) {                                  // SAC.py:70-97 on actor_target (SAC.py:227)
+            const int r = threadIdx.x;
+            if (r < rc) {
+                float lp = 0.f;
+                for (int c = 0; c < Aj; ++c) {
+                    const float mean = S.outb[r * S.op + c];
+                    const float ls = fminf(fmaxf(tgJ[NJ.extra_off + c], -20.f), 2.f);
+                    const float sd = expf(ls);
+                    const float eps = (r < nv) ? noise0[(size_t)r * am + c] : 0.f;
+                    const float u = mean + sd * eps;
+                    const float du = u - mean;
+                    lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                    lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                    S.abuf[r * S.ap + cj + c] = tanhf(u);
+                }
+                lp_next = lp;
+            }
+        } else {
+            for (int e = threadIdx.x; e < rc * Aj; e += kWG) {
+                const int r = e / Aj, c = e - r * Aj;
+                float v = S.outb[r * S.op + c];
+                if (a.use_policy_noise && r < nv) {   // TD3.py:196-198
+                    float nz = a.policy_noise_scale * (noise0[(size_t)r * am + c] * a.policy_noise);
+                    nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
+                    v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
+                }
+                S.abuf[r * S.ap + cj + c] = v;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- centralised target critic on [next_obs_all | a'_all]
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
+    for (int e = threadIdx.x; e < rc * AT; e += kWG) {
+        const int r = e / AT, c = e - r * AT;
+        S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
+    }
+    zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+    __syncthreads();
+    mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
+    float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
+    if (heads == 2) {
+        __syncthreads();
+        mlp_fwd(NC, ql, ql, tgC, S, ACT_NONE);
+        if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
+    }
+    if (threadIdx.x < nv) {
+        const float* rec = ring + (size_t)idx[threadIdx.x] * R.stride;
+        const float rew = rec[R.rew_off + ag], done = rec[R.done_off + ag];
+        S.y[threadIdx.x] = sac ? rew + a.gamma * (1.f - done) * (q + alpha * (-lp_next))
+                               : rew + a.gamma * q * (1.f - done);
+    }
+    __syncthreads();
+
+    // ---- critic heads: forward, MSE delta, backward
+    float lossp = 0.f;
+    for (int h = 0; h < heads; ++h) {
+        gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
+        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+        __syncthreads();
+        mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
+        const int npad = NC.L[h * ql + ql - 1].n_pad;
+        for (int e = threadIdx.x; e < rc * npad; e += kWG) {
+            const int r = e / npad, c = e - r * npad;
+            float d = 0.f;
+            if (c == 0 && r < nv) {
+                const float diff = S.outb[r * S.op] - S.y[r];
+                d = 2.f * diff * invB;
+                lossp += diff * diff;
+            }
+            S.outb[r * S.op + c] = d;
+        }
+        __syncthreads();
+        mlp_bwd(NC, h * ql, ql, thC, slab, S, true, false, 0, 0);
+    }
+    const float ls = block_sum(lossp, S.red);
+    if (threadIdx.x == 0) D.part[(((size_t)p * n + ag) * D.S + sl) * 4] = ls;
+}
+
+// -------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: actor
+// a = actor(s); Q(s, a) through the (already updated, frozen) critic; dQ/da; actor backward.
+// DDPG_simple.py:151-154, TD3.py:224-231, SAC.py:244-252, MADDPG_simple.py:178-183.
+__global__ __launch_bounds__(256) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const UnitSlice us = unit_slice(ns);
+    const int n = D.n_agents;
+    if (us.unit >= D.P * n) return;
+    const int p = us.unit / n, ag = us.unit - p * n, sl = us.slice;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[2 * ag];
     const NetDesc& NC = D.net[2 * ag + 1];
     const Lds S = carve(D, smem);
-    const int rc = D.rc, B = a.batch;
-    const bool sac = (D.algo == ALGO_SAC), maddpg = (D.algo == ALGO_MADDPG);
+    const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
+    const bool sac = (D.algo == ALGO_SAC);
     const size_t lbase = (size_t)p * D.learner_stride;
-    const size_t offA = lbase + D.net_off[2 * ag], offC = lbase + D.net_off[2 * ag + 1];
-    float* thA = D.theta + offA;
-    float* thC = D.theta + offC;
-    float* gA = D.grad + offA;
-    float* gC = D.grad + offC;
-    float* tgA = D.target + offA;
-    float* tgC = D.target + offC;
+    const float* thA = D.theta + lbase + D.net_off[2 * ag];
+    const float* thC = D.theta + lbase + D.net_off[2 * ag + 1];
+    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag];
     const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max;
-    float* noise0 = D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * D.act_max;
-    float* noise1 = noise0 + (size_t)D.batch_max * D.act_max;
+    const int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max + r0;
     const int am = D.act_max;
+    const float* noise1 = D.noise + (((size_t)p * n + ag) * 2 + 1) * D.batch_max * am + (size_t)r0 * am;
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const int Oa = R.obs_dim[ag], Aa = R.act_dim[ag], acol = R.act_off[ag] - R.act_off[0];
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
-
-    const unsigned long long counter = a.rng_counter;
-    if (a.device_rng) {
-        const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
-        draw_indices(idx, reinterpret_cast<int*>(S.y), B, a.size, counter, (unsigned)ag, key);
-        for (int e = threadIdx.x; e < B * am; e += kWG) {
-            float n0, n1;
-            normal2(philox4x32_10(counter, 0x4000u + (unsigned)ag, (unsigned)e, key), n0, n1);
-            noise0[e] = n0;
-            noise1[e] = n1;
-        }
-    }
-    __syncthreads();
-
-    // ================================ TD targets ================================
-    for (int r0 = 0; r0 < B; r0 += rc) {
-        const int nv = min(rc, B - r0);
-        float lp_next = 0.f;                        // SAC: log pi(a'|s') of row threadIdx.x
-        for (int j = 0; j < n; ++j) {
-            const NetDesc& NJ = D.net[2 * j];
-            const float* tgJ = D.target + lbase + D.net_off[2 * j];
-            const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
-            gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.nobs_off[j], Oj, 0);
-            zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
-            __syncthreads();
-            mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
-            if (sac) {                              // SAC.py:70-97 on actor_target (SAC.py:227)
-                const int r = threadIdx.x;
-                if (r < rc) {
-                    float lp = 0.f;
-                    for (int c = 0; c < Aj; ++c) {
-                        const float mean = S.outb[r * S.op + c];
-                        const float ls = fminf(fmaxf(tgJ[NJ.extra_off + c], -20.f), 2.f);
-                        const float sd = expf(ls);
-                        const float eps = (r < nv) ? noise0[(size_t)(r0 + r) * am + c] : 0.f;
-                        const float u = mean + sd * eps;
-                        const float du = u - mean;
-                        lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
-                        lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
-                        S.abuf[r * S.ap + cj + c] = tanhf(u);
-                    }
-                    lp_next = lp;
-                }
-            } else {
-                for (int e = threadIdx.x; e < rc * Aj; e += kWG) {
-                    const int r = e / Aj, c = e - r * Aj;
-                    float v = S.outb[r * S.op + c];
-                    if (a.use_policy_noise && r < nv) {   // TD3.py:196-198
-                        float nz = a.policy_noise_scale * (noise0[(size_t)(r0 + r) * am + c] * a.policy_noise);
-                        nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
-                        v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
-                    }
-                    S.abuf[r * S.ap + cj + c] = v;
-                }
-            }
-            __syncthreads();
-        }
-        // centralised target critic on [next_obs_all | a'_all]
-        gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.nobs_off[0], OT, 0);
-        for (int e = threadIdx.x; e < rc * AT; e += kWG) {
-            const int r = e / AT, c = e - r * AT;
-            S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
-        }
-        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        __syncthreads();
-        mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
-        float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
-        if (heads == 2) {
-            __syncthreads();
-            mlp_fwd(NC, ql, ql, tgC, S, ACT_NONE);
-            if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
-        }
-        if (threadIdx.x < nv) {
-            const float* rec = ring + (size_t)idx[r0 + threadIdx.x] * R.stride;
-            const float rew = rec[R.rew_off + ag], done = rec[R.done_off + ag];
-            S.y[r0 + threadIdx.x] = sac ? rew + a.gamma * (1.f - done) * (q + alpha * (-lp_next))
-                                        : rew + a.gamma * q * (1.f - done);
-        }
-        __syncthreads();
-    }
-
-    // ================================ critic step ================================
-    float lossp = 0.f;
-    for (int h = 0; h < heads; ++h) {
-        for (int r0 = 0; r0 < B; r0 += rc) {
-            const int nv = min(rc, B - r0);
-            gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], OT + AT, 0);
-            zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-            __syncthreads();
-            mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
-            const int npad = NC.L[h * ql + ql - 1].n_pad;
-            for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-                const int r = e / npad, c = e - r * npad;
-                float d = 0.f;
-                if (c == 0 && r < nv) {
-                    const float diff = S.outb[r * S.op] - S.y[r0 + r];
-                    d = 2.f * diff * invB;
-                    lossp += diff * diff;
-                }
-                S.outb[r * S.op + c] = d;
-            }
-            __syncthreads();
-            mlp_bwd(NC, h * ql, ql, thC, gC, S, r0 == 0, false, 0, 0);
-        }
-    }
-    const float closs = block_sum(lossp, S.red) * invB;
-    __syncthreads();
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    float* st = D.stats + ((size_t)p * n + ag) * ST_COUNT;
-    const int tC = steps[2 * ag + 1] + 1;
-    const bool fold_targets = !maddpg && a.do_actor;
-    const float gnC = adam_net(NC.size, thC, D.m + offC, D.v + offC, gC, fold_targets ? tgC : nullptr, a.critic_lr,
-                               a.adam_eps, a.beta1, a.beta2, a.critic_wd, a.clip_norm, tC, a.tau, S.red);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        steps[2 * ag + 1] = tC;
-        st[ST_CRITIC_LOSS] = closs;
-        st[ST_CRITIC_GNORM] = gnC;
-    }
-    if (!a.do_actor) return;
-
-    // ================================ actor step ================================
-    float alossp = 0.f, entp = 0.f, gls = 0.f;      // gls: d loss / d log_std[threadIdx.x] (SAC)
     const int ct0 = (OT + acol) / 16, ct1 = (OT + acol + Aa + 15) / 16;
-    const int nq = sac ? heads : 1;                 // SAC: mean of the twins; TD3: Q1 only (TD3.py:227)
+    const int nq = sac ? heads : 1;                 // SAC: mean of the twins (SAC.py:250); TD3: Q1 only (TD3.py:227)
     const float dq = sac ? -0.5f * invB : -invB;
-    for (int r0 = 0; r0 < B; r0 += rc) {
-        const int nv = min(rc, B - r0);
-        // -- a = actor(obs)
-        gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[ag], Oa, 0);
-        zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-        __syncthreads();
-        mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
-        float lp = 0.f;
-        if (sac) {
-            const int r = threadIdx.x;
-            if (r < rc) {
-                for (int c = 0; c < Aa; ++c) {
-                    const float mean = S.outb[r * S.op + c];
-                    const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
-                    const float sd = expf(ls);
-                    const float eps = (r < nv) ? noise1[(size_t)(r0 + r) * am + c] : 0.f;
-                    const float u = mean + sd * eps;
-                    const float du = u - mean;
-                    lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
-                    lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
-                    S.abuf[r * S.ap + c] = tanhf(u);
-                }
-            }
-        } else {
-            for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-                const int r = e / Aa, c = e - r * Aa;
-                S.abuf[r * S.ap + c] = S.outb[r * S.op + c];
+
+    // -- a = actor(obs)
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
+    zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
+    __syncthreads();
+    mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
+    float lp = 0.f;
+    if (sac) {
+        const int r = threadIdx.x;
+        if (r < rc) {
+            for (int c = 0; c < Aa; ++c) {
+                const float mean = S.outb[r * S.op + c];
+                const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
+                const float sd = expf(ls);
+                const float eps = (r < nv) ? noise1[(size_t)r * am + c] : 0.f;
+                const float u = mean + sd * eps;
+                const float du = u - mean;
+                lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                S.abuf[r * S.ap + c] = tanhf(u);
             }
         }
+    } else {
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
+            S.abuf[r * S.ap + c] = S.outb[r * S.op + c];
+        }
+    }
+    for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
+        const int r = e / Aa, c = e - r * Aa;
+        S.dabuf[r * S.ap + c] = 0.f;
+    }
+    __syncthreads();
+    // -- dQ/da through the critic head(s)
+    float qsum = 0.f;
+    for (int h = 0; h < nq; ++h) {
+        gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
+        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
+            const int r = e / Aa, c = e - r * Aa;
+            S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
+        }
+        __syncthreads();
+        mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
+        if (threadIdx.x < nv) qsum += S.outb[threadIdx.x * S.op];
+        __syncthreads();
+        const int npad = NC.L[h * ql + ql - 1].n_pad;
+        for (int e = threadIdx.x; e < rc * npad; e += kWG) {
+            const int r = e / npad, c = e - r * npad;
+            S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
+        }
+        __syncthreads();
+        mlp_bwd(NC, h * ql, ql, thC, nullptr, S, false, true, ct0, ct1);
+        for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
+            const int r = e / Aa, c = e - r * Aa;
+            S.dabuf[r * S.ap + c] += S.xin[r * S.xp + OT + acol + c];
+        }
+        __syncthreads();
+    }
+    float alossp = 0.f, entp = 0.f;
+    if (threadIdx.x < nv) {
+        if (sac) {
+            alossp = -(qsum * 0.5f) - alpha * (-lp);      // (-Q_pi - alpha*entropy), SAC.py:251
+            entp = -lp;
+        } else {
+            alossp = -qsum;
+        }
+    }
+    // -- actor forward again (activations for its backward), head delta, backward
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
+    zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
+    __syncthreads();
+    mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
+    const int napad = NA.L[NA.n_layers - 1].n_pad;
+    for (int e = threadIdx.x; e < rc * napad; e += kWG) {
+        const int r = e / napad, c = e - r * napad;
+        float d = 0.f;
+        if (r < nv && c < Aa) {
+            if (sac) {
+                const float av = S.abuf[r * S.ap + c];
+                d = S.dabuf[r * S.ap + c] * (1.f - av * av) + (alpha * invB) * (2.f * av);
+                const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
+                S.dabuf[r * S.ap + c] = d * expf(ls) * noise1[(size_t)r * am + c] - alpha * invB;   // d/d log_std
+            } else {
+                const float av = S.outb[r * S.op + c];      // tanh output
+                d = S.dabuf[r * S.ap + c] * (1.f - av * av);
+            }
+        } else if (sac && c < Aa) {
             S.dabuf[r * S.ap + c] = 0.f;
         }
-        __syncthreads();
-        // -- dQ/da through the critic head(s), parameters frozen
-        float qsum = 0.f;
-        for (int h = 0; h < nq; ++h) {
-            gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], OT + AT, 0);
-            zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-            __syncthreads();
-            for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-                const int r = e / Aa, c = e - r * Aa;
-                S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
-            }
-            __syncthreads();
-            mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
-            if (threadIdx.x < nv) qsum += S.outb[threadIdx.x * S.op];
-            __syncthreads();
-            const int npad = NC.L[h * ql + ql - 1].n_pad;
-            for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-                const int r = e / npad, c = e - r * npad;
-                S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
-            }
-            __syncthreads();
-            mlp_bwd(NC, h * ql, ql, thC, nullptr, S, false, true, ct0, ct1);
-            for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-                const int r = e / Aa, c = e - r * Aa;
-                S.dabuf[r * S.ap + c] += S.xin[r * S.xp + OT + acol + c];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x < nv) {
-            if (sac) {
-                alossp += -(qsum * 0.5f) - alpha * (-lp);     // (-Q_pi - alpha*entropy), SAC.py:251
-                entp += -lp;
-            } else {
-                alossp += -qsum;
-            }
-        }
-        // -- actor forward again (activations for its backward), head delta, backward
-        gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[ag], Oa, 0);
-        zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-        __syncthreads();
-        mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
-        const int napad = NA.L[NA.n_layers - 1].n_pad;
-        for (int e = threadIdx.x; e < rc * napad; e += kWG) {
-            const int r = e / napad, c = e - r * napad;
-            float d = 0.f;
-            if (r < nv && c < Aa) {
-                if (sac) {
-                    const float av = S.abuf[r * S.ap + c];
-                    d = S.dabuf[r * S.ap + c] * (1.f - av * av) + (alpha * invB) * (2.f * av);
-                    const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
-                    // per-element contribution to d/d log_std, column-summed below
-                    S.dabuf[r * S.ap + c] = d * expf(ls) * noise1[(size_t)(r0 + r) * am + c] - alpha * invB;
-                } else {
-                    const float av = S.outb[r * S.op + c];      // tanh output
-                    d = S.dabuf[r * S.ap + c] * (1.f - av * av);
-                }
-            } else if (sac && c < Aa) {
-                S.dabuf[r * S.ap + c] = 0.f;
-            }
-            S.outb[r * S.op + c] = d;
-        }
-        __syncthreads();
-        if (sac && threadIdx.x < Aa)
-            for (int r = 0; r < rc; ++r) gls += S.dabuf[r * S.ap + threadIdx.x];
-        mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+        S.outb[r * S.op + c] = d;
     }
-    if (sac && threadIdx.x < Aa) {
-        const float raw = thA[NA.extra_off + threadIdx.x];
-        gA[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? gls : 0.f;
-    }
-    const float aloss = block_sum(alossp, S.red) * invB;
-    const float ent_mean = sac ? block_sum(entp, S.red) * invB : 0.f;
     __syncthreads();
-    const int tA = steps[2 * ag] + 1;
-    const float gnA = adam_net(NA.size, thA, D.m + offA, D.v + offA, gA, maddpg ? nullptr : tgA, a.actor_lr, a.adam_eps,
-                               a.beta1, a.beta2, 0.f, a.clip_norm, tA, a.tau, S.red);
+    if (sac && threadIdx.x < Aa) {
+        float gls = 0.f;
+        for (int r = 0; r < rc; ++r) gls += S.dabuf[r * S.ap + threadIdx.x];
+        const float raw = thA[NA.extra_off + threadIdx.x];
+        slab[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? gls : 0.f;
+    }
+    mlp_bwd(NA, 0, NA.n_layers, thA, slab, S, true, false, 0, 0);
+    const float la = block_sum(alossp, S.red);
+    const float le = sac ? block_sum(entp, S.red) : 0.f;
     if (threadIdx.x == 0) {
-        steps[2 * ag] = tA;
-        st[ST_ACTOR_LOSS] = aloss;
-        st[ST_ACTOR_GNORM] = gnA;
-        if (sac) {
-            // Alpha.update_alpha (SAC.py:154-169,257-260): loss = (alpha*(entropy - H_target).detach()).mean()
+        float* pt = D.part + (((size_t)p * n + ag) * D.S + sl) * 4;
+        pt[0] = la;
+        pt[1] = le;
+    }
+}
+
+// ------------------------------------------------------------------- reduce + clip + Adam
+// Two bandwidth-bound launches over float4 lanes, `G` workgroups per (learner, agent) net:
+//   reduce_kernel: g = sum over the row-chunk slabs in a fixed order (deterministic), write g,
+//                  per-workgroup sum of squares -> gsq; workgroup 0 advances the Adam step count.
+//   adam_kernel  : total norm from gsq -> clip_grad_norm_ coefficient -> torch-order Adam ->
+//                  optional soft target update, streaming theta/m/v/target once.  Workgroup 0
+//                  also publishes the losses and performs SAC's alpha step (SAC.py:154-169,257-260).
+// which = 0: critic / Q-net, 1: actor.
+struct AdamArgs {
+    int which, ns, batch, soft, sac_alpha, G;
+    float lr, eps, beta1, beta2, wd, clip, tau, alpha_lr, target_entropy;
+};
+
+constexpr int kAdamVec = 8;      // float4 per thread per workgroup
+
+__device__ __forceinline__ int adam_net_index(const EngineDesc& D, int which, int ag) {
+    return (D.algo == ALGO_DQN) ? 0 : (which == 0 ? 2 * ag + 1 : 2 * ag);
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
+    __shared__ float red[8];
+    const EngineDesc& D = *Dp;
+    const int n = D.n_agents, unit = blockIdx.x / a.G, wg = blockIdx.x - unit * a.G;
+    const int p = unit / n, ag = unit - p * n;
+    const int net = adam_net_index(D, a.which, ag);
+    const NetDesc& N = D.net[net];
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
+    const int n4 = N.size / 4;
+    f32x4* g = reinterpret_cast<f32x4*>(D.grad + off);
+    const f32x4* slab = reinterpret_cast<const f32x4*>(D.slab + (size_t)p * D.S * D.learner_stride + D.net_off[net]);
+    const size_t ls4 = (size_t)D.learner_stride / 4;
+    float ss = 0.f;
+    const int base = wg * (kWG * kAdamVec);
+#pragma unroll
+    for (int j = 0; j < kAdamVec; ++j) {
+        const int i = base + j * kWG + threadIdx.x;
+        if (i < n4) {
+            f32x4 s = slab[i];
+            for (int k = 1; k < a.ns; ++k) s += slab[(size_t)k * ls4 + i];
+            g[i] = s;
+            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+        }
+    }
+    const float tot = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        D.gsq[(size_t)unit * D.Gmax + wg] = tot;
+        if (wg == 0) D.steps[(size_t)p * (kMaxNets + 1) + net] += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
+    const EngineDesc& D = *Dp;
+    const int n = D.n_agents, unit = blockIdx.x / a.G, wg = blockIdx.x - unit * a.G;
+    const int p = unit / n, ag = unit - p * n;
+    const int net = adam_net_index(D, a.which, ag);
+    const NetDesc& N = D.net[net];
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
+    const int n4 = N.size / 4, Gn = (n4 + kWG * kAdamVec - 1) / (kWG * kAdamVec);
+    float ss = 0.f;
+    for (int k = 0; k < Gn; ++k) ss += D.gsq[(size_t)unit * D.Gmax + k];      // same order in every workgroup
+    const float total = sqrtf(ss);
+    float coef = 1.f;
+    if (a.clip > 0.f) coef = fminf(a.clip / (total + 1e-6f), 1.f);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t = steps[net];                                                   // advanced by reduce_kernel
+    const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
+    const float step = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
+    const f32x4* g = reinterpret_cast<const f32x4*>(D.grad + off);
+    f32x4* th = reinterpret_cast<f32x4*>(D.theta + off);
+    f32x4* m = reinterpret_cast<f32x4*>(D.m + off);
+    f32x4* v = reinterpret_cast<f32x4*>(D.v + off);
+    f32x4* tg = reinterpret_cast<f32x4*>(D.target + off);
+    const int base = wg * (kWG * kAdamVec);
+#pragma unroll
+    for (int j = 0; j < kAdamVec; ++j) {
+        const int i = base + j * kWG + threadIdx.x;
+        if (i < n4) {
+            f32x4 gi = g[i] * coef, thi = th[i], mi = m[i], vi = v[i];
+            if (a.wd != 0.f) gi += a.wd * thi;
+            mi = mi + (gi - mi) * w1;
+            vi = vi * a.beta2 + (w2 * gi) * gi;
+            f32x4 denom;
+            denom.x = sqrtf(vi.x) / bc2s + a.eps; denom.y = sqrtf(vi.y) / bc2s + a.eps;
+            denom.z = sqrtf(vi.z) / bc2s + a.eps; denom.w = sqrtf(vi.w) / bc2s + a.eps;
+            thi = thi - step * (mi / denom);
+            m[i] = mi; v[i] = vi; th[i] = thi;
+            if (a.soft) tg[i] = tg[i] * tk + thi * a.tau;
+        }
+    }
+    if (wg == 0 && threadIdx.x == 0) {
+        const float* pt = D.part + ((size_t)p * n + ag) * D.S * 4;
+        float l0 = 0.f, l1 = 0.f;
+        for (int k = 0; k < a.ns; ++k) { l0 += pt[4 * k]; l1 += pt[4 * k + 1]; }
+        float* st = D.stats + ((size_t)p * n + ag) * ST_COUNT;
+        const float invB = 1.f / (float)a.batch;
+        st[a.which == 0 ? ST_CRITIC_LOSS : ST_ACTOR_LOSS] = l0 * invB;
+        st[a.which == 0 ? ST_CRITIC_GNORM : ST_ACTOR_GNORM] = total;
+        if (a.sac_alpha) {
             float* al = D.alpha + p * 4;
+            const float alpha = al[3];
+            const float ent_mean = l1 * invB;
             const float mean_term = ent_mean - a.target_entropy;
-            const float g = alpha * mean_term;            // d loss / d log_alpha
-            const int t = steps[kMaxNets] + 1;
+            const float gl = alpha * mean_term;            // d alpha_loss / d log_alpha
+            const int ta = steps[kMaxNets] + 1;
             float mi = al[1], vi = al[2];
-            mi = mi + (g - mi) * (1.f - a.beta1);
-            vi = vi * a.beta2 + ((1.f - a.beta2) * g) * g;
-            const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
-            const float denom = sqrtf(vi) / (float)sqrt(bc2) + 1e-8f;
-            al[0] = al[0] - (float)((double)a.alpha_lr / bc1) * (mi / denom);
+            mi = mi + (gl - mi) * (1.f - a.beta1);
+            vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
+            const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
+            const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
+            al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
             al[1] = mi;
             al[2] = vi;
             al[3] = expf(al[0]);
-            steps[kMaxNets] = t;
+            steps[kMaxNets] = ta;
             st[ST_ALPHA_LOSS] = alpha * mean_term;
             st[ST_ALPHA] = al[3];
             st[ST_ENTROPY] = ent_mean;

@@ -238,3 +238,14 @@ class Engine:
         ms = C.c_float(0)
         N.check(self._L.frl_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def profile(self, on):
+        N.check(self._L.frl_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """-> {slot name: (total ms, launches)} of frl_learn's kernels since profile(True)."""
+        ms = (C.c_double * 8)()
+        cnt = (C.c_longlong * 8)()
+        N.check(self._L.frl_profile_read(self._h, ms, cnt))
+        names = ["draw", "grad_critic", "adam_critic", "grad_actor", "adam_actor", "soft_update", "ppo", "_"]
+        return {names[k]: (ms[k], cnt[k]) for k in range(8) if cnt[k]}

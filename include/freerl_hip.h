@@ -201,6 +201,10 @@ int frl_gae(frl_engine* e, const float* td_delta_dev, const float* adv_done_dev,
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);
 int frl_timer_stop(frl_engine* e, float* ms_out);           /* synchronises */
+/* per-kernel durations of frl_learn's launch chain (HIP events around every launch while enabled):
+ * slots 0 draw, 1 grad(critic/Q), 2 adam(critic/Q), 3 grad(actor), 4 adam(actor), 5 soft update */
+int frl_profile_enable(frl_engine* e, int on);
+int frl_profile_read(frl_engine* e, double* ms_sum8_out, long long* count8_out);
 
 #ifdef __cplusplus
 }
