@@ -1,0 +1,176 @@
+"""Drop-in for the reference's `Buffer.py`: `from Buffer import Buffer` ->
+`from freerl_amd.Buffer import Buffer` (same constructor, methods and public attributes).
+
+class Buffer           <- TD3_file/Buffer.py:11-61 (= DQN_file/Buffer.py:12-62, DDPG/SAC/MADDPG copies)
+class Buffer_for_PPO   <- PPO_file/Buffer.py:266-323
+
+Storage is a GPU-resident ring of fp32 transition records (one 128-byte-aligned row per
+transition) instead of five float64 host arrays; `add` stages into pinned host memory,
+`sample(indices)` is ONE gather launch that writes the five dense fp32 tensors the reference
+returns.  float32 storage is lossless for what the reference stores: observations and actions
+arrive as float32, rewards are cast to float32 by `sample` anyway (Buffer.py:52), dones are
+0/1.
+"""
+import numpy as np
+import torch
+
+from . import _native as N
+from ._core import Engine, F32, resolve_device
+
+
+class _RingView:
+    """Shared implementation: a (learner, agent) view of an engine's replay ring."""
+
+    def _attach(self, engine, learner, agent, device):
+        self._e, self._learner, self._agent = engine, learner, agent
+        self._own = False
+        self.device = device
+        lay = engine.layout
+        self._obs = (lay.obs_off[agent], lay.obs_dim[agent])
+        self._act = (lay.act_off[agent], lay.act_dim[agent])
+        self._rew = (lay.rew_off + agent, 1)
+        self._nobs = (lay.next_obs_off[agent], lay.obs_dim[agent])
+        self._done = (lay.done_off + agent, 1)
+        self._extra = (lay.extra_off, lay.extra)
+
+    # -- cursor attributes the reference exposes (PER reads buffer._index, DQN_file/Buffer.py:96)
+    @property
+    def _index(self):
+        return self._e.cursor(self._learner)[0]
+
+    @_index.setter
+    def _index(self, v):
+        self._e.set_cursor(self._learner, int(v), self._e.cursor(self._learner)[1])
+
+    @property
+    def _size(self):
+        return self._e.cursor(self._learner)[1]
+
+    @_size.setter
+    def _size(self, v):
+        self._e.set_cursor(self._learner, self._e.cursor(self._learner)[0], int(v))
+
+    def __len__(self):
+        return self._size
+
+    def _gather(self, indices, fields):
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        outs = [torch.empty((idx.size, w), dtype=torch.float32, device="cuda:%d" % self._e.cfg.device_id)
+                for _, w in fields]
+        self._e.sample_into(self._learner, idx, fields, [t.data_ptr() for t in outs])
+        if self.device.type != "cuda":
+            outs = [t.to(self.device) for t in outs]
+        return outs
+
+    def _column(self, field, squeeze=False, dtype=None):
+        rows = self._e.read_rows(self._learner, 0, self.capacity)
+        a = rows[:, field[0]:field[0] + field[1]]
+        a = a[:, 0] if squeeze else a
+        return a.astype(dtype) if dtype is not None else a
+
+    # -- the reference's public ndarray fields, as read-only copies of the ring content
+    @property
+    def obs(self):
+        return self._column(self._obs)
+
+    @property
+    def actions(self):
+        return self._column(self._act)
+
+    @property
+    def rewards(self):
+        return self._column(self._rew, squeeze=True)
+
+    @property
+    def next_obs(self):
+        return self._column(self._nobs)
+
+    @property
+    def dones(self):
+        return self._column(self._done, squeeze=True, dtype=bool)
+
+
+class Buffer(_RingView):
+    """replay buffer for each agent (TD3_file/Buffer.py:11-61)."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device, *, batch_max=1024, _engine=None, _learner=0, _agent=0):
+        self.capacity = capacity = int(capacity)
+        if _engine is None:
+            hip_id, dev = resolve_device(device)
+            eng = Engine(N.ALGO_REPLAY_ONLY, int(obs_dim), int(act_dim), max(capacity, 1), device_id=hip_id,
+                         batch_max=batch_max)
+            self._attach(eng, 0, 0, dev)
+            self._own = True
+        else:
+            self._attach(_engine, _learner, _agent, device)
+        self._rec = np.zeros(self._e.width, dtype=F32)
+
+    def add(self, obs, action, reward, next_obs, done):
+        """add an experience to the memory (Buffer.py:28-38)."""
+        if self._own or self._e.n_agents == 1:
+            r = self._rec
+            r[self._obs[0]:self._obs[0] + self._obs[1]] = np.asarray(obs, dtype=F32).reshape(-1)
+            r[self._act[0]:self._act[0] + self._act[1]] = np.asarray(action, dtype=F32).reshape(-1)
+            r[self._rew[0]] = reward
+            r[self._nobs[0]:self._nobs[0] + self._nobs[1]] = np.asarray(next_obs, dtype=F32).reshape(-1)
+            r[self._done[0]] = float(done)
+            self._e.add(self._learner, r)
+        else:
+            raise RuntimeError("per-agent views of a joint MADDPG ring are written through MADDPG.add")
+
+    def sample(self, indices):
+        """(obs[B,O], actions[B,A'], rewards[B,1], next_obs[B,O], dones[B,1]) float32 on `device`
+        (Buffer.py:40-57)."""
+        return tuple(self._gather(indices, [self._obs, self._act, self._rew, self._nobs, self._done]))
+
+
+class Buffer_for_PPO(_RingView):
+    """PPO rollout storage (PPO_file/Buffer.py:266-323): transition + per-dimension old
+    log-probs + adv_done; `all()` returns the WHOLE arrays, `clear()` resets the counters only."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device, trick=None, *, batch_max=256, _engine=None, _learner=0):
+        self.capacity = capacity = int(capacity)
+        if trick is not None and trick.get("decaystd"):
+            raise NotImplementedError("trick['decaystd'] (scalar log-prob storage, Buffer.py:277-278) is not ported")
+        self._act_dim = int(act_dim)
+        if _engine is None:
+            hip_id, dev = resolve_device(device)
+            eng = Engine(N.ALGO_REPLAY_ONLY, int(obs_dim), int(act_dim), max(capacity, 1), device_id=hip_id,
+                         batch_max=batch_max, extra_cols=int(act_dim) + 1)
+            self._attach(eng, 0, 0, dev)
+            self._own = True
+        else:
+            self._attach(_engine, _learner, 0, device)
+        self._rec = np.zeros(self._e.width, dtype=F32)
+
+    def add(self, obs, action, reward, next_obs, done, action_log_probs, adv_done):
+        r = self._rec
+        r[self._obs[0]:self._obs[0] + self._obs[1]] = np.asarray(obs, dtype=F32).reshape(-1)
+        r[self._act[0]:self._act[0] + self._act[1]] = np.asarray(action, dtype=F32).reshape(-1)
+        r[self._rew[0]] = reward
+        r[self._nobs[0]:self._nobs[0] + self._nobs[1]] = np.asarray(next_obs, dtype=F32).reshape(-1)
+        r[self._done[0]] = float(done)
+        x0 = self._extra[0]
+        r[x0:x0 + self._act_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
+        r[x0 + self._act_dim] = float(adv_done)
+        self._e.add(self._learner, r)
+
+    def clear(self):
+        self._e.set_cursor(self._learner, 0, 0)
+
+    @property
+    def action_log_probs(self):
+        return self._column((self._extra[0], self._act_dim))
+
+    @property
+    def adv_dones(self):
+        return self._column((self._extra[0] + self._act_dim, 1), squeeze=True, dtype=bool)
+
+    def all(self):
+        idx = np.arange(self.capacity, dtype=np.int64)
+        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (self._extra[0], self._act_dim),
+                  (self._extra[0] + self._act_dim, 1)]
+        # one gather per <= 16*batch_max rows (C ABI limit)
+        step = 16 * self._e.batch_max
+        chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
+        return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))

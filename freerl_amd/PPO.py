@@ -1,0 +1,106 @@
+"""`PPO` with the reference's class surface (PPO_file/PPO_with_tricks.py:179-374), Gaussian actor.
+
+    PPO(dim_info, is_continue, actor_lr, critic_lr, horizon, device, trick=None, beta=False)
+
+The whole `learn()` (value pass, GAE scan, v_target, advantage normalisation, K_epochs x
+minibatch actor/critic steps) runs in three GPU launches.  Reference defect handled: the
+committed `learn` raises TypeError at :302 (`np.zeros(..., dtype=torch.float32)`); the evident
+intent (float32 advantages) is what runs here.  Not ported yet: discrete (Categorical) and Beta
+actors, ObsNorm / reward tricks that live in the caller's loop use `freerl_amd.normalization`.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _native as N
+from ._core import DeviceNet, Engine, OptimizerView, init_layers, resolve_device
+from .Buffer import Buffer_for_PPO
+
+_TRICK_DEFAULT = dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_scaling=False, orthogonal_init=False,
+                      adam_eps=False, lr_decay=False, tanh=False, Batch_ObsNorm=False)
+
+
+class Agent:
+    def __init__(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden):
+        al = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("mean_layer", action_dim, hidden)]
+        cl = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("l3", 1, hidden)]
+        ortho = bool(trick["orthogonal_init"])
+        fa = init_layers(al, orthogonal=[1.0, 1.0, 0.01] if ortho else None)     # :92-95
+        fc = init_layers(cl, orthogonal=[1.0, 1.0, 1.0] if ortho else None)      # :165-168
+        engine.set_params(0, np.concatenate([fa, np.zeros(action_dim, np.float32)]))   # log_std zeros (:85)
+        engine.set_params(1, fc)
+        eps = 1e-5 if trick["adam_eps"] else 1e-8                                 # :191-196
+        self.actor = DeviceNet(engine, 0, al, extra=("log_std", (1, action_dim)), act_mode=N.ACT_TANHHEAD)
+        self.critic = DeviceNet(engine, 1, cl)
+        self.actor_optimizer = OptimizerView(engine, 0, actor_lr, eps=eps)
+        self.critic_optimizer = OptimizerView(engine, 1, critic_lr, eps=eps)
+
+
+class PPO:
+    def __init__(self, dim_info, is_continue, actor_lr, critic_lr, horizon, device, trick=None, beta=False, *,
+                 rng="host", hidden=128, minibatch_max=256, seed=0):
+        obs_dim, action_dim = dim_info
+        if not is_continue:
+            raise NotImplementedError("Actor_discrete / Categorical (PPO_with_tricks.py:110-121) is not ported yet")
+        if beta:
+            raise NotImplementedError("Actor_Beta (PPO_with_tricks.py:123-156) is not ported yet")
+        self.trick = dict(_TRICK_DEFAULT, **(trick or {}))
+        if self.trick["Batch_ObsNorm"]:
+            raise NotImplementedError("trick['Batch_ObsNorm'] is not ported yet")
+        self.actor_dist = {"Beta": False}
+        hip_id, self.device = resolve_device(device)
+        self.horizon = int(horizon)
+        self._e = Engine(N.ALGO_PPO, obs_dim, action_dim, max(self.horizon, 2), hidden=hidden, batch_max=minibatch_max,
+                         extra_cols=action_dim + 1, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
+                         device_id=hip_id, seed=seed)
+        self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden)
+        self.buffer = Buffer_for_PPO(self.horizon, obs_dim, action_dim, self.device, _engine=self._e)
+        self.is_continue = is_continue
+        self.actor_lr, self.critic_lr = actor_lr, critic_lr
+        self._rng = rng
+        self._act_dim = action_dim
+        self.last_trace = None
+
+    def select_action(self, obs):
+        """a ~ N(mean, std), per-dimension log-prob; eps from torch's generator like
+        `Normal.sample()` (PPO_with_tricks.py:234-255).  Returns (action[A], log_pi[A])."""
+        eps = torch.randn(1, self._act_dim).numpy()
+        a, lp = self._e.act(0, N.ACT_PPO_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=eps,
+                            out_dim=self._act_dim, want_logp=True)
+        return a[0, 0], lp[0, 0]
+
+    def evaluate_action(self, obs):                                       # the mean (:257-270)
+        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim)[0, 0]
+
+    def add(self, obs, action, reward, next_obs, done, action_log_pi, adv_dones):
+        self.buffer.add(obs, action, reward, next_obs, done, action_log_pi, adv_dones)
+
+    def learn(self, minibatch_size, gamma, lmbda, clip_param, K_epochs, entropy_coefficient):
+        perms = None
+        if self._rng == "host":                                           # np.random.permutation per epoch (:320)
+            perms = np.stack([np.random.permutation(self.horizon) for _ in range(K_epochs)])[None]
+        out = self._e.ppo_learn(self.horizon, minibatch_size, K_epochs, gamma=gamma, lmbda=lmbda, clip=clip_param,
+                                ent_coef=entropy_coefficient, actor_lr=self.agent.actor_optimizer.lr,
+                                critic_lr=self.agent.critic_optimizer.lr,
+                                adam_eps=self.agent.actor_optimizer.param_groups[0]["eps"],
+                                adv_norm=self.trick["adv_norm"], perms=perms,
+                                want_trace=getattr(self, "track_loss", False))
+        self.last_trace = out.get("trace")
+
+    def lr_decay(self, episode_num, max_episodes):                        # :357-363
+        lr_a_now = self.actor_lr * (1 - episode_num / max_episodes)
+        lr_c_now = self.critic_lr * (1 - episode_num / max_episodes)
+        for p in self.agent.actor_optimizer.param_groups:
+            p["lr"] = lr_a_now
+        for p in self.agent.critic_optimizer.param_groups:
+            p["lr"] = lr_c_now
+
+    def save(self, model_dir):
+        torch.save(self.agent.actor.state_dict(), os.path.join(model_dir, "PPO.pt"))
+
+    @staticmethod
+    def load(dim_info, is_continue, model_dir, trick, beta):
+        policy = PPO(dim_info, is_continue, 0, 0, 2, device=torch.device("cpu"), trick=trick, beta=beta)
+        policy.agent.actor.load_state_dict(torch.load(os.path.join(model_dir, "PPO.pt")))
+        return policy

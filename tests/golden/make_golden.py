@@ -343,6 +343,125 @@ def gen_norm(out):
     out["rscale_y"] = np.array([np.asarray(rs(r)).reshape(-1)[0] for r in rr], dtype=np.float64)
 
 
+# ----------------------------------------------------------------------------- seeded trajectories
+# The reference driven exactly like its training loop drives it, with its OWN RNG streams
+# (np.random.seed / torch.manual_seed before construction, nn.Linear default init, legacy
+# np.random.choice, torch.randn_like / rsample / sample): pins init order, RNG draw order and
+# the learn() arithmetic end to end.  tests/test_gpu_classes.py replays the same call sequence
+# on freerl_amd's classes.
+TRAJ = dict(obs_dim=8, act_dim=2, n_actions=4, capacity=4096, n_table=600, batch=256, seed=0)
+
+
+def _traj_common(out, pol, rec, nets):
+    for k, v in rec.items():
+        out["loss_" + k.replace("update_", "")] = np.array(v, dtype=np.float32)
+    for name, mod in nets.items():
+        synth.pack_digest(name, t2n(mod.state_dict()), out, full_limit=0)
+
+
+def gen_traj_dqn(out):
+    t = TRAJ
+    mod = import_reference("DQN_file", "DQN")
+    np.random.seed(t["seed"]); torch.manual_seed(t["seed"])
+    pol = mod.DQN([t["obs_dim"], t["n_actions"]], False, 1e-3, t["capacity"], CPU)
+    synth.pack_digest("init", t2n(pol.agent.Qnet.state_dict()), out, full_limit=0)
+    tab = synth.transitions(123, t["n_table"], t["obs_dim"], 1, n_discrete=t["n_actions"])
+    fill(pol, tab)
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    acts = []
+    for k in range(5):
+        acts.append(pol.select_action(tab["obs"][k]))
+        pol.learn(t["batch"], 0.99, 0.01)
+    out["actions"] = np.array(acts, dtype=np.int64)
+    _traj_common(out, pol, rec, {"Qnet": pol.agent.Qnet, "Qnet_target": pol.agent.Qnet_target})
+
+
+def gen_traj_ac(name, out):
+    t = TRAJ
+    O, A = t["obs_dim"], t["act_dim"]
+    np.random.seed(t["seed"]); torch.manual_seed(t["seed"])
+    if name == "ddpg":
+        mod = import_reference("DDPG_file", "DDPG_simple")
+        pol = mod.DDPG([O, A], True, 1e-3, 1e-3, t["capacity"], CPU)
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.01)
+    elif name == "td3":
+        mod = import_reference("TD3_file", "TD3")
+        pol = mod.TD3([O, A], True, 1e-3, 1e-3, t["capacity"], CPU, trick=None,
+                      realize={"clip_double": True, "policy_noise": True, "twin_delay": True})
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1)
+    else:
+        mod = import_reference("SAC_file", "SAC")
+        pol = mod.SAC([O, A], True, 1e-3, 1e-3, t["capacity"], CPU,
+                      trick={"ObsNorm": False, "Batch_ObsNorm": False, "OUNoise": False, "GaussNoise": False})
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.005)
+    synth.pack_digest("init_actor", t2n(pol.agent.actor.state_dict()), out, full_limit=0)
+    synth.pack_digest("init_critic", t2n(pol.agent.critic.state_dict()), out, full_limit=0)
+    tab = synth.transitions(123, t["n_table"], O, A)
+    fill(pol, tab)
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    acts = []
+    for k in range(4):
+        acts.append(pol.select_action(tab["obs"][k]))       # SAC: consumes torch RNG (rsample)
+        learn()
+    out["actions"] = np.stack(acts).astype(np.float32)
+    if name == "sac":
+        out["alpha"] = np.float32(pol.alphas.alpha.item())
+    _traj_common(out, pol, rec, {"actor": pol.agent.actor, "critic": pol.agent.critic,
+                                 "actor_target": pol.agent.actor_target, "critic_target": pol.agent.critic_target})
+
+
+def gen_traj_maddpg(out):
+    dims = {"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]}
+    ids = list(dims)
+    mod = import_reference("MADDPG_file", "MADDPG_simple")
+    np.random.seed(0); torch.manual_seed(0)
+    pol = mod.MADDPG(copy.deepcopy(dims), True, 1e-3, 1e-3, 512, CPU)
+    tabs = {a: synth.transitions(125 + 100 * j, 200, dims[a][0], dims[a][1]) for j, a in enumerate(ids)}
+    for i in range(200):
+        pol.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
+                {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
+                {a: bool(tabs[a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    for k in range(3):
+        acts = pol.select_action({a: tabs[a]["obs"][k] for a in ids})
+        pol.learn(64, 0.95, 0.01)
+    for a in ids:
+        out["actions/" + a] = acts[a]
+        out["loss_critic/" + a] = np.array(recs[a]["update_critic"], dtype=np.float32)
+        out["loss_actor/" + a] = np.array(recs[a]["update_actor"], dtype=np.float32)
+        synth.pack_digest(a + "/actor", t2n(pol.agents[a].actor.state_dict()), out, full_limit=0)
+        synth.pack_digest(a + "/critic_target", t2n(pol.agents[a].critic_target.state_dict()), out, full_limit=0)
+
+
+def gen_traj_ppo(out):
+    O, A, T = 8, 2, 128
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    np.random.seed(0); torch.manual_seed(0)
+    trick = dict(cases.CASES["ppo"]["trick"], adv_norm=True, orthogonal_init=True)
+    pol = mod.PPO([O, A], True, 1e-3, 1e-3, T, CPU, trick=dict(trick), beta=False)
+    tab = synth.transitions(126, T, O, A)
+    g = np.random.default_rng(5)
+    adv_done = np.logical_or(tab["done"], g.random(T) < 0.03)
+    acts, logps = [], []
+    for i in range(T):
+        a, lp = pol.select_action(tab["obs"][i])                  # Normal.sample(): torch RNG
+        acts.append(a); logps.append(lp)
+        pol.add(tab["obs"][i], a, float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp, bool(adv_done[i]))
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+
+    class _P(_NpProxy):
+        def __init__(self):
+            types.ModuleType.__init__(self, "np_proxy")
+            self.captured = []
+            self.random = np.random                               # the REAL legacy stream (permutation)
+    mod.np = _P()
+    pol.learn(32, 0.99, 0.95, 0.2, 2, 0.01)
+    mod.np = np
+    out["actions"] = np.stack(acts).astype(np.float32)
+    out["logps"] = np.stack(logps).astype(np.float32)
+    _traj_common(out, pol, rec, {"actor": pol.agent.actor, "critic": pol.agent.critic})
+
+
 # ----------------------------------------------------------------------------- harness self-check
 def survey_known_answers():
     """SURVEY.md §8(c) recorded `DQN.learn` losses for torch-seeded init + legacy-RNG indices.
@@ -370,6 +489,9 @@ def main():
         "sac": gen_sac, "maddpg": gen_maddpg,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
         "norm": gen_norm,
+        "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
+        "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),
+        "traj_maddpg": gen_traj_maddpg, "traj_ppo": gen_traj_ppo,
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]

@@ -1,0 +1,224 @@
+"""Drop-in surface on the GPU: freerl_amd's classes are driven through the SAME seeded call
+sequence as the reference's own classes were (tests/golden/make_golden.py `gen_traj_*`):
+np.random.seed(0) / torch.manual_seed(0) BEFORE construction, default init, the legacy NumPy
+and torch generator draws inside select_action / learn.  Agreement therefore pins parameter
+init order, RNG draw order, the add -> learn ordering and the learn() arithmetic end to end.
+
+Tolerances: losses 1e-4 relative (north_star), parameters rtol 5e-4 / atol 5e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases, synth
+from tests.golden.make_golden import TRAJ
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOSS_RTOL, P_RTOL, P_ATOL = 1e-4, 5e-4, 5e-6
+CUDA = torch.device("cuda")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def sd2np(sd):
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def fill(policy, tab, discrete=False):
+    for i in range(len(tab["rew"])):
+        a = tab["act"][i]
+        policy.add(tab["obs"][i], a[0] if discrete else a, float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+
+
+def seed():
+    np.random.seed(TRAJ["seed"])
+    torch.manual_seed(TRAJ["seed"])
+
+
+def test_dqn_class_trajectory(tmp_path):
+    from freerl_amd.DQN import DQN
+    t, fx = TRAJ, gold("traj_dqn")
+    seed()
+    pol = DQN([t["obs_dim"], t["n_actions"]], False, 1e-3, t["capacity"], CUDA)
+    pol.track_loss = True
+    synth.check_digest("init", sd2np(pol.agent.Qnet.state_dict()), fx, 0, 0, "init")     # bit-exact init
+    tab = synth.transitions(123, t["n_table"], t["obs_dim"], 1, n_discrete=t["n_actions"])
+    fill(pol, tab, discrete=True)
+    assert len(pol.buffer) == t["n_table"] and pol.buffer._index == t["n_table"]
+    acts, losses = [], []
+    for k in range(5):
+        a = pol.select_action(tab["obs"][k])
+        assert isinstance(a, np.integer)
+        acts.append(a)
+        assert pol.learn(t["batch"], 0.99, 0.01) is None           # returns None like the reference
+        losses.append(pol.last_loss)
+    np.testing.assert_array_equal(np.array(acts), fx["actions"])
+    np.testing.assert_allclose(losses, fx["loss_Qnet"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", sd2np(pol.agent.Qnet.state_dict()), fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", sd2np(pol.agent.Qnet_target.state_dict()), fx, P_RTOL, P_ATOL)
+    # checkpoint layout: same keys / shapes / dtype, loadable by torch on the CPU (DQN.py:131-138)
+    pol.save(str(tmp_path))
+    sd = torch.load(os.path.join(str(tmp_path), "DQN.pt"))
+    assert list(sd.keys()) == ["l1.weight", "l1.bias", "l2.weight", "l2.bias"]
+    assert sd["l1.weight"].shape == (128, 8) and sd["l2.weight"].shape == (4, 128) and sd["l1.weight"].dtype == torch.float32
+    pol2 = DQN.load([t["obs_dim"], t["n_actions"]], False, str(tmp_path))
+    for k in range(8):
+        assert pol2.evaluate_action(tab["obs"][k]) == pol.evaluate_action(tab["obs"][k])
+    # Buffer.sample through the class: 5 float32 tensors with the reference's shapes
+    o, a, r, no, d = pol.sample(32)
+    assert o.shape == (32, 8) and a.shape == (32, 1) and r.shape == (32, 1) and d.shape == (32, 1) and o.is_cuda
+    with pytest.raises(ValueError):
+        DQN([8, 4], True, 1e-3, 100, CUDA)
+
+
+@pytest.mark.parametrize("name", ["ddpg", "td3", "sac"])
+def test_actor_critic_class_trajectory(name, tmp_path):
+    t, fx = TRAJ, gold("traj_" + name)
+    O, A = t["obs_dim"], t["act_dim"]
+    seed()
+    if name == "ddpg":
+        from freerl_amd.DDPG import DDPG
+        pol = DDPG([O, A], True, 1e-3, 1e-3, t["capacity"], CUDA)
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.01)
+    elif name == "td3":
+        from freerl_amd.TD3 import TD3
+        pol = TD3([O, A], True, 1e-3, 1e-3, t["capacity"], CUDA, trick=None,
+                  realize={"clip_double": True, "policy_noise": True, "twin_delay": True})
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1)
+    else:
+        from freerl_amd.SAC import SAC
+        with pytest.raises(TypeError):
+            SAC([O, A], True, 1e-3, 1e-3, 10, CUDA)             # trick is required (SAC.py:181)
+        seed()
+        pol = SAC([O, A], True, 1e-3, 1e-3, t["capacity"], CUDA,
+                  trick={"ObsNorm": False, "Batch_ObsNorm": False, "OUNoise": False, "GaussNoise": False})
+        learn = lambda: pol.learn(t["batch"], 0.99, 0.005)
+    pol.track_loss = True
+    synth.check_digest("init_actor", sd2np(pol.agent.actor.state_dict()), fx, 0, 0, "init")
+    synth.check_digest("init_critic", sd2np(pol.agent.critic.state_dict()), fx, 0, 0, "init")
+    tab = synth.transitions(123, t["n_table"], O, A)
+    fill(pol, tab)
+    acts, cl, al = [], [], []
+    for k in range(4):
+        a = pol.select_action(tab["obs"][k])
+        assert a.shape == (A,) and a.dtype == np.float32
+        acts.append(a)
+        learn()
+        cl.append(pol.last_losses[0])
+        if pol.last_losses[1] is not None:
+            al.append(pol.last_losses[1])
+    np.testing.assert_allclose(np.stack(acts), fx["actions"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=LOSS_RTOL, atol=2e-6)
+    for net in ("actor", "critic", "actor_target", "critic_target"):
+        synth.check_digest(net, sd2np(getattr(pol.agent, net).state_dict()), fx, P_RTOL, P_ATOL, name)
+    if name == "sac":
+        np.testing.assert_allclose(pol.alphas.alpha.item(), fx["alpha"], rtol=1e-5)
+        assert list(pol.agent.actor.state_dict().keys())[0] == "log_std"       # SAC.pt key order
+    if name == "td3":
+        assert pol.total_it == 4
+    pol.save(str(tmp_path))
+    fname = {"ddpg": "DDPG.pt", "td3": "TD3.pt", "sac": "SAC.pt"}[name]
+    sd = torch.load(os.path.join(str(tmp_path), fname))
+    assert sd["l1.weight"].shape == (128, O)
+
+
+def test_maddpg_class_trajectory(tmp_path):
+    from freerl_amd.MADDPG import MADDPG
+    fx = gold("traj_maddpg")
+    dims = {"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]}
+    ids = list(dims)
+    np.random.seed(0); torch.manual_seed(0)
+    pol = MADDPG(dict(dims), True, 1e-3, 1e-3, 512, CUDA)
+    pol.track_loss = True
+    tabs = {a: synth.transitions(125 + 100 * j, 200, dims[a][0], dims[a][1]) for j, a in enumerate(ids)}
+    for i in range(200):
+        pol.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
+                {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
+                {a: bool(tabs[a]["done"][i]) for a in ids})
+    assert len(pol.buffers["agent_1"]) == 200
+    cl = {a: [] for a in ids}
+    al = {a: [] for a in ids}
+    for k in range(3):
+        acts = pol.select_action({a: tabs[a]["obs"][k] for a in ids})
+        pol.learn(64, 0.95, 0.01)
+        for a in ids:
+            cl[a].append(pol.last_losses[a][0]); al[a].append(pol.last_losses[a][1])
+    for a in ids:
+        np.testing.assert_allclose(acts[a], fx["actions/" + a], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(cl[a], fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(al[a], fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=2e-6)
+        synth.check_digest(a + "/actor", sd2np(pol.agents[a].actor.state_dict()), fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic_target", sd2np(pol.agents[a].critic_target.state_dict()), fx, P_RTOL, P_ATOL)
+    pol.save(str(tmp_path))
+    data = torch.load(os.path.join(str(tmp_path), "MADDPG.pth"))
+    assert list(data.keys()) == ids and data["agent_1"]["l3.weight"].shape == (3, 128)
+    o, a, r, no, d = pol.buffers["agent_2"].sample(np.arange(10))
+    np.testing.assert_array_equal(o.cpu().numpy(), tabs["agent_2"]["obs"][:10])
+    np.testing.assert_array_equal(r.cpu().numpy()[:, 0], tabs["agent_2"]["rew"][:10])
+
+
+def test_ppo_class_trajectory(tmp_path):
+    from freerl_amd.PPO import PPO
+    fx = gold("traj_ppo")
+    O, A, T = 8, 2, 128
+    np.random.seed(0); torch.manual_seed(0)
+    trick = dict(cases.CASES["ppo"]["trick"], adv_norm=True, orthogonal_init=True)
+    pol = PPO([O, A], True, 1e-3, 1e-3, T, CUDA, trick=dict(trick), beta=False)
+    pol.track_loss = True
+    tab = synth.transitions(126, T, O, A)
+    g = np.random.default_rng(5)
+    adv_done = np.logical_or(tab["done"], g.random(T) < 0.03)
+    acts, logps = [], []
+    for i in range(T):
+        a, lp = pol.select_action(tab["obs"][i])
+        acts.append(a); logps.append(lp)
+        pol.add(tab["obs"][i], a, float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp, bool(adv_done[i]))
+    np.testing.assert_allclose(np.stack(acts), fx["actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.stack(logps), fx["logps"], rtol=1e-4, atol=1e-5)
+    assert len(pol.buffer) == T
+    pol.learn(32, 0.99, 0.95, 0.2, 2, 0.01)
+    assert len(pol.buffer) == 0                                     # buffer.clear() (:354)
+    np.testing.assert_allclose(pol.last_trace[0, :, 0], fx["loss_actor"], rtol=5e-4, atol=1e-5)
+    np.testing.assert_allclose(pol.last_trace[0, :, 1], fx["loss_critic"], rtol=5e-4)
+    synth.check_digest("actor", sd2np(pol.agent.actor.state_dict()), fx, 2e-3, 2e-5)
+    synth.check_digest("critic", sd2np(pol.agent.critic.state_dict()), fx, 2e-3, 2e-5)
+    pol.lr_decay(10, 100)
+    assert abs(pol.agent.actor_optimizer.param_groups[0]["lr"] - 1e-3 * 0.9) < 1e-12
+    pol.save(str(tmp_path))
+    sd = torch.load(os.path.join(str(tmp_path), "PPO.pt"))
+    assert list(sd.keys())[0] == "log_std" and sd["mean_layer.weight"].shape == (A, 128)
+
+
+def test_buffer_module_standalone():
+    """`from freerl_amd.Buffer import Buffer` used the way the reference scripts use Buffer.py."""
+    from freerl_amd.Buffer import Buffer, Buffer_for_PPO
+    from oracle.buffer import Buffer as OBuffer
+    c = cases.CASES["buffer"]
+    inp = cases.buffer_inputs(c)
+    buf = Buffer(c["capacity"], c["obs_dim"], c["act_dim"], CUDA)
+    ob = OBuffer(c["capacity"], c["obs_dim"], c["act_dim"])
+    tab = inp["table"]
+    for i in range(c["n_add"]):
+        args = (tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+        buf.add(*args); ob.add(*args)
+    assert (buf._index, buf._size, len(buf), buf.capacity) == (ob._index, ob._size, len(ob), ob.capacity)
+    for got, want in zip(buf.sample(inp["idx"]), ob.sample(inp["idx"])):
+        assert got.dtype == torch.float32 and got.is_cuda
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(buf.obs, ob.obs.astype(np.float32))
+    np.testing.assert_array_equal(buf.dones, ob.dones)
+    pb = Buffer_for_PPO(16, 3, 2, CUDA)
+    for i in range(16):
+        pb.add(np.full(3, i, np.float32), np.full(2, -i, np.float32), float(i), np.full(3, i + 1, np.float32), i % 5 == 0,
+               np.array([0.1 * i, 0.2 * i], np.float32), i % 7 == 0)
+    o, a, r, no, d, lp, ad = pb.all()
+    assert o.shape == (16, 3) and lp.shape == (16, 2) and ad.shape == (16, 1)
+    np.testing.assert_allclose(lp.cpu().numpy()[3], [0.3, 0.6], rtol=1e-6)
+    np.testing.assert_array_equal(ad.cpu().numpy()[:, 0], [float(i % 7 == 0) for i in range(16)])
+    pb.clear()
+    assert len(pb) == 0 and pb._index == 0
