@@ -15,14 +15,14 @@
 namespace frl {
 
 struct Lds {
-    float* xin; int xp;
-    float* h1; float* h2; int hp;
-    float* outb; int op;
-    float* y;          // [batch_pad] TD targets / v_targets
-    float* abuf;       // [rc][ap] actions produced by the actor(s)
-    float* dabuf;      // [rc][ap] d loss / d action (or eps staging)
+    lds_f xin; int xp;
+    lds_f h1; lds_f h2; int hp;
+    lds_f outb; int op;
+    lds_f y;           // [batch_pad] TD targets / v_targets
+    lds_f abuf;        // [rc][ap] actions produced by the actor(s)
+    lds_f dabuf;       // [rc][ap] d loss / d action (or eps staging)
     int ap;
-    float* red;        // [8] reduction scratch
+    lds_f red;         // [8] reduction scratch
     int rc;
 };
 
@@ -35,7 +35,7 @@ __device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int ki
     S.hp = hidden + 4;
     S.op = out_pad_max + 4;
     S.ap = act_pad + 4;
-    float* p = smem;
+    lds_f p = (lds_f)smem;
     S.xin = p; p += rc * S.xp;
     S.h1 = p; p += rc * S.hp;
     S.h2 = p; p += rc * S.hp;
@@ -60,55 +60,64 @@ __device__ __forceinline__ float act_grad(float h, int act) {
 }
 
 // Y[rc][n_pad] = act(X[rc][k_pad] * W^T + b)
-__device__ __forceinline__ void linear_fwd(const LayerDesc& L, const float* __restrict__ theta, const float* X,
-                                           int ldx, float* Y, int ldy, int act, int rc) {
-    const float* W = theta + L.w_off;
-    const float* b = theta + L.b_off;
+__device__ __forceinline__ void linear_fwd(const LayerDesc& L, g_cf theta, lds_cf X, int ldx, lds_f Y, int ldy,
+                                           int act, int rc) {
+    g_cf W = theta + L.w_off;
+    g_cf b = theta + L.b_off;
     const int kpad = L.k_pad;
     for_tile_blocks(rc / 16, L.n_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
         constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
         f32x4 acc[BM][BN];
         acc_zero(acc);
         mma_nt<BM, BN>(acc, X, ldx, mt0 * 16, W, kpad, nt0 * 16, kpad);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16,
-                              [&](int r, int c, float v) { Y[r * ldy + c] = act_apply(v + b[c], act); });
+        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v) {
+            v += ld4(b + c4);
+            v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+            st4(Y + r * ldy + c4, v);
+        });
     });
 }
 
 // dX[rc][k tiles ct0..ct1) = (dY[rc][n_pad] * W) (.) act'(H)   written in place over H (pitch ldh).
 // act_prev == ACT_NONE: plain store (used for d/d(first-layer input)).
-__device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, const float* __restrict__ theta, const float* dY,
-                                              int ldy, float* H, int ldh, int act_prev, int rc, int ct0, int ct1) {
-    const float* W = theta + L.w_off;
+__device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, g_cf theta, lds_cf dY, int ldy, lds_f H, int ldh,
+                                              int act_prev, int rc, int ct0, int ct1) {
+    g_cf W = theta + L.w_off;
     const int kpad = L.k_pad, npad = L.n_pad;
     for_tile_blocks(rc / 16, ct1 - ct0, [&](auto bm, auto bn, int mt0, int nt0) {
         constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
         f32x4 acc[BM][BN];
         acc_zero(acc);
         mma_nn<BM, BN>(acc, dY, ldy, mt0 * 16, W, kpad, (ct0 + nt0) * 16, npad);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, (ct0 + nt0) * 16, [&](int r, int c, float v) {
-            float* h = H + r * ldh + c;
-            *h = (act_prev == ACT_NONE) ? v : v * act_grad(*h, act_prev);
+        tile_epilogue<BM, BN>(acc, mt0 * 16, (ct0 + nt0) * 16, [&](int r, int c4, f32x4 v) {
+            lds_f h = H + r * ldh + c4;
+            if (act_prev != ACT_NONE) {
+                const f32x4 hv = ld4((lds_cf)h);
+                v.x *= act_grad(hv.x, act_prev); v.y *= act_grad(hv.y, act_prev);
+                v.z *= act_grad(hv.z, act_prev); v.w *= act_grad(hv.w, act_prev);
+            }
+            st4(h, v);
         });
     });
 }
 
 // G.W[n_pad][k_pad] (=|+=) dY^T * X ;  G.b (=|+=) column sums of dY
-__device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, float* __restrict__ G, const float* dY, int ldy,
-                                              const float* X, int ldx, int rc, bool first) {
-    float* GW = G + L.w_off;
+__device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf dY, int ldy, lds_cf X, int ldx, int rc,
+                                              bool first) {
+    g_f GW = G + L.w_off;
     const int kpad = L.k_pad;
     for_tile_blocks(L.n_pad / 16, L.k_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
         constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
         f32x4 acc[BM][BN];
         acc_zero(acc);
         mma_tn<BM, BN>(acc, dY, ldy, mt0 * 16, X, ldx, nt0 * 16, rc);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c, float v) {
-            float* g = GW + (size_t)r * kpad + c;
-            *g = first ? v : (*g + v);
+        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v) {
+            g_f g = GW + (size_t)r * kpad + c4;
+            if (!first) v += ld4((g_cf)g);
+            st4(g, v);
         });
     });
-    float* Gb = G + L.b_off;
+    g_f Gb = G + L.b_off;
     for (int n = threadIdx.x; n < L.n_pad; n += kWG) {
         float s = 0.f;
         for (int r = 0; r < rc; ++r) s += dY[r * ldy + n];
@@ -117,13 +126,12 @@ __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, float* __restr
 }
 
 // Forward of layers [l0, l0+nl) of net N: xin -> h1 [-> h2] -> outb.  Ends with a barrier.
-__device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, const float* __restrict__ theta,
-                                        const Lds& S, int out_act) {
-    const float* in = S.xin;
+__device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act) {
+    lds_cf in = S.xin;
     int ldin = S.xp;
     for (int i = 0; i < nl; ++i) {
         const bool last = (i == nl - 1);
-        float* out = last ? S.outb : (i == 0 ? S.h1 : S.h2);
+        lds_f out = last ? S.outb : (i == 0 ? S.h1 : S.h2);
         const int ldo = last ? S.op : S.hp;
         linear_fwd(N.L[l0 + i], theta, in, ldin, out, ldo, last ? out_act : N.hidden_act, S.rc);
         __syncthreads();
@@ -135,14 +143,13 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, const 
 // Backward of layers [l0, l0+nl): head delta in outb (zero in padded columns and invalid rows).
 // G != nullptr accumulates weight/bias gradients (first: overwrite).  want_dx0 leaves
 // d loss / d xin in xin for column tiles [ct0, ct1).  Ends with a barrier.
-__device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, const float* __restrict__ theta,
-                                        float* __restrict__ G, const Lds& S, bool first, bool want_dx0, int ct0,
-                                        int ct1) {
+__device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf theta, g_f G, const Lds& S, bool first,
+                                        bool want_dx0, int ct0, int ct1) {
     for (int i = nl - 1; i >= 0; --i) {
         const bool last = (i == nl - 1);
-        const float* D = last ? S.outb : (i == 0 ? S.h1 : S.h2);
+        lds_cf D = last ? S.outb : (i == 0 ? S.h1 : S.h2);
         const int ldd = last ? S.op : S.hp;
-        float* X = (i == 0) ? S.xin : (i == 1 ? S.h1 : S.h2);
+        lds_f X = (i == 0) ? S.xin : (i == 1 ? S.h1 : S.h2);
         const int ldx = (i == 0) ? S.xp : S.hp;
         const LayerDesc& L = N.L[l0 + i];
         if (G) {
@@ -160,9 +167,8 @@ __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, const 
 }
 
 // X[r][dst0 + c] = ring[idx[r0 + r]][src0 + c] for r < nvalid, c < ncols; 0 for r >= nvalid
-__device__ __forceinline__ void gather_cols(float* X, int ldx, int rc, int nvalid, const int* __restrict__ idx,
-                                            const float* __restrict__ ring, int stride, int src0, int ncols,
-                                            int dst0) {
+__device__ __forceinline__ void gather_cols(lds_f X, int ldx, int rc, int nvalid, g_ci idx, g_cf ring, int stride,
+                                            int src0, int ncols, int dst0) {
     const int total = rc * ncols;
     for (int e = threadIdx.x; e < total; e += kWG) {
         const int r = e / ncols, c = e - r * ncols;
@@ -171,7 +177,7 @@ __device__ __forceinline__ void gather_cols(float* X, int ldx, int rc, int nvali
         X[r * ldx + dst0 + c] = v;
     }
 }
-__device__ __forceinline__ void zero_cols(float* X, int ldx, int rc, int c0, int c1) {
+__device__ __forceinline__ void zero_cols(lds_f X, int ldx, int rc, int c0, int c1) {
     const int w = c1 - c0;
     if (w <= 0) return;
     for (int e = threadIdx.x; e < rc * w; e += kWG) {
@@ -194,10 +200,9 @@ __device__ __forceinline__ double powi_d(double b, int t) {
 // Global-norm clip + Adam (+ optional soft target update) over one net's parameter block.
 // torch semantics: clip_grad_norm_(params, clip) then optim.Adam.step() (single-tensor order),
 // then theta_t <- theta_t*(1-tau) + theta*tau.  Returns the pre-clip gradient norm.
-__device__ __forceinline__ float adam_net(int size, float* __restrict__ theta, float* __restrict__ m,
-                                          float* __restrict__ v, const float* __restrict__ g,
-                                          float* __restrict__ target, float lr, float eps, float b1, float b2,
-                                          float wd, float clip_norm, int t_new, float tau, float* red) {
+__device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_cf g, g_f target, float lr, float eps,
+                                          float b1, float b2, float wd, float clip_norm, int t_new, float tau,
+                                          lds_f red) {
     float ss = 0.f;
     for (int i = threadIdx.x; i < size; i += kWG) {
         const float x = g[i];
@@ -228,8 +233,7 @@ __device__ __forceinline__ float adam_net(int size, float* __restrict__ theta, f
     return total;
 }
 
-__device__ __forceinline__ void soft_update_net(int size, float* __restrict__ target, const float* __restrict__ theta,
-                                                float tau) {
+__device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta, float tau) {
     const float tk = 1.f - tau;
     for (int i = threadIdx.x; i < size; i += kWG) target[i] = target[i] * tk + theta[i] * tau;
 }
@@ -237,8 +241,8 @@ __device__ __forceinline__ void soft_update_net(int size, float* __restrict__ ta
 // Draw `batch` distinct row indices in [0,size) into idx (global, this learner's slice) using
 // `lidx` (LDS int[batch]) for the duplicate check: rejection keeps the draw uniform over
 // subsets, like np.random.choice(size, batch, replace=False) (DQN.py:97).
-__device__ __forceinline__ void draw_indices(int* __restrict__ idx, int* lidx, int batch, int size,
-                                             unsigned long long counter, unsigned stream, unsigned long long key) {
+__device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
+                                             unsigned stream, unsigned long long key) {
     for (int i = threadIdx.x; i < batch; i += kWG)
         lidx[i] = (int)uniform_index(philox4x32_10(counter, stream, (unsigned)i, key), (unsigned)size);
     __syncthreads();

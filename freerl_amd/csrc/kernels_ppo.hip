@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __res
     const NetDesc& N = D.net[1];
     const RecordDesc& R = D.rec;
     const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
-    const float* theta = D.theta + (size_t)p * D.learner_stride + D.net_off[1];
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
+    g_cf theta = as_global(D.theta + (size_t)p * D.learner_stride + D.net_off[1]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     const int O = R.obs_dim[0], kpad = N.L[0].k_pad;
     float v0 = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __res
             if (pass == 0) {
                 v0 = v;
             } else {
-                const float* rec = ring + (size_t)(r0 + threadIdx.x) * R.stride;
+                g_cf rec = ring + (size_t)(r0 + threadIdx.x) * R.stride;
                 const size_t o = (size_t)p * T + r0 + threadIdx.x;
                 a.vs[o] = v0;
                 a.td[o] = rec[R.rew_off] + a.gamma * (1.f - rec[R.done_off]) * v - v0;
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __res
 struct Affine { float a, b; };
 __device__ __forceinline__ Affine compose(Affine f, Affine g) { return Affine{f.a * g.a, f.a * g.b + f.b}; }   // f(g(x))
 
-__device__ __forceinline__ void gae_scan(const float* __restrict__ delta, const float* __restrict__ ring, int stride,
-                                         int adv_done_col, int T, float c, float* __restrict__ adv, float* lds) {
+__device__ __forceinline__ void gae_scan(g_cf delta, g_cf ring, int stride, int adv_done_col, int T, float c, g_f adv,
+                                         lds_f lds) {
     const int t = threadIdx.x, L = (T + kWG - 1) / kWG;
     const int s0 = min(t * L, T), s1 = min(s0 + L, T);
     Affine f{1.f, 0.f};
@@ -99,17 +99,18 @@ __device__ __forceinline__ void gae_scan(const float* __restrict__ delta, const 
 }
 
 __global__ __launch_bounds__(256) void ppo_gae_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
-    __shared__ float lds[16];
+    __shared__ float lds_s[16];
+    lds_f lds = (lds_f)lds_s;
     const EngineDesc& D = *Dp;
     const int p = blockIdx.x, T = a.horizon;
     const RecordDesc& R = D.rec;
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    float* adv_raw = a.adv_raw + (size_t)p * T;
-    float* adv = a.adv + (size_t)p * T;
-    const float* vs = a.vs + (size_t)p * T;
-    float* vt = a.vtarget + (size_t)p * T;
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_f adv_raw = as_global(a.adv_raw + (size_t)p * T);
+    g_f adv = as_global(a.adv + (size_t)p * T);
+    g_cf vs = as_global(a.vs + (size_t)p * T);
+    g_f vt = as_global(a.vtarget + (size_t)p * T);
     const int adv_done_col = R.extra_off + R.extra - 1;   // last extra column (PPO_file/Buffer.py:282)
-    gae_scan(a.td + (size_t)p * T, ring, R.stride, adv_done_col, T, a.gamma * a.lmbda, adv_raw, lds);
+    gae_scan(as_global(a.td + (size_t)p * T), ring, R.stride, adv_done_col, T, a.gamma * a.lmbda, adv_raw, lds);
     // v_target = adv + V(s) (:313); optional (adv - mean)/(std + 1e-8), unbiased std (:314-315)
     float s1 = 0.f;
     for (int i = threadIdx.x; i < T; i += kWG) {
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const EngineDesc* __restri
 // stand-alone K3 entry (frl_gae): adv_done given as a dense array
 __global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict__ delta, const float* __restrict__ adv_done,
                                                          int T, float c, float* __restrict__ adv) {
-    __shared__ float lds[16];
+    __shared__ float lds_s[16];
     const size_t o = (size_t)blockIdx.x * T;
-    gae_scan(delta + o, adv_done + o, 1, 0, T, c, adv + o, lds);
+    gae_scan(as_global(delta + o), as_global(adv_done + o), 1, 0, T, c, as_global(adv + o), (lds_f)lds_s);
 }
 
 // ---- all minibatch updates of one learner in one launch
@@ -149,13 +150,13 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     const RecordDesc& R = D.rec;
     const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
     const size_t offA = (size_t)p * D.learner_stride + D.net_off[0], offC = (size_t)p * D.learner_stride + D.net_off[1];
-    float* thA = D.theta + offA;
-    float* thC = D.theta + offC;
-    float* gA = D.grad + offA;
-    float* gC = D.grad + offC;
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    const float* adv = a.adv + (size_t)p * T;
-    const float* vt = a.vtarget + (size_t)p * T;
+    g_f thA = as_global(D.theta + offA);
+    g_f thC = as_global(D.theta + offC);
+    g_f gA = as_global(D.grad + offA);
+    g_f gC = as_global(D.grad + offC);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_cf adv = as_global(a.adv + (size_t)p * T);
+    g_cf vt = as_global(a.vtarget + (size_t)p * T);
     const int O = R.obs_dim[0], A = R.act_dim[0], logp_col = R.extra_off;
     const int napad = NA.L[NA.n_layers - 1].n_pad, ncpad = NC.L[NC.n_layers - 1].n_pad;
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
@@ -166,11 +167,11 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
 
     for (int k = 0; k < a.k_epochs; ++k) {
-        const int* perm = a.perm + ((size_t)p * a.k_epochs + k) * T;
+        g_ci perm = as_global_i(a.perm + ((size_t)p * a.k_epochs + k) * T);
         for (int s = 0; s < T; s += mb) {
             const int m = min(mb, T - s);
             const float invm = 1.f / (float)m;
-            const int* idx = perm + s;
+            g_ci idx = perm + s;
             // ---------------- actor: clipped surrogate + entropy bonus (:324-346)
             float lossp = 0.f, gls = 0.f, ent = 0.f;
             if (threadIdx.x < A) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                     const int r = threadIdx.x;
                     float coef = 0.f;
                     if (r < nv) {
-                        const float* rec = ring + (size_t)idx[r0 + r] * R.stride;
+                        g_cf rec = ring + (size_t)idx[r0 + r] * R.stride;
                         float lp_now = 0.f, lp_old = 0.f;
                         for (int c = 0; c < A; ++c) {
                             const float mean = S.outb[r * S.op + c];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             const float aloss = block_sum(lossp, S.red) * invm - a.ent_coef * ent_sum;
             __syncthreads();
             ++tA;
-            adam_net(NA.size, thA, D.m + offA, D.v + offA, gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+            adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                      a.clip_norm, tA, 0.f, S.red);
             __syncthreads();
             // ---------------- critic: mse(v_target[idx], V(obs[idx])) (:349-351)
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             const float closs = block_sum(closs_p, S.red) * invm;
             __syncthreads();
             ++tC;
-            adam_net(NC.size, thC, D.m + offC, D.v + offC, gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+            adam_net(NC.size, thC, as_global(D.m + offC), as_global(D.v + offC), gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                      a.clip_norm, tC, 0.f, S.red);
             __syncthreads();
             if (threadIdx.x == 0) {

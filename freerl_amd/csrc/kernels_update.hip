@@ -50,13 +50,13 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const int n = D.n_agents, p = blockIdx.x / n, ag = blockIdx.x - p * n, B = a.batch;
-    int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max;
+    g_i idx = (g_i)(D.idx + ((size_t)p * n + ag) * D.batch_max);
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
-    draw_indices(idx, reinterpret_cast<int*>(smem), B, a.size, a.rng_counter, (unsigned)ag, key);
+    draw_indices(idx, (FRL_LDS int*)smem, B, a.size, a.rng_counter, (unsigned)ag, key);
     if (want_noise) {
         const int am = D.act_max;
-        float* noise0 = D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am;
-        float* noise1 = noise0 + (size_t)D.batch_max * am;
+        g_f noise0 = as_global(D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am);
+        g_f noise1 = noise0 + (size_t)D.batch_max * am;
         for (int e = threadIdx.x; e < B * am; e += kWG) {
             float n0, n1;
             normal2(philox4x32_10(a.rng_counter, 0x4000u + (unsigned)ag, (unsigned)e, key), n0, n1);
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(const EngineDesc* __restr
     const Lds S = carve(D, smem);
     const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
     const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
-    const float* theta = D.theta + base;
-    const float* target = D.target + base;
-    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0];
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    const int* idx = D.idx + (size_t)p * D.n_agents * D.batch_max + r0;
+    g_cf theta = as_global(D.theta + base);
+    g_cf target = as_global(D.target + base);
+    g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
     const int O = R.obs_dim[0], nA = N.L[nl - 1].n, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
 
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(const EngineDesc* __restr
     for (int r = threadIdx.x; r < nv; r += kWG) {
         float mx = S.outb[r * S.op];
         for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
-        const float* rec = ring + (size_t)idx[r] * R.stride;
+        g_cf rec = ring + (size_t)idx[r] * R.stride;
         S.y[r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
     }
     __syncthreads();
@@ -138,13 +138,13 @@ __global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __rest
     const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
     const bool sac = (D.algo == ALGO_SAC);
     const size_t lbase = (size_t)p * D.learner_stride;
-    const float* thC = D.theta + lbase + D.net_off[2 * ag + 1];
-    const float* tgC = D.target + lbase + D.net_off[2 * ag + 1];
-    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag + 1];
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    const int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max + r0;
+    g_cf thC = as_global(D.theta + lbase + D.net_off[2 * ag + 1]);
+    g_cf tgC = as_global(D.target + lbase + D.net_off[2 * ag + 1]);
+    g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag + 1]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    const float* noise0 = D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am + (size_t)r0 * am;
+    g_cf noise0 = as_global(D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __rest
     float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
     for (int j = 0; j < n; ++j) {
         const NetDesc& NJ = D.net[2 * j];
-        const float* tgJ = D.target + lbase + D.net_off[2 * j];
+        g_cf tgJ = as_global(D.target + lbase + D.net_off[2 * j]);
         const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __rest
         if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
     }
     if (threadIdx.x < nv) {
-        const float* rec = ring + (size_t)idx[threadIdx.x] * R.stride;
+        g_cf rec = ring + (size_t)idx[threadIdx.x] * R.stride;
         const float rew = rec[R.rew_off + ag], done = rec[R.done_off + ag];
         S.y[threadIdx.x] = sac ? rew + a.gamma * (1.f - done) * (q + alpha * (-lp_next))
                                : rew + a.gamma * q * (1.f - done);
@@ -256,13 +256,13 @@ __global__ __launch_bounds__(256) void ac_actor_kernel(const EngineDesc* __restr
     const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
     const bool sac = (D.algo == ALGO_SAC);
     const size_t lbase = (size_t)p * D.learner_stride;
-    const float* thA = D.theta + lbase + D.net_off[2 * ag];
-    const float* thC = D.theta + lbase + D.net_off[2 * ag + 1];
-    float* slab = D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag];
-    const float* ring = D.replay + (size_t)p * D.capacity * R.stride;
-    const int* idx = D.idx + ((size_t)p * n + ag) * D.batch_max + r0;
+    g_cf thA = as_global(D.theta + lbase + D.net_off[2 * ag]);
+    g_cf thC = as_global(D.theta + lbase + D.net_off[2 * ag + 1]);
+    g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    const float* noise1 = D.noise + (((size_t)p * n + ag) * 2 + 1) * D.batch_max * am + (size_t)r0 * am;
+    g_cf noise1 = as_global(D.noise + (((size_t)p * n + ag) * 2 + 1) * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const int Oa = R.obs_dim[ag], Aa = R.act_dim[ag], acol = R.act_off[ag] - R.act_off[0];
@@ -401,7 +401,8 @@ __device__ __forceinline__ int adam_net_index(const EngineDesc& D, int which, in
 }
 
 __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
-    __shared__ float red[8];
+    __shared__ float red_s[8];
+    lds_f red = (lds_f)red_s;
     const EngineDesc& D = *Dp;
     const int n = D.n_agents, unit = blockIdx.x / a.G, wg = blockIdx.x - unit * a.G;
     const int p = unit / n, ag = unit - p * n;
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restric
     const NetDesc& N = D.net[net];
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
     const int n4 = N.size / 4;
-    f32x4* g = reinterpret_cast<f32x4*>(D.grad + off);
-    const f32x4* slab = reinterpret_cast<const f32x4*>(D.slab + (size_t)p * D.S * D.learner_stride + D.net_off[net]);
+    FRL_GLB f32x4* g = (FRL_GLB f32x4*)(D.grad + off);
+    const FRL_GLB f32x4* slab = (const FRL_GLB f32x4*)(D.slab + (size_t)p * D.S * D.learner_stride + D.net_off[net]);
     const size_t ls4 = (size_t)D.learner_stride / 4;
     float ss = 0.f;
     const int base = wg * (kWG * kAdamVec);
@@ -449,11 +450,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict_
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     const float step = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
     const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
-    const f32x4* g = reinterpret_cast<const f32x4*>(D.grad + off);
-    f32x4* th = reinterpret_cast<f32x4*>(D.theta + off);
-    f32x4* m = reinterpret_cast<f32x4*>(D.m + off);
-    f32x4* v = reinterpret_cast<f32x4*>(D.v + off);
-    f32x4* tg = reinterpret_cast<f32x4*>(D.target + off);
+    const FRL_GLB f32x4* g = (const FRL_GLB f32x4*)(D.grad + off);
+    FRL_GLB f32x4* th = (FRL_GLB f32x4*)(D.theta + off);
+    FRL_GLB f32x4* m = (FRL_GLB f32x4*)(D.m + off);
+    FRL_GLB f32x4* v = (FRL_GLB f32x4*)(D.v + off);
+    FRL_GLB f32x4* tg = (FRL_GLB f32x4*)(D.target + off);
     const int base = wg * (kWG * kAdamVec);
 #pragma unroll
     for (int j = 0; j < kAdamVec; ++j) {
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __re
     const EngineDesc& D = *Dp;
     const int p = blockIdx.x / D.n_nets, net = blockIdx.x - p * D.n_nets;
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
-    soft_update_net(D.net[net].size, D.target + off, D.theta + off, tau);
+    soft_update_net(D.net[net].size, as_global(D.target + off), as_global(D.theta + off), tau);
 }
 
 }  // namespace frl
