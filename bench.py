@@ -148,14 +148,28 @@ def main():
     prof = e.profile_read()
     e.profile(False)
 
+    # env-steps/s: the full rollout-and-update loop (act -> exploration -> env.step on the host pool ->
+    # add -> learn, one env per learner = the reference's UTD 1) on the synthetic obs-8/act-2 task
+    from freerl_amd.envpool import EnvPool, rollout
+    pool = EnvPool("SynLinear-v0", P, n_threads=4, seed=1000 + rank)
+    rollout(e, pool, args.warmup, start_steps=0, batch=BATCH)
+    ro = rollout(e, pool, args.steps, start_steps=0, batch=BATCH)
+    env_sps_local = ro["env_steps"] / ro["seconds"]
+    ro_updates = ro["updates"] / ro["seconds"]
+    pool.close()
+
     metrics = torch.tensor([dt, float(P * args.steps), kernel_ms], dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = metrics.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(metrics, op=dist.ReduceOp.SUM)                    # the metric all-reduce (RCCL over xGMI)
         dt_max, total_updates, kernel_ms = float(tmax[0]), float(metrics[1]), float(tmax[2])
+        es = torch.tensor([env_sps_local, ro_updates], dtype=torch.float64, device="cuda")
+        dist.all_reduce(es, op=dist.ReduceOp.SUM)
+        env_sps, ro_ups = float(es[0]), float(es[1])
     else:
         dt_max, total_updates = dt, float(P * args.steps)
+        env_sps, ro_ups = env_sps_local, ro_updates
 
     if rank == 0:
         fl_a, by_a = e.learn_work(BATCH, True)
@@ -199,7 +213,10 @@ def main():
                                    "device-drawn indices/noise",
                        "learners_per_gpu": P, "updates_per_step": P * world, "row_chunk": rc, "lds_bytes": lds,
                        "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world},
-            "env_steps_per_sec": None,
+            "env_steps_per_sec": env_sps,
+            "rollout": {"env": "SynLinear-v0 (obs 8, act 2)", "envs_per_learner": 1, "env_workers": 4,
+                        "updates_per_sec_in_loop": ro_ups,
+                        "loop": "act kernel -> D2H -> Gaussian exploration -> host env pool step -> staged add -> learn"},
             "single_learner_updates_per_sec": single,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -62,6 +62,18 @@ class PpoArgs(C.Structure):
                 ("adv_out", C.POINTER(C.c_float)), ("vtarget_out", C.POINTER(C.c_float))]
 
 
+class RolloutArgs(C.Structure):
+    _fields_ = [("n_steps", C.c_int), ("envs_per_learner", C.c_int), ("start_steps", C.c_int), ("learn_every", C.c_int),
+                ("policy_freq", C.c_int), ("epsilon", C.c_float), ("explore_sigma", C.c_float), ("learn", LearnArgs)]
+
+
+class RolloutStats(C.Structure):
+    _fields_ = [("env_steps", C.c_longlong), ("updates", C.c_longlong), ("episodes", C.c_longlong),
+                ("return_sum", C.c_double), ("seconds", C.c_double)]
+
+
+ENV_PENDULUM, ENV_CARTPOLE, ENV_SYNLINEAR, ENV_SYNLINEAR_DISCRETE, ENV_PENDULUM_SHORT = range(5)
+
 _P = C.POINTER
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 _fp, _ip, _i64p = _P(C.c_float), _P(C.c_int), _P(C.c_int64)
@@ -99,6 +111,13 @@ SIGNATURES = {
     "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "frl_envpool_create": (_i, [_i, _i, _i, C.c_uint64, _P(C.c_double), _i, _P(_vp)]),
+    "frl_envpool_destroy": (_i, [_vp]),
+    "frl_envpool_dims": (_i, [_vp, _ip, _ip, _ip, _ip, _fp, _ip]),
+    "frl_envpool_reset": (_i, [_vp, _fp]),
+    "frl_envpool_set_state": (_i, [_vp, _i, _P(C.c_double)]),
+    "frl_envpool_step": (_i, [_vp, _fp, _fp, _fp, _P(C.c_uint8), _P(C.c_uint8), _fp]),
+    "frl_rollout": (_i, [_vp, _vp, _P(RolloutArgs), _P(RolloutStats)]),
     "frl_timer_start": (_i, [_vp]),
     "frl_timer_stop": (_i, [_vp, _fp]),
     "frl_profile_enable": (_i, [_vp, _i]),
@@ -109,7 +128,7 @@ _lib = None
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))] + \
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp", ".inc"))] + \
            [os.path.join(CSRC, "device", f) for f in sorted(os.listdir(os.path.join(CSRC, "device")))] + [HEADER]
 
 

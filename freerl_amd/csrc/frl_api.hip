@@ -2,6 +2,7 @@
 // staging, parameter import/export, kernel launches.  Compiled with hipcc for gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -910,3 +911,4 @@ extern "C" int frl_profile_read(frl_engine* e, double* ms_sum8, long long* count
 }
 
 #include "frl_api_ppo.inc"
+#include "frl_api_rollout.inc"

@@ -1,0 +1,90 @@
+"""Python face of the native vectorised env pool and the rollout collector (include/freerl_hip.h,
+`frl_envpool_*`, `frl_rollout`).  The pool itself is host C++ (worker threads + pinned staging) and
+needs no GPU; `rollout()` drives a GPU engine with it."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+KINDS = {"Pendulum-v1": N.ENV_PENDULUM, "PendulumShort-v1": N.ENV_PENDULUM_SHORT, "CartPole-v1": N.ENV_CARTPOLE,
+         "SynLinear-v0": N.ENV_SYNLINEAR, "SynLinearDiscrete-v0": N.ENV_SYNLINEAR_DISCRETE}
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class EnvPool:
+    def __init__(self, env_name, n_envs, n_threads=1, seed=0):
+        self._L = N.lib()
+        kind = KINDS[env_name]
+        params, n_params = None, 0
+        if env_name.startswith("SynLinear"):        # same A, B as freerl_amd.envs.LinearGaussianEnv
+            from .envs import LinearGaussianEnv
+            ref = LinearGaussianEnv(env_name.endswith("Discrete-v0"))
+            flat = np.ascontiguousarray(np.concatenate([ref.A.reshape(-1), ref.B.reshape(-1)]), dtype=np.float64)
+            self._params = flat
+            params, n_params = flat.ctypes.data_as(C.POINTER(C.c_double)), flat.size
+        h = C.c_void_p()
+        N.check(self._L.frl_envpool_create(kind, int(n_envs), int(n_threads), int(seed), params, n_params, C.byref(h)))
+        self._h = h
+        n, o, a, na, ms = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ma = C.c_float()
+        N.check(self._L.frl_envpool_dims(h, C.byref(n), C.byref(o), C.byref(a), C.byref(na), C.byref(ma), C.byref(ms)))
+        self.n, self.obs_dim, self.act_dim, self.n_actions = n.value, o.value, a.value, na.value
+        self.max_action, self.max_steps = ma.value, ms.value
+        self.env_name = env_name
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.frl_envpool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        obs = np.empty((self.n, self.obs_dim), np.float32)
+        N.check(self._L.frl_envpool_reset(self._h, _fp(obs)))
+        return obs
+
+    def set_state(self, env, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        N.check(self._L.frl_envpool_set_state(self._h, int(env), s.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def step(self, actions):
+        """actions [n, act_dim] (env units; discrete: indices) -> (next_obs, reward, terminated,
+        truncated, obs_next): obs_next is the reset observation where the episode ended."""
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, self.act_dim)
+        nobs = np.empty((self.n, self.obs_dim), np.float32)
+        onext = np.empty((self.n, self.obs_dim), np.float32)
+        rew = np.empty(self.n, np.float32)
+        term = np.empty(self.n, np.uint8)
+        trunc = np.empty(self.n, np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        N.check(self._L.frl_envpool_step(self._h, _fp(a), _fp(nobs), _fp(rew), term.ctypes.data_as(u8),
+                                         trunc.ctypes.data_as(u8), _fp(onext)))
+        return nobs, rew, term.astype(bool), trunc.astype(bool), onext
+
+
+def rollout(engine, pool, n_steps, *, envs_per_learner=1, start_steps=500, learn_every=1, policy_freq=2, epsilon=0.1,
+            explore_sigma=0.1, batch=256, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4,
+            clip_norm=0.5, use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, target_entropy=None):
+    """Run `n_steps` vector steps of the rollout-and-update loop; returns a dict of counters."""
+    a = N.RolloutArgs()
+    a.n_steps, a.envs_per_learner, a.start_steps, a.learn_every = int(n_steps), int(envs_per_learner), int(start_steps), int(learn_every)
+    a.policy_freq, a.epsilon, a.explore_sigma = int(policy_freq), epsilon, explore_sigma
+    la = a.learn
+    la.batch, la.do_actor, la.use_policy_noise = int(batch), 1, int(bool(use_policy_noise))
+    la.gamma, la.tau, la.actor_lr, la.critic_lr, la.alpha_lr = gamma, tau, actor_lr, critic_lr, alpha_lr
+    la.adam_eps, la.clip_norm = 1e-8, clip_norm
+    la.policy_noise, la.noise_clip, la.max_action, la.policy_noise_scale = policy_noise, noise_clip, pool.max_action or 1.0, 1.0
+    la.target_entropy = float(-pool.act_dim if target_entropy is None else target_entropy)
+    st = N.RolloutStats()
+    N.check(engine._L.frl_rollout(engine._h, pool._h, C.byref(a), C.byref(st)))
+    return dict(env_steps=st.env_steps, updates=st.updates, episodes=st.episodes, return_sum=st.return_sum,
+                seconds=st.seconds)

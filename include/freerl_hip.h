@@ -198,6 +198,43 @@ int frl_ppo_learn(frl_engine* e, const frl_ppo_args* args);
 int frl_gae(frl_engine* e, const float* td_delta_dev, const float* adv_done_dev, int n_seq, int horizon,
             float gamma, float lmbda, float* adv_out_dev);
 
+/* ---------------------------------------------------------------- env pool + rollout
+ * The step BEFORE the path: the reference steps one Python env inline per update (DQN.py:316) and
+ * pays H2D + D2H per step in select_action (DQN.py:77,83).  The pool steps n env instances on
+ * host worker threads into pinned staging; frl_rollout runs the whole per-step order of the
+ * reference loop (select_action -> exploration -> env.step -> add -> learn; DQN.py:294-339,
+ * TD3.py:403-450) for P learners x E instances per launch chain. */
+enum frl_env_kind { FRL_ENV_PENDULUM = 0, FRL_ENV_CARTPOLE = 1, FRL_ENV_SYNLINEAR = 2, FRL_ENV_SYNLINEAR_DISCRETE = 3,
+                    FRL_ENV_PENDULUM_SHORT = 4 };
+typedef struct frl_envpool frl_envpool;
+/* params: optional SynLinear matrices A[8][8] then B[8][2] (doubles), else NULL */
+int frl_envpool_create(int kind, int n_envs, int n_threads, uint64_t seed, const double* params, int n_params,
+                       frl_envpool** out);
+int frl_envpool_destroy(frl_envpool* p);
+int frl_envpool_dims(const frl_envpool* p, int* n_envs, int* obs_dim, int* act_dim, int* n_actions, float* max_action,
+                     int* max_steps);
+int frl_envpool_reset(frl_envpool* p, float* obs_out);                       /* host [n][obs_dim] */
+int frl_envpool_set_state(frl_envpool* p, int env, const double* state);     /* test hook: physical state of one env */
+/* actions host [n][act_dim] in env units (discrete: [n] indices as float); outputs host arrays:
+ * next_obs = observation of the transition, obs_next = what the policy sees next (reset obs after a done) */
+int frl_envpool_step(frl_envpool* p, const float* actions, float* next_obs, float* reward, uint8_t* terminated,
+                     uint8_t* truncated, float* obs_next);
+typedef struct frl_rollout_args {
+    int n_steps;             /* vector steps (each steps every env once) */
+    int envs_per_learner;    /* E; the pool must hold P*E envs, env i feeds learner i/E */
+    int start_steps;         /* learn once every ring holds more rows than this (`step > start_steps`) */
+    int learn_every;         /* vector steps per frl_learn call; 0: collect only */
+    int policy_freq;         /* TD3 delayed actor update (TD3.py:224) */
+    float epsilon;           /* DQN epsilon-greedy (DQN.py:307) */
+    float explore_sigma;     /* Gaussian action-noise std as a fraction of max_action (gauss_scale*gauss_sigma, TD3.py:412) */
+    frl_learn_args learn;    /* idx / noise / stats_out must be NULL */
+} frl_rollout_args;
+typedef struct frl_rollout_stats {
+    long long env_steps, updates, episodes;
+    double return_sum, seconds;
+} frl_rollout_stats;
+int frl_rollout(frl_engine* e, frl_envpool* p, const frl_rollout_args* args, frl_rollout_stats* out);
+
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);
 int frl_timer_stop(frl_engine* e, float* ms_out);           /* synchronises */

@@ -42,12 +42,14 @@ def test_ctypes_structs_match_c_layout(native, tmp_path):
     probe = tmp_path / "probe.c"
     probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "freerl_hip.h"\nint main(){'
                      'printf("%zu %zu %zu %zu ", sizeof(frl_config), sizeof(frl_record_layout), sizeof(frl_learn_args), sizeof(frl_ppo_args));'
+                     'printf("%zu %zu ", sizeof(frl_rollout_args), sizeof(frl_rollout_stats));'
                      'printf("%zu %zu %zu %zu\\n", offsetof(frl_config, seed), offsetof(frl_learn_args, idx), offsetof(frl_learn_args, stats_out), offsetof(frl_ppo_args, perms));'
                      'return 0;}')
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(native.Config), C.sizeof(native.RecordLayout), C.sizeof(native.LearnArgs), C.sizeof(native.PpoArgs),
+            C.sizeof(native.RolloutArgs), C.sizeof(native.RolloutStats),
             native.Config.seed.offset, native.LearnArgs.idx.offset, native.LearnArgs.stats_out.offset,
             native.PpoArgs.perms.offset]
     assert got == want

@@ -438,3 +438,42 @@ def test_full_size_device_rng_properties(N):
         np.testing.assert_array_equal(r1[k], r2[k])
     np.testing.assert_array_equal(r1["a"], r1["at"])
     np.testing.assert_array_equal(r1["c"], r1["ct"])
+
+
+def test_rollout_collector_fills_the_ring_consistently(N):
+    """frl_rollout on a population: collect-only first (transitions land in the right rings, next_obs
+    of step t is obs of step t+1 unless the episode ended), then with learning (updates counted,
+    losses finite, parameters move)."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    P, E = 3, 2
+    e = Engine(N.ALGO_TD3, 3, 1, 400, twin_critic=True, batch_max=32, n_learners=P, seed=5)
+    rng = np.random.default_rng(1)
+    for p in range(P):
+        for net in (0, 1):
+            flat = (rng.standard_normal(e.num_params(net)) * 0.1).astype(np.float32)
+            e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
+            e.set_params(net, flat, N.PARAM_TARGET, learner=p)
+    pool = EnvPool("PendulumShort-v1", P * E, n_threads=2, seed=9)
+    out = rollout(e, pool, 50, envs_per_learner=E, learn_every=0, explore_sigma=0.1, batch=32)
+    assert out["env_steps"] == 50 * P * E and out["updates"] == 0 and out["episodes"] == P * E      # 40-step episodes
+    lay = e.layout
+    for p in range(P):
+        assert e.cursor(p) == (100, 100)
+        rows = e.read_rows(p, 0, 100)
+        for env in range(E):
+            tr = rows[env::E]                                  # this env's transitions in time order
+            obs, nobs = tr[:, lay.obs_off[0]:lay.obs_off[0] + 3], tr[:, lay.next_obs_off[0]:lay.next_obs_off[0] + 3]
+            same = np.all(np.abs(nobs[:-1] - obs[1:]) < 1e-6, axis=1)
+            assert same.sum() == len(same) - 1                 # exactly one episode boundary (step 40) in 50 steps
+            assert np.all(np.abs(np.linalg.norm(obs[:, :2], axis=1) - 1) < 1e-5)      # (cos, sin)
+            assert np.all(tr[:, lay.done_off] == 0)            # Pendulum never terminates (truncation is not `done`)
+            assert np.all(np.abs(tr[:, lay.act_off[0]]) <= 1.0)
+    before = e.get_params(1, learner=1).copy()
+    out = rollout(e, pool, 20, envs_per_learner=E, start_steps=64, learn_every=1, policy_freq=2, batch=32)
+    assert out["updates"] == 20 * P
+    st = e.stats()
+    assert np.all(np.isfinite(st)) and np.all(st[:, 0, N.STAT_CRITIC_LOSS] > 0)
+    assert not np.allclose(before, e.get_params(1, learner=1))
+    assert e.opt_step(1, learner=2) == 20 and e.opt_step(0, learner=2) == 10
+    pool.close(); e.close()
