@@ -5,8 +5,9 @@
 The whole `learn()` (value pass, GAE scan, v_target, advantage normalisation, K_epochs x
 minibatch actor/critic steps) runs in three GPU launches.  Reference defect handled: the
 committed `learn` raises TypeError at :302 (`np.zeros(..., dtype=torch.float32)`); the evident
-intent (float32 advantages) is what runs here.  Not ported yet: discrete (Categorical) and Beta
-actors, ObsNorm / reward tricks that live in the caller's loop use `freerl_amd.normalization`.
+intent (float32 advantages) is what runs here.  Gaussian (`Actor`) and Categorical
+(`Actor_discrete`) policies are ported; `Actor_Beta` is not.  ObsNorm / reward tricks that live in
+the caller's loop use `freerl_amd.normalization`.
 """
 import os
 
@@ -22,16 +23,22 @@ _TRICK_DEFAULT = dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_s
 
 
 class Agent:
-    def __init__(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden):
-        al = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("mean_layer", action_dim, hidden)]
+    def __init__(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden, is_continue=True):
+        head = "mean_layer" if is_continue else "l3"
+        al = [("l1", hidden, obs_dim), ("l2", hidden, hidden), (head, action_dim, hidden)]
         cl = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("l3", 1, hidden)]
         ortho = bool(trick["orthogonal_init"])
-        fa = init_layers(al, orthogonal=[1.0, 1.0, 0.01] if ortho else None)     # :92-95
+        # Actor (:79-108) applies orthogonal_init, Actor_discrete (:110-121) does not
+        fa = init_layers(al, orthogonal=[1.0, 1.0, 0.01] if (ortho and is_continue) else None)     # :92-95
         fc = init_layers(cl, orthogonal=[1.0, 1.0, 1.0] if ortho else None)      # :165-168
-        engine.set_params(0, np.concatenate([fa, np.zeros(action_dim, np.float32)]))   # log_std zeros (:85)
+        if is_continue:
+            engine.set_params(0, np.concatenate([fa, np.zeros(action_dim, np.float32)]))   # log_std zeros (:85)
+        else:
+            engine.set_params(0, fa)
         engine.set_params(1, fc)
         eps = 1e-5 if trick["adam_eps"] else 1e-8                                 # :191-196
-        self.actor = DeviceNet(engine, 0, al, extra=("log_std", (1, action_dim)), act_mode=N.ACT_TANHHEAD)
+        self.actor = DeviceNet(engine, 0, al, extra=("log_std", (1, action_dim)) if is_continue else None,
+                               act_mode=N.ACT_TANHHEAD if is_continue else N.ACT_RAW)
         self.critic = DeviceNet(engine, 1, cl)
         self.actor_optimizer = OptimizerView(engine, 0, actor_lr, eps=eps)
         self.critic_optimizer = OptimizerView(engine, 1, critic_lr, eps=eps)
@@ -41,8 +48,6 @@ class PPO:
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, horizon, device, trick=None, beta=False, *,
                  rng="host", hidden=128, minibatch_max=256, seed=0):
         obs_dim, action_dim = dim_info
-        if not is_continue:
-            raise NotImplementedError("Actor_discrete / Categorical (PPO_with_tricks.py:110-121) is not ported yet")
         if beta:
             raise NotImplementedError("Actor_Beta (PPO_with_tricks.py:123-156) is not ported yet")
         self.trick = dict(_TRICK_DEFAULT, **(trick or {}))
@@ -51,11 +56,12 @@ class PPO:
         self.actor_dist = {"Beta": False}
         hip_id, self.device = resolve_device(device)
         self.horizon = int(horizon)
+        stored = action_dim if is_continue else 1            # Buffer act_dim (Buffer.py:3-9)
         self._e = Engine(N.ALGO_PPO, obs_dim, action_dim, max(self.horizon, 2), hidden=hidden, batch_max=minibatch_max,
-                         extra_cols=action_dim + 1, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
-                         device_id=hip_id, seed=seed)
-        self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden)
-        self.buffer = Buffer_for_PPO(self.horizon, obs_dim, action_dim, self.device, _engine=self._e)
+                         extra_cols=stored + 1, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
+                         discrete=not is_continue, device_id=hip_id, seed=seed)
+        self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue)
+        self.buffer = Buffer_for_PPO(self.horizon, obs_dim, stored, self.device, _engine=self._e)
         self.is_continue = is_continue
         self.actor_lr, self.critic_lr = actor_lr, critic_lr
         self._rng = rng
@@ -65,12 +71,20 @@ class PPO:
     def select_action(self, obs):
         """a ~ N(mean, std), per-dimension log-prob; eps from torch's generator like
         `Normal.sample()` (PPO_with_tricks.py:234-255).  Returns (action[A], log_pi[A])."""
+        if not self.is_continue:
+            # Categorical(probs).sample() draws `empty(1, nA).exponential_(1)` and takes argmax(p / q)
+            q = torch.empty(1, self._act_dim).exponential_(1).numpy()
+            a, lp = self._e.act(0, N.ACT_CAT_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=q,
+                                want_logp=True)
+            return np.int64(a[0, 0, 0]), np.float32(lp[0, 0, 0])
         eps = torch.randn(1, self._act_dim).numpy()
         a, lp = self._e.act(0, N.ACT_PPO_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=eps,
                             out_dim=self._act_dim, want_logp=True)
         return a[0, 0], lp[0, 0]
 
-    def evaluate_action(self, obs):                                       # the mean (:257-270)
+    def evaluate_action(self, obs):                                       # the mean / argmax prob (:257-270)
+        if not self.is_continue:
+            return np.int64(self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1))[0, 0, 0])
         return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim)[0, 0]
 
     def add(self, obs, action, reward, next_obs, done, action_log_pi, adv_dones):

@@ -21,7 +21,7 @@ FRL_STAT_COUNT = 8
 ALGO_REPLAY_ONLY, ALGO_DQN, ALGO_DDPG, ALGO_TD3, ALGO_SAC, ALGO_MADDPG, ALGO_PPO = -1, 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 PARAM_ONLINE, PARAM_TARGET, PARAM_ADAM_M, PARAM_ADAM_V, PARAM_GRAD = 0, 1, 2, 3, 4
-ACT_RAW, ACT_ARGMAX, ACT_TANHHEAD, ACT_SAC_SAMPLE, ACT_PPO_SAMPLE = 0, 1, 2, 3, 4
+ACT_RAW, ACT_ARGMAX, ACT_TANHHEAD, ACT_SAC_SAMPLE, ACT_PPO_SAMPLE, ACT_CAT_SAMPLE = 0, 1, 2, 3, 4, 5
 STAT_CRITIC_LOSS, STAT_ACTOR_LOSS, STAT_ALPHA_LOSS, STAT_ALPHA, STAT_CRITIC_GNORM, STAT_ACTOR_GNORM, STAT_ENTROPY = range(7)
 
 

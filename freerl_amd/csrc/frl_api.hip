@@ -257,7 +257,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.capacity = c.capacity;
     h.batch_max = c.batch_max > 0 ? c.batch_max : 256;
     h.seed = c.seed;
-    h.n_discrete = (c.algo == FRL_ALGO_DQN) ? c.act_dim[0] : 0;
+    h.n_discrete = (c.algo == FRL_ALGO_DQN || (c.algo == FRL_ALGO_PPO && c.discrete)) ? c.act_dim[0] : 0;
     build_record(h.rec, c);
     const RecordDesc& R = h.rec;
     const int H = h.hidden;
@@ -268,7 +268,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);   // MLP, DQN.py:32-45
     } else if (c.algo == FRL_ALGO_PPO) {
         h.n_nets = 2;
-        build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, hact, ACT_TANH, c.act_dim[0]);
+        if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits
+            build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);
+        else
+            build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, hact, ACT_TANH, c.act_dim[0]);
         build_net(h.net[1], {{H, c.obs_dim[0]}, {H, H}, {1, H}}, 1, hact, ACT_NONE, 0);
     } else if (e->has_nets) {
         h.n_nets = 2 * c.n_agents;
@@ -300,6 +303,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.lds_out_pad = outp;
     h.lds_batch_pad = pad32(h.batch_max);
     h.lds_act_pad = pad16(std::max(R.act_total, 1));
+    if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
     // row chunk: the largest of {64,32,16} whose LDS footprint still lets 3 workgroups share a CU
     // (12 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
     h.rc = 64;
@@ -662,6 +666,7 @@ static int launch_act(frl_engine* e, int net, int mode, int head, int use_target
     const int nl = N.n_layers / N.heads;
     if (in_dim != N.L[head * nl].k) return fail(FRL_ERR_INVALID, "in_dim %d != layer input %d", in_dim, N.L[head * nl].k);
     if ((mode == FRL_ACT_SAC_SAMPLE || mode == FRL_ACT_PPO_SAMPLE) && N.extra_n == 0) return fail(FRL_ERR_INVALID, "net has no log_std");
+    if (mode == FRL_ACT_CAT_SAMPLE && !eps_dev) return fail(FRL_ERR_INVALID, "FRL_ACT_CAT_SAMPLE needs the Exp(1) draws in eps");
     if (n_rows < 1) return fail(FRL_ERR_INVALID, "n_rows must be >= 1");
     ActArgs a;
     a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
@@ -709,9 +714,10 @@ extern "C" int frl_act(frl_engine* e, int net, int mode, int head, int use_targe
     int rc = launch_act(e, net, mode, head, use_target, n_rows, in_dim, e->d_act_in, eps_host ? e->d_act_eps : nullptr,
                         e->d_act_out, logp_host ? e->d_act_logp : nullptr);
     if (rc) return rc;
-    const size_t got = (mode == FRL_ACT_ARGMAX) ? rows : out_n;
+    const bool one_per_row = (mode == FRL_ACT_ARGMAX || mode == FRL_ACT_CAT_SAMPLE);
+    const size_t got = one_per_row ? rows : out_n;
     HIP_TRY(hipMemcpyAsync(out_host, e->d_act_out, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    if (logp_host) HIP_TRY(hipMemcpyAsync(logp_host, e->d_act_logp, out_n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (logp_host) HIP_TRY(hipMemcpyAsync(logp_host, e->d_act_logp, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return FRL_OK;
 }

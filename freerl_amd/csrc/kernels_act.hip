@@ -14,7 +14,8 @@ enum ActMode : int {
     ACTM_ARGMAX = 1,     // DQN greedy action (index as float)
     ACTM_TANH = 2,       // tanh(head): deterministic actors, SAC/PPO evaluate_action
     ACTM_SAC_SAMPLE = 3, // tanh(mean + std*eps)
-    ACTM_PPO_SAMPLE = 4  // a = tanh(head) + std*eps ; logp per dimension
+    ACTM_PPO_SAMPLE = 4, // a = tanh(head) + std*eps ; logp per dimension
+    ACTM_CAT_SAMPLE = 5  // Categorical(softmax(head)).sample() = argmax(p / q), q ~ Exp(1); logp of the draw
 };
 
 struct ActArgs {
@@ -59,6 +60,26 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
                 if (v > mx) { mx = v; best = j; }
             }
             a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;
+        }
+        return;
+    }
+    if (a.mode == ACTM_CAT_SAMPLE) {        // PPO_with_tricks.py:249-251 (torch single-draw multinomial)
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            float mx = S.outb[r * S.op];
+            for (int j = 1; j < nout; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+            float sum = 0.f;
+            for (int j = 0; j < nout; ++j) sum += expf(S.outb[r * S.op + j] - mx);
+            const size_t row = (size_t)p * a.n_rows + r0 + r;
+            int best = 0;
+            float bestv = -1.f, pbest = 0.f, psum = 0.f;
+            for (int j = 0; j < nout; ++j) {
+                const float pj = expf(S.outb[r * S.op + j] - mx) / sum;
+                psum += pj;
+                const float v = pj / a.eps[row * nout + j];
+                if (v > bestv) { bestv = v; best = j; pbest = pj; }
+            }
+            a.out[row] = (float)best;
+            if (a.out_logp) a.out_logp[row] = logf(fminf(fmaxf(pbest / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
         }
         return;
     }

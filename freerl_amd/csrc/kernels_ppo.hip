@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_cf adv = as_global(a.adv + (size_t)p * T);
     g_cf vt = as_global(a.vtarget + (size_t)p * T);
-    const int O = R.obs_dim[0], A = R.act_dim[0], logp_col = R.extra_off;
+    const bool discrete = D.n_discrete > 0;
+    const int O = R.obs_dim[0], A = discrete ? D.n_discrete : R.act_dim[0], logp_col = R.extra_off;
     const int napad = NA.L[NA.n_layers - 1].n_pad, ncpad = NC.L[NC.n_layers - 1].n_pad;
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     int tA = steps[0], tC = steps[1];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             g_ci idx = perm + s;
             // ---------------- actor: clipped surrogate + entropy bonus (:324-346)
             float lossp = 0.f, gls = 0.f, ent = 0.f;
-            if (threadIdx.x < A) {
+            if (!discrete && threadIdx.x < A) {
                 const float ls = fminf(fmaxf(thA[NA.extra_off + threadIdx.x], -20.f), 2.f);
                 ent = kHalfLog2PiPlusHalf + ls;
             }
@@ -184,7 +185,52 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
                 zero_cols(S.xin, S.xp, rc, O, NA.L[0].k_pad);
                 __syncthreads();
-                mlp_fwd(NA, 0, NA.n_layers, thA, S, ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                mlp_fwd(NA, 0, NA.n_layers, thA, S, discrete ? ACT_NONE : ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                if (discrete) {
+                    // Categorical(probs = softmax(l3)) (:333-336): one thread per row does the softmax,
+                    // log-prob of the stored action, entropy, ratio and the logits' delta
+                    if (threadIdx.x < rc) {
+                        const int r = threadIdx.x;
+                        if (r < nv) {
+                            g_cf rec = ring + (size_t)idx[r0 + r] * R.stride;
+                            float mx = S.outb[r * S.op];
+                            for (int c = 1; c < A; ++c) mx = fmaxf(mx, S.outb[r * S.op + c]);
+                            float sum = 0.f;
+                            for (int c = 0; c < A; ++c) sum += expf(S.outb[r * S.op + c] - mx);
+                            float psum = 0.f;
+                            for (int c = 0; c < A; ++c) psum += expf(S.outb[r * S.op + c] - mx) / sum;
+                            const int ar = (int)rec[R.act_off[0]];
+                            float entr = 0.f, lp_now = 0.f;
+                            for (int c = 0; c < A; ++c) {
+                                const float pc = expf(S.outb[r * S.op + c] - mx) / sum;
+                                const float lg = logf(fminf(fmaxf(pc / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+                                entr -= lg * pc;
+                                if (c == ar) lp_now = lg;
+                            }
+                            const float ratio = expf(lp_now - rec[logp_col]);
+                            const float Ar = adv[idx[r0 + r]];
+                            const float s1 = ratio * Ar;
+                            const float s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
+                            lossp += -fminf(s1, s2) - a.ent_coef * entr;
+                            const float coef = (s1 <= s2 ? Ar : 0.f) * (-invm) * ratio;
+                            for (int c = 0; c < napad; ++c) {
+                                float d = 0.f;
+                                if (c < A) {
+                                    const float pc = expf(S.outb[r * S.op + c] - mx) / sum;
+                                    const float lg = logf(fminf(fmaxf(pc / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+                                    d = coef * ((c == ar ? 1.f : 0.f) - pc) + (a.ent_coef * invm) * pc * (lg + entr);
+                                }
+                                S.abuf[r * S.ap + c] = d;      // staged: outb is still being read by this row
+                            }
+                        } else {
+                            for (int c = 0; c < napad; ++c) S.abuf[r * S.ap + c] = 0.f;
+                        }
+                        for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
+                    }
+                    __syncthreads();
+                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+                    continue;
+                }
                 // per-row ratio and d loss / d sum(logp)
                 if (threadIdx.x < rc) {
                     const int r = threadIdx.x;
@@ -230,11 +276,11 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                     for (int r = 0; r < rc; ++r) gls += S.abuf[r * S.ap + threadIdx.x];
                 mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
             }
-            if (threadIdx.x < A) {
+            if (!discrete && threadIdx.x < A) {
                 const float raw = thA[NA.extra_off + threadIdx.x];
                 gA[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? (gls - a.ent_coef) : 0.f;
             }
-            const float aloss = block_sum(lossp, S.red) * invm - a.ent_coef * ent_sum;
+            const float aloss = block_sum(lossp, S.red) * invm - (discrete ? 0.f : a.ent_coef * ent_sum);
             __syncthreads();
             ++tA;
             adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,

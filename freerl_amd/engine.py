@@ -158,12 +158,12 @@ class Engine:
             obs = obs[None]
         P, n_rows, in_dim = obs.shape
         assert P == self.P
-        od = 1 if mode == N.ACT_ARGMAX else int(out_dim)
+        od = 1 if mode in (N.ACT_ARGMAX, N.ACT_CAT_SAMPLE) else int(out_dim)
         out = np.empty((P, n_rows, od), dtype=F32)
         logp = np.empty((P, n_rows, od), dtype=F32) if want_logp else None
         ep = None
         if eps is not None:
-            eps = np.ascontiguousarray(eps, dtype=F32).reshape(P, n_rows, od)
+            eps = np.ascontiguousarray(eps, dtype=F32).reshape(P, n_rows, -1)
             ep = _fp(eps)
         N.check(self._L.frl_act(self._h, int(net), int(mode), int(head), int(bool(use_target)), n_rows, in_dim,
                                 _fp(obs), ep, _fp(out), _fp(logp) if want_logp else None))

@@ -52,7 +52,9 @@ enum frl_act_mode {
     FRL_ACT_ARGMAX = 1,     /* DQN.select_action, DQN.py:70-84 */
     FRL_ACT_TANHHEAD = 2,   /* TD3/DDPG/MADDPG select_action (TD3.py:163-170), SAC/PPO evaluate_action */
     FRL_ACT_SAC_SAMPLE = 3, /* SAC.select_action, SAC.py:192-198: tanh(mean + std*eps) */
-    FRL_ACT_PPO_SAMPLE = 4  /* PPO.select_action, PPO_with_tricks.py:234-255: a = mean + std*eps, per-dim log-prob */
+    FRL_ACT_PPO_SAMPLE = 4, /* PPO.select_action, PPO_with_tricks.py:234-255: a = mean + std*eps, per-dim log-prob */
+    FRL_ACT_CAT_SAMPLE = 5  /* discrete PPO (:249-251): Categorical(softmax).sample() = argmax(p/q), q ~ Exp(1) in eps
+                               [P][n_rows][n_actions]; out / logp are [P][n_rows] (index as float, log-prob of the draw) */
 };
 
 /* per-(learner, agent) statistics written by frl_learn; index into stats[.][FRL_STAT_COUNT] */

@@ -32,11 +32,18 @@ def gae(td_delta, adv_dones, gamma, lmbda):
     return adv
 
 
+F32_EPS = float(np.finfo(np.float32).eps)
+
+
 class PPO:
-    def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick):
+    def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False):
         self.trick = trick
+        self.discrete = discrete
         act = "tanh" if trick.get("tanh") else "relu"
-        self.pi = MLP(["l1", "l2", "mean_layer"], hidden_act=act, out_act="tanh")   # mean = tanh(...) (:99)
+        if discrete:    # Actor_discrete (:110-121): ReLU hidden layers regardless of trick['tanh'], softmax head
+            self.pi = MLP(["l1", "l2", "l3"], hidden_act="relu", out_act=None)
+        else:
+            self.pi = MLP(["l1", "l2", "mean_layer"], hidden_act=act, out_act="tanh")   # mean = tanh(...) (:99)
         self.v = MLP(["l1", "l2", "l3"], hidden_act=act)
         self.actor = nn.copy_params(actor_p)
         self.critic = nn.copy_params(critic_p)
@@ -44,7 +51,7 @@ class PPO:
         self.actor_opt = Adam(self.actor, actor_lr, eps=eps)
         self.critic_opt = Adam(self.critic, critic_lr, eps=eps)
         self.horizon = int(horizon)
-        self.buffer = BufferForPPO(horizon, obs_dim, act_dim)
+        self.buffer = BufferForPPO(horizon, obs_dim, 1 if discrete else act_dim)
         self.actor_losses, self.critic_losses = [], []
         self.adv_raw = self.v_target = None
 
@@ -53,8 +60,23 @@ class PPO:
         log_std = np.clip(np.broadcast_to(self.actor["log_std"], mean.shape), -20, 2).astype(F32)   # :102
         return mean, log_std, acts
 
-    def evaluate_action(self, obs):                      # :257-270: the mean
+    def probs(self, obs):
+        z = self.pi.forward(self.actor, obs)[0]
+        z = z - z.max(axis=1, keepdims=True)
+        e = np.exp(z)
+        return (e / e.sum(axis=1, keepdims=True)).astype(F32)
+
+    def evaluate_action(self, obs):                      # :257-270: the mean / argmax of the probabilities
+        if self.discrete:
+            return int(np.argmax(self.probs(nn.f32(obs).reshape(1, -1))[0]))
         return self._dist(nn.f32(obs).reshape(1, -1))[0][0]
+
+    def select_action_discrete(self, obs, q):
+        """Categorical(probs).sample() == argmax(probs / q), q ~ Exp(1) per class (torch's
+        single-draw multinomial); log_prob = log(clamp(p_a)) (:249-251)."""
+        p = self.probs(nn.f32(obs).reshape(1, -1))[0]
+        a = int(np.argmax(p / nn.f32(q).reshape(-1)))
+        return a, F32(np.log(np.clip(p[a] / p.sum(dtype=F32), F32_EPS, 1 - F32_EPS)))
 
     def select_action(self, obs, eps):                   # :234-255: a ~ N(mean,std); per-dim log-prob
         mean, log_std, _ = self._dist(nn.f32(obs).reshape(1, -1))
@@ -84,6 +106,10 @@ class PPO:
             for s in range(0, T, minibatch_size):
                 ix = perm[s:s + minibatch_size]
                 mb = len(ix)
+                if self.discrete:
+                    self._discrete_actor_step(obs[ix], action[ix], logp_old[ix], adv[ix], clip_param, ent_coef)
+                    self._critic_step(obs[ix], v_target[ix])
+                    continue
                 # ---- actor (:324-346)
                 body = {kk: vv for kk, vv in self.actor.items() if kk != "log_std"}
                 mean, acts = self.pi.forward(body, obs[ix])
@@ -112,12 +138,41 @@ class PPO:
                 nn.clip_grad_norm(g, 0.5)
                 self.actor_opt.step(self.actor, g)
                 self.actor_losses.append(aloss)
-                # ---- critic (:349-351): mse(v_target[idx], V(obs[idx]))
-                v_s, vacts = self.v.forward(self.critic, obs[ix])
-                closs, dv = nn.mse(v_s, v_target[ix])
-                _, gc = self.v.backward(self.critic, vacts, dv, need_dx=False)
-                gc = {kk: gc[kk] for kk in self.critic}
-                nn.clip_grad_norm(gc, 0.5)
-                self.critic_opt.step(self.critic, gc)
-                self.critic_losses.append(closs)
+                self._critic_step(obs[ix], v_target[ix])
         self.buffer.clear()                                                          # :354
+
+    def _critic_step(self, obs, v_target):
+        """critic (:349-351): mse(v_target[idx], V(obs[idx]))"""
+        v_s, vacts = self.v.forward(self.critic, obs)
+        closs, dv = nn.mse(v_s, v_target)
+        _, gc = self.v.backward(self.critic, vacts, dv, need_dx=False)
+        gc = {kk: gc[kk] for kk in self.critic}
+        nn.clip_grad_norm(gc, 0.5)
+        self.critic_opt.step(self.critic, gc)
+        self.critic_losses.append(closs)
+
+    def _discrete_actor_step(self, obs, action, logp_old, A, clip_param, ent_coef):
+        """Categorical branch (:333-336): dist = Categorical(probs=softmax(l3(.))); entropy and
+        log-prob from the clamped, renormalised probabilities."""
+        mb = obs.shape[0]
+        z, acts = self.pi.forward(self.actor, obs)
+        zs = z - z.max(axis=1, keepdims=True)
+        e = np.exp(zs)
+        p = (e / e.sum(axis=1, keepdims=True)).astype(F32)
+        logit = np.log(np.clip(p / p.sum(axis=1, keepdims=True, dtype=F32), F32_EPS, 1 - F32_EPS)).astype(F32)
+        a = action.astype(np.int64).reshape(-1)
+        lp = logit[np.arange(mb), a].reshape(-1, 1)
+        ent = -(logit * p).sum(axis=1, keepdims=True)
+        ratio = np.exp(lp - logp_old.sum(axis=1, keepdims=True))
+        surr1 = ratio * A
+        surr2 = np.clip(ratio, 1 - clip_param, 1 + clip_param).astype(F32) * A
+        aloss = F32(-np.mean(np.minimum(surr1, surr2), dtype=F32) - F32(ent_coef) * np.mean(ent, dtype=F32))
+        coef = np.where(surr1 <= surr2, A, F32(0)) * F32(-1.0 / mb) * ratio
+        onehot = np.zeros_like(p)
+        onehot[np.arange(mb), a] = 1
+        dz = coef * (onehot - p) + F32(ent_coef / mb) * p * (logit + ent)
+        _, g = self.pi.backward(self.actor, acts, dz.astype(F32), need_dx=False)
+        g = {kk: g[kk] for kk in self.actor}
+        nn.clip_grad_norm(g, 0.5)
+        self.actor_opt.step(self.actor, g)
+        self.actor_losses.append(aloss)

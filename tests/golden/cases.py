@@ -71,6 +71,13 @@ CASES = {
                                   reward_scaling=False, orthogonal_init=False, adam_eps=True,
                                   lr_decay=False, tanh=True, Batch_ObsNorm=False),
                        table_seed=127, param_seed=1510, perm_seed=2510),
+    # PPO discrete: Actor_discrete + Categorical (PPO_with_tricks.py:110-121,333-336), CartPole-like dims
+    "ppo_discrete": dict(kind="ppo_discrete", obs_dim=4, n_actions=3, horizon=192, minibatch=64, k_epochs=2,
+                         gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                         trick=dict(adv_norm=True, ObsNorm=False, reward_norm=False, reward_scaling=False,
+                                    orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
+                                    Batch_ObsNorm=False),
+                         table_seed=128, param_seed=1520, perm_seed=2520),
 }
 
 
@@ -130,6 +137,18 @@ def ppo_inputs(c):
     tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
     actor = synth.mlp_params(c["param_seed"], actor_layers(O, A, head="mean_layer"))
     actor = dict([("log_std", g.uniform(-0.5, 0.3, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
+    perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
+    return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)
+
+
+def ppo_discrete_inputs(c):
+    O, nA, T = c["obs_dim"], c["n_actions"], c["horizon"]
+    tab = synth.transitions(c["table_seed"], T, O, 1, n_discrete=nA)
+    g = np.random.default_rng(c["table_seed"] + 1)
+    tab["logp"] = (-np.abs(g.standard_normal((T, 1))) - 0.7).astype(np.float32)    # one stored log-prob per step
+    tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
+    actor = synth.mlp_params(c["param_seed"], actor_layers(O, nA, head="l3"))
     critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
     perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
     return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)

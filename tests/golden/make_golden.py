@@ -320,6 +320,39 @@ def gen_ppo(name, out):
     out["buffer_size_after"] = np.int64(len(pol.buffer))
 
 
+def gen_ppo_discrete(out):
+    c = cases.CASES["ppo_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    pol = mod.PPO([c["obs_dim"], c["n_actions"]], False, c["actor_lr"], c["critic_lr"], c["horizon"], CPU,
+                  trick=dict(c["trick"]), beta=False)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+    out["evaluate_action"] = np.array([pol.evaluate_action(tab["obs"][i]) for i in range(16)], dtype=np.int64)
+    # Categorical.sample() consumes torch's generator as `empty(1, nA).exponential_(1)` followed by
+    # argmax(probs / q) (single-draw multinomial): seed per call so the tests can redraw q
+    sel = []
+    for i in range(12):
+        torch.manual_seed(900 + i)
+        sel.append(pol.select_action(tab["obs"][i]))
+    out["select_action"] = np.array([int(a) for a, _ in sel], dtype=np.int64)
+    out["select_logp"] = np.array([float(lp) for _, lp in sel], dtype=np.float32)
+    proxy = _NpProxy(inp["perms"])
+    mod.np = proxy
+    pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    mod.np = np
+    out["adv_raw"] = proxy.captured[0].astype(np.float32)
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+
+
 # ----------------------------------------------------------------------------- normalisers
 def gen_norm(out):
     mod = import_reference("PPO_file", "PPO_with_tricks")
@@ -488,6 +521,7 @@ def main():
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
+        "ppo_discrete": gen_ppo_discrete,
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),

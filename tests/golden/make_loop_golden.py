@@ -47,6 +47,8 @@ LOOPS = {
                           "--random_steps 30 --start_steps 100 --batch_size 64 --buffer_size 1000 --device cpu"),
     "loop_ppo_pendulum": ("PPO_file", "PPO_with_tricks", "--env_name PendulumShort-v1 --seed 0 --max_episodes 4 --save_freq 2 "
                           "--horizon 64 --minibatch_size 32 --K_epochs 2 --device cpu"),
+    "loop_ppo_cartpole": ("PPO_file", "PPO_with_tricks", "--env_name CartPole-v1 --seed 0 --max_episodes 8 --save_freq 4 "
+                          "--horizon 64 --minibatch_size 32 --K_epochs 2 --device cpu"),
     "loop_maddpg_spread": ("MADDPG_file", "MADDPG_simple", "--env_name simple_spread_v3 --N 3 --seed 100 --max_episodes 6 "
                            "--save_freq 100 --start_steps 50 --batch_size 32 --buffer_size 500 --device cpu"),
 }

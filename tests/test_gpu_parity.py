@@ -477,3 +477,46 @@ def test_rollout_collector_fills_the_ring_consistently(N):
     assert not np.allclose(before, e.get_params(1, learner=1))
     assert e.opt_step(1, learner=2) == 20 and e.opt_step(0, learner=2) == 10
     pool.close(); e.close()
+
+
+def test_ppo_discrete_learn(N):
+    """Actor_discrete + Categorical (PPO_with_tricks.py:110-121, 249-251, 333-336)."""
+    import torch
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    c = cases.CASES["ppo_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    fx = gold("ppo_discrete")
+    O, nA, T = c["obs_dim"], c["n_actions"], c["horizon"]
+    e = Engine(N.ALGO_PPO, O, nA, T, batch_max=c["minibatch"], extra_cols=2, discrete=True)
+    e.set_params(0, flat_params(inp["params"]["actor"], AC_NAMES))
+    e.set_params(1, flat_params(inp["params"]["critic"], AC_NAMES))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, nA, c["actor_lr"], c["critic_lr"], T, c["trick"],
+                   discrete=True)
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = e.act(0, N.ACT_ARGMAX, tab["obs"][:16])[0, :, 0].astype(np.int64)
+    np.testing.assert_array_equal(ev, fx["evaluate_action"])
+    qs = []
+    for i in range(12):
+        torch.manual_seed(900 + i)
+        qs.append(torch.empty(1, nA).exponential_(1).numpy()[0])
+    a, lp = e.act(0, N.ACT_CAT_SAMPLE, tab["obs"][:12], eps=np.stack(qs), want_logp=True)
+    np.testing.assert_array_equal(a[0, :, 0].astype(np.int64), fx["select_action"])
+    np.testing.assert_allclose(lp[0, :, 0], fx["select_logp"], rtol=1e-5, atol=1e-6)
+    out = e.ppo_learn(T, c["minibatch"], c["k_epochs"], gamma=c["gamma"], lmbda=c["lmbda"], clip=c["clip"],
+                      ent_coef=c["ent"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], adv_norm=True,
+                      perms=np.stack(inp["perms"])[None], want_trace=True, want_adv=True)
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(out["adv"][0], fx["adv_raw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["trace"][0, :, 0], fx["loss_actor"], rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(out["trace"][0, :, 1], fx["loss_critic"], rtol=2e-4)
+    ga = unflat_params(e.get_params(0), orc.actor, AC_NAMES)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
+    synth.check_digest("actor", ga, fx, 2e-3, 2e-5, "hip-vs-reference")
+    e.close()

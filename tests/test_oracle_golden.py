@@ -198,3 +198,31 @@ def test_normalizers():
     rr = g.standard_normal(8)
     got = np.array([np.asarray(rs(r)).reshape(-1)[0] for r in rr])
     np.testing.assert_allclose(got, fx["rscale_y"], rtol=1e-12)
+
+
+def test_ppo_discrete_learn():
+    c = cases.CASES["ppo_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    fx = gold("ppo_discrete")
+    pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["n_actions"], c["actor_lr"],
+                  c["critic_lr"], c["horizon"], c["trick"], discrete=True)
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = [pol.evaluate_action(tab["obs"][i]) for i in range(16)]
+    np.testing.assert_array_equal(np.array(ev), fx["evaluate_action"])
+    import torch
+    sel = []
+    for i in range(12):         # redraw the Exp(1) variates Categorical.sample() consumed under the same seed
+        torch.manual_seed(900 + i)
+        q = torch.empty(1, c["n_actions"]).exponential_(1).numpy()
+        sel.append(pol.select_action_discrete(tab["obs"][i], q))
+    np.testing.assert_array_equal(np.array([a for a, _ in sel]), fx["select_action"])
+    np.testing.assert_allclose(np.array([lp for _, lp in sel]), fx["select_logp"], rtol=1e-5, atol=1e-6)
+    pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(pol.adv_raw.reshape(-1), fx["adv_raw"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
+    synth.check_digest("actor", pol.actor, fx, 1e-3, 1e-5)
+    synth.check_digest("critic", pol.critic, fx, 1e-3, 1e-5)
