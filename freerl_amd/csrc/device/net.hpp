@@ -34,7 +34,7 @@ __device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int ki
     S.xp = kin_pad_max + 4;
     S.hp = hidden + 4;
     S.op = out_pad_max + 4;
-    S.ap = act_pad + 4;
+    S.ap = act_pad;
     lds_f p = (lds_f)smem;
     S.xin = p; p += rc * S.xp;
     S.h1 = p; p += rc * S.hp;

@@ -173,7 +173,7 @@ static void build_record(RecordDesc& R, const frl_config& c) {
 }
 
 static int lds_bytes_for(const EngineDesc& h, int rc) {
-    const int xp = h.lds_kin_pad + 4, hp = h.hidden + 4, op = h.lds_out_pad + 4, ap = h.lds_act_pad + 4;
+    const int xp = h.lds_kin_pad + 4, hp = h.hidden + 4, op = h.lds_out_pad + 4, ap = h.lds_act_pad;
     const long long fl = (long long)rc * (xp + 2 * hp + op + 2 * ap) + h.lds_batch_pad + 8;
     return (int)(fl * 4);
 }
@@ -301,13 +301,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);
     h.lds_kin_pad = kin;
     h.lds_out_pad = outp;
-    h.lds_batch_pad = pad32(h.batch_max);
-    h.lds_act_pad = pad16(std::max(R.act_total, 1));
+    h.lds_batch_pad = 64;                                   // y holds one row chunk (rc <= 64) of TD targets
+    h.lds_act_pad = (std::max(R.act_total, 1) + 3) / 4 * 4; // abuf / dabuf are scalar-accessed: no tile padding
     if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
-    // row chunk: the largest of {64,32,16} whose LDS footprint still lets 3 workgroups share a CU
-    // (12 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
+    // row chunk: the largest of {64,32,16} whose LDS footprint still lets 4 workgroups share a CU
+    // (16 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
     h.rc = 64;
-    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 53 * 1024) h.rc /= 2;
+    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 40 * 1024) h.rc /= 2;
     if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
     e->lds_bytes = lds_bytes_for(h, h.rc);
     h.S = (h.batch_max + h.rc - 1) / h.rc;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
 // ------------------------------------------------------------------------------------- DQN
 // DQN.learn (DQN_file/DQN.py:104-118) for one row chunk: y = r + gamma*max_a Q_t(s',a)*(1-d);
 // delta = 2(Q(s)[a] - y)/B on the taken action; backward -> partial slab.
-__global__ __launch_bounds__(256) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dqn_grad_kernel(const EngineDesc* __restr
 // ------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: critic
 // TD target with the target nets, twin/single critic forward, MSE delta, backward -> slab.
 // DDPG_simple.py:139-149, TD3.py:193-213, SAC.py:226-238, MADDPG_simple.py:169-176.
-__global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void ac_critic_kernel(const EngineDesc* __rest
 // -------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: actor
 // a = actor(s); Q(s, a) through the (already updated, frozen) critic; dQ/da; actor backward.
 // DDPG_simple.py:151-154, TD3.py:224-231, SAC.py:244-252, MADDPG_simple.py:178-183.
-__global__ __launch_bounds__(256) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
