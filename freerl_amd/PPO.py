@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import DeviceNet, Engine, OptimizerView, init_layers, resolve_device
+from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, init_layers, resolve_device
 from .Buffer import Buffer_for_PPO
 
 _TRICK_DEFAULT = dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_scaling=False, orthogonal_init=False,
@@ -51,8 +51,6 @@ class PPO:
         if beta:
             raise NotImplementedError("Actor_Beta (PPO_with_tricks.py:123-156) is not ported yet")
         self.trick = dict(_TRICK_DEFAULT, **(trick or {}))
-        if self.trick["Batch_ObsNorm"]:
-            raise NotImplementedError("trick['Batch_ObsNorm'] is not ported yet")
         self.actor_dist = {"Beta": False}
         hip_id, self.device = resolve_device(device)
         self.horizon = int(horizon)
@@ -62,6 +60,9 @@ class PPO:
                          discrete=not is_continue, device_id=hip_id, seed=seed)
         self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue)
         self.buffer = Buffer_for_PPO(self.horizon, obs_dim, stored, self.device, _engine=self._e)
+        if self.trick["Batch_ObsNorm"]:                                   # PPO_with_tricks.py:225-226
+            self._e.obsnorm_enable(True)
+            self.batch_size_obs_norm = BatchObsNormView(self._e)
         self.is_continue = is_continue
         self.actor_lr, self.critic_lr = actor_lr, critic_lr
         self._rng = rng
@@ -84,8 +85,10 @@ class PPO:
 
     def evaluate_action(self, obs):                                       # the mean / argmax prob (:257-270)
         if not self.is_continue:
-            return np.int64(self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1))[0, 0, 0])
-        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim)[0, 0]
+            return np.int64(self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1),
+                                        normalize=False)[0, 0, 0])
+        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim,
+                           normalize=False)[0, 0]          # no Batch_ObsNorm in evaluate_action (:257-270)
 
     def add(self, obs, action, reward, next_obs, done, action_log_pi, adv_dones):
         self.buffer.add(obs, action, reward, next_obs, done, action_log_pi, adv_dones)

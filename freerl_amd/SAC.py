@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
+from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
 from .Buffer import Buffer
 from .TD3 import critic_layers
 
@@ -62,8 +62,6 @@ class SAC:
             raise NotImplementedError("SAC_add_discrete.py is out of scope (SURVEY.md §2.1)")
         if trick is None:
             raise TypeError("SAC needs the `trick` dict (the reference indexes it, SAC.py:181)")
-        if trick.get("Batch_ObsNorm"):
-            raise NotImplementedError("trick['Batch_ObsNorm'] is not ported yet")
         hip_id, self.device = resolve_device(device)
         self._e = Engine(N.ALGO_SAC, obs_dim, action_dim, max(int(buffer_size), 1), twin_critic=True, hidden=hidden,
                          batch_max=batch_max, device_id=hip_id, seed=seed)
@@ -71,6 +69,9 @@ class SAC:
         self.buffer = Buffer(buffer_size, obs_dim, act_dim=action_dim, device=self.device, _engine=self._e)
         self.is_continue = is_continue
         self.trick = trick
+        if trick.get("Batch_ObsNorm"):                                   # SAC.py:181-182
+            self._e.obsnorm_enable(True)
+            self.batch_size_obs_norm = BatchObsNormView(self._e)
         self.adaptive_alpha = True                                       # SAC.py:185
         self.alphas = Alpha(self._e, action_dim, alpha=0.01)             # SAC.py:188
         self._rng = rng
@@ -85,7 +86,8 @@ class SAC:
                            out_dim=self._act_dim)[0, 0]
 
     def evaluate_action(self, obs):                                      # tanh(mean) (SAC.py:200-204)
-        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim)[0, 0]
+        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim,
+                           normalize=False)[0, 0]        # the reference does not apply Batch_ObsNorm here
 
     def add(self, obs, action, reward, next_obs, done):
         self.buffer.add(obs, action, reward, next_obs, done)

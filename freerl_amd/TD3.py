@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
+from ._core import (BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, init_layers, init_layers_ddpg,
+                    resolve_device)
 from .Buffer import Buffer
 
 
@@ -28,10 +29,12 @@ def critic_layers(in_dim, hidden, twin):
 class Agent:
     """Agent (TD3.py:123-147): actor, critic (Critic_TD3 when clip_double), Adam each, targets = deepcopy."""
 
-    def __init__(self, engine, obs_dim, action_dim, dim_info, actor_lr, critic_lr, twin, hidden, critic_wd=0.0):
+    def __init__(self, engine, obs_dim, action_dim, dim_info, actor_lr, critic_lr, twin, hidden, critic_wd=0.0,
+                 net_init=False):
         al, cl = actor_layers(obs_dim, action_dim, hidden), critic_layers(sum(dim_info), hidden, twin)
-        fa = init_layers(al)            # torch RNG order: actor l1..l3, then critic l1..l3[,l4..l6] (TD3.py:125-129)
-        fc = init_layers(cl)
+        init = init_layers_ddpg if net_init else init_layers
+        fa = init(al)                   # torch RNG order: actor l1..l3, then critic l1..l3[,l4..l6] (TD3.py:125-129)
+        fc = init(cl)
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
             engine.set_params(0, fa, kind)
             engine.set_params(1, fc, kind)
@@ -52,7 +55,8 @@ class TD3:
     _ALGO, _FILE = N.ALGO_TD3, "TD3.pt"
 
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, realize=None, *,
-                 rng="host", hidden=128, batch_max=1024, seed=0, critic_weight_decay=0.0):
+                 rng="host", hidden=128, batch_max=1024, seed=0, critic_weight_decay=0.0, net_init=False,
+                 batch_obs_norm=False):
         obs_dim, action_dim = dim_info
         if not is_continue:
             raise ValueError("the discrete branch of TD3.select_action is dead code in the reference (TD3.py:169)")
@@ -61,7 +65,11 @@ class TD3:
         twin = bool(self.realize["clip_double"])
         self._e = Engine(self._ALGO, obs_dim, action_dim, max(int(buffer_size), 1), twin_critic=twin, hidden=hidden,
                          batch_max=batch_max, device_id=hip_id, seed=seed)
-        self.agent = Agent(self._e, obs_dim, action_dim, dim_info, actor_lr, critic_lr, twin, hidden, critic_weight_decay)
+        self.agent = Agent(self._e, obs_dim, action_dim, dim_info, actor_lr, critic_lr, twin, hidden, critic_weight_decay,
+                           net_init)
+        if batch_obs_norm:                                              # DDPG.py:160-161
+            self._e.obsnorm_enable(True)
+            self.batch_size_obs_norm = BatchObsNormView(self._e)
         self.buffer = Buffer(buffer_size, obs_dim, act_dim=action_dim, device=self.device, _engine=self._e)
         self.is_continue = is_continue
         self.trick = trick
@@ -75,7 +83,9 @@ class TD3:
         return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim)[0, 0]
 
     def evaluate_action(self, obs):
-        return self.select_action(obs)
+        """deterministic policy; DDPG.py:173-181 does NOT apply Batch_ObsNorm here (select_action does)."""
+        return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim,
+                           normalize=False)[0, 0]
 
     def add(self, obs, action, reward, next_obs, done):
         self.buffer.add(obs, action, reward, next_obs, done)
@@ -128,13 +138,14 @@ class DDPG(TD3):
     _ALGO, _FILE = N.ALGO_DDPG, "DDPG.pt"
 
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, supplement=None, **kw):
-        wd = 1e-3 if (supplement or {}).get("weight_decay") else 0.0
-        for k in ("ObsNorm", "Batch_ObsNorm", "net_init"):
-            if (supplement or {}).get(k):
-                raise NotImplementedError("DDPG.py supplement[%r] is not ported yet (DESIGN.md, out of scope list)" % k)
+        sup = supplement or {}
+        self.supplement = supplement
+        # DDPG.py supplements: weight_decay (critic Adam, :131-134), net_init (:78-86), Batch_ObsNorm
+        # (:160-161,190-192); OUNoise / ObsNorm live in the caller's loop (freerl_amd.train)
         super().__init__(dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=trick,
                          realize={"clip_double": False, "policy_noise": False, "twin_delay": False},
-                         critic_weight_decay=wd, **kw)
+                         critic_weight_decay=1e-3 if sup.get("weight_decay") else 0.0,
+                         net_init=bool(sup.get("net_init")), batch_obs_norm=bool(sup.get("Batch_ObsNorm")), **kw)
 
     def learn(self, batch_size, gamma, tau):                            # DDPG_simple.py:137-156
         super().learn(batch_size, gamma, tau, 0.0, 0.0, 1.0, 1, 1.0)

@@ -146,6 +146,43 @@ def init_layers(layers, orthogonal=None):
     return np.concatenate([np.concatenate([w.reshape(-1), b.reshape(-1)]) for w, b in ws])
 
 
+def init_layers_ddpg(layers, final=3e-3):
+    """DDPG.py net_init (DDPG.py:57-68,78-86): default nn.Linear draws for every layer first, then
+    `other_net_init` on all but the last layer (U(+-1/sqrt(weight.size(0))) — the reference takes
+    size(0), i.e. out_features) and `final_net_init` U(+-3e-3) on the last, weight then bias each."""
+    shapes = [(o, i) for _, o, i in layers]
+    for o, i in shapes:
+        linear_init(o, i)                                   # consumed, then overwritten like the reference does
+    parts = []
+    for j, (o, i) in enumerate(shapes):
+        lim = final if j == len(shapes) - 1 else 1.0 / (o ** 0.5)
+        w = torch.empty(o, i).uniform_(-lim, lim).numpy().astype(F32)
+        b = torch.empty(o).uniform_(-lim, lim).numpy().astype(F32)
+        parts += [w.reshape(-1), b.reshape(-1)]
+    return np.concatenate(parts)
+
+
+class BatchObsNormView:
+    """`policy.batch_size_obs_norm.running_ms.{mean,std}` (SAC.py:586, DDPG.py:160): reads the engine's
+    device-side Normalization_batch_size statistics."""
+
+    def __init__(self, engine):
+        self._e = engine
+        self.running_ms = self
+
+    @property
+    def n(self):
+        return self._e.obsnorm_stats()["n"]
+
+    @property
+    def mean(self):
+        return torch.from_numpy(self._e.obsnorm_stats()["mean"].reshape(1, -1))
+
+    @property
+    def std(self):
+        return torch.from_numpy(self._e.obsnorm_stats()["std"].reshape(1, -1))
+
+
 def as_f32(x, n):
     a = np.asarray(x, dtype=F32).reshape(-1)
     if a.size != n:

@@ -22,6 +22,7 @@ ALGO_REPLAY_ONLY, ALGO_DQN, ALGO_DDPG, ALGO_TD3, ALGO_SAC, ALGO_MADDPG, ALGO_PPO
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 PARAM_ONLINE, PARAM_TARGET, PARAM_ADAM_M, PARAM_ADAM_V, PARAM_GRAD = 0, 1, 2, 3, 4
 ACT_RAW, ACT_ARGMAX, ACT_TANHHEAD, ACT_SAC_SAMPLE, ACT_PPO_SAMPLE, ACT_CAT_SAMPLE = 0, 1, 2, 3, 4, 5
+ACT_NO_OBSNORM = 0x100
 STAT_CRITIC_LOSS, STAT_ACTOR_LOSS, STAT_ALPHA_LOSS, STAT_ALPHA, STAT_CRITIC_GNORM, STAT_ACTOR_GNORM, STAT_ENTROPY = range(7)
 
 
@@ -104,6 +105,9 @@ SIGNATURES = {
     "frl_opt_step_set": (_i, [_vp, _i, _i, _i]),
     "frl_alpha_get": (_i, [_vp, _i, _fp, _ip]),
     "frl_alpha_set": (_i, [_vp, _i, _fp, _i]),
+    "frl_obsnorm_enable": (_i, [_vp, _i]),
+    "frl_obsnorm_get": (_i, [_vp, _i, _fp]),
+    "frl_obsnorm_set": (_i, [_vp, _i, _fp]),
     "frl_act": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
     "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "frl_learn": (_i, [_vp, _P(LearnArgs)]),

@@ -177,6 +177,17 @@ __device__ __forceinline__ void gather_cols(lds_f X, int ldx, int rc, int nvalid
         X[r * ldx + dst0 + c] = v;
     }
 }
+// Batch_ObsNorm: X[r][c0 + c] = (X[r][c0 + c] - mean[c]) / (std[c] + 1e-8) for r < nvalid
+// (Normalization_batch_size.__call__, PPO_file/normalization.py:78-84); stats = {n, mean[O], S[O], std[O]}
+__device__ __forceinline__ void normalize_cols(lds_f X, int ldx, int nvalid, int c0, int ncols, g_cf stats, int O) {
+    g_cf mean = stats + 1, sd = stats + 1 + 2 * O;
+    for (int e = threadIdx.x; e < nvalid * ncols; e += kWG) {
+        const int r = e / ncols, c = e - r * ncols;
+        lds_f x = X + r * ldx + c0 + c;
+        *x = (*x - mean[c]) / (sd[c] + 1e-8f);
+    }
+}
+
 __device__ __forceinline__ void zero_cols(lds_f X, int ldx, int rc, int c0, int c1) {
     const int w = c1 - c0;
     if (w <= 0) return;

@@ -216,6 +216,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->h.slab) hipFree(e->h.slab);
     if (e->h.part) hipFree(e->h.part);
     if (e->h.gsq) hipFree(e->h.gsq);
+    if (e->h.obsnorm) hipFree(e->h.obsnorm);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return FRL_OK;
@@ -347,6 +348,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
+        CREATE_TRY(dalloc_zero(&h.obsnorm, P * (size_t)(1 + 3 * c.obs_dim[0]), e->stream));
         CREATE_TRY(hipHostMalloc((void**)&e->h_idx, e->idx_count * sizeof(int)));
         CREATE_TRY(hipHostMalloc((void**)&e->h_noise, e->noise_count * sizeof(float)));
     }
@@ -657,8 +659,9 @@ extern "C" int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int
 }
 
 // -------------------------------------------------------------------------------------- act
-static int launch_act(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim,
+static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_target, int n_rows, int in_dim,
                       const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev) {
+    int mode = mode_flags & ~FRL_ACT_NO_OBSNORM;
     if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
     if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
     const NetDesc& N = e->h.net[net];
@@ -668,8 +671,10 @@ static int launch_act(frl_engine* e, int net, int mode, int head, int use_target
     if ((mode == FRL_ACT_SAC_SAMPLE || mode == FRL_ACT_PPO_SAMPLE) && N.extra_n == 0) return fail(FRL_ERR_INVALID, "net has no log_std");
     if (mode == FRL_ACT_CAT_SAMPLE && !eps_dev) return fail(FRL_ERR_INVALID, "FRL_ACT_CAT_SAMPLE needs the Exp(1) draws in eps");
     if (n_rows < 1) return fail(FRL_ERR_INVALID, "n_rows must be >= 1");
+    const bool no_norm = (mode_flags & FRL_ACT_NO_OBSNORM) != 0;
     ActArgs a;
     a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
+    a.normalize = (!no_norm && e->h.obs_norm_on && e->h.n_agents == 1 && in_dim == e->h.rec.obs_dim[0]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
     dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
     hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
@@ -714,7 +719,8 @@ extern "C" int frl_act(frl_engine* e, int net, int mode, int head, int use_targe
     int rc = launch_act(e, net, mode, head, use_target, n_rows, in_dim, e->d_act_in, eps_host ? e->d_act_eps : nullptr,
                         e->d_act_out, logp_host ? e->d_act_logp : nullptr);
     if (rc) return rc;
-    const bool one_per_row = (mode == FRL_ACT_ARGMAX || mode == FRL_ACT_CAT_SAMPLE);
+    const int base_mode = mode & ~FRL_ACT_NO_OBSNORM;
+    const bool one_per_row = (base_mode == FRL_ACT_ARGMAX || base_mode == FRL_ACT_CAT_SAMPLE);
     const size_t got = one_per_row ? rows : out_n;
     HIP_TRY(hipMemcpyAsync(out_host, e->d_act_out, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (logp_host) HIP_TRY(hipMemcpyAsync(logp_host, e->d_act_logp, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -806,6 +812,8 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
         hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)a.batch * sizeof(int), e->stream, e->d, a, needs_noise ? 1 : 0);
         prof_end(e);
     }
+    if (h.obs_norm_on && h.algo != ALGO_DQN && h.n_agents == 1)      // sample(): norm(obs) updates the statistics first
+        hipLaunchKernelGGL(obsnorm_kernel, dim3(h.P), blk, 0, e->stream, e->d, a.batch, 0);
     AdamArgs ad;
     memset(&ad, 0, sizeof ad);
     ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
@@ -899,6 +907,32 @@ extern "C" int frl_timer_stop(frl_engine* e, float* ms_out) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     if (ms_out) *ms_out = ms;
+    return FRL_OK;
+}
+
+// Batch_ObsNorm (Normalization_batch_size): switch + statistics {n, mean[O], S[O], std[O]} per learner
+extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
+    ENG(e);
+    if (!e->has_nets || e->h.n_agents != 1) return fail(FRL_ERR_STATE, "Batch_ObsNorm is implemented for the single-agent engines");
+    e->h.obs_norm_on = on ? 1 : 0;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d, &e->h, sizeof e->h, hipMemcpyHostToDevice));
+    return FRL_OK;
+}
+extern "C" int frl_obsnorm_get(frl_engine* e, int learner, float* stats_out) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || !stats_out) return fail(FRL_ERR_INVALID, "bad argument");
+    const size_t w = 1 + 3 * (size_t)e->h.rec.obs_dim[0];
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(stats_out, e->h.obsnorm + learner * w, w * sizeof(float), hipMemcpyDeviceToHost));
+    return FRL_OK;
+}
+extern "C" int frl_obsnorm_set(frl_engine* e, int learner, const float* stats) {
+    ENG(e);
+    if (!e->has_nets || learner < 0 || learner >= e->h.P || !stats) return fail(FRL_ERR_INVALID, "bad argument");
+    const size_t w = 1 + 3 * (size_t)e->h.rec.obs_dim[0];
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->h.obsnorm + learner * w, stats, w * sizeof(float), hipMemcpyHostToDevice));
     return FRL_OK;
 }
 

@@ -25,6 +25,7 @@ struct ActArgs {
     int n_rows;          // rows per learner
     int head;            // critic head (0/1) for ACTM_RAW on twin critics
     int in_dim;          // logical input width (obs dim, or obs+act for critics)
+    int normalize;       // apply Batch_ObsNorm to the first obs_dim input columns (policy / value nets on raw obs)
     const float* in;     // [P][n_rows][in_dim] dense
     const float* eps;    // [P][n_rows][out_dim] standard normal draws, or nullptr
     float* out;          // [P][n_rows][out_dim]   (ARGMAX: out_dim = 1)
@@ -46,6 +47,11 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     for (int e = threadIdx.x; e < rc * kpad; e += kWG) {
         const int r = e / kpad, c = e - r * kpad;
         S.xin[r * S.xp + c] = (r < nv && c < K) ? in[(size_t)r * K + c] : 0.f;
+    }
+    if (D.obs_norm_on && a.normalize) {          // select_action: norm(obs, update=False) (SAC.py:194-195)
+        __syncthreads();
+        normalize_cols(S.xin, S.xp, nv, 0, D.rec.obs_dim[0], as_global(D.obsnorm + (size_t)p * (1 + 3 * D.rec.obs_dim[0])),
+                       D.rec.obs_dim[0]);
     }
     __syncthreads();
     const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;

@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __res
             const int r = e / kpad, c = e - r * kpad;
             S.xin[r * S.xp + c] = (r < nv && c < O) ? ring[(size_t)(r0 + r) * R.stride + src + c] : 0.f;
         }
+        if (D.obs_norm_on) {
+            __syncthreads();
+            normalize_cols(S.xin, S.xp, nv, 0, O, as_global(D.obsnorm + (size_t)p * (1 + 3 * O)), O);
+        }
         __syncthreads();
         mlp_fwd(N, 0, N.n_layers, theta, S, ACT_NONE);
         if (threadIdx.x < nv) {
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     g_cf adv = as_global(a.adv + (size_t)p * T);
     g_cf vt = as_global(a.vtarget + (size_t)p * T);
     const bool discrete = D.n_discrete > 0;
+    g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + (size_t)p * (1 + 3 * R.obs_dim[0])) : nullptr;
     const int O = R.obs_dim[0], A = discrete ? D.n_discrete : R.act_dim[0], logp_col = R.extra_off;
     const int napad = NA.L[NA.n_layers - 1].n_pad, ncpad = NC.L[NC.n_layers - 1].n_pad;
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 const int nv = min(rc, m - r0);
                 gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
                 zero_cols(S.xin, S.xp, rc, O, NA.L[0].k_pad);
+                if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, O, bn, O); }
                 __syncthreads();
                 mlp_fwd(NA, 0, NA.n_layers, thA, S, discrete ? ACT_NONE : ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
                 if (discrete) {
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 const int nv = min(rc, m - r0);
                 gather_cols(S.xin, S.xp, rc, nv, idx + r0, ring, R.stride, R.obs_off[0], O, 0);
                 zero_cols(S.xin, S.xp, rc, O, NC.L[0].k_pad);
+                if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, O, bn, O); }
                 __syncthreads();
                 mlp_fwd(NC, 0, NC.n_layers, thC, S, ACT_NONE);
                 for (int e = threadIdx.x; e < rc * ncpad; e += kWG) {

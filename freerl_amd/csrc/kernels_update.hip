@@ -66,6 +66,39 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
     }
 }
 
+// ----------------------------------------------------------------------------- Batch_ObsNorm
+// RunningMeanStd_batch_size.update (PPO_file/normalization.py:61-71; SAC.py:215, DDPG.py:191) with
+// the batch mean of the sampled observations: n += 1; first call: mean = std = xbar; afterwards a
+// Welford step on the batch means.  One workgroup per learner, before the gradient kernels.
+__global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows) {
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.x, O = D.rec.obs_dim[0];
+    const RecordDesc& R = D.rec;
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max);
+    g_f st = as_global(D.obsnorm + (size_t)p * (1 + 3 * O));
+    const float n = st[0] + 1.f;
+    for (int c = threadIdx.x; c < O; c += kWG) {
+        float s = 0.f;
+        for (int r = 0; r < batch; ++r) s += ring[(size_t)(all_rows ? r : idx[r]) * R.stride + R.obs_off[0] + c];
+        const float xbar = s / (float)batch;
+        g_f mean = st + 1 + c, S = st + 1 + O + c, sd = st + 1 + 2 * O + c;
+        if (n == 1.f) {
+            *mean = xbar;
+            *sd = xbar;
+        } else {
+            const float old = *mean;
+            const float m2 = old + (xbar - old) / n;
+            const float S2 = *S + (xbar - old) * (xbar - m2);
+            *mean = m2;
+            *S = S2;
+            *sd = sqrtf(S2 / n);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st[0] = n;
+}
+
 // ------------------------------------------------------------------------------------- DQN
 // DQN.learn (DQN_file/DQN.py:104-118) for one row chunk: y = r + gamma*max_a Q_t(s',a)*(1-d);
 // delta = 2(Q(s)[a] - y)/B on the taken action; backward -> partial slab.
@@ -149,6 +182,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
+    g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
 
     // ---- a' = actor_target_j(s'_j) for every agent j (MADDPG_simple.py:155; n = 1 otherwise)
     float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
@@ -158,6 +192,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
         const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
+        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn, Oj); }
         __syncthreads();
         mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
         if (sac) {                                  // SAC.py:70-97 on actor_target (SAC.py:227)
@@ -198,6 +233,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
         S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
     }
     zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
     __syncthreads();
     mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
     float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
     for (int h = 0; h < heads; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
         __syncthreads();
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
@@ -271,10 +308,12 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
     const int ct0 = (OT + acol) / 16, ct1 = (OT + acol + Aa + 15) / 16;
     const int nq = sac ? heads : 1;                 // SAC: mean of the twins (SAC.py:250); TD3: Q1 only (TD3.py:227)
     const float dq = sac ? -0.5f * invB : -invB;
+    g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
 
     // -- a = actor(obs)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
+    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
     __syncthreads();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     float lp = 0.f;
@@ -309,6 +348,7 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
     for (int h = 0; h < nq; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
         __syncthreads();
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
@@ -343,6 +383,7 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
     // -- actor forward again (activations for its backward), head delta, backward
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
+    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
     __syncthreads();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     const int napad = NA.L[NA.n_layers - 1].n_pad;

@@ -151,7 +151,7 @@ class Engine:
         N.check(self._L.frl_alpha_set(self._h, int(learner), _fp(v), int(step)))
 
     # ------------------------------------------------------------------ forward
-    def act(self, net, mode, obs, *, eps=None, head=0, use_target=False, out_dim=None, want_logp=False):
+    def act(self, net, mode, obs, *, eps=None, head=0, use_target=False, out_dim=None, want_logp=False, normalize=True):
         """obs [P, n_rows, in_dim] (or [n_rows, in_dim] when P == 1) -> out [P, n_rows, out_dim]."""
         obs = np.ascontiguousarray(obs, dtype=F32)
         if obs.ndim == 2:
@@ -165,7 +165,8 @@ class Engine:
         if eps is not None:
             eps = np.ascontiguousarray(eps, dtype=F32).reshape(P, n_rows, -1)
             ep = _fp(eps)
-        N.check(self._L.frl_act(self._h, int(net), int(mode), int(head), int(bool(use_target)), n_rows, in_dim,
+        flags = int(mode) | (0 if normalize else N.ACT_NO_OBSNORM)
+        N.check(self._L.frl_act(self._h, int(net), flags, int(head), int(bool(use_target)), n_rows, in_dim,
                                 _fp(obs), ep, _fp(out), _fp(logp) if want_logp else None))
         return (out, logp) if want_logp else out
 
@@ -249,3 +250,13 @@ class Engine:
         N.check(self._L.frl_profile_read(self._h, ms, cnt))
         names = ["draw", "grad_critic", "adam_critic", "grad_actor", "adam_actor", "soft_update", "ppo", "_"]
         return {names[k]: (ms[k], cnt[k]) for k in range(8) if cnt[k]}
+
+    def obsnorm_enable(self, on=True):
+        N.check(self._L.frl_obsnorm_enable(self._h, int(bool(on))))
+
+    def obsnorm_stats(self, learner=0):
+        """-> dict(n, mean[O], S[O], std[O]) of the Batch_ObsNorm running statistics."""
+        O = self.layout.obs_dim[0]
+        buf = np.zeros(1 + 3 * O, dtype=F32)
+        N.check(self._L.frl_obsnorm_get(self._h, int(learner), _fp(buf)))
+        return dict(n=int(buf[0]), mean=buf[1:1 + O].copy(), S=buf[1 + O:1 + 2 * O].copy(), std=buf[1 + 2 * O:].copy())

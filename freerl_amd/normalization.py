@@ -1,7 +1,8 @@
 """Host-side normalisers with the reference's surface (PPO_file/normalization.py:17-101; inline
 copies in SAC.py:334-421, DDPG.py:305-403): `Normalization`, `RewardScaling` run once per env
 step in the CALLER's loop on single observations/rewards, so they stay host code here too.
-(`Normalization_batch_size`, the per-sampled-batch variant, is not ported yet.)"""
+`Normalization_batch_size`, the per-sampled-batch variant that runs inside `sample()` on device
+tensors, lives in the engine (`frl_obsnorm_*`, enabled by trick/supplement `Batch_ObsNorm`)."""
 import numpy as np
 
 

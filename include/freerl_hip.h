@@ -57,6 +57,10 @@ enum frl_act_mode {
                                [P][n_rows][n_actions]; out / logp are [P][n_rows] (index as float, log-prob of the draw) */
 };
 
+/* OR into `mode`: skip Batch_ObsNorm for this call — the reference's evaluate_action does not normalise
+ * although select_action does (SAC.py:200-204 vs :194-195; DDPG.py:173-181 vs :165-166) */
+#define FRL_ACT_NO_OBSNORM 0x100
+
 /* per-(learner, agent) statistics written by frl_learn; index into stats[.][FRL_STAT_COUNT] */
 enum frl_stat {
     FRL_STAT_CRITIC_LOSS = 0, FRL_STAT_ACTOR_LOSS = 1, FRL_STAT_ALPHA_LOSS = 2, FRL_STAT_ALPHA = 3,
@@ -161,6 +165,15 @@ int frl_opt_step_set(frl_engine* e, int learner, int net, int t);
 /* SAC Alpha (SAC.py:154-169): vals = {log_alpha, exp_avg, exp_avg_sq, alpha} */
 int frl_alpha_get(frl_engine* e, int learner, float* vals4_out, int* step_out);
 int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int step);
+
+/* Batch_ObsNorm (`Normalization_batch_size`, PPO_file/normalization.py:53-84; SAC.py:181-182,215-217;
+ * DDPG.py:160-161,190-192; PPO_with_tricks.py:225-226,297-299): when enabled, every learn call first
+ * updates the running statistics with the batch mean of the sampled observations, then obs and
+ * next_obs are normalised wherever the path reads them; select_action normalises without updating.
+ * stats = {n, mean[O], S[O], std[O]} */
+int frl_obsnorm_enable(frl_engine* e, int on);
+int frl_obsnorm_get(frl_engine* e, int learner, float* stats_out);
+int frl_obsnorm_set(frl_engine* e, int learner, const float* stats);
 
 /* ---------------------------------------------------------------- forward (select_action)
  * in_host [P][n_rows][in_dim], eps_host [P][n_rows][out_dim] or NULL, out_host [P][n_rows][out_dim]

@@ -13,6 +13,7 @@ import numpy as np
 from . import nn
 from .buffer import Buffer
 from .nn import F32, MLP, Adam
+from .normalization import NormalizationBatch
 
 LOG2 = math.log(2.0)
 LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
@@ -107,7 +108,9 @@ class TD3:
     DDPG_simple (DDPG_file/DDPG_simple.py:100-179)."""
 
     def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, capacity, twin=True,
-                 use_policy_noise=True, twin_delay=True, critic_weight_decay=0.0):
+                 use_policy_noise=True, twin_delay=True, critic_weight_decay=0.0, batch_obs_norm=False):
+        # DDPG.py:160-161: Normalization_batch_size over the sampled observations
+        self.bn = NormalizationBatch(obs_dim) if batch_obs_norm else None
         self.actor, self.actor_t = nn.copy_params(actor_p), nn.copy_params(actor_p)
         self.critic, self.critic_t = nn.copy_params(critic_p), nn.copy_params(critic_p)
         self.pi = MLP(["l1", "l2", "l3"], out_act="tanh")
@@ -119,8 +122,11 @@ class TD3:
         self.total_it = 0
         self.critic_losses, self.actor_losses = [], []
 
-    def select_action(self, obs):                       # TD3.py:163-170
-        return self.pi.forward(self.actor, nn.f32(obs).reshape(1, -1))[0][0]
+    def select_action(self, obs):                       # TD3.py:163-170 (DDPG.py:165-166: norm, update=False)
+        o = nn.f32(obs).reshape(1, -1)
+        if self.bn is not None:
+            o = self.bn(o, update=False)
+        return self.pi.forward(self.actor, o)[0][0]
 
     def add(self, *a):
         self.buffer.add(*a)
@@ -137,6 +143,9 @@ class TD3:
                    policy_freq=1, policy_noise_scale=1.0):
         self.total_it += 1                              # TD3.py:191
         obs, act, rew, nobs, done = self.buffer.sample(idx)
+        if self.bn is not None:                         # DDPG.py:190-192: update on obs only
+            obs = self.bn(obs)
+            nobs = self.bn(nobs, update=False)
         a_next = self.pi.forward(self.actor_t, nobs)[0]
         if self.use_policy_noise:                       # TD3.py:196-198
             n = np.clip(F32(policy_noise_scale) * (nn.f32(noise) * F32(policy_noise)), -noise_clip, noise_clip).astype(F32)
@@ -169,11 +178,13 @@ class TD3:
         return closs, aloss
 
 
-def DDPG(actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, capacity, critic_weight_decay=0.0):
-    """DDPG_simple.learn (DDPG_simple.py:137-156) = the TD3 skeleton with a single critic, no
-    target-policy noise and an actor/target update on every call."""
+def DDPG(actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, capacity, critic_weight_decay=0.0,
+         batch_obs_norm=False):
+    """DDPG_simple.learn (DDPG_simple.py:137-156; DDPG.py:203-222 with its supplements) = the TD3
+    skeleton with a single critic, no target-policy noise and an actor/target update on every call."""
     return TD3(actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, capacity, twin=False,
-               use_policy_noise=False, twin_delay=False, critic_weight_decay=critic_weight_decay)
+               use_policy_noise=False, twin_delay=False, critic_weight_decay=critic_weight_decay,
+               batch_obs_norm=batch_obs_norm)
 
 
 # ---------------------------------------------------------------------------------------- SAC
@@ -220,7 +231,8 @@ class SAC:
     Adam lr 1e-4, alpha0 = 0.01, target_entropy = -act_dim)."""
 
     def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, capacity, alpha0=0.01,
-                 alpha_lr=1e-4):
+                 alpha_lr=1e-4, batch_obs_norm=False):
+        self.bn = NormalizationBatch(obs_dim) if batch_obs_norm else None      # SAC.py:181-182
         self.actor, self.actor_t = nn.copy_params(actor_p), nn.copy_params(actor_p)
         self.critic, self.critic_t = nn.copy_params(critic_p), nn.copy_params(critic_p)
         self.pi = GaussianActor()
@@ -235,7 +247,10 @@ class SAC:
         self.critic_losses, self.actor_losses, self.alpha_losses, self.alphas = [], [], [], []
 
     def select_action(self, obs, eps):                  # SAC.py:192-198
-        return self.pi.forward(self.actor, nn.f32(obs).reshape(1, -1), nn.f32(eps).reshape(1, -1))[0][0]
+        o = nn.f32(obs).reshape(1, -1)
+        if self.bn is not None:
+            o = self.bn(o, update=False)
+        return self.pi.forward(self.actor, o, nn.f32(eps).reshape(1, -1))[0][0]
 
     def evaluate_action(self, obs):                     # SAC.py:200-204: tanh(mean)
         return self.pi.forward(self.actor, nn.f32(obs).reshape(1, -1), None)[0][0]
@@ -245,6 +260,9 @@ class SAC:
 
     def learn_with(self, idx, eps_next, eps_new, gamma, tau):       # SAC.py:222-260
         obs, act, rew, nobs, done = self.buffer.sample(idx)
+        if self.bn is not None:                         # SAC.py:215-217
+            obs = self.bn(obs)
+            nobs = self.bn(nobs, update=False)
         B = obs.shape[0]
         a_next, logpi_next, _ = self.pi.forward(self.actor_t, nobs, nn.f32(eps_next))
         (q1t, _), (q2t, _) = self.qnet.forward(self.critic_t, np.concatenate([nobs, a_next], axis=1))

@@ -71,6 +71,14 @@ CASES = {
                                   reward_scaling=False, orthogonal_init=False, adam_eps=True,
                                   lr_decay=False, tanh=True, Batch_ObsNorm=False),
                        table_seed=127, param_seed=1510, perm_seed=2510),
+    # DDPG.py (DDPG_file/DDPG.py:150-222) with supplements weight_decay + Batch_ObsNorm
+    "ddpg_full": dict(kind="ddpg", obs_dim=8, act_dim=2, capacity=4096, n_table=1024, batch=256,
+                      n_learn=4, gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                      table_seed=123, param_seed=1130, idx_seed=2130),
+    # SAC with trick['Batch_ObsNorm'] (SAC.py:181-182,194-195,215-217)
+    "sac_bn": dict(kind="sac", obs_dim=8, act_dim=2, capacity=4096, n_table=1024, batch=256,
+                   n_learn=3, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3,
+                   table_seed=123, param_seed=1330, idx_seed=2330, noise_seed=3330),
     # PPO discrete: Actor_discrete + Categorical (PPO_with_tricks.py:110-121,333-336), CartPole-like dims
     "ppo_discrete": dict(kind="ppo_discrete", obs_dim=4, n_actions=3, horizon=192, minibatch=64, k_epochs=2,
                          gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,

@@ -165,6 +165,53 @@ def gen_ddpg(out):
     _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
 
 
+def gen_ddpg_full(out):
+    c = cases.CASES["ddpg_full"]
+    inp = cases.ac_inputs(c, twin=False)
+    mod = import_reference("DDPG_file", "DDPG")
+    sup = {"weight_decay": True, "OUNoise": True, "ObsNorm": False, "net_init": True, "Batch_ObsNorm": True}
+    pol = mod.DDPG([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, trick=None,
+                   supplement=sup)
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["select_action"] = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(16)])   # normalised, no update
+    out["bn_mean"] = pol.batch_size_obs_norm.running_ms.mean.numpy()
+    out["bn_std"] = pol.batch_size_obs_norm.running_ms.std.numpy()
+    _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
+
+
+def gen_sac_bn(out):
+    c = cases.CASES["sac_bn"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    mod = import_reference("SAC_file", "SAC")
+    trick = {"ObsNorm": False, "Batch_ObsNorm": True, "OUNoise": False, "GaussNoise": False}
+    pol = mod.SAC([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, trick=trick)
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    eps = [torch.as_tensor(e) for pair in inp["noise"] for e in pair]
+    import torch.distributions.normal as tdn
+    with inject(np.random, "choice", feeder(inp["idx"])), inject(tdn, "_standard_normal", feeder(eps)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["evaluate_action"] = np.stack([pol.evaluate_action(inp["table"]["obs"][i]) for i in range(8)])
+    sa_eps = [torch.as_tensor(synth.normal(c["noise_seed"] + 900 + i, (1, c["act_dim"]))) for i in range(8)]
+    with inject(tdn, "_standard_normal", feeder(sa_eps)):
+        out["select_action"] = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(8)])
+    out["bn_mean"] = pol.batch_size_obs_norm.running_ms.mean.numpy()
+    out["bn_std"] = pol.batch_size_obs_norm.running_ms.std.numpy()
+    out["alpha"] = np.float32(pol.alphas.alpha.item())
+    _ac_outputs(pol, out, rec, ["update_critic", "update_actor"])
+
+
 def gen_td3(name, out):
     c = cases.CASES[name]
     inp = cases.ac_inputs(c, twin=True)
@@ -443,6 +490,30 @@ def gen_traj_ac(name, out):
                                  "actor_target": pol.agent.actor_target, "critic_target": pol.agent.critic_target})
 
 
+def gen_traj_ddpg_full(out):
+    """DDPG_file/DDPG.py class with its default supplement dict (weight_decay, net_init, Batch_ObsNorm on)."""
+    t = TRAJ
+    O, A = t["obs_dim"], t["act_dim"]
+    mod = import_reference("DDPG_file", "DDPG")
+    np.random.seed(t["seed"]); torch.manual_seed(t["seed"])
+    sup = {"weight_decay": True, "OUNoise": True, "ObsNorm": False, "net_init": True, "Batch_ObsNorm": True}
+    pol = mod.DDPG([O, A], True, 1e-3, 1e-3, t["capacity"], CPU, trick=None, supplement=sup)
+    synth.pack_digest("init_actor", t2n(pol.agent.actor.state_dict()), out, full_limit=0)
+    synth.pack_digest("init_critic", t2n(pol.agent.critic.state_dict()), out, full_limit=0)
+    tab = synth.transitions(123, t["n_table"], O, A)
+    fill(pol, tab)
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    acts = []
+    for k in range(4):
+        acts.append(pol.select_action(tab["obs"][k]))
+        pol.learn(t["batch"], 0.99, 0.01)
+    out["actions"] = np.stack(acts).astype(np.float32)
+    out["bn_mean"] = pol.batch_size_obs_norm.running_ms.mean.numpy()
+    out["bn_std"] = pol.batch_size_obs_norm.running_ms.std.numpy()
+    _traj_common(out, pol, rec, {"actor": pol.agent.actor, "critic": pol.agent.critic,
+                                 "actor_target": pol.agent.actor_target, "critic_target": pol.agent.critic_target})
+
+
 def gen_traj_maddpg(out):
     dims = {"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]}
     ids = list(dims)
@@ -517,7 +588,7 @@ def survey_known_answers():
 
 def main():
     gens = {
-        "buffer": gen_buffer, "dqn": gen_dqn, "ddpg": gen_ddpg,
+        "buffer": gen_buffer, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
@@ -525,7 +596,7 @@ def main():
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),
-        "traj_maddpg": gen_traj_maddpg, "traj_ppo": gen_traj_ppo,
+        "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_ppo": gen_traj_ppo,
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]

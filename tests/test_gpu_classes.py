@@ -127,6 +127,34 @@ def test_actor_critic_class_trajectory(name, tmp_path):
     assert sd["l1.weight"].shape == (128, O)
 
 
+def test_ddpg_py_default_supplement_class_trajectory():
+    """DDPG_file/DDPG.py's class with its default supplement dict: net_init draws, critic weight decay
+    and Batch_ObsNorm inside sample()/select_action."""
+    from freerl_amd.DDPG import DDPG
+    t, fx = TRAJ, gold("traj_ddpg_full")
+    O, A = t["obs_dim"], t["act_dim"]
+    seed()
+    sup = {"weight_decay": True, "OUNoise": True, "ObsNorm": False, "net_init": True, "Batch_ObsNorm": True}
+    pol = DDPG([O, A], True, 1e-3, 1e-3, t["capacity"], CUDA, trick=None, supplement=sup)
+    pol.track_loss = True
+    synth.check_digest("init_actor", sd2np(pol.agent.actor.state_dict()), fx, 0, 0, "init")      # net_init draws bit-exact
+    synth.check_digest("init_critic", sd2np(pol.agent.critic.state_dict()), fx, 0, 0, "init")
+    tab = synth.transitions(123, t["n_table"], O, A)
+    fill(pol, tab)
+    acts, cl, al = [], [], []
+    for k in range(4):
+        acts.append(pol.select_action(tab["obs"][k]))
+        pol.learn(t["batch"], 0.99, 0.01)
+        cl.append(pol.last_losses[0]); al.append(pol.last_losses[1])
+    np.testing.assert_allclose(np.stack(acts), fx["actions"], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=2e-4)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=5e-4, atol=2e-5)
+    np.testing.assert_allclose(pol.batch_size_obs_norm.running_ms.mean.numpy(), fx["bn_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pol.batch_size_obs_norm.running_ms.std.numpy(), fx["bn_std"], rtol=1e-4, atol=1e-7)
+    for net in ("actor", "critic", "actor_target", "critic_target"):
+        synth.check_digest(net, sd2np(getattr(pol.agent, net).state_dict()), fx, 5e-3, 5e-5, "ddpg.py")
+
+
 def test_maddpg_class_trajectory(tmp_path):
     from freerl_amd.MADDPG import MADDPG
     fx = gold("traj_maddpg")

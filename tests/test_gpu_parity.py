@@ -520,3 +520,65 @@ def test_ppo_discrete_learn(N):
         np.testing.assert_allclose(ga[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
     synth.check_digest("actor", ga, fx, 2e-3, 2e-5, "hip-vs-reference")
     e.close()
+
+
+def test_ddpg_full_batch_obs_norm_and_weight_decay(N):
+    """DDPG.py supplements on the engine: critic Adam weight_decay 1e-3 + device-side Batch_ObsNorm."""
+    from oracle import algos
+    c = cases.CASES["ddpg_full"]
+    inp = cases.ac_inputs(c, twin=False)
+    fx = gold("ddpg_full")
+    e = _setup_ac(N, N.ALGO_DDPG, c, inp, False, AC_NAMES)
+    e.obsnorm_enable(True)
+    orc = algos.DDPG(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                     c["critic_lr"], c["capacity"], critic_weight_decay=1e-3, batch_obs_norm=True)
+    _fill_oracle(orc, inp["table"])
+    cl, al = [], []
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     critic_weight_decay=1e-3, idx=inp["idx"][k], want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS]); al.append(st[0, 0, N.STAT_ACTOR_LOSS])
+        orc.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+    # normalised inputs are O(x/std), std ~ 0.03-0.08 (the reference's first update sets std = batch mean)
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=2e-4)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=5e-4, atol=2e-5)
+    stats = e.obsnorm_stats()
+    assert stats["n"] == c["n_learn"]
+    np.testing.assert_allclose(stats["mean"], fx["bn_mean"][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(stats["std"], fx["bn_std"][0], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(stats["mean"], orc.bn.running_ms.mean[0], rtol=1e-5, atol=1e-7)
+    sa = e.act(0, N.ACT_TANHHEAD, inp["table"]["obs"][:16], out_dim=c["act_dim"])[0]
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=5e-3, atol=5e-4)
+    ga = unflat_params(e.get_params(0), orc.actor, AC_NAMES)
+    gc = unflat_params(e.get_params(1), orc.critic, AC_NAMES)
+    for k in orc.critic:
+        np.testing.assert_allclose(gc[k], orc.critic[k], rtol=5e-3, atol=5e-5, err_msg=k)
+    synth.check_digest("actor", ga, fx, 5e-3, 5e-5, "hip-vs-reference")
+    e.close()
+
+
+def test_sac_batch_obs_norm(N):
+    from oracle import algos
+    c = cases.CASES["sac_bn"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    fx = gold("sac_bn")
+    an = ["l1", "l2", "mean_layer"]
+    e = _setup_ac(N, N.ALGO_SAC, c, inp, True, an, "log_std")
+    e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
+    e.obsnorm_enable(True)
+    cl, al = [], []
+    for k in range(c["n_learn"]):
+        nz = np.stack([inp["noise"][k][0], inp["noise"][k][1]])[None, None]
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     alpha_lr=1e-4, target_entropy=-float(c["act_dim"]), idx=inp["idx"][k], noise=nz, want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS]); al.append(st[0, 0, N.STAT_ACTOR_LOSS])
+    np.testing.assert_allclose(cl, fx["loss_critic"], rtol=2e-4)
+    np.testing.assert_allclose(al, fx["loss_actor"], rtol=5e-4, atol=2e-5)
+    np.testing.assert_allclose(e.obsnorm_stats()["std"], fx["bn_std"][0], rtol=1e-4, atol=1e-7)
+    # SAC.evaluate_action does not normalise (SAC.py:200-204), select_action does (:194-195)
+    ev = e.act(0, N.ACT_TANHHEAD, inp["table"]["obs"][:8], out_dim=c["act_dim"], normalize=False)[0]
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=5e-3, atol=5e-4)
+    eps = np.stack([synth.normal(c["noise_seed"] + 900 + i, (1, c["act_dim"]))[0] for i in range(8)])
+    sa = e.act(0, N.ACT_SAC_SAMPLE, inp["table"]["obs"][:8], eps=eps, out_dim=c["act_dim"])[0]
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=5e-3, atol=5e-4)
+    e.close()

@@ -64,13 +64,14 @@ def test_dqn_learn():
     assert pol.opt.t == int(fx["step"])
 
 
-def _check_ac(pol, fx):
-    synth.check_digest("actor", pol.actor, fx, P_RTOL, P_ATOL)
-    synth.check_digest("critic", pol.critic, fx, P_RTOL, P_ATOL)
-    synth.check_digest("actor_target", pol.actor_t, fx, P_RTOL, P_ATOL)
-    synth.check_digest("critic_target", pol.critic_t, fx, P_RTOL, P_ATOL)
-    synth.check_digest("critic_m", pol.critic_opt.m, fx, 5e-4, 1e-7)
-    synth.check_digest("critic_v", pol.critic_opt.v, fx, 5e-4, 1e-9)
+def _check_ac(pol, fx, rtol=P_RTOL, atol=P_ATOL, moments=True):
+    synth.check_digest("actor", pol.actor, fx, rtol, atol)
+    synth.check_digest("critic", pol.critic, fx, rtol, atol)
+    synth.check_digest("actor_target", pol.actor_t, fx, rtol, atol)
+    synth.check_digest("critic_target", pol.critic_t, fx, rtol, atol)
+    if moments:
+        synth.check_digest("critic_m", pol.critic_opt.m, fx, 5e-4, 1e-7)
+        synth.check_digest("critic_v", pol.critic_opt.v, fx, 5e-4, 1e-9)
     assert pol.actor_opt.t == int(fx["actor_step"]) and pol.critic_opt.t == int(fx["critic_step"])
 
 
@@ -226,3 +227,40 @@ def test_ppo_discrete_learn():
     np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
     synth.check_digest("actor", pol.actor, fx, 1e-3, 1e-5)
     synth.check_digest("critic", pol.critic, fx, 1e-3, 1e-5)
+
+
+def test_ddpg_full_weight_decay_and_batch_obs_norm():
+    """DDPG.py (DDPG_file/DDPG.py:150-222) with supplements weight_decay + Batch_ObsNorm."""
+    c = cases.CASES["ddpg_full"]
+    inp = cases.ac_inputs(c, twin=False)
+    fx = gold("ddpg_full")
+    pol = algos.DDPG(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                     c["critic_lr"], c["capacity"], critic_weight_decay=1e-3, batch_obs_norm=True)
+    fill(pol, inp["table"])
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+    # the normalised observations are O(x / std) with std ~ 0.03-0.08 here (the reference's first
+    # update sets std = batch mean): fp32 differences are amplified ~20x, tolerances follow
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(pol.bn.running_ms.mean, fx["bn_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pol.bn.running_ms.std, fx["bn_std"], rtol=1e-4, atol=1e-7)
+    sa = np.stack([pol.select_action(inp["table"]["obs"][i]) for i in range(16)])
+    np.testing.assert_allclose(sa, fx["select_action"], rtol=2e-3, atol=2e-4)
+    _check_ac(pol, fx, 5e-3, 5e-5, moments=False)
+
+
+def test_sac_batch_obs_norm():
+    c = cases.CASES["sac_bn"]
+    inp = cases.ac_inputs(c, twin=True, gaussian=True)
+    fx = gold("sac_bn")
+    pol = algos.SAC(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"],
+                    c["critic_lr"], c["capacity"], batch_obs_norm=True)
+    fill(pol, inp["table"])
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], inp["noise"][k][0], inp["noise"][k][1], c["gamma"], c["tau"])
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(pol.bn.running_ms.std, fx["bn_std"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(pol.alpha, fx["alpha"], rtol=1e-6)
+    _check_ac(pol, fx, 5e-3, 5e-5, moments=False)
