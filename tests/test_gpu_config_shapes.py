@@ -1,0 +1,133 @@
+"""BASELINE.json's configs as parity cases at their FULL shapes (C3 PPO HalfCheetah-v4
+O=17 A=6 horizon 2048 mb 64; C4 SAC Humanoid-v4 O=376 A=17 B=256; C5 MADDPG simple_spread n=3 O=18 A=5
+B=1024): HIP engine vs the oracle run live on the same seeded inputs (no env library needed: the path
+starts at the replay buffer).  Also exercises the wide-input tile paths (k_pad 400, 25 column tiles)
+and 32-chunk batches.  Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from tests.golden import cases, synth
+from tests.hip_helpers import flat_params, records, rel_err, unflat_params
+
+pytestmark = pytest.mark.gpu
+AC = ["l1", "l2", "l3"]
+TWIN = ["l1", "l2", "l3", "l4", "l5", "l6"]
+
+
+@pytest.fixture(scope="module")
+def N():
+    from freerl_amd import _native
+    assert _native.device_count() > 0
+    return _native
+
+
+def test_c4_sac_humanoid_shape(N):
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    O, A, B, n_tab = 376, 17, 256, 600
+    tab = synth.transitions(31, n_tab, O, A)
+    an = ["l1", "l2", "mean_layer"]
+    actor = synth.mlp_params(41, cases.actor_layers(O, A, head="mean_layer"))
+    actor = dict([("log_std", np.random.default_rng(42).uniform(-0.5, 0.2, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(43, cases.critic_layers(O + A, twin=True))
+    e = Engine(N.ALGO_SAC, O, A, 2000, twin_critic=True, batch_max=B)
+    lds, rc = e.lds_bytes()
+    assert lds <= 160 * 1024 and rc in (16, 32, 64)
+    for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+        e.set_params(0, flat_params(actor, an, "log_std"), kind)
+        e.set_params(1, flat_params(critic, TWIN), kind)
+    e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
+    e.add_batch(records([tab]))
+    orc = algos.SAC(actor, critic, O, A, 1e-3, 1e-3, 2000)
+    for i in range(n_tab):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    for k in range(2):
+        idx = synth.indices(50 + k, n_tab, B)
+        e0, e1 = synth.normal(60 + k, (B, A)), synth.normal(70 + k, (B, A))
+        st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4, target_entropy=-float(A),
+                     idx=idx, noise=np.stack([e0, e1])[None, None], want_stats=True)
+        cl, al, ll = orc.learn_with(idx, e0, e1, 0.99, 0.005)
+        np.testing.assert_allclose(st[0, 0, N.STAT_CRITIC_LOSS], cl, rtol=1e-4)
+        np.testing.assert_allclose(st[0, 0, N.STAT_ACTOR_LOSS], al, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(st[0, 0, N.STAT_ALPHA_LOSS], ll, rtol=1e-4)
+    ga = unflat_params(e.get_params(0), orc.actor, an, "log_std")
+    gc = unflat_params(e.get_params(1, N.PARAM_TARGET), orc.critic_t, TWIN)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    for k in orc.critic_t:
+        np.testing.assert_allclose(gc[k], orc.critic_t[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    ev = e.act(0, N.ACT_TANHHEAD, tab["obs"][:40], out_dim=A)[0]
+    want = np.stack([orc.evaluate_action(tab["obs"][i]) for i in range(40)])
+    np.testing.assert_allclose(ev, want, rtol=1e-4, atol=1e-5)
+    e.close()
+
+
+def test_c5_maddpg_spread_shape(N):
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    n, O, A, B, n_tab = 3, 18, 5, 1024, 1500
+    ids = ["agent_%d" % j for j in range(n)]
+    dims = {a: [O, A] for a in ids}
+    tabs = {a: synth.transitions(80 + j, n_tab, O, A) for j, a in enumerate(ids)}
+    params = {a: dict(actor=synth.mlp_params(90 + 2 * j, cases.actor_layers(O, A)),
+                      critic=synth.mlp_params(91 + 2 * j, cases.critic_layers(n * (O + A)))) for j, a in enumerate(ids)}
+    e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, 2048, batch_max=B)
+    for j, a in enumerate(ids):
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(2 * j, flat_params(params[a]["actor"], AC), kind)
+            e.set_params(2 * j + 1, flat_params(params[a]["critic"], AC), kind)
+    e.add_batch(records([tabs[a] for a in ids]))
+    orc = algos.MADDPG(params, dims, 1e-3, 1e-3, 2048)
+    for i in range(n_tab):
+        orc.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
+                {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
+                {a: bool(tabs[a]["done"][i]) for a in ids})
+    idx = [synth.indices(100 + j, n_tab, B) for j in range(n)]
+    st = e.learn(B, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=np.stack(idx)[None], want_stats=True)
+    orc.learn_with(idx, 0.95, 0.01)
+    for j, a in enumerate(ids):
+        np.testing.assert_allclose(st[0, j, N.STAT_CRITIC_LOSS], orc.critic_losses[a][0], rtol=1e-4)
+        np.testing.assert_allclose(st[0, j, N.STAT_ACTOR_LOSS], orc.actor_losses[a][0], rtol=1e-4, atol=1e-6)
+        got = unflat_params(e.get_params(2 * j + 1), orc.critic[a], AC)
+        for k in orc.critic[a]:
+            np.testing.assert_allclose(got[k], orc.critic[a][k], rtol=5e-4, atol=5e-6, err_msg=a + k)
+        got = unflat_params(e.get_params(2 * j, N.PARAM_TARGET), orc.actor_t[a], AC)
+        for k in orc.actor_t[a]:
+            np.testing.assert_allclose(got[k], orc.actor_t[a][k], rtol=5e-4, atol=5e-6, err_msg=a + k)
+    e.close()
+
+
+def test_c3_ppo_halfcheetah_shape(N):
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    O, A, T, mb, K = 17, 6, 2048, 64, 2           # K_epochs 2 of the config's 10 keeps the oracle in seconds
+    c = dict(obs_dim=O, act_dim=A, horizon=T, table_seed=140, param_seed=150, perm_seed=160, k_epochs=K)
+    inp = cases.ppo_inputs(c)
+    trick = dict(cases.CASES["ppo"]["trick"], adv_norm=True)
+    an = ["l1", "l2", "mean_layer"]
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=mb, extra_cols=A + 1)
+    e.set_params(0, flat_params(inp["params"]["actor"], an, "log_std"))
+    e.set_params(1, flat_params(inp["params"]["critic"], AC))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, 1e-3, 1e-3, T, trick)
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    out = e.ppo_learn(T, mb, K, gamma=0.99, lmbda=0.95, clip=0.2, ent_coef=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                      adv_norm=True, perms=np.stack(inp["perms"])[None], want_trace=True, want_adv=True)
+    orc.learn_with(inp["perms"], mb, 0.99, 0.95, 0.2, K, 0.01)
+    # GAE over the full 2048-step horizon: scan vs the sequential fp32 recurrence
+    np.testing.assert_allclose(out["adv"][0], orc.adv_raw.reshape(-1), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out["v_target"][0], orc.v_target.reshape(-1), rtol=2e-4, atol=2e-5)
+    n_mb = T // mb
+    # 64 sequential Adam steps per net and epoch: compare the loss trace with a tolerance that grows with the step
+    got_a, want_a = out["trace"][0, :, 0], np.array(orc.actor_losses)
+    got_c, want_c = out["trace"][0, :, 1], np.array(orc.critic_losses)
+    assert got_a.shape == (K * n_mb,)
+    np.testing.assert_allclose(got_a[:n_mb], want_a[:n_mb], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(got_c[:n_mb], want_c[:n_mb], rtol=2e-3)
+    np.testing.assert_allclose(got_c, want_c, rtol=2e-2)
+    assert e.opt_step(0) == K * n_mb and e.cursor(0) == (0, 0)
+    e.close()
