@@ -11,7 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
-LIB_PATH = os.path.join(LIB_DIR, "libfreerl_hip.so")
+# FRL_HIP_VARIANT=<name> selects a developer build (tools/phase_timing.py): lib<...>_<name>.so compiled with
+# the extra flags in FRL_HIPCC_FLAGS.  Unset = the product library.
+_VARIANT = os.environ.get("FRL_HIP_VARIANT", "")
+LIB_PATH = os.path.join(LIB_DIR, "libfreerl_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 HEADER = os.path.join(ROOT, "include", "freerl_hip.h")
 
 FRL_MAX_AGENTS = 8
@@ -150,6 +153,8 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            "-Wno-pass-failed", "-o", LIB_PATH, os.path.join(CSRC, "frl_api.hip")]
+    if _VARIANT:
+        cmd += os.environ.get("FRL_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

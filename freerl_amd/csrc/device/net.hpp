@@ -14,6 +14,44 @@
 
 namespace frl {
 
+// Developer instrument (tools/phase_timing.py; built only with -DFRL_PHASE_TIMING): thread 0 of a few
+// sampled workgroups stamps the shader clock at every barrier-delimited phase of the gradient kernels.
+#ifdef FRL_PHASE_TIMING
+// Stamps go to LDS (256 extra words after S.red, see lds_bytes_for) and are dumped once at kernel end: a global store per stamp
+// would put a write acknowledgement in front of every barrier's vmcnt(0) and distort what is measured.
+constexpr int kPhaseMax = 44, kPhaseBlocks = 8, kPhaseWords = 5 * kPhaseMax;   // 4 waves' arrivals + wave 0's releases
+__device__ int g_phase_clock[kPhaseBlocks][kPhaseWords];
+__device__ int g_phase_stride = 509;
+#define FRL_STAMP_(S, slot, ctr)                                                                   \
+    do {                                                                                           \
+        const int k_ = (int)(S).red[ctr];                                                          \
+        if (k_ < kPhaseMax) ((FRL_LDS int*)((S).red + 8))[(slot) * kPhaseMax + k_] = (int)clock64(); \
+        (S).red[ctr] = (float)(k_ + 1);                                                            \
+    } while (0)
+#define FRL_PHASE(S)                                                                               \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) FRL_STAMP_(S, threadIdx.x >> 6, 4 + (threadIdx.x >> 6));      \
+        lds_barrier();                                                                             \
+        if (threadIdx.x == 0) FRL_STAMP_(S, 4, 3);                                                 \
+    } while (0)
+#define FRL_PHASE_INIT(S)                                                                          \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) (S).red[4 + (threadIdx.x >> 6)] = 0.f;                        \
+        if (threadIdx.x == 0) { (S).red[3] = 0.f; FRL_STAMP_(S, 4, 3); }                           \
+    } while (0)
+#define FRL_PHASE_DUMP(S)                                                                          \
+    do {                                                                                           \
+        __syncthreads();                                                                           \
+        if (blockIdx.x % g_phase_stride == 0 && blockIdx.x / g_phase_stride < kPhaseBlocks)        \
+            for (int i_ = threadIdx.x; i_ < kPhaseWords; i_ += kWG)                                \
+                g_phase_clock[blockIdx.x / g_phase_stride][i_] = ((FRL_LDS int*)((S).red + 8))[i_]; \
+    } while (0)
+#else
+#define FRL_PHASE(S) lds_barrier()
+#define FRL_PHASE_INIT(S) do {} while (0)
+#define FRL_PHASE_DUMP(S) do {} while (0)
+#endif
+
 struct Lds {
     lds_f xin; int xp;
     lds_f h1; lds_f h2; int hp;
@@ -59,37 +97,55 @@ __device__ __forceinline__ float act_grad(float h, int act) {
     return 1.f;
 }
 
-// Y[rc][n_pad] = act(X[rc][k_pad] * W^T + b)
+// Y[rc][n_pad] = act(X[rc][k_pad] * W^T + b);  theta holds Wk[k_pad][n_pad] (contraction-major) then b[n_pad]
 __device__ __forceinline__ void linear_fwd(const LayerDesc& L, g_cf theta, lds_cf X, int ldx, lds_f Y, int ldy,
                                            int act, int rc) {
     g_cf W = theta + L.w_off;
     g_cf b = theta + L.b_off;
-    const int kpad = L.k_pad;
-    for_tile_blocks(rc / 16, L.n_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
-        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
-        f32x4 acc[BM][BN];
-        acc_zero(acc);
-        mma_nt<BM, BN>(acc, X, ldx, mt0 * 16, W, kpad, nt0 * 16, kpad);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v) {
-            v += ld4(b + c4);
-            v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
-            st4(Y + r * ldy + c4, v);
+    const int kpad = L.k_pad, npad = L.n_pad, q4 = (lane_id() >> 4) * 4;
+    auto finish = [&](int r, int c4, f32x4 v, f32x4 bias) {
+        v += bias;
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        st4(Y + r * ldy + c4, v);
+    };
+#ifndef FRL_FWD_IL
+#define FRL_FWD_IL 1
+#endif
+    if (FRL_FWD_IL && npad % 64 == 0) {
+        for_il_blocks(rc / 16, npad / 64, [&](auto bm, int mt0, int g) {
+            constexpr int BM = decltype(bm)::value;
+            f32x4 acc[BM][4], bias[4];
+            acc_zero(acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[r] = ld4(b + g * 64 + 4 * q4 + 4 * r);      // in flight with the weights
+            mma_w_any<BM, 4, W_IL>(acc, X, ldx, mt0 * 16, W, npad, g * 64, kpad);
+            tile_epilogue<BM, 4, W_IL>(acc, mt0 * 16, g * 64, [&](int r, int c4, f32x4 v, int slot) { finish(r, c4, v, bias[slot]); });
         });
-    });
+    } else {
+        for_tile_blocks(rc / 16, npad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
+            constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+            f32x4 acc[BM][BN], bias[BN];
+            acc_zero(acc);
+#pragma unroll
+            for (int y = 0; y < BN; ++y) bias[y] = ld4(b + (nt0 + y) * 16 + q4);
+            mma_w_any<BM, BN, W_ROWS>(acc, X, ldx, mt0 * 16, W, npad, nt0 * 16, kpad);
+            tile_epilogue<BM, BN, W_ROWS>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v, int slot) { finish(r, c4, v, bias[slot]); });
+        });
+    }
 }
 
-// dX[rc][k tiles ct0..ct1) = (dY[rc][n_pad] * W) (.) act'(H)   written in place over H (pitch ldh).
-// act_prev == ACT_NONE: plain store (used for d/d(first-layer input)).
+// dX[rc][k tiles ct0..ct1) = (dY[rc][n_pad] * W) (.) act'(H)   written in place over H (pitch ldh); the contraction
+// runs along the rows of Wk[k_pad][n_pad].  act_prev == ACT_NONE: plain store (used for d/d(first-layer input)).
 __device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, g_cf theta, lds_cf dY, int ldy, lds_f H, int ldh,
                                               int act_prev, int rc, int ct0, int ct1) {
     g_cf W = theta + L.w_off;
-    const int kpad = L.k_pad, npad = L.n_pad;
+    const int npad = L.n_pad;
     for_tile_blocks(rc / 16, ct1 - ct0, [&](auto bm, auto bn, int mt0, int nt0) {
         constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
         f32x4 acc[BM][BN];
         acc_zero(acc);
-        mma_nn<BM, BN>(acc, dY, ldy, mt0 * 16, W, kpad, (ct0 + nt0) * 16, npad);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, (ct0 + nt0) * 16, [&](int r, int c4, f32x4 v) {
+        mma_w_any<BM, BN, W_COLS>(acc, dY, ldy, mt0 * 16, W, npad, (ct0 + nt0) * 16, npad);
+        tile_epilogue<BM, BN, W_COLS>(acc, mt0 * 16, (ct0 + nt0) * 16, [&](int r, int c4, f32x4 v, int) {
             lds_f h = H + r * ldh + c4;
             if (act_prev != ACT_NONE) {
                 const f32x4 hv = ld4((lds_cf)h);
@@ -101,22 +157,44 @@ __device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, g_cf theta, ld
     });
 }
 
-// G.W[n_pad][k_pad] (=|+=) dY^T * X ;  G.b (=|+=) column sums of dY
+// G.Wk[k_pad][n_pad] (=|+=) X^T * dY ;  G.b (=|+=) column sums of dY
 __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf dY, int ldy, lds_cf X, int ldx, int rc,
                                               bool first) {
     g_f GW = G + L.w_off;
-    const int kpad = L.k_pad;
-    for_tile_blocks(L.n_pad / 16, L.k_pad / 16, [&](auto bm, auto bn, int mt0, int nt0) {
-        constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
-        f32x4 acc[BM][BN];
-        acc_zero(acc);
-        mma_tn<BM, BN>(acc, dY, ldy, mt0 * 16, X, ldx, nt0 * 16, rc);
-        tile_epilogue<BM, BN>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v) {
-            g_f g = GW + (size_t)r * kpad + c4;
-            if (!first) v += ld4((g_cf)g);
-            st4(g, v);
+    const int kpad = L.k_pad, npad = L.n_pad;
+    auto finish = [&](int k, int n4, f32x4 v) {
+        g_f g = GW + (size_t)k * npad + n4;
+        if (first) { st4_stream(g, v); return; }           // a slab is written once and read once by reduce_kernel
+        st4(g, v + ld4((g_cf)g));
+    };
+    if (npad % 64 == 0) {
+        const int w = wave_id(), groups = npad / 64, tk = kpad / 16;
+        if (tk % 2 == 0 && groups * (tk / 2) >= kWaves) {
+            for (int blk = w; blk < groups * (tk / 2); blk += kWaves) {
+                const int g = blk % groups, kt0 = (blk / groups) * 2;
+                f32x4 acc[4][2];
+                acc_zero(acc);
+                mma_dw_il<2>(acc, dY, ldy, g * 64, X, ldx, kt0 * 16, rc);
+                dw_il_epilogue<2>(acc, g * 64, kt0 * 16, finish);
+            }
+        } else {
+            for (int blk = w; blk < groups * tk; blk += kWaves) {
+                const int g = blk % groups, kt0 = blk / groups;
+                f32x4 acc[4][1];
+                acc_zero(acc);
+                mma_dw_il<1>(acc, dY, ldy, g * 64, X, ldx, kt0 * 16, rc);
+                dw_il_epilogue<1>(acc, g * 64, kt0 * 16, finish);
+            }
+        }
+    } else {
+        for_tile_blocks(kpad / 16, npad / 16, [&](auto bm, auto bn, int kt0, int nt0) {
+            constexpr int BM = decltype(bm)::value, BN = decltype(bn)::value;
+            f32x4 acc[BM][BN];
+            acc_zero(acc);
+            mma_tn<BM, BN>(acc, X, ldx, kt0 * 16, dY, ldy, nt0 * 16, rc);
+            tile_epilogue<BM, BN, W_ROWS>(acc, kt0 * 16, nt0 * 16, [&](int k, int n4, f32x4 v, int) { finish(k, n4, v); });
         });
-    });
+    }
     g_f Gb = G + L.b_off;
     for (int n = threadIdx.x; n < L.n_pad; n += kWG) {
         float s = 0.f;
@@ -134,7 +212,7 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
         lds_f out = last ? S.outb : (i == 0 ? S.h1 : S.h2);
         const int ldo = last ? S.op : S.hp;
         linear_fwd(N.L[l0 + i], theta, in, ldin, out, ldo, last ? out_act : N.hidden_act, S.rc);
-        __syncthreads();
+        FRL_PHASE(S);
         in = out;
         ldin = ldo;
     }
@@ -154,14 +232,14 @@ __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf t
         const LayerDesc& L = N.L[l0 + i];
         if (G) {
             linear_bwd_dw(L, G, D, ldd, X, ldx, S.rc, first);
-            __syncthreads();
+            FRL_PHASE(S);
         }
         if (i > 0) {
             linear_bwd_dx(L, theta, D, ldd, X, ldx, N.hidden_act, S.rc, 0, L.k_pad / 16);
-            __syncthreads();
+            FRL_PHASE(S);
         } else if (want_dx0) {
             linear_bwd_dx(L, theta, D, ldd, X, ldx, ACT_NONE, S.rc, ct0, ct1);
-            __syncthreads();
+            FRL_PHASE(S);
         }
     }
 }

@@ -174,7 +174,10 @@ static void build_record(RecordDesc& R, const frl_config& c) {
 
 static int lds_bytes_for(const EngineDesc& h, int rc) {
     const int xp = h.lds_kin_pad + 4, hp = h.hidden + 4, op = h.lds_out_pad + 4, ap = h.lds_act_pad;
-    const long long fl = (long long)rc * (xp + 2 * hp + op + 2 * ap) + h.lds_batch_pad + 8;
+    long long fl = (long long)rc * (xp + 2 * hp + op + 2 * ap) + h.lds_batch_pad + 8;
+#ifdef FRL_PHASE_TIMING
+    fl += 256;                                              // stamp area of the developer instrument (device/net.hpp)
+#endif
     return (int)(fl * 4);
 }
 
@@ -308,7 +311,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     // row chunk: the largest of {64,32,16} whose LDS footprint still lets 4 workgroups share a CU
     // (16 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
     h.rc = 64;
-    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 40 * 1024) h.rc /= 2;
+    while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;   // two workgroups per CU (160 KB LDS)
+    if (const char* force = getenv("FRL_RC")) {             // developer knob: rows per workgroup (16 / 32 / 64)
+        const int v = atoi(force);
+        if (v == 16 || v == 32 || v == 64) h.rc = v;
+    }
     if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
     e->lds_bytes = lds_bytes_for(h, h.rc);
     h.S = (h.batch_max + h.rc - 1) / h.rc;
@@ -593,6 +600,8 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
     if (!base || !host) return fail(FRL_ERR_INVALID, "bad kind / NULL buffer");
     const NetDesc& N = e->h.net[net];
     float* dev = base + (size_t)learner * e->h.learner_stride + e->h.net_off[net];
+    // host order = the reference's state_dict order: per nn.Linear weight[out][in] then bias; device block =
+    // Wk[k_pad][n_pad] (frl_desc.h)
     std::vector<float> blk(N.size, 0.f);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!to_device) HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
@@ -601,7 +610,7 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
         const LayerDesc& L = N.L[i];
         for (int r = 0; r < L.n; ++r)
             for (int c = 0; c < L.k; ++c) {
-                float& d = blk[L.w_off + (size_t)r * L.k_pad + c];
+                float& d = blk[L.w_off + (size_t)c * L.n_pad + r];
                 if (to_device) d = host[o]; else host[o] = d;
                 ++o;
             }
@@ -950,5 +959,14 @@ extern "C" int frl_profile_read(frl_engine* e, double* ms_sum8, long long* count
     return FRL_OK;
 }
 
+#ifdef FRL_PHASE_TIMING
+// developer build only (tools/phase_timing.py): not part of include/freerl_hip.h
+extern "C" int frl_debug_phase_clocks(int* out, int stride) {
+    if (stride > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(frl::g_phase_stride), &stride, sizeof(int), 0, hipMemcpyHostToDevice);
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(frl::g_phase_clock), sizeof(int) * frl::kPhaseBlocks * frl::kPhaseWords, 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 #include "frl_api_ppo.inc"
 #include "frl_api_rollout.inc"

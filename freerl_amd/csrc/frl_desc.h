@@ -11,7 +11,9 @@ constexpr int kMaxNets = 2 * kMaxAgents;
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 enum Algo : int { ALGO_DQN = 0, ALGO_DDPG = 1, ALGO_TD3 = 2, ALGO_SAC = 3, ALGO_MADDPG = 4, ALGO_PPO = 5 };
 
-// One nn.Linear in the engine-internal layout: W[n_pad][k_pad] row-major, zero padded, then b[n_pad].
+// One nn.Linear in the engine-internal layout: Wk[k_pad][n_pad] (CONTRACTION-major for the forward pass: row =
+// input feature, n contiguous), zero padded, then b[n_pad].  theta / target / m / v / grad / slab all use it;
+// see device/tile.hpp (WMode) for why.
 struct LayerDesc {
     int n, k;            // logical out / in features
     int n_pad, k_pad;    // padded to multiples of 16

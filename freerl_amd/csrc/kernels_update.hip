@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restri
 // ------------------------------------------------------------------------------------- DQN
 // DQN.learn (DQN_file/DQN.py:104-118) for one row chunk: y = r + gamma*max_a Q_t(s',a)*(1-d);
 // delta = 2(Q(s)[a] - y)/B on the taken action; backward -> partial slab.
-__global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 2) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __re
 
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
-    __syncthreads();
+    lds_barrier();
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
     for (int r = threadIdx.x; r < nv; r += kWG) {
         float mx = S.outb[r * S.op];
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __re
         g_cf rec = ring + (size_t)idx[r] * R.stride;
         S.y[r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
     }
-    __syncthreads();
+    lds_barrier();
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
-    __syncthreads();
+    lds_barrier();
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
     float lossp = 0.f;
     for (int e = threadIdx.x; e < rc * npad; e += kWG) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __re
         }
         S.outb[r * S.op + j] = d;
     }
-    __syncthreads();
+    lds_barrier();
     mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 4) void dqn_grad_kernel(const EngineDesc* __re
 // ------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: critic
 // TD target with the target nets, twin/single critic forward, MSE delta, backward -> slab.
 // DDPG_simple.py:139-149, TD3.py:193-213, SAC.py:226-238, MADDPG_simple.py:169-176.
-__global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 2) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
     g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
+    FRL_PHASE_INIT(S);
 
     // ---- a' = actor_target_j(s'_j) for every agent j (MADDPG_simple.py:155; n = 1 otherwise)
     float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
         const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
-        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn, Oj); }
-        __syncthreads();
+        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn, Oj); }
+        FRL_PHASE(S);
         mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
         if (sac) {                                  // SAC.py:70-97 on actor_target (SAC.py:227)
             const int r = threadIdx.x;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
                 S.abuf[r * S.ap + cj + c] = v;
             }
         }
-        __syncthreads();
+        FRL_PHASE(S);
     }
     // ---- centralised target critic on [next_obs_all | a'_all]
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
@@ -233,12 +234,12 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
         S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
     }
     zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
-    __syncthreads();
+    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+    FRL_PHASE(S);
     mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
     float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
     if (heads == 2) {
-        __syncthreads();
+        FRL_PHASE(S);
         mlp_fwd(NC, ql, ql, tgC, S, ACT_NONE);
         if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
     }
@@ -248,15 +249,15 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
         S.y[threadIdx.x] = sac ? rew + a.gamma * (1.f - done) * (q + alpha * (-lp_next))
                                : rew + a.gamma * q * (1.f - done);
     }
-    __syncthreads();
+    FRL_PHASE(S);
 
     // ---- critic heads: forward, MSE delta, backward
     float lossp = 0.f;
     for (int h = 0; h < heads; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
-        __syncthreads();
+        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+        FRL_PHASE(S);
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
         for (int e = threadIdx.x; e < rc * npad; e += kWG) {
@@ -269,9 +270,10 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
             }
             S.outb[r * S.op + c] = d;
         }
-        __syncthreads();
+        FRL_PHASE(S);
         mlp_bwd(NC, h * ql, ql, thC, slab, S, true, false, 0, 0);
     }
+    FRL_PHASE_DUMP(S);
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[(((size_t)p * n + ag) * D.S + sl) * 4] = ls;
 }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 4) void ac_critic_kernel(const EngineDesc* __r
 // -------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: actor
 // a = actor(s); Q(s, a) through the (already updated, frozen) critic; dQ/da; actor backward.
 // DDPG_simple.py:151-154, TD3.py:224-231, SAC.py:244-252, MADDPG_simple.py:178-183.
-__global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, 2) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
     // -- a = actor(obs)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
-    __syncthreads();
+    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
+    lds_barrier();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     float lp = 0.f;
     if (sac) {
@@ -342,34 +344,34 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
         const int r = e / Aa, c = e - r * Aa;
         S.dabuf[r * S.ap + c] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // -- dQ/da through the critic head(s)
     float qsum = 0.f;
     for (int h = 0; h < nq; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
-        __syncthreads();
+        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+        lds_barrier();
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
             S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
         }
-        __syncthreads();
+        lds_barrier();
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         if (threadIdx.x < nv) qsum += S.outb[threadIdx.x * S.op];
-        __syncthreads();
+        lds_barrier();
         const int npad = NC.L[h * ql + ql - 1].n_pad;
         for (int e = threadIdx.x; e < rc * npad; e += kWG) {
             const int r = e / npad, c = e - r * npad;
             S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
         }
-        __syncthreads();
+        lds_barrier();
         mlp_bwd(NC, h * ql, ql, thC, nullptr, S, false, true, ct0, ct1);
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
             S.dabuf[r * S.ap + c] += S.xin[r * S.xp + OT + acol + c];
         }
-        __syncthreads();
+        lds_barrier();
     }
     float alossp = 0.f, entp = 0.f;
     if (threadIdx.x < nv) {
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
     // -- actor forward again (activations for its backward), head delta, backward
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-    if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
-    __syncthreads();
+    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
+    lds_barrier();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     const int napad = NA.L[NA.n_layers - 1].n_pad;
     for (int e = threadIdx.x; e < rc * napad; e += kWG) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, 4) void ac_actor_kernel(const EngineDesc* __re
         }
         S.outb[r * S.op + c] = d;
     }
-    __syncthreads();
+    lds_barrier();
     if (sac && threadIdx.x < Aa) {
         float gls = 0.f;
         for (int r = 0; r < rc; ++r) gls += S.dabuf[r * S.ap + threadIdx.x];

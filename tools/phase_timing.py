@@ -1,0 +1,71 @@
+"""Developer instrument: where does a gradient-kernel workgroup spend its cycles?
+
+Builds the `phase` variant of the library (-DFRL_PHASE_TIMING), runs the bench workload's TD3 learn step
+and prints, for 8 sampled workgroups of `ac_critic_kernel`, the shader-clock cycles between consecutive
+barrier-delimited phases (thread 0's view; 4 workgroups share a CU, so a phase's time includes the other
+three's interleaved work — read the numbers as shares, not latencies).
+
+    FRL_HIP_VARIANT=phase FRL_HIPCC_FLAGS=-DFRL_PHASE_TIMING python tools/phase_timing.py [P] > gpurun_out/phase.txt
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FRL_HIP_VARIANT", "phase")
+os.environ.setdefault("FRL_HIPCC_FLAGS", "-DFRL_PHASE_TIMING")
+from freerl_amd import _native as N  # noqa: E402
+
+FWD = lambda n: ["%s l%d" % (n, i) for i in (1, 2, 3)]
+BWD = ["delta", "dW3", "dX3", "dW2", "dX2", "dW1"]
+LABELS_TD3 = (["gather s'"] + FWD("pi'") + ["a' = clip(pi'+noise)", "gather [s'|a']"] + FWD("Q1'") + ["q1 read"] + FWD("Q2'") +
+              ["y = r + g min q", "gather [s|a]"] + FWD("Q1") + BWD + ["gather [s|a]"] + FWD("Q2") + BWD)
+
+
+def main():
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    N.build()
+    from freerl_amd.engine import Engine
+    L = N.lib()
+    fn = L.frl_debug_phase_clocks
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_int), C.c_int]
+    import bench
+    B = bench.BATCH
+    e = bench.make_engine(N, Engine, P, 0, 1)    # the bench workload: replay 1e6 filled, random-init weights
+    rc = e.lds_bytes()[1]
+    nblk = P * ((B + rc - 1) // rc)
+    KMAX = 44
+    buf = (C.c_int * (8 * 5 * KMAX))()
+    stride = max(1, nblk // 8 - 3)
+    assert fn(buf, stride) == 0
+    for it in range(6):
+        e.learn(B, **bench.td3_kwargs(0))
+    assert fn(buf, 0) == 0
+    raw = np.array(buf[:], dtype=np.int64).reshape(8, 5, KMAX)
+    nb = len(LABELS_TD3)
+    arrive = raw[:, :4, :nb].astype(np.float64)                              # [block][wave][barrier]
+    rel0 = raw[:, 4, :nb + 1].astype(np.float64)                             # init stamp, then wave 0's release of each barrier
+    t0 = rel0[:, :1]
+    unwrap = lambda a, ref: a + 2.0 ** 32 * (a < ref - 2.0 ** 31)            # 32-bit stamps
+    arrive = unwrap(arrive, t0[:, None, :])
+    rel0 = unwrap(rel0, t0)
+    release = np.repeat(rel0[:, None, 1:], 4, axis=1)
+    prev = np.repeat(rel0[:, None, :-1], 4, axis=1)
+    work = arrive - prev
+    wait = release - arrive
+    t = None
+    total = (rel0[:, -1] - rel0[:, 0]).mean()
+    print("P=%d, %d rows per workgroup, sampled every %d blocks; mean cycles per workgroup %.0f" % (P, rc, stride, total))
+    print("%-24s %9s %9s %9s %9s %7s" % ("phase (ends at barrier)", "work mean", "work max", "work min", "wait mean", "share"))
+    for k, lab in enumerate(LABELS_TD3):
+        w = work[:, :, k]
+        print("%-24s %9.0f %9.0f %9.0f %9.0f %6.1f%%" % (lab, w.mean(), w.max(axis=1).mean(), w.min(axis=1).mean(),
+              wait[:, :, k].mean(), 100 * (w.mean() + wait[:, :, k].mean()) / total))
+    print("sum work %.0f  sum wait %.0f" % (work.mean(axis=(0, 1)).sum(), wait.mean(axis=(0, 1)).sum()))
+    e.close()
+
+
+if __name__ == "__main__":
+    main()
