@@ -17,37 +17,46 @@ namespace frl {
 // Developer instrument (tools/phase_timing.py; built only with -DFRL_PHASE_TIMING): thread 0 of a few
 // sampled workgroups stamps the shader clock at every barrier-delimited phase of the gradient kernels.
 #ifdef FRL_PHASE_TIMING
-// Stamps go to LDS (256 extra words after S.red, see lds_bytes_for) and are dumped once at kernel end: a global store per stamp
-// would put a write acknowledgement in front of every barrier's vmcnt(0) and distort what is measured.
-constexpr int kPhaseMax = 44, kPhaseBlocks = 8, kPhaseWords = 5 * kPhaseMax;   // 4 waves' arrivals + wave 0's releases
+// Stamps go to (static) LDS and are dumped once at kernel end: a global store per stamp would put a write
+// acknowledgement in front of the next vmcnt wait and distort what is measured.
+constexpr int kPhaseMax = 64, kPhaseBlocks = 8, kPhaseWords = 5 * kPhaseMax;   // 4 waves' arrivals + wave 0's releases
 __device__ int g_phase_clock[kPhaseBlocks][kPhaseWords];
 __device__ int g_phase_stride = 509;
-#define FRL_STAMP_(S, slot, ctr)                                                                   \
+__device__ __forceinline__ FRL_LDS int* phase_buf() {
+    __shared__ int buf[kPhaseWords + 8];
+    return (FRL_LDS int*)buf;
+}
+#define FRL_STAMP_(slot, ctr)                                                                      \
     do {                                                                                           \
-        const int k_ = (int)(S).red[ctr];                                                          \
-        if (k_ < kPhaseMax) ((FRL_LDS int*)((S).red + 8))[(slot) * kPhaseMax + k_] = (int)clock64(); \
-        (S).red[ctr] = (float)(k_ + 1);                                                            \
+        FRL_LDS int* b_ = phase_buf();                                                             \
+        const int k_ = b_[kPhaseWords + (ctr)];                                                    \
+        if (k_ < kPhaseMax) b_[(slot) * kPhaseMax + k_] = (int)clock64();                          \
+        b_[kPhaseWords + (ctr)] = k_ + 1;                                                          \
     } while (0)
+// extra stamp inside a phase (wave 0's "release" row): FRL_MARK()
+#define FRL_MARK() do { if (threadIdx.x == 0) FRL_STAMP_(4, 4); } while (0)
 #define FRL_PHASE(S)                                                                               \
     do {                                                                                           \
-        if ((threadIdx.x & 63) == 0) FRL_STAMP_(S, threadIdx.x >> 6, 4 + (threadIdx.x >> 6));      \
+        if ((threadIdx.x & 63) == 0) FRL_STAMP_(threadIdx.x >> 6, threadIdx.x >> 6);               \
         lds_barrier();                                                                             \
-        if (threadIdx.x == 0) FRL_STAMP_(S, 4, 3);                                                 \
+        if (threadIdx.x == 0) FRL_STAMP_(4, 4);                                                    \
     } while (0)
 #define FRL_PHASE_INIT(S)                                                                          \
     do {                                                                                           \
-        if ((threadIdx.x & 63) == 0) (S).red[4 + (threadIdx.x >> 6)] = 0.f;                        \
-        if (threadIdx.x == 0) { (S).red[3] = 0.f; FRL_STAMP_(S, 4, 3); }                           \
+        if (threadIdx.x < 8) phase_buf()[kPhaseWords + threadIdx.x] = 0;                           \
+        __syncthreads();                                                                           \
+        if (threadIdx.x == 0) FRL_STAMP_(4, 4);                                                    \
     } while (0)
 #define FRL_PHASE_DUMP(S)                                                                          \
     do {                                                                                           \
         __syncthreads();                                                                           \
         if (blockIdx.x % g_phase_stride == 0 && blockIdx.x / g_phase_stride < kPhaseBlocks)        \
             for (int i_ = threadIdx.x; i_ < kPhaseWords; i_ += kWG)                                \
-                g_phase_clock[blockIdx.x / g_phase_stride][i_] = ((FRL_LDS int*)((S).red + 8))[i_]; \
+                g_phase_clock[blockIdx.x / g_phase_stride][i_] = phase_buf()[i_];                  \
     } while (0)
 #else
 #define FRL_PHASE(S) lds_barrier()
+#define FRL_MARK() do {} while (0)
 #define FRL_PHASE_INIT(S) do {} while (0)
 #define FRL_PHASE_DUMP(S) do {} while (0)
 #endif
@@ -85,6 +94,21 @@ __device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int ki
     return S;
 }
 
+// compile-time activation for the hot epilogues (a runtime `act` per element costs a branch per element and drags
+// the tanhf expansion into every epilogue); dispatch_act() turns the runtime value into the template argument once.
+template <int ACT>
+__device__ __forceinline__ f32x4 act_apply4(f32x4 v) {
+    if constexpr (ACT == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (ACT == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+    return v;
+}
+template <class F>
+__device__ __forceinline__ void dispatch_act(int act, F f) {
+    if (act == ACT_RELU) f(std::integral_constant<int, ACT_RELU>{});
+    else if (act == ACT_TANH) f(std::integral_constant<int, ACT_TANH>{});
+    else f(std::integral_constant<int, ACT_NONE>{});
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_TANH) return tanhf(v);
@@ -103,15 +127,10 @@ __device__ __forceinline__ void linear_fwd(const LayerDesc& L, g_cf theta, lds_c
     g_cf W = theta + L.w_off;
     g_cf b = theta + L.b_off;
     const int kpad = L.k_pad, npad = L.n_pad, q4 = (lane_id() >> 4) * 4;
-    auto finish = [&](int r, int c4, f32x4 v, f32x4 bias) {
-        v += bias;
-        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
-        st4(Y + r * ldy + c4, v);
-    };
-#ifndef FRL_FWD_IL
-#define FRL_FWD_IL 1
-#endif
-    if (FRL_FWD_IL && npad % 64 == 0) {
+    dispatch_act(act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    auto finish = [&](int r, int c4, f32x4 v, f32x4 bias) { st4(Y + r * ldy + c4, act_apply4<ACT>(v + bias)); };
+    if (npad % 64 == 0) {
         for_il_blocks(rc / 16, npad / 64, [&](auto bm, int mt0, int g) {
             constexpr int BM = decltype(bm)::value;
             f32x4 acc[BM][4], bias[4];
@@ -132,6 +151,7 @@ __device__ __forceinline__ void linear_fwd(const LayerDesc& L, g_cf theta, lds_c
             tile_epilogue<BM, BN, W_ROWS>(acc, mt0 * 16, nt0 * 16, [&](int r, int c4, f32x4 v, int slot) { finish(r, c4, v, bias[slot]); });
         });
     }
+    });
 }
 
 // dX[rc][k tiles ct0..ct1) = (dY[rc][n_pad] * W) (.) act'(H)   written in place over H (pitch ldh); the contraction
@@ -195,11 +215,131 @@ __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf 
             tile_epilogue<BM, BN, W_ROWS>(acc, kt0 * 16, nt0 * 16, [&](int k, int n4, f32x4 v, int) { finish(k, n4, v); });
         });
     }
+    // bias gradient = column sums of dY.  The last wave(s) take it (the first ones own the odd tile block when the
+    // tile count does not divide by 4); 8 independent partial sums keep 8 LDS reads in flight — as one dependent
+    // chain of rc reads this loop was the longest thing in every dW phase.
     g_f Gb = G + L.b_off;
-    for (int n = threadIdx.x; n < L.n_pad; n += kWG) {
-        float s = 0.f;
-        for (int r = 0; r < rc; ++r) s += dY[r * ldy + n];
+    for (int n = kWG - 1 - threadIdx.x; n < L.n_pad; n += kWG) {
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rc; r += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] += dY[(r + j) * ldy + n];
+        }
+        const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         Gb[n] = first ? s : (Gb[n] + s);
+    }
+}
+
+// ---- narrow heads (n <= 4 outputs: Q values, 1-4 action dimensions) ---------------------------------------------
+// A 16-wide padded MFMA tile per head costs a whole barrier-delimited phase for 1/16 useful work, three times per
+// head and update (forward, dW, dX) — after the 128x128 layers were pipelined these phases were a third of the
+// kernel.  Instead the head rides on its neighbours: forward = dot products in the epilogue of the hidden layer
+// that feeds it (each lane owns 16 of a row's columns), backward = one VALU pass over the LDS-resident activations.
+__device__ __forceinline__ bool head_fusable(const NetDesc& N, int l0, int nl) {
+    if (nl < 2) return false;
+    const LayerDesc& LH = N.L[l0 + nl - 1];
+    const LayerDesc& LP = N.L[l0 + nl - 2];
+    return LH.n <= 4 && LH.n_pad == 16 && LP.n_pad % 64 == 0 && LP.n_pad <= 256 && LH.k_pad == LP.n_pad;
+}
+
+// Hidden layer L (as linear_fwd) + partial head outputs: outb[r][4*g + o] = sum over column group g of h[r][c] * WH[c][o]
+__device__ __forceinline__ void linear_fwd_head(const LayerDesc& L, const LayerDesc& LH, g_cf theta, lds_cf X, int ldx, lds_f Y,
+                                                int ldy, int act, int rc, lds_f outb, int op) {
+    g_cf W = theta + L.w_off;
+    g_cf b = theta + L.b_off;
+    g_cf WH = theta + LH.w_off;                       // Wk[L.n_pad][16]
+    const int kpad = L.k_pad, npad = L.n_pad, l = lane_id(), q = l >> 4, row = l & 15;
+    dispatch_act(act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    for_il_blocks(rc / 16, npad / 64, [&](auto bm, int mt0, int g) {
+        constexpr int BM = decltype(bm)::value;
+        f32x4 acc[BM][4], bias[4], part[BM];
+        acc_zero(acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = ld4(b + g * 64 + 16 * q + 4 * r);
+        mma_w_any<BM, 4, W_IL>(acc, X, ldx, mt0 * 16, W, npad, g * 64, kpad);
+#pragma unroll
+        for (int x = 0; x < BM; ++x) part[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c4 = g * 64 + 16 * q + 4 * r;
+            const f32x4 w0 = ld4(WH + (c4 + 0) * 16), w1 = ld4(WH + (c4 + 1) * 16), w2 = ld4(WH + (c4 + 2) * 16),
+                        w3 = ld4(WH + (c4 + 3) * 16);
+#pragma unroll
+            for (int x = 0; x < BM; ++x) {
+                const f32x4 v = act_apply4<ACT>(f32x4{acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]} + bias[r]);
+                st4(Y + (mt0 * 16 + x * 16 + row) * ldy + c4, v);
+                part[x] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < BM; ++x) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                part[x][c] += __shfl_xor(part[x][c], 16, 64);
+                part[x][c] += __shfl_xor(part[x][c], 32, 64);
+            }
+            if (q == 0) st4(outb + (mt0 * 16 + x * 16 + row) * op + 4 * g, part[x]);
+        }
+    });
+    });
+}
+
+// outb[r][0..16) = out_act(b + sum of the `groups` partials), zero beyond the head's n outputs; one thread per row
+__device__ __forceinline__ void head_finalize(const LayerDesc& LH, g_cf theta, lds_f outb, int op, int rc, int groups, int out_act) {
+    const int r = threadIdx.x;
+    if (r < rc) {
+        lds_f o = outb + r * op;
+        f32x4 s = ld4(theta + LH.b_off);
+        for (int g = 0; g < groups; ++g) s += ld4((lds_cf)(o + 4 * g));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < LH.n) v[c] = act_apply(s[c], out_act);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        st4(o, v); st4(o + 4, z); st4(o + 8, z); st4(o + 12, z);
+    }
+}
+
+// Head backward in one pass: delta d[r][0..4) in outb.  Thread k < k_pad owns hidden unit k: dWk[k][:] = sum_r h[r][k] d[r],
+// and h[r][k] <- (d[r] . WH[k]) * act'(h[r][k]) in place (the delta of the hidden layer).  The last 16 threads sum the
+// bias gradient.  G == nullptr: input gradient only.
+__device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G, lds_cf outb, int op, lds_f H, int ldh,
+                                         int act_prev, int rc, bool first) {
+    const int k = threadIdx.x;
+    if (k < LH.k_pad) {
+        const f32x4 w = ld4(theta + LH.w_off + k * 16);
+        f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rc; r += 4) {
+            float h[4];
+            f32x4 d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = H[(r + j) * ldh + k]; d[j] = ld4(outb + (r + j) * op); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gw += h[j] * d[j];
+                const float dx = d[j].x * w.x + d[j].y * w.y + d[j].z * w.z + d[j].w * w.w;
+                H[(r + j) * ldh + k] = dx * act_grad(h[j], act_prev);
+            }
+        }
+        if (G) {
+            g_f g = G + LH.w_off + k * 16;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (first) { st4_stream(g, gw); st4_stream(g + 4, z); st4_stream(g + 8, z); st4_stream(g + 12, z); }
+            else st4(g, gw + ld4((g_cf)g));
+        }
+    }
+    const int t = kWG - 1 - threadIdx.x;
+    if (G && t < 16) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t < 4)
+            for (int r = 0; r < rc; r += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] += outb[(r + j) * op + t];
+            }
+        const float s = (p[0] + p[1]) + (p[2] + p[3]);
+        g_f gb = G + LH.b_off + t;
+        *gb = first ? s : (*gb + s);
     }
 }
 
@@ -207,10 +347,19 @@ __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf 
 __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act) {
     lds_cf in = S.xin;
     int ldin = S.xp;
+    const bool fuse = head_fusable(N, l0, nl);
     for (int i = 0; i < nl; ++i) {
         const bool last = (i == nl - 1);
         lds_f out = last ? S.outb : (i == 0 ? S.h1 : S.h2);
         const int ldo = last ? S.op : S.hp;
+        if (fuse && i == nl - 2) {
+            const LayerDesc& LH = N.L[l0 + nl - 1];
+            linear_fwd_head(N.L[l0 + i], LH, theta, in, ldin, out, ldo, N.hidden_act, S.rc, S.outb, S.op);
+            FRL_PHASE(S);
+            head_finalize(LH, theta, S.outb, S.op, S.rc, N.L[l0 + i].n_pad / 64, out_act);
+            FRL_PHASE(S);
+            return;
+        }
         linear_fwd(N.L[l0 + i], theta, in, ldin, out, ldo, last ? out_act : N.hidden_act, S.rc);
         FRL_PHASE(S);
         in = out;
@@ -223,6 +372,7 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
 // d loss / d xin in xin for column tiles [ct0, ct1).  Ends with a barrier.
 __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf theta, g_f G, const Lds& S, bool first,
                                         bool want_dx0, int ct0, int ct1) {
+    const bool fuse = head_fusable(N, l0, nl);
     for (int i = nl - 1; i >= 0; --i) {
         const bool last = (i == nl - 1);
         lds_cf D = last ? S.outb : (i == 0 ? S.h1 : S.h2);
@@ -230,6 +380,11 @@ __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf t
         lds_f X = (i == 0) ? S.xin : (i == 1 ? S.h1 : S.h2);
         const int ldx = (i == 0) ? S.xp : S.hp;
         const LayerDesc& L = N.L[l0 + i];
+        if (last && fuse) {
+            head_bwd(L, theta, G, D, ldd, X, ldx, N.hidden_act, S.rc, first);
+            FRL_PHASE(S);
+            continue;
+        }
         if (G) {
             linear_bwd_dw(L, G, D, ldd, X, ldx, S.rc, first);
             FRL_PHASE(S);

@@ -175,9 +175,6 @@ static void build_record(RecordDesc& R, const frl_config& c) {
 static int lds_bytes_for(const EngineDesc& h, int rc) {
     const int xp = h.lds_kin_pad + 4, hp = h.hidden + 4, op = h.lds_out_pad + 4, ap = h.lds_act_pad;
     long long fl = (long long)rc * (xp + 2 * hp + op + 2 * ap) + h.lds_batch_pad + 8;
-#ifdef FRL_PHASE_TIMING
-    fl += 256;                                              // stamp area of the developer instrument (device/net.hpp)
-#endif
     return (int)(fl * 4);
 }
 
@@ -305,7 +302,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);
     h.lds_kin_pad = kin;
     h.lds_out_pad = outp;
-    h.lds_batch_pad = 64;                                   // y holds one row chunk (rc <= 64) of TD targets
+    h.lds_batch_pad = 128;                                  // y holds one row chunk (rc <= 128) of TD targets
     h.lds_act_pad = (std::max(R.act_total, 1) + 3) / 4 * 4; // abuf / dabuf are scalar-accessed: no tile padding
     if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
     // row chunk: the largest of {64,32,16} whose LDS footprint still lets 4 workgroups share a CU
@@ -314,7 +311,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;   // two workgroups per CU (160 KB LDS)
     if (const char* force = getenv("FRL_RC")) {             // developer knob: rows per workgroup (16 / 32 / 64)
         const int v = atoi(force);
-        if (v == 16 || v == 32 || v == 64) h.rc = v;
+        if (v == 16 || v == 32 || v == 64 || v == 128) h.rc = v;
     }
     if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
     e->lds_bytes = lds_bytes_for(h, h.rc);

@@ -18,6 +18,10 @@
 
 #include "device/net.hpp"
 
+#ifndef FRL_GRAD_WGS
+#define FRL_GRAD_WGS 2      // gradient-kernel workgroups per CU the register budget is sized for (frl_create picks rc to match)
+#endif
+
 namespace frl {
 
 namespace {
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restri
 // ------------------------------------------------------------------------------------- DQN
 // DQN.learn (DQN_file/DQN.py:104-118) for one row chunk: y = r + gamma*max_a Q_t(s',a)*(1-d);
 // delta = 2(Q(s)[a] - y)/B on the taken action; backward -> partial slab.
-__global__ __launch_bounds__(256, 2) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void dqn_grad_kernel(const EngineDesc* __re
 // ------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: critic
 // TD target with the target nets, twin/single critic forward, MSE delta, backward -> slab.
 // DDPG_simple.py:139-149, TD3.py:193-213, SAC.py:226-238, MADDPG_simple.py:169-176.
-__global__ __launch_bounds__(256, 2) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
@@ -184,6 +188,16 @@ __global__ __launch_bounds__(256, 2) void ac_critic_kernel(const EngineDesc* __r
     const float invB = 1.f / (float)B;
     g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
     FRL_PHASE_INIT(S);
+#ifdef FRL_EXP_TOUCH      // experiment: pull every weight line this kernel will read into L2 up front
+    {
+        float acc_t = 0.f;
+        g_cf spans[3] = {as_global(D.target + lbase + D.net_off[2 * ag]), tgC, thC};
+        const int sizes[3] = {D.net[2 * ag].size, NC.size, NC.size};
+        for (int sidx = 0; sidx < 3; ++sidx)
+            for (int o = threadIdx.x * 32; o < sizes[sidx]; o += kWG * 32) acc_t += spans[sidx][o];
+        if (acc_t == 123456.789f) S.red[0] = acc_t;
+    }
+#endif
 
     // ---- a' = actor_target_j(s'_j) for every agent j (MADDPG_simple.py:155; n = 1 otherwise)
     float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void ac_critic_kernel(const EngineDesc* __r
 // -------------------------------------------------------- DDPG / TD3 / SAC / MADDPG: actor
 // a = actor(s); Q(s, a) through the (already updated, frozen) critic; dQ/da; actor backward.
 // DDPG_simple.py:151-154, TD3.py:224-231, SAC.py:244-252, MADDPG_simple.py:178-183.
-__global__ __launch_bounds__(256, 2) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+__global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);

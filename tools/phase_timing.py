@@ -18,8 +18,8 @@ os.environ.setdefault("FRL_HIP_VARIANT", "phase")
 os.environ.setdefault("FRL_HIPCC_FLAGS", "-DFRL_PHASE_TIMING")
 from freerl_amd import _native as N  # noqa: E402
 
-FWD = lambda n: ["%s l%d" % (n, i) for i in (1, 2, 3)]
-BWD = ["delta", "dW3", "dX3", "dW2", "dX2", "dW1"]
+FWD = lambda n: [n + " l1", n + " l2 + head dots", n + " head finalize"]
+BWD = ["delta", "head bwd (dW3,dX3)", "dW2", "dX2", "dW1"]
 LABELS_TD3 = (["gather s'"] + FWD("pi'") + ["a' = clip(pi'+noise)", "gather [s'|a']"] + FWD("Q1'") + ["q1 read"] + FWD("Q2'") +
               ["y = r + g min q", "gather [s|a]"] + FWD("Q1") + BWD + ["gather [s|a]"] + FWD("Q2") + BWD)
 
@@ -36,7 +36,7 @@ def main():
     e = bench.make_engine(N, Engine, P, 0, 1)    # the bench workload: replay 1e6 filled, random-init weights
     rc = e.lds_bytes()[1]
     nblk = P * ((B + rc - 1) // rc)
-    KMAX = 44
+    KMAX = 64
     buf = (C.c_int * (8 * 5 * KMAX))()
     stride = max(1, nblk // 8 - 3)
     assert fn(buf, stride) == 0
@@ -44,6 +44,12 @@ def main():
         e.learn(B, **bench.td3_kwargs(0))
     assert fn(buf, 0) == 0
     raw = np.array(buf[:], dtype=np.int64).reshape(8, 5, KMAX)
+    if os.environ.get("FRL_RAW_MARKS"):        # wave 0's stamp row as-is (FRL_MARK() experiments)
+        row = raw[:, 4, :].astype(np.float64)
+        d = np.diff(row, axis=1)
+        print("wave-0 stamp-to-stamp cycles, mean over sampled workgroups:")
+        print(np.round(d.mean(axis=0)).astype(int).tolist())
+        return
     nb = len(LABELS_TD3)
     arrive = raw[:, :4, :nb].astype(np.float64)                              # [block][wave][barrier]
     rel0 = raw[:, 4, :nb + 1].astype(np.float64)                             # init stamp, then wave 0's release of each barrier
