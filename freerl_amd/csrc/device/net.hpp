@@ -239,12 +239,15 @@ __device__ __forceinline__ bool head_fusable(const NetDesc& N, int l0, int nl) {
     if (nl < 2) return false;
     const LayerDesc& LH = N.L[l0 + nl - 1];
     const LayerDesc& LP = N.L[l0 + nl - 2];
-    return LH.n <= 4 && LH.n_pad == 16 && LP.n_pad % 64 == 0 && LP.n_pad <= 256 && LH.k_pad == LP.n_pad;
+    return LH.n <= 4 && LH.n_pad == 16 && LP.n_pad % 64 == 0 && LP.n_pad <= 128 && LH.k_pad == LP.n_pad;
 }
 
 // Hidden layer L (as linear_fwd) + partial head outputs: outb[r][4*g + o] = sum over column group g of h[r][c] * WH[c][o]
-__device__ __forceinline__ void linear_fwd_head(const LayerDesc& L, const LayerDesc& LH, g_cf theta, lds_cf X, int ldx, lds_f Y,
-                                                int ldy, int act, int rc, lds_f outb, int op) {
+// ONE: single-output head (every critic): the 16 head weights a lane needs are scalars fetched with the layer's own
+// weights; otherwise they are float4s (4 outputs) fetched in the epilogue.
+template <bool ONE>
+__device__ __forceinline__ void linear_fwd_head_t(const LayerDesc& L, const LayerDesc& LH, g_cf theta, lds_cf X, int ldx, lds_f Y,
+                                                  int ldy, int act, int rc, lds_f outb, int op) {
     g_cf W = theta + L.w_off;
     g_cf b = theta + L.b_off;
     g_cf WH = theta + LH.w_off;                       // Wk[L.n_pad][16]
@@ -254,28 +257,36 @@ __device__ __forceinline__ void linear_fwd_head(const LayerDesc& L, const LayerD
     for_il_blocks(rc / 16, npad / 64, [&](auto bm, int mt0, int g) {
         constexpr int BM = decltype(bm)::value;
         f32x4 acc[BM][4], bias[4], part[BM];
+        float w1[ONE ? 16 : 1];
         acc_zero(acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = ld4(b + g * 64 + 16 * q + 4 * r);
+        if constexpr (ONE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w1[j] = WH[(g * 64 + 16 * q + j) * 16];
+        }
         mma_w_any<BM, 4, W_IL>(acc, X, ldx, mt0 * 16, W, npad, g * 64, kpad);
 #pragma unroll
         for (int x = 0; x < BM; ++x) part[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c4 = g * 64 + 16 * q + 4 * r;
-            const f32x4 w0 = ld4(WH + (c4 + 0) * 16), w1 = ld4(WH + (c4 + 1) * 16), w2 = ld4(WH + (c4 + 2) * 16),
-                        w3 = ld4(WH + (c4 + 3) * 16);
+            f32x4 w0, w1v, w2, w3;
+            if constexpr (!ONE) {
+                w0 = ld4(WH + (c4 + 0) * 16); w1v = ld4(WH + (c4 + 1) * 16); w2 = ld4(WH + (c4 + 2) * 16); w3 = ld4(WH + (c4 + 3) * 16);
+            }
 #pragma unroll
             for (int x = 0; x < BM; ++x) {
                 const f32x4 v = act_apply4<ACT>(f32x4{acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]} + bias[r]);
                 st4(Y + (mt0 * 16 + x * 16 + row) * ldy + c4, v);
-                part[x] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
+                if constexpr (ONE) part[x].x += (v.x * w1[4 * r] + v.y * w1[4 * r + 1]) + (v.z * w1[4 * r + 2] + v.w * w1[4 * r + 3]);
+                else part[x] += v.x * w0 + v.y * w1v + v.z * w2 + v.w * w3;
             }
         }
 #pragma unroll
         for (int x = 0; x < BM; ++x) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < (ONE ? 1 : 4); ++c) {
                 part[x][c] += __shfl_xor(part[x][c], 16, 64);
                 part[x][c] += __shfl_xor(part[x][c], 32, 64);
             }
@@ -283,6 +294,11 @@ __device__ __forceinline__ void linear_fwd_head(const LayerDesc& L, const LayerD
         }
     });
     });
+}
+__device__ __forceinline__ void linear_fwd_head(const LayerDesc& L, const LayerDesc& LH, g_cf theta, lds_cf X, int ldx, lds_f Y,
+                                                int ldy, int act, int rc, lds_f outb, int op) {
+    if (LH.n == 1) linear_fwd_head_t<true>(L, LH, theta, X, ldx, Y, ldy, act, rc, outb, op);
+    else linear_fwd_head_t<false>(L, LH, theta, X, ldx, Y, ldy, act, rc, outb, op);
 }
 
 // outb[r][0..16) = out_act(b + sum of the `groups` partials), zero beyond the head's n outputs; one thread per row
@@ -301,16 +317,18 @@ __device__ __forceinline__ void head_finalize(const LayerDesc& LH, g_cf theta, l
     }
 }
 
-// Head backward in one pass: delta d[r][0..4) in outb.  Thread k < k_pad owns hidden unit k: dWk[k][:] = sum_r h[r][k] d[r],
-// and h[r][k] <- (d[r] . WH[k]) * act'(h[r][k]) in place (the delta of the hidden layer).  The last 16 threads sum the
-// bias gradient.  G == nullptr: input gradient only.
+// Head backward in one pass: delta d[r][0..4) in outb.  Hidden unit k is owned by TWO lanes of one wave (lane
+// halves 0-31 / 32-63), each taking half of the rows: dWk[k][:] = sum_r h[r][k] d[r] (halves combined by a shuffle),
+// and h[r][k] <- (d[r] . WH[k]) * act'(h[r][k]) in place (the delta of the hidden layer).  The last 16 threads also
+// sum the bias gradient.  G == nullptr: input gradient only.  k_pad <= 128 (32 units per wave).
 __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G, lds_cf outb, int op, lds_f H, int ldh,
                                          int act_prev, int rc, bool first) {
-    const int k = threadIdx.x;
+    const int l = lane_id(), half = l >> 5, k = (threadIdx.x >> 6) * 32 + (l & 31);
+    const int hr = rc / 2, r_lo = half * hr;
     if (k < LH.k_pad) {
         const f32x4 w = ld4(theta + LH.w_off + k * 16);
         f32x4 gw = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < rc; r += 4) {
+        for (int r = r_lo; r < r_lo + hr; r += 4) {
             float h[4];
             f32x4 d[4];
 #pragma unroll
@@ -322,7 +340,9 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
                 H[(r + j) * ldh + k] = dx * act_grad(h[j], act_prev);
             }
         }
-        if (G) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gw[c] += __shfl_xor(gw[c], 32, 64);
+        if (G && half == 0) {
             g_f g = G + LH.w_off + k * 16;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (first) { st4_stream(g, gw); st4_stream(g + 4, z); st4_stream(g + 8, z); st4_stream(g + 12, z); }
