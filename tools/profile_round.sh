@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
+# kernel trace + stats first, then one --pmc pass per counter group (never combined with other traces).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- $BENCH > $O/pmc$i.log 2>&1
+  python $R/tools/pmc_summary.py $O/pmc$i $O/pmc$i.json
+done
+python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_kernel
+cd $R && timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+rm -rf $O/stats $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
+ls -la $O
