@@ -346,7 +346,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (int i = 0; i < h.n_nets; ++i) h.Gmax = std::max(h.Gmax, (h.net[i].size / 4 + 256 * kAdamVec - 1) / (256 * kAdamVec));
         CREATE_TRY(dalloc_zero(&h.gsq, P * (size_t)h.n_agents * h.Gmax, e->stream));
         e->idx_count = P * h.n_agents * h.batch_max;
-        e->noise_count = P * h.n_agents * 2 * (size_t)h.batch_max * h.act_max;
+        h.noise_sets = std::max(2, h.n_agents);
+        e->noise_count = P * h.n_agents * h.noise_sets * (size_t)h.batch_max * h.act_max;
         CREATE_TRY(dalloc_zero(&h.idx, e->idx_count, e->stream));
         CREATE_TRY(dalloc_zero(&h.noise, e->noise_count, e->stream));
         CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
@@ -755,9 +756,9 @@ static int upload_idx_noise(frl_engine* e, const int64_t* idx, const float* nois
         HIP_TRY(hipMemcpyAsync(h.idx, e->h_idx, e->idx_count * sizeof(int), hipMemcpyHostToDevice, e->stream));
     }
     if (noise) {
-        // host [P][n_agents][2][batch][act_max] -> device [P][n_agents][2][batch_max][act_max]
+        // host [P][n_agents][noise_sets][batch][act_max] -> device [P][n_agents][noise_sets][batch_max][act_max]
         const int am = h.act_max;
-        for (size_t s = 0; s < (size_t)h.P * h.n_agents * 2; ++s)
+        for (size_t s = 0; s < (size_t)h.P * h.n_agents * h.noise_sets; ++s)
             memcpy(e->h_noise + s * h.batch_max * am, noise + s * batch * am, (size_t)batch * am * sizeof(float));
         HIP_TRY(hipMemcpyAsync(h.noise, e->h_noise, e->noise_count * sizeof(float), hipMemcpyHostToDevice, e->stream));
     }
@@ -785,7 +786,8 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     const bool dev_rng = (args->idx == nullptr);
     if (dev_rng && min_size < 2 * args->batch)
         return fail(FRL_ERR_STATE, "device index draw needs len(buffer) >= 2*batch (have %d); pass idx", min_size);
-    const bool needs_noise = (h.algo == ALGO_SAC) || (h.algo == ALGO_TD3 && args->use_policy_noise);
+    const bool td3_like = (h.algo == ALGO_TD3 || h.algo == ALGO_MADDPG);       // MADDPG + noise/delay = MATD3_simple.py
+    const bool needs_noise = (h.algo == ALGO_SAC) || (td3_like && args->use_policy_noise);
     if (!dev_rng && needs_noise && !args->noise) return fail(FRL_ERR_INVALID, "idx given without noise: both or neither");
     int rc = flush_stage(e);
     if (rc) return rc;
@@ -796,7 +798,7 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     a.batch = args->batch;
     a.size = min_size;
     a.device_rng = dev_rng ? 1 : 0;
-    a.do_actor = (h.algo == ALGO_TD3) ? (args->do_actor ? 1 : 0) : 1;
+    a.do_actor = td3_like ? (args->do_actor ? 1 : 0) : 1;
     a.gamma = args->gamma; a.tau = args->tau;
     a.actor_lr = args->actor_lr; a.critic_lr = args->critic_lr; a.alpha_lr = args->alpha_lr;
     a.adam_eps = args->adam_eps > 0 ? args->adam_eps : 1e-8f;
@@ -806,7 +808,7 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     a.policy_noise = args->policy_noise; a.noise_clip = args->noise_clip;
     a.max_action = args->max_action != 0.f ? args->max_action : 1.f;
     a.policy_noise_scale = args->policy_noise_scale;
-    a.use_policy_noise = (h.algo == ALGO_TD3 && args->use_policy_noise) ? 1 : 0;
+    a.use_policy_noise = (td3_like && args->use_policy_noise) ? 1 : 0;
     a.target_entropy = args->target_entropy;
     a.rng_counter = e->rng_counter++;
     const int ns = (a.batch + h.rc - 1) / h.rc;
@@ -846,7 +848,7 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
         hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, e->stream, e->d, ad);
         prof_end(e);
     }
-    if (maddpg) {
+    if (maddpg && a.do_actor) {                       // MATD3_simple.py:245-246: targets move with the delayed policy step
         prof_begin(e, PK_SOFT);
         hipLaunchKernelGGL(soft_update_kernel, dim3(h.P * h.n_nets), blk, 0, e->stream, e->d, a.tau);
         prof_end(e);

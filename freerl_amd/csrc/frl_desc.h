@@ -75,7 +75,9 @@ struct EngineDesc {
     int Gmax;             // workgroups per net in the reduce/adam launches
     float* replay;        // [P][capacity][rec.stride]
     int* idx;             // [P][n_agents][batch_max] sampled row indices
-    float* noise;         // [P][2][batch_max][act_max] standard-normal draws (TD3 policy noise, SAC eps', eps)
+    float* noise;         // [P][n_agents][noise_sets][batch_max][act_max] standard-normal draws: set 0 = TD3 policy noise /
+                          // SAC eps', set 1 = SAC eps; MATD3: set j = the policy noise on agent j's target action
+    int noise_sets;       // max(2, n_agents)
     float* stats;         // [P][n_agents][ST_COUNT]
     int* steps;           // [P][kMaxNets + 1] Adam step counters (+1: SAC alpha)
     float* alpha;         // [P][4]: log_alpha, m, v, alpha (SAC)

@@ -58,14 +58,16 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
     draw_indices(idx, (FRL_LDS int*)smem, B, a.size, a.rng_counter, (unsigned)ag, key);
     if (want_noise) {
-        const int am = D.act_max;
-        g_f noise0 = as_global(D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am);
-        g_f noise1 = noise0 + (size_t)D.batch_max * am;
-        for (int e = threadIdx.x; e < B * am; e += kWG) {
-            float n0, n1;
-            normal2(philox4x32_10(a.rng_counter, 0x4000u + (unsigned)ag, (unsigned)e, key), n0, n1);
-            noise0[e] = n0;
-            noise1[e] = n1;
+        const int am = D.act_max, NS = D.noise_sets;
+        for (int s2 = 0; s2 < NS; s2 += 2) {          // two sets per Philox draw
+            g_f noise0 = as_global(D.noise + (((size_t)p * n + ag) * NS + s2) * D.batch_max * am);
+            g_f noise1 = noise0 + (size_t)D.batch_max * am;
+            for (int e = threadIdx.x; e < B * am; e += kWG) {
+                float n0, n1;
+                normal2(philox4x32_10(a.rng_counter, 0x4000u + (unsigned)ag + 0x100u * (unsigned)s2, (unsigned)e, key), n0, n1);
+                noise0[e] = n0;
+                if (s2 + 1 < NS) noise1[e] = n1;
+            }
         }
     }
 }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    g_cf noise0 = as_global(D.noise + ((size_t)p * n + ag) * 2 * D.batch_max * am + (size_t)r0 * am);
+    g_cf noise_u = as_global(D.noise + ((size_t)p * n + ag) * D.noise_sets * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         const NetDesc& NJ = D.net[2 * j];
         g_cf tgJ = as_global(D.target + lbase + D.net_off[2 * j]);
         const int Oj = R.obs_dim[j], Aj = R.act_dim[j], cj = R.act_off[j] - R.act_off[0];
+        g_cf noise0 = noise_u + (size_t)j * D.batch_max * am;     // set j (n = 1: set 0); MATD3_simple.py:199-201
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
         if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn, Oj); }
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    g_cf noise1 = as_global(D.noise + (((size_t)p * n + ag) * 2 + 1) * D.batch_max * am + (size_t)r0 * am);
+    g_cf noise1 = as_global(D.noise + (((size_t)p * n + ag) * D.noise_sets + 1) * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const int Oa = R.obs_dim[ag], Aa = R.act_dim[ag], acol = R.act_off[ag] - R.act_off[0];

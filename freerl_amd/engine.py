@@ -188,7 +188,7 @@ class Engine:
             keep.append(ix)
             a.idx = ix.ctypes.data_as(C.POINTER(C.c_int64))
         if noise is not None:
-            nz = np.ascontiguousarray(noise, dtype=F32).reshape(self.P, self.n_agents, 2, int(batch), self.act_max)
+            nz = np.ascontiguousarray(noise, dtype=F32).reshape(self.P, self.n_agents, max(2, self.n_agents), int(batch), self.act_max)
             keep.append(nz)
             a.noise = _fp(nz)
         stats = None

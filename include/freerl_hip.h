@@ -103,8 +103,9 @@ typedef struct frl_record_layout {
  * (DQN.py:104, DDPG_simple.py:137, TD3.py:189, SAC.py:222, MADDPG_simple.py:165). */
 typedef struct frl_learn_args {
     int batch;                 /* min(len(buffer), batch_size) is the caller's job (DQN.py:95-96) */
-    int do_actor;              /* TD3: total_it % policy_freq == 0 (TD3.py:224); else 1 */
-    int use_policy_noise;      /* TD3 realize['policy_noise'] */
+    int do_actor;              /* TD3 / MATD3: total_it % policy_freq == 0 (TD3.py:224, MATD3_simple.py:236,245: actor step
+                                  AND target update); else 1 */
+    int use_policy_noise;      /* TD3 / MATD3 realize['policy_noise'] (FRL_ALGO_MADDPG + twin_critic + these two = MATD3_simple.py) */
     float gamma, tau;
     float actor_lr, critic_lr; /* DQN: critic_lr = Qnet_lr */
     float alpha_lr;            /* SAC Alpha, 1e-4 (SAC.py:155) */
@@ -115,8 +116,9 @@ typedef struct frl_learn_args {
     float target_entropy;      /* SAC: -act_dim (SAC.py:160) */
     const int64_t* idx;        /* host [P][n_agents][batch] rows drawn by the caller (np.random.choice,
                                   DQN.py:97) for bit-identical sampling; NULL: drawn on the device */
-    const float* noise;        /* host [P][n_agents][2][batch][act_max] N(0,1) draws the reference takes
-                                  from torch's generator (TD3.py:197 slot 0; SAC.py:227 slot 0, :244 slot 1);
+    const float* noise;        /* host [P][n_agents][S][batch][act_max], S = max(2, n_agents): N(0,1) draws the reference
+                                  takes from torch's generator (TD3.py:197 slot 0; SAC.py:227 slot 0, :244 slot 1;
+                                  MATD3_simple.py:200: slot j = randn_like(action[agent j]) inside agent i's sample());
                                   NULL: drawn on the device */
     float* stats_out;          /* host [P][n_agents][FRL_STAT_COUNT] or NULL (NULL: call is asynchronous) */
 } frl_learn_args;

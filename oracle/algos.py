@@ -361,3 +361,54 @@ class MADDPG:
         for a in self.ids:                              # MADDPG_simple.py:188-195: actor then critic
             nn.soft_update(self.actor_t[a], self.actor[a], tau)
             nn.soft_update(self.critic_t[a], self.critic[a], tau)
+
+
+class MATD3(MADDPG):
+    """MADDPG_file/MATD3_simple.py:151-262: MADDPG with twin centralised critics (Critic_TD3 :88-124, min of the
+    targets :222-224, loss on both heads :229-231, actor through Q1 only :240-241), target policy smoothing on EVERY
+    agent's target action (:199-201, one randn_like per agent inside each agent's sample()) and the delayed actor
+    step + target update (:236,245-246)."""
+
+    def __init__(self, params, dims, actor_lr, critic_lr, capacity):
+        super().__init__(params, dims, actor_lr, critic_lr, capacity)
+        self.q = QNet(True)
+        self.total_it = 0
+
+    def learn_with(self, idx_per_agent, noise_per_agent, gamma, tau, policy_noise_scale, policy_noise, noise_clip,
+                   max_action, policy_freq):
+        """noise_per_agent[i][j]: the [B, A_j] draw for agent j's target action inside agent i's sample()."""
+        self.total_it += 1
+        do_actor = (self.total_it % policy_freq == 0)
+        for i, aid in enumerate(self.ids):
+            idx = idx_per_agent[i]
+            batch = {a: self.buffers[a].sample(idx) for a in self.ids}
+            next_act = {}
+            for j, a in enumerate(self.ids):
+                n = np.clip(F32(policy_noise_scale) * (nn.f32(noise_per_agent[i][j]) * F32(policy_noise)), -noise_clip,
+                            noise_clip).astype(F32)
+                at = self.pi.forward(self.actor_t[a], batch[a][3])[0]
+                next_act[a] = (np.clip(at * F32(max_action) + n, -max_action, max_action) / F32(max_action)).astype(F32)
+            x_next = np.concatenate([batch[a][3] for a in self.ids] + [next_act[a] for a in self.ids], axis=1)
+            (q1t, _), two = self.q.forward(self.critic_t[aid], x_next)
+            y = batch[aid][2] + F32(gamma) * np.minimum(q1t, two[0]) * (F32(1) - batch[aid][4])
+            x = np.concatenate([batch[a][0] for a in self.ids] + [batch[a][1] for a in self.ids], axis=1)
+            closs, _ = _critic_step(self.q, self.critic[aid], self.critic_opt[aid], x, y)
+            self.critic_losses[aid].append(closs)
+            if do_actor:
+                a_new, pacts = self.pi.forward(self.actor[aid], batch[aid][0])
+                acts = {a: batch[a][1] for a in self.ids}
+                acts[aid] = a_new
+                x2 = np.concatenate([batch[a][0] for a in self.ids] + [acts[a] for a in self.ids], axis=1)
+                q2, q2a = self.q.q1.forward(self.critic[aid], x2)
+                aloss = F32(-np.mean(q2, dtype=F32))
+                dx, _ = self.q.q1.backward(self.critic[aid], q2a, np.full_like(q2, F32(-1.0 / q2.shape[0])), need_dx=True)
+                off = sum(self.dims[a][0] for a in self.ids) + sum(self.dims[a][1] for a in self.ids[:i])
+                _, ga = self.pi.backward(self.actor[aid], pacts, dx[:, off:off + self.dims[aid][1]], need_dx=False)
+                ga = {k: ga[k] for k in self.actor[aid]}
+                nn.clip_grad_norm(ga, 0.5)
+                self.actor_opt[aid].step(self.actor[aid], ga)
+                self.actor_losses[aid].append(aloss)
+        if do_actor:
+            for a in self.ids:                          # MATD3_simple.py:248-255: actor then critic per agent
+                nn.soft_update(self.actor_t[a], self.actor[a], tau)
+                nn.soft_update(self.critic_t[a], self.critic[a], tau)

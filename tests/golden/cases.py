@@ -57,6 +57,11 @@ CASES = {
     "maddpg": dict(kind="maddpg", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
                    capacity=512, n_table=256, batch=64, n_learn=2, gamma=0.95, tau=0.01,
                    actor_lr=1e-3, critic_lr=1e-3, table_seed=125, param_seed=1400, idx_seed=2400),
+    # MATD3_simple.learn (MADDPG_file/MATD3_simple.py:217-262): twin critics, per-agent target smoothing, delayed policy
+    "matd3": dict(kind="matd3", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
+                  capacity=512, n_table=256, batch=64, n_learn=4, gamma=0.95, tau=0.01,
+                  actor_lr=1e-3, critic_lr=1e-3, policy_noise=0.2, noise_clip=0.5, max_action=1.0, policy_freq=2,
+                  policy_noise_scale=1.0, table_seed=125, param_seed=1450, idx_seed=2450, noise_seed=3450),
     # PPO_with_tricks.learn (PPO_file/PPO_with_tricks.py:290-354), Gaussian actor, no tricks
     "ppo": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
                 gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
@@ -116,7 +121,7 @@ def ac_inputs(c, twin, gaussian=False):
     return out
 
 
-def maddpg_inputs(c):
+def maddpg_inputs(c, twin=False):
     dims = c["dims"]
     ids = list(dims.keys())
     total = sum(o + a for o, a in dims.values())
@@ -128,11 +133,15 @@ def maddpg_inputs(c):
     for j, aid in enumerate(ids):
         o, a = dims[aid]
         params[aid] = dict(actor=synth.mlp_params(c["param_seed"] + 10 * j, actor_layers(o, a)),
-                           critic=synth.mlp_params(c["param_seed"] + 10 * j + 1, critic_layers(total)))
+                           critic=synth.mlp_params(c["param_seed"] + 10 * j + 1, critic_layers(total, twin=twin)))
     # MADDPG_simple.learn re-samples once PER AGENT per learn call (MADDPG_simple.py:169)
     idx = [[synth.indices(c["idx_seed"] + 10 * k + j, c["n_table"], c["batch"]) for j in range(len(ids))]
            for k in range(c["n_learn"])]
-    return dict(tables=tabs, params=params, idx=idx, ids=ids)
+    out = dict(tables=tabs, params=params, idx=idx, ids=ids)
+    if "noise_seed" in c:      # MATD3: noise[k][i][j] = the draw for agent j's target action inside agent i's sample()
+        out["noise"] = [[[synth.normal(c["noise_seed"] + 100 * k + 10 * i + j, (c["batch"], dims[aj][1]))
+                          for j, aj in enumerate(ids)] for i in range(len(ids))] for k in range(c["n_learn"])]
+    return out
 
 
 def ppo_inputs(c):

@@ -299,6 +299,38 @@ def gen_maddpg(out):
             synth.pack_digest(a + "/" + net, t2n(getattr(ag, net).state_dict()), out)
 
 
+def gen_matd3(out):
+    c = cases.CASES["matd3"]
+    inp = cases.maddpg_inputs(c, twin=True)
+    ids = inp["ids"]
+    mod = import_reference("MADDPG_file", "MATD3_simple")
+    realize = dict(clip_double=True, policy_noise=True, twin_delay=True)
+    pol = mod.MATD3(copy.deepcopy(c["dims"]), True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, realize=realize)
+    for aid in ids:
+        ag = pol.agents[aid]
+        for net in ("actor", "critic"):
+            load(getattr(ag, net), inp["params"][aid][net])
+            load(getattr(ag, net + "_target"), inp["params"][aid][net])
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    flat_idx = [ix for per_call in inp["idx"] for ix in per_call]
+    flat_noise = [torch.from_numpy(nz) for per_call in inp["noise"] for per_agent in per_call for nz in per_agent]
+    with inject(np.random, "choice", feeder(flat_idx)), inject(torch, "randn_like", feeder(flat_noise)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"], c["policy_noise_scale"], c["policy_noise"], c["noise_clip"],
+                      c["max_action"], c["policy_freq"])
+    for a in ids:
+        ag = pol.agents[a]
+        out["loss_critic/" + a] = np.array(recs[a]["update_critic"], dtype=np.float32)
+        out["loss_actor/" + a] = np.array(recs[a]["update_actor"], dtype=np.float32)
+        for net in ("actor", "critic", "actor_target", "critic_target"):
+            synth.pack_digest(a + "/" + net, t2n(getattr(ag, net).state_dict()), out)
+
+
 # ----------------------------------------------------------------------------- PPO
 class _NpProxy(types.ModuleType):
     """`np` as seen by PPO_with_tricks.py only: `np.zeros(h, dtype=torch.float32)` at
@@ -537,6 +569,30 @@ def gen_traj_maddpg(out):
         synth.pack_digest(a + "/critic_target", t2n(pol.agents[a].critic_target.state_dict()), out, full_limit=0)
 
 
+def gen_traj_matd3(out):
+    """Seeded class trajectory of MATD3_simple: default init, np.random.choice per agent, torch.randn_like per (i, j)."""
+    dims = {"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]}
+    ids = list(dims)
+    mod = import_reference("MADDPG_file", "MATD3_simple")
+    np.random.seed(0); torch.manual_seed(0)
+    pol = mod.MATD3(copy.deepcopy(dims), True, 1e-3, 1e-3, 512, CPU, realize=dict(clip_double=True, policy_noise=True, twin_delay=True))
+    tabs = {a: synth.transitions(125 + 100 * j, 200, dims[a][0], dims[a][1]) for j, a in enumerate(ids)}
+    for i in range(200):
+        pol.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
+                {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
+                {a: bool(tabs[a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    for k in range(4):
+        acts = pol.select_action({a: tabs[a]["obs"][k] for a in ids})
+        pol.learn(64, 0.95, 0.01, 1.0, 0.2, 0.5, 1.0, 2)
+    for a in ids:
+        out["actions/" + a] = acts[a]
+        out["loss_critic/" + a] = np.array(recs[a]["update_critic"], dtype=np.float32)
+        out["loss_actor/" + a] = np.array(recs[a]["update_actor"], dtype=np.float32)
+        synth.pack_digest(a + "/actor", t2n(pol.agents[a].actor.state_dict()), out, full_limit=0)
+        synth.pack_digest(a + "/critic_target", t2n(pol.agents[a].critic_target.state_dict()), out, full_limit=0)
+
+
 def gen_traj_ppo(out):
     O, A, T = 8, 2, 128
     mod = import_reference("PPO_file", "PPO_with_tricks")
@@ -590,13 +646,14 @@ def main():
     gens = {
         "buffer": gen_buffer, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
-        "sac": gen_sac, "maddpg": gen_maddpg,
+        "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
         "ppo_discrete": gen_ppo_discrete,
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),
-        "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_ppo": gen_traj_ppo,
+        "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_matd3": gen_traj_matd3,
+        "traj_ppo": gen_traj_ppo,
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]

@@ -190,6 +190,42 @@ def test_maddpg_class_trajectory(tmp_path):
     np.testing.assert_array_equal(r.cpu().numpy()[:, 0], tabs["agent_2"]["rew"][:10])
 
 
+def test_matd3_class_trajectory(tmp_path):
+    """MATD3_simple.py's class on the seeded trajectory: default init, per-agent index draws, randn per (i, j)."""
+    from freerl_amd.MATD3 import MATD3
+    fx = gold("traj_matd3")
+    dims = {"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]}
+    ids = list(dims)
+    np.random.seed(0); torch.manual_seed(0)
+    pol = MATD3(dict(dims), True, 1e-3, 1e-3, 512, CUDA, realize=dict(clip_double=True, policy_noise=True, twin_delay=True))
+    pol.track_loss = True
+    tabs = {a: synth.transitions(125 + 100 * j, 200, dims[a][0], dims[a][1]) for j, a in enumerate(ids)}
+    for i in range(200):
+        pol.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
+                {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
+                {a: bool(tabs[a]["done"][i]) for a in ids})
+    cl = {a: [] for a in ids}
+    al = {a: [] for a in ids}
+    for k in range(4):
+        acts = pol.select_action({a: tabs[a]["obs"][k] for a in ids})
+        pol.learn(64, 0.95, 0.01, 1.0, 0.2, 0.5, 1.0, 2)
+        for a in ids:
+            cl[a].append(pol.last_losses[a][0])
+            if pol.total_it % 2 == 0:
+                al[a].append(pol.last_losses[a][1])
+    for a in ids:
+        np.testing.assert_allclose(acts[a], fx["actions/" + a], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(cl[a], fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(al[a], fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=2e-6)
+        synth.check_digest(a + "/actor", sd2np(pol.agents[a].actor.state_dict()), fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic_target", sd2np(pol.agents[a].critic_target.state_dict()), fx, P_RTOL, P_ATOL)
+    pol.save(str(tmp_path))
+    assert list(torch.load(os.path.join(str(tmp_path), "MADDPG.pth")).keys()) == ids
+    with pytest.raises(TypeError):
+        MATD3(dict(dims), True, 1e-3, 1e-3, 512, CUDA, realize=dict(clip_double=False, policy_noise=True, twin_delay=True)).learn(
+            64, 0.95, 0.01, 1.0, 0.2, 0.5, 1.0, 2)
+
+
 def test_ppo_class_trajectory(tmp_path):
     from freerl_amd.PPO import PPO
     fx = gold("traj_ppo")

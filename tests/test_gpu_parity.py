@@ -49,10 +49,10 @@ def note(key, val):
     REPORT[key] = float(val)
 
 
-def assert_params_close(got, want, label):
+def assert_params_close(got, want, label, atol=P_ATOL):
     worst = 0.0
     for k in want:
-        np.testing.assert_allclose(got[k], want[k], rtol=P_RTOL, atol=P_ATOL, err_msg="%s %s" % (label, k))
+        np.testing.assert_allclose(got[k], want[k], rtol=P_RTOL, atol=atol, err_msg="%s %s" % (label, k))
         worst = max(worst, rel_err(got[k], want[k]))
     note("param_relerr/" + label, worst)
 
@@ -325,6 +325,60 @@ def test_maddpg_learn(N):
         for kind, oa, oc, tag in ((N.PARAM_ONLINE, orc.actor, orc.critic, ""), (N.PARAM_TARGET, orc.actor_t, orc.critic_t, "_t")):
             assert_params_close(unflat_params(e.get_params(2 * j, kind), oa[a], AC_NAMES), oa[a], "maddpg/%s/actor%s" % (a, tag))
             assert_params_close(unflat_params(e.get_params(2 * j + 1, kind), oc[a], AC_NAMES), oc[a], "maddpg/%s/critic%s" % (a, tag))
+    e.close()
+
+
+def test_matd3_learn(N):
+    """MATD3_simple.learn = FRL_ALGO_MADDPG + twin_critic + policy noise on every agent's target action + do_actor."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    c = cases.CASES["matd3"]
+    inp = cases.maddpg_inputs(c, twin=True)
+    fx = gold("matd3")
+    ids = inp["ids"]
+    n = len(ids)
+    od = [c["dims"][a][0] for a in ids]
+    ad = [c["dims"][a][1] for a in ids]
+    am = max(ad)
+    e = Engine(N.ALGO_MADDPG, od, ad, c["capacity"], batch_max=c["batch"], twin_critic=True)
+    for j, a in enumerate(ids):
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(2 * j, flat_params(inp["params"][a]["actor"], AC_NAMES), kind)
+            e.set_params(2 * j + 1, flat_params(inp["params"][a]["critic"], TWIN_NAMES), kind)
+    e.add_batch(records([inp["tables"][a] for a in ids]))
+    orc = algos.MATD3(inp["params"], c["dims"], c["actor_lr"], c["critic_lr"], c["capacity"])
+    for i in range(c["n_table"]):
+        orc.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    cl = {a: [] for a in ids}
+    al = {a: [] for a in ids}
+    for k in range(c["n_learn"]):
+        nz = np.zeros((1, n, max(2, n), c["batch"], am), np.float32)
+        for i in range(n):
+            for j in range(n):
+                nz[0, i, j, :, :ad[j]] = inp["noise"][k][i][j]
+        do_actor = ((k + 1) % c["policy_freq"] == 0)
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     use_policy_noise=True, policy_noise=c["policy_noise"], noise_clip=c["noise_clip"],
+                     max_action=c["max_action"], policy_noise_scale=c["policy_noise_scale"], do_actor=do_actor,
+                     idx=np.stack(inp["idx"][k])[None], noise=nz, want_stats=True)
+        for j, a in enumerate(ids):
+            cl[a].append(st[0, j, N.STAT_CRITIC_LOSS])
+            if do_actor:
+                al[a].append(st[0, j, N.STAT_ACTOR_LOSS])
+        orc.learn_with(inp["idx"][k], inp["noise"][k], c["gamma"], c["tau"], c["policy_noise_scale"], c["policy_noise"],
+                       c["noise_clip"], c["max_action"], c["policy_freq"])
+    for j, a in enumerate(ids):
+        np.testing.assert_allclose(cl[a], fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(al[a], fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=1e-6)
+        note("loss_relerr/matd3_critic_" + a, rel_err(cl[a], fx["loss_critic/" + a], 1e-6))
+        for kind, oa, oc, tag in ((N.PARAM_ONLINE, orc.actor, orc.critic, ""), (N.PARAM_TARGET, orc.actor_t, orc.critic_t, "_t")):
+            assert_params_close(unflat_params(e.get_params(2 * j, kind), oa[a], AC_NAMES), oa[a], "matd3/%s/actor%s" % (a, tag))
+            # 8 Adam steps (4 calls x 2 heads' gradients) on elements whose gradient is ~0: Adam's update is ~lr whatever
+            # the gradient's size, so a rounding-level gradient difference moves such an element by up to lr/100
+            assert_params_close(unflat_params(e.get_params(2 * j + 1, kind), oc[a], TWIN_NAMES), oc[a], "matd3/%s/critic%s" % (a, tag),
+                                atol=2e-5)
     e.close()
 
 

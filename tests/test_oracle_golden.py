@@ -155,6 +155,31 @@ def test_maddpg_learn():
         synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
 
 
+def test_matd3_learn():
+    """MATD3_simple.learn: twin critics, per-target-agent policy noise, delayed actor + target updates."""
+    c = cases.CASES["matd3"]
+    inp = cases.maddpg_inputs(c, twin=True)
+    fx = gold("matd3")
+    ids = inp["ids"]
+    pol = algos.MATD3(inp["params"], c["dims"], c["actor_lr"], c["critic_lr"], c["capacity"])
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], inp["noise"][k], c["gamma"], c["tau"], c["policy_noise_scale"], c["policy_noise"],
+                       c["noise_clip"], c["max_action"], c["policy_freq"])
+    for a in ids:
+        assert len(pol.actor_losses[a]) == c["n_learn"] // c["policy_freq"]
+        np.testing.assert_allclose(np.array(pol.critic_losses[a]), fx["loss_critic/" + a], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(np.array(pol.actor_losses[a]), fx["loss_actor/" + a], rtol=LOSS_RTOL, atol=1e-7)
+        synth.check_digest(a + "/actor", pol.actor[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic", pol.critic[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/actor_target", pol.actor_t[a], fx, P_RTOL, P_ATOL)
+        synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
+
+
 @pytest.mark.parametrize("name", ["ppo", "ppo_tricks"])
 def test_ppo_learn(name):
     c = cases.CASES[name]
