@@ -50,6 +50,10 @@ class PPO:
         obs_dim, action_dim = dim_info
         if beta:
             raise NotImplementedError("Actor_Beta (PPO_with_tricks.py:123-156) is not ported yet")
+        # `trick=None` is how PPO_file/PPO.py's class is built (PPO.py:156, it has no tricks and PPO_with_tricks.py
+        # would fail on trick[...]): that file trains with ONE cautious AdamW (c_adamw.py) over actor + critic at
+        # lr = actor_lr, eps 1e-6 (PPO.py:121,145-152)
+        self._cautious = trick is None
         self.trick = dict(_TRICK_DEFAULT, **(trick or {}))
         self.actor_dist = {"Beta": False}
         hip_id, self.device = resolve_device(device)
@@ -100,7 +104,8 @@ class PPO:
         out = self._e.ppo_learn(self.horizon, minibatch_size, K_epochs, gamma=gamma, lmbda=lmbda, clip=clip_param,
                                 ent_coef=entropy_coefficient, actor_lr=self.agent.actor_optimizer.lr,
                                 critic_lr=self.agent.critic_optimizer.lr,
-                                adam_eps=self.agent.actor_optimizer.param_groups[0]["eps"],
+                                adam_eps=1e-6 if self._cautious else self.agent.actor_optimizer.param_groups[0]["eps"],
+                                optimizer=1 if self._cautious else 0,
                                 adv_norm=self.trick["adv_norm"], perms=perms,
                                 want_trace=getattr(self, "track_loss", False))
         self.last_trace = out.get("trace")

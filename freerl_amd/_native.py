@@ -62,7 +62,7 @@ class PpoArgs(C.Structure):
     _fields_ = [("horizon", C.c_int), ("minibatch", C.c_int), ("k_epochs", C.c_int), ("adv_norm", C.c_int),
                 ("gamma", C.c_float), ("lmbda", C.c_float), ("clip", C.c_float), ("ent_coef", C.c_float),
                 ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("adam_eps", C.c_float), ("clip_norm", C.c_float),
-                ("perms", C.POINTER(C.c_int64)), ("loss_trace_out", C.POINTER(C.c_float)),
+                ("optimizer", C.c_int), ("perms", C.POINTER(C.c_int64)), ("loss_trace_out", C.POINTER(C.c_float)),
                 ("adv_out", C.POINTER(C.c_float)), ("vtarget_out", C.POINTER(C.c_float))]
 
 

@@ -497,6 +497,53 @@ __device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_c
     return total;
 }
 
+// PPO.py's optimiser (PPO_file/c_adamw.py:80-127, "cautious" AdamW, weight_decay 0) after clip_grad_norm_ on this
+// net: m = m*b1 + (1-b1) g; v = v*b2 + (1-b2) g g; denom = sqrt(v) + eps (no bias correction in denom);
+// step = lr*sqrt(1-b2^t)/(1-b1^t); mask = (m*g > 0) / max(mean(m*g > 0), 1e-3) with the mean over ONE PARAMETER TENSOR
+// (a weight matrix, a bias vector, log_std); p -= step * (m*mask)/denom.
+__device__ __forceinline__ float cadamw_net(const NetDesc& N, g_f theta, g_f m, g_f v, g_cf g, float lr, float eps, float b1,
+                                            float b2, float clip_norm, int t_new, lds_f red) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < N.size; i += kWG) {
+        const float x = g[i];
+        ss += x * x;
+    }
+    const float total = sqrtf(block_sum(ss, red));
+    float coef = 1.f;
+    if (clip_norm > 0.f) coef = fminf(clip_norm / (total + 1e-6f), 1.f);
+    const double bc1 = 1.0 - powi_d((double)b1, t_new), bc2 = 1.0 - powi_d((double)b2, t_new);
+    const float step = (float)((double)lr * sqrt(bc2) / bc1);
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    const int n_tensors = 2 * N.n_layers + (N.extra_n > 0 ? 1 : 0);
+    for (int ti = 0; ti < n_tensors; ++ti) {
+        int off, span, numel;
+        if (ti < 2 * N.n_layers) {
+            const LayerDesc& L = N.L[ti >> 1];
+            if (ti & 1) { off = L.b_off; span = L.n_pad; numel = L.n; }
+            else { off = L.w_off; span = L.n_pad * L.k_pad; numel = L.n * L.k; }
+        } else {
+            off = N.extra_off; span = N.extra_n; numel = N.extra_n;
+        }
+        float cnt = 0.f;
+        for (int i = threadIdx.x; i < span; i += kWG) {
+            const float gi = g[off + i] * coef;
+            const float mi = m[off + i] * b1 + w1 * gi;
+            const float vi = v[off + i] * b2 + (w2 * gi) * gi;
+            m[off + i] = mi;
+            v[off + i] = vi;
+            cnt += (mi * gi > 0.f) ? 1.f : 0.f;          // padding: m = g = 0, never counted
+        }
+        const float mean = block_sum(cnt, red) / (float)numel;
+        const float scale = 1.f / fmaxf(mean, 1e-3f);
+        for (int i = threadIdx.x; i < span; i += kWG) {  // m, v were written by this same thread
+            const float gi = g[off + i] * coef, mi = m[off + i], vi = v[off + i];
+            const float mask = (mi * gi > 0.f) ? scale : 0.f;
+            theta[off + i] = theta[off + i] - step * ((mi * mask) / (sqrtf(vi) + eps));
+        }
+    }
+    return total;
+}
+
 __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta, float tau) {
     const float tk = 1.f - tau;
     for (int i = threadIdx.x; i < size; i += kWG) target[i] = target[i] * tk + theta[i] * tau;

@@ -13,6 +13,7 @@ struct PpoArgs {
     int horizon, minibatch, k_epochs, adv_norm;
     float gamma, lmbda, clip, ent_coef;
     float actor_lr, critic_lr, adam_eps, beta1, beta2, clip_norm;
+    int optimizer;    // 0 torch Adam per net, 1 PPO.py's cautious AdamW (lr = actor_lr for both nets)
     // device scratch, per learner blocks of `horizon` floats
     float* td;        // [P][T] td_delta, then (after GAE) unused
     float* vs;        // [P][T] V(s)
@@ -289,8 +290,11 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             const float aloss = block_sum(lossp, S.red) * invm - (discrete ? 0.f : a.ent_coef * ent_sum);
             __syncthreads();
             ++tA;
-            adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
-                     a.clip_norm, tA, 0.f, S.red);
+            if (a.optimizer == 1)
+                cadamw_net(NA, thA, as_global(D.m + offA), as_global(D.v + offA), gA, a.actor_lr, a.adam_eps, a.beta1, a.beta2, a.clip_norm, tA, S.red);
+            else
+                adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+                         a.clip_norm, tA, 0.f, S.red);
             __syncthreads();
             // ---------------- critic: mse(v_target[idx], V(obs[idx])) (:349-351)
             float closs_p = 0.f;
@@ -317,8 +321,11 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             const float closs = block_sum(closs_p, S.red) * invm;
             __syncthreads();
             ++tC;
-            adam_net(NC.size, thC, as_global(D.m + offC), as_global(D.v + offC), gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
-                     a.clip_norm, tC, 0.f, S.red);
+            if (a.optimizer == 1)      // one AdamW over both nets: the actor's learning rate (PPO.py:121)
+                cadamw_net(NC, thC, as_global(D.m + offC), as_global(D.v + offC), gC, a.actor_lr, a.adam_eps, a.beta1, a.beta2, a.clip_norm, tC, S.red);
+            else
+                adam_net(NC.size, thC, as_global(D.m + offC), as_global(D.v + offC), gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
+                         a.clip_norm, tC, 0.f, S.red);
             __syncthreads();
             if (threadIdx.x == 0) {
                 const int j = k * n_mb + s / mb;

@@ -209,11 +209,13 @@ class Engine:
         return fl.value, by.value
 
     def ppo_learn(self, horizon, minibatch, k_epochs, *, gamma, lmbda, clip, ent_coef, actor_lr, critic_lr,
-                  adam_eps=1e-8, clip_norm=0.5, adv_norm=False, perms=None, want_trace=False, want_adv=False):
+                  adam_eps=1e-8, clip_norm=0.5, adv_norm=False, perms=None, want_trace=False, want_adv=False,
+                  optimizer=0):
         a = N.PpoArgs()
         a.horizon, a.minibatch, a.k_epochs, a.adv_norm = int(horizon), int(minibatch), int(k_epochs), int(bool(adv_norm))
         a.gamma, a.lmbda, a.clip, a.ent_coef = gamma, lmbda, clip, ent_coef
         a.actor_lr, a.critic_lr, a.adam_eps, a.clip_norm = actor_lr, critic_lr, adam_eps, clip_norm
+        a.optimizer = int(optimizer)
         keep = []
         if perms is not None:
             pm = np.ascontiguousarray(perms, dtype=np.int64).reshape(self.P, int(k_epochs), int(horizon))

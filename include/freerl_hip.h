@@ -204,6 +204,10 @@ typedef struct frl_ppo_args {
     float actor_lr, critic_lr; /* per call so that PPO.lr_decay (:357-363) is the caller's arithmetic */
     float adam_eps;            /* 1e-5 with trick['adam_eps'] (:191-196) */
     float clip_norm;           /* 0.5 */
+    int optimizer;             /* 0: torch.optim.Adam per net (PPO_with_tricks.py:191-196);
+                                  1: PPO.py's combined cautious AdamW over actor + critic parameters (PPO.py:121,145-152,
+                                     c_adamw.py:80-127): lr = actor_lr for both nets, eps = adam_eps (1e-6 there), mask =
+                                     (exp_avg*grad > 0) / max(mean, 1e-3) PER PARAMETER TENSOR, no bias correction in denom */
     const int64_t* perms;      /* host [P][k_epochs][horizon] np.random.permutation draws (:320), or NULL */
     float* loss_trace_out;     /* host [P][k_epochs*n_mb][2] (actor, critic) losses or NULL */
     float* adv_out;            /* host [P][horizon] raw GAE advantages or NULL */

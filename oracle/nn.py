@@ -74,6 +74,35 @@ class MLP:
         return (d if need_dx else None), grads
 
 
+class CautiousAdamW:
+    """PPO_file/c_adamw.py:80-127 (the AdamW PPO.py:121 builds over actor + critic parameters): eps 1e-6, weight_decay 0,
+    bias correction folded into the step size, and the "cautious" mask (exp_avg*grad > 0) rescaled by its per-tensor mean."""
+
+    def __init__(self, params, lr, eps=1e-6, betas=(0.9, 0.999)):
+        self.lr, self.eps = float(lr), float(eps)
+        self.b1, self.b2 = betas
+        self.t = 0
+        self.m = {k: np.zeros_like(v) for k, v in params.items()}
+        self.v = {k: np.zeros_like(v) for k, v in params.items()}
+
+    def step(self, params, grads):
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        step_size = self.lr * math.sqrt(bc2) / bc1
+        for k in params:
+            g = grads[k]
+            m, v = self.m[k], self.v[k]
+            m *= F32(self.b1)
+            m += F32(1.0 - self.b1) * g
+            v *= F32(self.b2)
+            v += F32(1.0 - self.b2) * g * g
+            denom = np.sqrt(v) + F32(self.eps)
+            mask = (m * g > 0).astype(F32)
+            mask /= max(F32(mask.mean(dtype=F32)), F32(1e-3))
+            params[k] += F32(-step_size) * ((m * mask) / denom)
+
+
 class Adam:
     """torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay, no amsgrad), the
     single-tensor CPU implementation's operation order:

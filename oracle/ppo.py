@@ -36,7 +36,10 @@ F32_EPS = float(np.finfo(np.float32).eps)
 
 
 class PPO:
-    def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False):
+    def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False,
+                 optimizer="adam"):
+        """optimizer="c_adamw": PPO_file/PPO.py:109-152,213-286 — the same clipped-surrogate learn with no tricks and ONE
+        cautious AdamW (lr = actor_lr) over actor + critic parameters, each net's gradients clipped to 0.5 on its own."""
         self.trick = trick
         self.discrete = discrete
         act = "tanh" if trick.get("tanh") else "relu"
@@ -48,8 +51,12 @@ class PPO:
         self.actor = nn.copy_params(actor_p)
         self.critic = nn.copy_params(critic_p)
         eps = 1e-5 if trick.get("adam_eps") else 1e-8                               # :191-196
-        self.actor_opt = Adam(self.actor, actor_lr, eps=eps)
-        self.critic_opt = Adam(self.critic, critic_lr, eps=eps)
+        if optimizer == "c_adamw":        # per-tensor state: one optimiser over both nets == one per net with the same lr
+            self.actor_opt = nn.CautiousAdamW(self.actor, actor_lr)
+            self.critic_opt = nn.CautiousAdamW(self.critic, actor_lr)
+        else:
+            self.actor_opt = Adam(self.actor, actor_lr, eps=eps)
+            self.critic_opt = Adam(self.critic, critic_lr, eps=eps)
         self.horizon = int(horizon)
         self.buffer = BufferForPPO(horizon, obs_dim, 1 if discrete else act_dim)
         self.actor_losses, self.critic_losses = [], []

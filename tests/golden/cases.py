@@ -69,6 +69,13 @@ CASES = {
                            orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
                            Batch_ObsNorm=False),
                 table_seed=126, param_seed=1500, perm_seed=2500),
+    # PPO.py (PPO_file/PPO.py:213-286): no tricks, ONE cautious AdamW (c_adamw.py) over actor + critic, lr = actor_lr
+    "ppo_py": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
+                   gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=3e-3,
+                   trick=dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_scaling=False,
+                              orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
+                              Batch_ObsNorm=False),
+                   table_seed=129, param_seed=1530, perm_seed=2530),
     # PPO with adv_norm + tanh hidden activations + Adam eps 1e-5
     "ppo_tricks": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
                        gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,

@@ -399,6 +399,42 @@ def gen_ppo(name, out):
     out["buffer_size_after"] = np.int64(len(pol.buffer))
 
 
+def gen_ppo_py(out):
+    """PPO_file/PPO.py: update_ac_ (one cautious AdamW over actor + critic).  PPO.py's GAE array is float64 but the
+    recurrence runs on float32 scalars under NumPy 2, like PPO_with_tricks'."""
+    c = cases.CASES["ppo_py"]
+    inp = cases.ppo_inputs(c)
+    import warnings
+    warnings.simplefilter("ignore", FutureWarning)          # c_adamw's deprecation notice
+    mod = import_reference("PPO_file", "PPO")
+    pol = mod.PPO([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["horizon"], CPU)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    losses = {"actor": [], "critic": []}
+    orig = pol.agent.update_ac_
+
+    def rec(la, lc):
+        losses["actor"].append(float(la.detach())); losses["critic"].append(float(lc.detach()))
+        return orig(la, lc)
+    pol.agent.update_ac_ = rec
+    out["evaluate_action"] = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    with inject(np.random, "permutation", feeder(inp["perms"])):
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    out["loss_actor"] = np.array(losses["actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(losses["critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+    st = pol.agent.ac_optimizer.state
+    out["opt_step"] = np.int64(st[pol.agent.actor.l1.weight]["step"])
+    synth.pack_digest("opt_exp_avg", {"critic.l2.weight": st[pol.agent.critic.l2.weight]["exp_avg"].numpy(),
+                                      "actor.log_std": st[pol.agent.actor.log_std]["exp_avg"].numpy()}, out, full_limit=0)
+    out["buffer_size_after"] = np.int64(len(pol.buffer))
+
+
 def gen_ppo_discrete(out):
     c = cases.CASES["ppo_discrete"]
     inp = cases.ppo_discrete_inputs(c)
@@ -648,7 +684,7 @@ def main():
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
-        "ppo_discrete": gen_ppo_discrete,
+        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py,
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),

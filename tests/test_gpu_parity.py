@@ -429,6 +429,47 @@ def test_ppo_learn(N, name):
     e.close()
 
 
+def test_ppo_py_cautious_adamw(N):
+    """PPO_file/PPO.py: frl_ppo_learn with optimizer = 1 (c_adamw.py's cautious AdamW, lr = actor_lr for both nets)."""
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    c = cases.CASES["ppo_py"]
+    inp = cases.ppo_inputs(c)
+    fx = gold("ppo_py")
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    an = ["l1", "l2", "mean_layer"]
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=c["minibatch"], extra_cols=A + 1)
+    e.set_params(0, flat_params(inp["params"]["actor"], an, "log_std"))
+    e.set_params(1, flat_params(inp["params"]["critic"], AC_NAMES))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, c["actor_lr"], c["critic_lr"], T, c["trick"],
+                   optimizer="c_adamw")
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    out = e.ppo_learn(T, c["minibatch"], c["k_epochs"], gamma=c["gamma"], lmbda=c["lmbda"], clip=c["clip"], ent_coef=c["ent"],
+                      actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], adam_eps=1e-6, optimizer=1,
+                      perms=np.stack(inp["perms"])[None], want_trace=True)
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(out["trace"][0, :, 0], fx["loss_actor"], rtol=5e-4, atol=5e-6)
+    np.testing.assert_allclose(out["trace"][0, :, 1], fx["loss_critic"], rtol=5e-4)
+    note("loss_relerr/ppo_py_critic", rel_err(out["trace"][0, :, 1], fx["loss_critic"], 1e-6))
+    ga = unflat_params(e.get_params(0), orc.actor, an, "log_std")
+    gc = unflat_params(e.get_params(1), orc.critic, AC_NAMES)
+    # the cautious mask flips single elements on rounding-level differences of exp_avg*grad (each flip moves that element
+    # by ~lr): per-element agreement for all but a handful, aggregate agreement through the digests
+    for got, want in ((ga, orc.actor), (gc, orc.critic)):
+        for k in want:
+            bad = np.abs(got[k] - want[k]) > (2e-5 + 2e-3 * np.abs(want[k]))
+            assert bad.mean() < 2e-3, (k, int(bad.sum()), bad.size)
+    synth.check_digest("actor", ga, fx, 5e-3, 5e-4, "hip-vs-reference")
+    synth.check_digest("critic", gc, fx, 5e-3, 5e-4, "hip-vs-reference")
+    assert e.opt_step(0) == e.opt_step(1) == int(fx["opt_step"])
+    e.close()
+
+
 # --------------------------------------------------------------- population / device RNG / scale
 def test_population_learners_are_independent(N):
     """P = 3 learners with identical inputs but different sample indices each equal their own oracle."""

@@ -155,6 +155,31 @@ def test_maddpg_learn():
         synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
 
 
+def test_ppo_py_cautious_adamw():
+    """PPO_file/PPO.py: the no-trick learn with ONE cautious AdamW (c_adamw.py) over actor + critic."""
+    c = cases.CASES["ppo_py"]
+    inp = cases.ppo_inputs(c)
+    fx = gold("ppo_py")
+    pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                  c["actor_lr"], c["critic_lr"], c["horizon"], c["trick"], optimizer="c_adamw")
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=2e-4)
+    assert pol.actor_opt.t == int(fx["opt_step"]) == c["k_epochs"] * (c["horizon"] // c["minibatch"])
+    # the mask makes single elements flip on rounding-level differences of exp_avg*grad: compare in aggregate
+    synth.check_digest("actor", pol.actor, fx, 5e-3, 5e-4)
+    synth.check_digest("critic", pol.critic, fx, 5e-3, 5e-4)
+    synth.check_digest("opt_exp_avg", {"critic.l2.weight": pol.critic_opt.m["l2.weight"], "actor.log_std": pol.actor_opt.m["log_std"]},
+                       fx, 2e-3, 1e-6)
+    assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
+
+
 def test_matd3_learn():
     """MATD3_simple.learn: twin critics, per-target-agent policy noise, delayed actor + target updates."""
     c = cases.CASES["matd3"]
