@@ -5,9 +5,9 @@
 The whole `learn()` (value pass, GAE scan, v_target, advantage normalisation, K_epochs x
 minibatch actor/critic steps) runs in three GPU launches.  Reference defect handled: the
 committed `learn` raises TypeError at :302 (`np.zeros(..., dtype=torch.float32)`); the evident
-intent (float32 advantages) is what runs here.  Gaussian (`Actor`) and Categorical
-(`Actor_discrete`) policies are ported; `Actor_Beta` is not.  ObsNorm / reward tricks that live in
-the caller's loop use `freerl_amd.normalization`.
+intent (float32 advantages) is what runs here.  Gaussian (`Actor`), Categorical (`Actor_discrete`) and
+Beta (`Actor_Beta`) policies are ported.  ObsNorm / reward tricks that live in the caller's loop use
+`freerl_amd.normalization`.  `trick=None` builds PPO_file/PPO.py's class (one cautious AdamW).
 """
 import os
 
@@ -22,8 +22,46 @@ _TRICK_DEFAULT = dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_s
                       adam_eps=False, lr_decay=False, tanh=False, Batch_ObsNorm=False)
 
 
+class BetaActorNet(DeviceNet):
+    """`agent.actor` of Actor_Beta (PPO_with_tricks.py:120-151): the reference keeps `alpha_layer` and `beta_layer`
+    as two nn.Linear on the shared trunk; the engine holds them as one 2A-wide head [alpha_layer ; beta_layer]."""
+
+    def __init__(self, engine, hidden, obs_dim, action_dim):
+        super().__init__(engine, 0, [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("head", 2 * action_dim, hidden)],
+                         act_mode=N.ACT_RAW)
+        self._A, self._H = action_dim, hidden
+
+    def keys(self):
+        return ["l1.weight", "l1.bias", "l2.weight", "l2.bias", "alpha_layer.weight", "alpha_layer.bias",
+                "beta_layer.weight", "beta_layer.bias"]
+
+    def _split(self, flat):
+        parts = super()._split(flat)
+        A = self._A
+        w, b = parts.pop("head.weight"), parts.pop("head.bias")
+        parts.update({"alpha_layer.weight": w[:A], "beta_layer.weight": w[A:], "alpha_layer.bias": b[:A], "beta_layer.bias": b[A:]})
+        return parts
+
+    def load_state_dict(self, sd, strict=True):
+        if strict and set(sd.keys()) != set(self.keys()):
+            raise RuntimeError("Error(s) in loading state_dict: expected keys %s, got %s" % (self.keys(), list(sd.keys())))
+        t = lambda k: np.asarray(torch.as_tensor(sd[k]).detach().cpu().numpy(), dtype=np.float32).reshape(-1)
+        flat = [t(k) for k in ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "alpha_layer.weight", "beta_layer.weight",
+                               "alpha_layer.bias", "beta_layer.bias")]
+        self._e.set_params(self._net, np.concatenate(flat), self._kind, self._learner)
+
+    def alpha_beta(self, obs):
+        """-> (alpha, beta) torch tensors [rows, A] = softplus(head) + 1 (:140-143)."""
+        z = self(obs)
+        sp = torch.nn.functional.softplus(z) + 1.0
+        return sp[:, :self._A], sp[:, self._A:]
+
+
 class Agent:
-    def __init__(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden, is_continue=True):
+    def __init__(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden, is_continue=True, beta=False):
+        if beta:
+            self._init_beta(engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden)
+            return
         head = "mean_layer" if is_continue else "l3"
         al = [("l1", hidden, obs_dim), ("l2", hidden, hidden), (head, action_dim, hidden)]
         cl = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("l3", 1, hidden)]
@@ -44,25 +82,45 @@ class Agent:
         self.critic_optimizer = OptimizerView(engine, 1, critic_lr, eps=eps)
 
 
+    def _init_beta(self, engine, obs_dim, action_dim, actor_lr, critic_lr, trick, hidden):
+        # torch RNG order: l1, l2, alpha_layer, beta_layer default draws, then (orthogonal) the same four in order (:123-133)
+        al = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("alpha_layer", action_dim, hidden), ("beta_layer", action_dim, hidden)]
+        cl = [("l1", hidden, obs_dim), ("l2", hidden, hidden), ("l3", 1, hidden)]
+        ortho = bool(trick["orthogonal_init"])
+        fa = init_layers(al, orthogonal=[1.0, 1.0, 0.01, 0.01] if ortho else None)
+        fc = init_layers(cl, orthogonal=[1.0, 1.0, 1.0] if ortho else None)
+        self.actor = BetaActorNet(engine, hidden, obs_dim, action_dim)
+        # init_layers returns [l1.w l1.b l2.w l2.b alpha.w alpha.b beta.w beta.b]; the engine wants [.. alpha.w beta.w alpha.b beta.b]
+        o = hidden * obs_dim + hidden + hidden * hidden + hidden
+        hw, A = hidden * action_dim, action_dim
+        aw, ab, bw, bb = fa[o:o + hw], fa[o + hw:o + hw + A], fa[o + hw + A:o + 2 * hw + A], fa[o + 2 * hw + A:]
+        engine.set_params(0, np.concatenate([fa[:o], aw, bw, ab, bb]))
+        engine.set_params(1, fc)
+        eps = 1e-5 if trick["adam_eps"] else 1e-8
+        self.critic = DeviceNet(engine, 1, cl)
+        self.actor_optimizer = OptimizerView(engine, 0, actor_lr, eps=eps)
+        self.critic_optimizer = OptimizerView(engine, 1, critic_lr, eps=eps)
+
+
 class PPO:
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, horizon, device, trick=None, beta=False, *,
                  rng="host", hidden=128, minibatch_max=256, seed=0):
         obs_dim, action_dim = dim_info
-        if beta:
-            raise NotImplementedError("Actor_Beta (PPO_with_tricks.py:123-156) is not ported yet")
+        if beta and not is_continue:
+            raise ValueError("Actor_Beta is a continuous-action policy (PPO_with_tricks.py:182-186)")
         # `trick=None` is how PPO_file/PPO.py's class is built (PPO.py:156, it has no tricks and PPO_with_tricks.py
         # would fail on trick[...]): that file trains with ONE cautious AdamW (c_adamw.py) over actor + critic at
         # lr = actor_lr, eps 1e-6 (PPO.py:121,145-152)
         self._cautious = trick is None
         self.trick = dict(_TRICK_DEFAULT, **(trick or {}))
-        self.actor_dist = {"Beta": False}
+        self.actor_dist = {"Beta": bool(beta)}
         hip_id, self.device = resolve_device(device)
         self.horizon = int(horizon)
         stored = action_dim if is_continue else 1            # Buffer act_dim (Buffer.py:3-9)
         self._e = Engine(N.ALGO_PPO, obs_dim, action_dim, max(self.horizon, 2), hidden=hidden, batch_max=minibatch_max,
                          extra_cols=stored + 1, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
-                         discrete=not is_continue, device_id=hip_id, seed=seed)
-        self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue)
+                         discrete=not is_continue, device_id=hip_id, seed=seed, actor_dist=1 if beta else 0)
+        self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue, beta=bool(beta))
         self.buffer = Buffer_for_PPO(self.horizon, obs_dim, stored, self.device, _engine=self._e)
         if self.trick["Batch_ObsNorm"]:                                   # PPO_with_tricks.py:225-226
             self._e.obsnorm_enable(True)
@@ -82,6 +140,13 @@ class PPO:
             a, lp = self._e.act(0, N.ACT_CAT_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=q,
                                 want_logp=True)
             return np.int64(a[0, 0, 0]), np.float32(lp[0, 0, 0])
+        if self.actor_dist["Beta"]:
+            # alpha, beta come from the GPU forward; the Beta variate itself is torch's own sampler on the host (its gamma
+            # rejection sampler consumes the generator in C++ and cannot be fed injected draws): one [1, A] draw per env step
+            al, be = self.agent.actor.alpha_beta(np.asarray(obs, dtype=np.float32).reshape(1, -1))
+            dist = torch.distributions.Beta(al, be)
+            act = dist.sample()
+            return act.numpy().squeeze(0), dist.log_prob(act).numpy().squeeze(0)      # action in [0,1] (:243-247)
         eps = torch.randn(1, self._act_dim).numpy()
         a, lp = self._e.act(0, N.ACT_PPO_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=eps,
                             out_dim=self._act_dim, want_logp=True)
@@ -91,6 +156,9 @@ class PPO:
         if not self.is_continue:
             return np.int64(self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1),
                                         normalize=False)[0, 0, 0])
+        if self.actor_dist["Beta"]:                                       # mean alpha/(alpha+beta) mapped to [-1,1] (:259-261)
+            al, be = self.agent.actor.alpha_beta(np.asarray(obs, dtype=np.float32).reshape(1, -1))
+            return (2 * (al / (al + be) - 0.5)).numpy().squeeze(0)
         return self._e.act(0, N.ACT_TANHHEAD, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), out_dim=self._act_dim,
                            normalize=False)[0, 0]          # no Batch_ObsNorm in evaluate_action (:257-270)
 

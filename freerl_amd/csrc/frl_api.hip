@@ -271,7 +271,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         h.n_nets = 2;
         if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits
             build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);
-        else
+        else if (c.actor_dist == 1) {   // Actor_Beta (:120-151): alpha_layer and beta_layer share the trunk = one 2A-wide head
+            build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {2 * c.act_dim[0], H}}, 1, hact, ACT_NONE, 0);
+            h.beta_actor = 1;
+        } else
             build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, hact, ACT_TANH, c.act_dim[0]);
         build_net(h.net[1], {{H, c.obs_dim[0]}, {H, H}, {1, H}}, 1, hact, ACT_NONE, 0);
     } else if (e->has_nets) {
@@ -305,6 +308,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.lds_batch_pad = 128;                                  // y holds one row chunk (rc <= 128) of TD targets
     h.lds_act_pad = (std::max(R.act_total, 1) + 3) / 4 * 4; // abuf / dabuf are scalar-accessed: no tile padding
     if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
+    if (c.algo == FRL_ALGO_PPO && c.actor_dist == 1) h.lds_act_pad = std::max(h.lds_act_pad, pad16(2 * c.act_dim[0]));
     // row chunk: the largest of {64,32,16} whose LDS footprint still lets 4 workgroups share a CU
     // (16 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
     h.rc = 64;

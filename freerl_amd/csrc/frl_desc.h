@@ -86,6 +86,7 @@ struct EngineDesc {
     // LDS carve parameters (must match between host lds_bytes() and device carve_lds())
     int lds_kin_pad, lds_out_pad, lds_batch_pad, lds_act_pad;
     int n_discrete;       // DQN: number of discrete actions (0 otherwise)
+    int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner
     // [1 + 3*O] floats = {n, mean[O], S[O], std[O]}; obs_norm_on switches every gather / act to
     // (x - mean) / (std + 1e-8)

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device/net.hpp"
+#include "device/special.hpp"
 
 namespace frl {
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_cf adv = as_global(a.adv + (size_t)p * T);
     g_cf vt = as_global(a.vtarget + (size_t)p * T);
-    const bool discrete = D.n_discrete > 0;
+    const bool discrete = D.n_discrete > 0, beta = D.beta_actor != 0;
     g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + (size_t)p * (1 + 3 * R.obs_dim[0])) : nullptr;
     const int O = R.obs_dim[0], A = discrete ? D.n_discrete : R.act_dim[0], logp_col = R.extra_off;
     const int napad = NA.L[NA.n_layers - 1].n_pad, ncpad = NC.L[NC.n_layers - 1].n_pad;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             g_ci idx = perm + s;
             // ---------------- actor: clipped surrogate + entropy bonus (:324-346)
             float lossp = 0.f, gls = 0.f, ent = 0.f;
-            if (!discrete && threadIdx.x < A) {
+            if (!discrete && !beta && threadIdx.x < A) {
                 const float ls = fminf(fmaxf(thA[NA.extra_off + threadIdx.x], -20.f), 2.f);
                 ent = kHalfLog2PiPlusHalf + ls;
             }
@@ -192,7 +193,56 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 zero_cols(S.xin, S.xp, rc, O, NA.L[0].k_pad);
                 if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, O, bn, O); }
                 __syncthreads();
-                mlp_fwd(NA, 0, NA.n_layers, thA, S, discrete ? ACT_NONE : ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                mlp_fwd(NA, 0, NA.n_layers, thA, S, (discrete || beta) ? ACT_NONE : ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                if (beta) {
+                    // Beta(alpha, beta) per action dimension (:325-332): alpha = softplus(z_a) + 1, beta = softplus(z_b) + 1;
+                    // log_prob(a) = (alpha-1) ln a + (beta-1) ln(1-a) - ln B; entropy = ln B - (alpha-1) psi(alpha) -
+                    // (beta-1) psi(beta) + (alpha+beta-2) psi(alpha+beta), summed over dimensions.  One thread per row.
+                    if (threadIdx.x < rc) {
+                        const int r = threadIdx.x;
+                        if (r < nv) {
+                            g_cf rec = ring + (size_t)idx[r0 + r] * R.stride;
+                            double lp_now = 0.0, lp_old = 0.0, entr = 0.0;
+                            for (int c = 0; c < A; ++c) {
+                                const float za = S.outb[r * S.op + c], zb = S.outb[r * S.op + A + c];
+                                const double al = (double)(za > 20.f ? za : log1pf(expf(za))) + 1.0;
+                                const double be = (double)(zb > 20.f ? zb : log1pf(expf(zb))) + 1.0;
+                                const double x = (double)rec[R.act_off[0] + c];
+                                const double lB = lbeta_d(al, be);
+                                lp_now += (al - 1.0) * log(x) + (be - 1.0) * log1p(-x) - lB;
+                                lp_old += (double)rec[logp_col + c];
+                                entr += lB - (al - 1.0) * digamma_d(al) - (be - 1.0) * digamma_d(be) + (al + be - 2.0) * digamma_d(al + be);
+                            }
+                            const float ratio = expf((float)(lp_now - lp_old));
+                            const float Ar = adv[idx[r0 + r]];
+                            const float s1 = ratio * Ar;
+                            const float s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
+                            lossp += -fminf(s1, s2) - a.ent_coef * (float)entr;
+                            const double coef = (double)((s1 <= s2 ? Ar : 0.f) * (-invm) * ratio), ce = (double)(a.ent_coef * invm);
+                            for (int c = 0; c < A; ++c) {
+                                const float za = S.outb[r * S.op + c], zb = S.outb[r * S.op + A + c];
+                                const double al = (double)(za > 20.f ? za : log1pf(expf(za))) + 1.0;
+                                const double be = (double)(zb > 20.f ? zb : log1pf(expf(zb))) + 1.0;
+                                const double x = (double)rec[R.act_off[0] + c];
+                                const double psi_ab = digamma_d(al + be), tri_ab = trigamma_d(al + be);
+                                const double dlp_a = log(x) - digamma_d(al) + psi_ab, dlp_b = log1p(-x) - digamma_d(be) + psi_ab;
+                                const double dH_a = -(al - 1.0) * trigamma_d(al) + (al + be - 2.0) * tri_ab;
+                                const double dH_b = -(be - 1.0) * trigamma_d(be) + (al + be - 2.0) * tri_ab;
+                                const double sa = za > 20.f ? 1.0 : 1.0 / (1.0 + exp(-(double)za));     // d softplus / dz
+                                const double sb = zb > 20.f ? 1.0 : 1.0 / (1.0 + exp(-(double)zb));
+                                S.abuf[r * S.ap + c] = (float)((coef * dlp_a - ce * dH_a) * sa);
+                                S.abuf[r * S.ap + A + c] = (float)((coef * dlp_b - ce * dH_b) * sb);
+                            }
+                            for (int c = 2 * A; c < napad; ++c) S.abuf[r * S.ap + c] = 0.f;
+                        } else {
+                            for (int c = 0; c < napad; ++c) S.abuf[r * S.ap + c] = 0.f;
+                        }
+                        for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
+                    }
+                    __syncthreads();
+                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+                    continue;
+                }
                 if (discrete) {
                     // Categorical(probs = softmax(l3)) (:333-336): one thread per row does the softmax,
                     // log-prob of the stored action, entropy, ratio and the logits' delta
@@ -283,11 +333,11 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                     for (int r = 0; r < rc; ++r) gls += S.abuf[r * S.ap + threadIdx.x];
                 mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
             }
-            if (!discrete && threadIdx.x < A) {
+            if (!discrete && !beta && threadIdx.x < A) {
                 const float raw = thA[NA.extra_off + threadIdx.x];
                 gA[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? (gls - a.ent_coef) : 0.f;
             }
-            const float aloss = block_sum(lossp, S.red) * invm - (discrete ? 0.f : a.ent_coef * ent_sum);
+            const float aloss = block_sum(lossp, S.red) * invm - ((discrete || beta) ? 0.f : a.ent_coef * ent_sum);
             __syncthreads();
             ++tA;
             if (a.optimizer == 1)

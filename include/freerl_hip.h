@@ -84,6 +84,8 @@ typedef struct frl_config {
     int capacity;                 /* replay rows per learner (PPO: horizon) */
     int batch_max;                /* largest batch / minibatch a learn call will use */
     int extra_cols;               /* extra record columns (PPO: act_dim log-probs + 1 adv_done) */
+    int actor_dist;               /* PPO, continuous: 0 Gaussian `Actor` (PPO_with_tricks.py:79-108), 1 `Actor_Beta` (:120-151):
+                                     the actor's head is [alpha_layer ; beta_layer] = 2*act_dim outputs, no log_std */
     int device_id;
     uint64_t seed;                /* device Philox key (fast path only) */
 } frl_config;

@@ -37,13 +37,17 @@ F32_EPS = float(np.finfo(np.float32).eps)
 
 class PPO:
     def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False,
-                 optimizer="adam"):
+                 optimizer="adam", beta=False):
         """optimizer="c_adamw": PPO_file/PPO.py:109-152,213-286 — the same clipped-surrogate learn with no tricks and ONE
         cautious AdamW (lr = actor_lr) over actor + critic parameters, each net's gradients clipped to 0.5 on its own."""
         self.trick = trick
         self.discrete = discrete
+        self.beta = beta
         act = "tanh" if trick.get("tanh") else "relu"
-        if discrete:    # Actor_discrete (:110-121): ReLU hidden layers regardless of trick['tanh'], softmax head
+        if beta:        # Actor_Beta (:120-151): alpha_layer and beta_layer on the shared trunk
+            self.pi = None
+            self.trunk = MLP(["l1", "l2"], hidden_act=act, out_act=act)
+        elif discrete:    # Actor_discrete (:110-121): ReLU hidden layers regardless of trick['tanh'], softmax head
             self.pi = MLP(["l1", "l2", "l3"], hidden_act="relu", out_act=None)
         else:
             self.pi = MLP(["l1", "l2", "mean_layer"], hidden_act=act, out_act="tanh")   # mean = tanh(...) (:99)
@@ -73,7 +77,61 @@ class PPO:
         e = np.exp(z)
         return (e / e.sum(axis=1, keepdims=True)).astype(F32)
 
+    # ---- Beta policy -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _softplus(z):
+        return np.where(z > 20, z, np.log1p(np.exp(np.minimum(z, 20)))).astype(F32)
+
+    def _alpha_beta(self, obs):
+        """-> alpha, beta, (trunk activations, z_alpha, z_beta)"""
+        tp = {k: v for k, v in self.actor.items() if k.startswith(("l1.", "l2."))}
+        h, acts = self.trunk.forward(tp, obs)
+        za = h @ self.actor["alpha_layer.weight"].T + self.actor["alpha_layer.bias"]
+        zb = h @ self.actor["beta_layer.weight"].T + self.actor["beta_layer.bias"]
+        return self._softplus(za) + F32(1), self._softplus(zb) + F32(1), (h, acts, za.astype(F32), zb.astype(F32))
+
+    def beta_log_prob(self, obs, a):                     # Beta(alpha, beta).log_prob(a), per dimension (:241-251)
+        from scipy.special import gammaln
+        al, be, _ = self._alpha_beta(nn.f32(obs).reshape(1, -1))
+        a = nn.f32(a).reshape(1, -1).astype(np.float64)
+        al, be = al.astype(np.float64), be.astype(np.float64)
+        return ((al - 1) * np.log(a) + (be - 1) * np.log1p(-a) - (gammaln(al) + gammaln(be) - gammaln(al + be)))[0].astype(F32)
+
+    def _beta_actor_step(self, obs, action, logp_old, A, clip_param, ent_coef):
+        """Beta branch of the actor update (:325-332,337-346); special functions in float64 (scipy), the rest fp32."""
+        from scipy.special import digamma, gammaln, polygamma
+        mb = obs.shape[0]
+        al32, be32, (h, tacts, za, zb) = self._alpha_beta(obs)
+        al, be, x = al32.astype(np.float64), be32.astype(np.float64), action.astype(np.float64)
+        lB = gammaln(al) + gammaln(be) - gammaln(al + be)
+        logp = (al - 1) * np.log(x) + (be - 1) * np.log1p(-x) - lB
+        ent = (lB - (al - 1) * digamma(al) - (be - 1) * digamma(be) + (al + be - 2) * digamma(al + be)).sum(axis=1, keepdims=True)
+        ratio = np.exp((logp.sum(axis=1, keepdims=True) - logp_old.astype(np.float64).sum(axis=1, keepdims=True))).astype(F32)
+        surr1 = ratio * A
+        surr2 = np.clip(ratio, 1 - clip_param, 1 + clip_param).astype(F32) * A
+        aloss = F32(-np.mean(np.minimum(surr1, surr2), dtype=F32) - F32(ent_coef) * F32(np.mean(ent)))
+        coef = (np.where(surr1 <= surr2, A, F32(0)) * F32(-1.0 / mb) * ratio).astype(np.float64)
+        ce = ent_coef / mb
+        psi_ab, tri_ab = digamma(al + be), polygamma(1, al + be)
+        d_al = coef * (np.log(x) - digamma(al) + psi_ab) - ce * (-(al - 1) * polygamma(1, al) + (al + be - 2) * tri_ab)
+        d_be = coef * (np.log1p(-x) - digamma(be) + psi_ab) - ce * (-(be - 1) * polygamma(1, be) + (al + be - 2) * tri_ab)
+        sig = lambda z: np.where(z > 20, 1.0, 1.0 / (1.0 + np.exp(-z.astype(np.float64))))
+        dza, dzb = (d_al * sig(za)).astype(F32), (d_be * sig(zb)).astype(F32)
+        g = {"alpha_layer.weight": dza.T @ h, "alpha_layer.bias": dza.sum(axis=0),
+             "beta_layer.weight": dzb.T @ h, "beta_layer.bias": dzb.sum(axis=0)}
+        dh = dza @ self.actor["alpha_layer.weight"] + dzb @ self.actor["beta_layer.weight"]
+        tp = {k: v for k, v in self.actor.items() if k.startswith(("l1.", "l2."))}
+        _, gt = self.trunk.backward(tp, tacts, dh.astype(F32), need_dx=False)      # applies the trunk's last activation's derivative
+        g.update(gt)
+        g = {kk: g[kk].astype(F32) for kk in self.actor}
+        nn.clip_grad_norm(g, 0.5)
+        self.actor_opt.step(self.actor, g)
+        self.actor_losses.append(aloss)
+
     def evaluate_action(self, obs):                      # :257-270: the mean / argmax of the probabilities
+        if self.beta:                                    # Actor_Beta.mean (:145-151) mapped [0,1] -> [-1,1] (:259-261)
+            al, be, _ = self._alpha_beta(nn.f32(obs).reshape(1, -1))
+            return (F32(2) * (al / (al + be) - F32(0.5)))[0]
         if self.discrete:
             return int(np.argmax(self.probs(nn.f32(obs).reshape(1, -1))[0]))
         return self._dist(nn.f32(obs).reshape(1, -1))[0][0]
@@ -107,12 +165,15 @@ class PPO:
         if self.trick.get("adv_norm"):                                               # :314-315
             std = np.sqrt(np.sum((adv - adv.mean(dtype=F32)) ** 2, dtype=F32) / F32(T - 1))   # unbiased
             adv = (adv - adv.mean(dtype=F32)) / (std + F32(1e-8))
-        body = {k: v for k, v in self.actor.items() if k != "log_std"}
         for k in range(k_epochs):
             perm = perms[k]
             for s in range(0, T, minibatch_size):
                 ix = perm[s:s + minibatch_size]
                 mb = len(ix)
+                if self.beta:
+                    self._beta_actor_step(obs[ix], action[ix], logp_old[ix], adv[ix], clip_param, ent_coef)
+                    self._critic_step(obs[ix], v_target[ix])
+                    continue
                 if self.discrete:
                     self._discrete_actor_step(obs[ix], action[ix], logp_old[ix], adv[ix], clip_param, ent_coef)
                     self._critic_step(obs[ix], v_target[ix])

@@ -76,6 +76,13 @@ CASES = {
                               orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
                               Batch_ObsNorm=False),
                    table_seed=129, param_seed=1530, perm_seed=2530),
+    # PPO with Actor_Beta (PPO_with_tricks.py:120-151,240-251,325-332): actions in (0,1), alpha/beta heads, adv_norm
+    "ppo_beta": dict(kind="ppo_beta", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
+                     gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                     trick=dict(adv_norm=True, ObsNorm=False, reward_norm=False, reward_scaling=False,
+                                orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
+                                Batch_ObsNorm=False),
+                     table_seed=130, param_seed=1540, perm_seed=2540),
     # PPO with adv_norm + tanh hidden activations + Adam eps 1e-5
     "ppo_tricks": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
                        gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
@@ -161,6 +168,20 @@ def ppo_inputs(c):
     tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
     actor = synth.mlp_params(c["param_seed"], actor_layers(O, A, head="mean_layer"))
     actor = dict([("log_std", g.uniform(-0.5, 0.3, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
+    perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
+    return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)
+
+
+def ppo_beta_inputs(c):
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    tab = synth.transitions(c["table_seed"], T, O, A)
+    g = np.random.default_rng(c["table_seed"] + 1)
+    tab["act"] = g.uniform(0.03, 0.97, (T, A)).astype(np.float32)        # Beta samples live in (0, 1)
+    tab["logp"] = (0.4 * g.standard_normal((T, A)) + 0.1).astype(np.float32)
+    tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
+    H_ = H
+    actor = synth.mlp_params(c["param_seed"], [("l1", H_, O), ("l2", H_, H_), ("alpha_layer", A, H_), ("beta_layer", A, H_)])
     critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
     perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
     return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)

@@ -399,6 +399,36 @@ def gen_ppo(name, out):
     out["buffer_size_after"] = np.int64(len(pol.buffer))
 
 
+def gen_ppo_beta(out):
+    """PPO_with_tricks with beta=True (Actor_Beta): learn() on stored actions in (0,1); log_prob/mean probes."""
+    c = cases.CASES["ppo_beta"]
+    inp = cases.ppo_beta_inputs(c)
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    pol = mod.PPO([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["horizon"], CPU,
+                  trick=dict(c["trick"]), beta=True)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    out["evaluate_action"] = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    with torch.no_grad():
+        al, be = pol.agent.actor(torch.as_tensor(tab["obs"][:16]))
+        out["alpha"], out["beta"] = al.numpy(), be.numpy()
+        out["log_prob"] = torch.distributions.Beta(al, be).log_prob(torch.as_tensor(tab["act"][:16])).numpy()
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+    proxy = _NpProxy(inp["perms"])
+    mod.np = proxy
+    pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    mod.np = np
+    out["adv_raw"] = proxy.captured[0].astype(np.float32)
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+
+
 def gen_ppo_py(out):
     """PPO_file/PPO.py: update_ac_ (one cautious AdamW over actor + critic).  PPO.py's GAE array is float64 but the
     recurrence runs on float32 scalars under NumPy 2, like PPO_with_tricks'."""
@@ -684,7 +714,7 @@ def main():
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
-        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py,
+        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_beta": gen_ppo_beta,
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),

@@ -286,3 +286,46 @@ def test_buffer_module_standalone():
     np.testing.assert_array_equal(ad.cpu().numpy()[:, 0], [float(i % 7 == 0) for i in range(16)])
     pb.clear()
     assert len(pb) == 0 and pb._index == 0
+
+
+def test_ppo_beta_class():
+    """PPO(beta=True): Actor_Beta state_dict layout, default-init RNG order, mean / sample / learn through the class."""
+    from freerl_amd.PPO import PPO
+    from oracle import ppo as oppo
+    O, A, T = 8, 2, 128
+    trick = dict(cases.CASES["ppo_beta"]["trick"])
+    torch.manual_seed(3)
+    ref_l1 = torch.nn.Linear(O, 128); ref_l2 = torch.nn.Linear(128, 128)
+    ref_al = torch.nn.Linear(128, A); ref_be = torch.nn.Linear(128, A)      # Actor_Beta's construction order (:123-126)
+    torch.manual_seed(3); np.random.seed(3)
+    pol = PPO([O, A], True, 1e-3, 1e-3, T, CUDA, trick=trick, beta=True)
+    sd = pol.agent.actor.state_dict()
+    assert list(sd.keys()) == ["l1.weight", "l1.bias", "l2.weight", "l2.bias", "alpha_layer.weight", "alpha_layer.bias",
+                               "beta_layer.weight", "beta_layer.bias"]
+    np.testing.assert_array_equal(sd["alpha_layer.weight"].numpy(), ref_al.weight.detach().numpy())
+    np.testing.assert_array_equal(sd["beta_layer.bias"].numpy(), ref_be.bias.detach().numpy())
+    np.testing.assert_array_equal(sd["l2.weight"].numpy(), ref_l2.weight.detach().numpy())
+    pol.agent.actor.load_state_dict(sd)                                      # round trip
+    np.testing.assert_array_equal(pol.agent.actor.state_dict()["beta_layer.weight"].numpy(), sd["beta_layer.weight"].numpy())
+    orc = oppo.PPO(sd2np(sd), sd2np(pol.agent.critic.state_dict()), O, A, 1e-3, 1e-3, T, trick, beta=True)
+    tab = synth.transitions(131, T, O, A)
+    g = np.random.default_rng(9)
+    adv_done = np.logical_or(tab["done"], g.random(T) < 0.03)
+    for i in range(T):
+        a, lp = pol.select_action(tab["obs"][i])
+        assert a.shape == (A,) and lp.shape == (A,) and np.all((a > 0) & (a < 1))
+        np.testing.assert_allclose(lp, orc.beta_log_prob(tab["obs"][i], a), rtol=2e-4, atol=2e-5)
+        pol.add(tab["obs"][i], a, float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp, bool(adv_done[i]))
+        orc.add(tab["obs"][i], a, float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp, bool(adv_done[i]))
+    np.testing.assert_allclose(pol.evaluate_action(tab["obs"][5]), orc.evaluate_action(tab["obs"][5]), rtol=1e-5, atol=1e-6)
+    np.random.seed(11)
+    perms = [np.random.permutation(T) for _ in range(2)]
+    np.random.seed(11)
+    pol.track_loss = True
+    pol.learn(64, 0.99, 0.95, 0.2, 2, 0.01)
+    orc.learn_with(perms, 64, 0.99, 0.95, 0.2, 2, 0.01)
+    np.testing.assert_allclose(pol.last_trace[0, :, 0], np.array(orc.actor_losses), rtol=5e-4, atol=5e-6)
+    np.testing.assert_allclose(pol.last_trace[0, :, 1], np.array(orc.critic_losses), rtol=5e-4)
+    got = sd2np(pol.agent.actor.state_dict())
+    for k in orc.actor:
+        np.testing.assert_allclose(got[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)

@@ -429,6 +429,60 @@ def test_ppo_learn(N, name):
     e.close()
 
 
+def _beta_flat(p):
+    """Actor_Beta state_dict -> the engine's 3-layer net whose head is [alpha_layer ; beta_layer]."""
+    return np.concatenate([p["l1.weight"].ravel(), p["l1.bias"], p["l2.weight"].ravel(), p["l2.bias"],
+                           p["alpha_layer.weight"].ravel(), p["beta_layer.weight"].ravel(), p["alpha_layer.bias"],
+                           p["beta_layer.bias"]]).astype(np.float32)
+
+
+def _beta_unflat(flat, like):
+    out, o = {}, 0
+    A = like["alpha_layer.bias"].size
+    for k in ("l1.weight", "l1.bias", "l2.weight", "l2.bias"):
+        out[k] = flat[o:o + like[k].size].reshape(like[k].shape); o += like[k].size
+    for k in ("alpha_layer.weight", "beta_layer.weight", "alpha_layer.bias", "beta_layer.bias"):
+        out[k] = flat[o:o + like[k].size].reshape(like[k].shape); o += like[k].size
+    assert o == flat.size and A > 0
+    return out
+
+
+def test_ppo_beta_actor(N):
+    """Actor_Beta (PPO_with_tricks.py:120-151,325-332): frl_config.actor_dist = 1."""
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    c = cases.CASES["ppo_beta"]
+    inp = cases.ppo_beta_inputs(c)
+    fx = gold("ppo_beta")
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=c["minibatch"], extra_cols=A + 1, actor_dist=1)
+    e.set_params(0, _beta_flat(inp["params"]["actor"]))
+    e.set_params(1, flat_params(inp["params"]["critic"], AC_NAMES))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, c["actor_lr"], c["critic_lr"], T, c["trick"], beta=True)
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    z = e.act(0, N.ACT_RAW, tab["obs"][:16], out_dim=2 * A)[0]                # head pre-activations [alpha | beta]
+    sp = lambda v: np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20)))) + 1
+    np.testing.assert_allclose(sp(z[:, :A]), fx["alpha"], rtol=1e-5)
+    np.testing.assert_allclose(sp(z[:, A:]), fx["beta"], rtol=1e-5)
+    out = e.ppo_learn(T, c["minibatch"], c["k_epochs"], gamma=c["gamma"], lmbda=c["lmbda"], clip=c["clip"], ent_coef=c["ent"],
+                      actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], adv_norm=c["trick"]["adv_norm"],
+                      perms=np.stack(inp["perms"])[None], want_trace=True, want_adv=True)
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(out["adv"][0], fx["adv_raw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["trace"][0, :, 0], fx["loss_actor"], rtol=2e-4, atol=5e-6)
+    np.testing.assert_allclose(out["trace"][0, :, 1], fx["loss_critic"], rtol=2e-4)
+    ga = _beta_unflat(e.get_params(0), orc.actor)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
+    synth.check_digest("actor", ga, fx, 2e-3, 2e-5, "hip-vs-reference")
+    e.close()
+
+
 def test_ppo_py_cautious_adamw(N):
     """PPO_file/PPO.py: frl_ppo_learn with optimizer = 1 (c_adamw.py's cautious AdamW, lr = actor_lr for both nets)."""
     from freerl_amd.engine import Engine

@@ -155,6 +155,29 @@ def test_maddpg_learn():
         synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
 
 
+def test_ppo_beta_actor():
+    """PPO_with_tricks.py with beta=True (Actor_Beta :120-151): alpha/beta heads, Beta log-prob / entropy / mean."""
+    c = cases.CASES["ppo_beta"]
+    inp = cases.ppo_beta_inputs(c)
+    fx = gold("ppo_beta")
+    pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                  c["actor_lr"], c["critic_lr"], c["horizon"], c["trick"], beta=True)
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    ev = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-5, atol=1e-6)
+    lp = np.stack([pol.beta_log_prob(tab["obs"][i], tab["act"][i]) for i in range(16)])
+    np.testing.assert_allclose(lp, fx["log_prob"], rtol=2e-5, atol=2e-6)
+    pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    np.testing.assert_allclose(pol.adv_raw.reshape(-1), fx["adv_raw"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=LOSS_RTOL, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=LOSS_RTOL)
+    synth.check_digest("actor", pol.actor, fx, 2e-3, 2e-5)
+    synth.check_digest("critic", pol.critic, fx, 2e-3, 2e-5)
+
+
 def test_ppo_py_cautious_adamw():
     """PPO_file/PPO.py: the no-trick learn with ONE cautious AdamW (c_adamw.py) over actor + critic."""
     c = cases.CASES["ppo_py"]
