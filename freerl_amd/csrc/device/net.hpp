@@ -5,8 +5,9 @@
 //     h1,h2[rc][hp]   hidden activations, overwritten IN PLACE by their deltas on the way back
 //     outb [rc][op]   head output / head delta
 // Pitches are (width + 4) floats: 16-byte aligned rows and conflict-light MFMA operand reads.
-// Weight gradients are accumulated in the learner's global `grad` block (one owner per
-// element, plain read-modify-write), parameters/Adam state/targets are streamed once per step.
+// Weight gradients go to the block G the caller passes: a workgroup's own partial slab, written once (off-policy
+// kernels), or the learner's `grad` block accumulated over a minibatch's row chunks (PPO: one owner per element,
+// plain read-modify-write).  Parameters / Adam state / targets are streamed once per step by the Adam kernels.
 #pragma once
 #include "../frl_desc.h"
 #include "rng.hpp"
@@ -14,8 +15,8 @@
 
 namespace frl {
 
-// Developer instrument (tools/phase_timing.py; built only with -DFRL_PHASE_TIMING): thread 0 of a few
-// sampled workgroups stamps the shader clock at every barrier-delimited phase of the gradient kernels.
+// Developer instrument (tools/phase_timing.py; built only with -DFRL_PHASE_TIMING): every wave of a few sampled
+// workgroups stamps the shader clock when it arrives at a barrier, wave 0 also when it is released.
 #ifdef FRL_PHASE_TIMING
 // Stamps go to (static) LDS and are dumped once at kernel end: a global store per stamp would put a write
 // acknowledgement in front of the next vmcnt wait and distort what is measured.

@@ -309,8 +309,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.lds_act_pad = (std::max(R.act_total, 1) + 3) / 4 * 4; // abuf / dabuf are scalar-accessed: no tile padding
     if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
     if (c.algo == FRL_ALGO_PPO && c.actor_dist == 1) h.lds_act_pad = std::max(h.lds_act_pad, pad16(2 * c.act_dim[0]));
-    // row chunk: the largest of {64,32,16} whose LDS footprint still lets 4 workgroups share a CU
-    // (16 waves/CU hide the L2 latency of the weight reads; profiles/README.md)
+    // row chunk: the largest of {64,32,16} whose LDS footprint still lets TWO workgroups share a CU.  Measured
+    // (profiles/README.md v4): 64 rows x 2 workgroups beats 32 x 3, 32 x 4 and 128 x 1 — more rows per weight fragment
+    // fetched and half the gradient slabs, while two workgroups still overlap each other's barrier phases
     h.rc = 64;
     while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;   // two workgroups per CU (160 KB LDS)
     if (const char* force = getenv("FRL_RC")) {             // developer knob: rows per workgroup (16 / 32 / 64)
