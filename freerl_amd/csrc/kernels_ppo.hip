@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
+    // blockIdx.y: 0 = the actor's steps, 1 = the critic's.  Within learn() the two nets never read each other (the
+    // advantages and value targets were fixed by the GAE pass, PPO_with_tricks.py:300-316), so their K_epochs x minibatch
+    // step sequences run as two independent persistent workgroups.
     const int p = blockIdx.x, T = a.horizon, mb = a.minibatch, rc = D.rc;
+    const bool do_actor = (blockIdx.y == 0), do_critic = (blockIdx.y == 1);
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
     const RecordDesc& R = D.rec;
@@ -180,6 +184,8 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
             const int m = min(mb, T - s);
             const float invm = 1.f / (float)m;
             g_ci idx = perm + s;
+            const int j_tr = k * n_mb + s / mb;
+            if (do_actor) {
             // ---------------- actor: clipped surrogate + entropy bonus (:324-346)
             float lossp = 0.f, gls = 0.f, ent = 0.f;
             if (!discrete && !beta && threadIdx.x < A) {
@@ -346,6 +352,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                          a.clip_norm, tA, 0.f, S.red);
             __syncthreads();
+            if (threadIdx.x == 0) trace[2 * j_tr] = aloss;
+            }
+            if (!do_critic) continue;
             // ---------------- critic: mse(v_target[idx], V(obs[idx])) (:349-351)
             float closs_p = 0.f;
             for (int r0 = 0; r0 < m; r0 += rc) {
@@ -377,20 +386,14 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 adam_net(NC.size, thC, as_global(D.m + offC), as_global(D.v + offC), gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                          a.clip_norm, tC, 0.f, S.red);
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const int j = k * n_mb + s / mb;
-                trace[2 * j] = aloss;
-                trace[2 * j + 1] = closs;
-            }
+            if (threadIdx.x == 0) trace[2 * j_tr + 1] = closs;
         }
     }
     if (threadIdx.x == 0) {
-        steps[0] = tA;
-        steps[1] = tC;
         float* st = D.stats + (size_t)p * D.n_agents * ST_COUNT;
         const int j = a.k_epochs * n_mb - 1;
-        st[ST_ACTOR_LOSS] = trace[2 * j];
-        st[ST_CRITIC_LOSS] = trace[2 * j + 1];
+        if (do_actor) { steps[0] = tA; st[ST_ACTOR_LOSS] = trace[2 * j]; }
+        if (do_critic) { steps[1] = tC; st[ST_CRITIC_LOSS] = trace[2 * j + 1]; }
     }
 }
 
