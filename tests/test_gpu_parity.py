@@ -731,3 +731,21 @@ def test_sac_batch_obs_norm(N):
     sa = e.act(0, N.ACT_SAC_SAMPLE, inp["table"]["obs"][:8], eps=eps, out_dim=c["act_dim"])[0]
     np.testing.assert_allclose(sa, fx["select_action"], rtol=5e-3, atol=5e-4)
     e.close()
+
+
+# ------------------------------------------------------------------ the population-sized row chunk
+@pytest.mark.parametrize("rows", ["64", "16"])
+def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
+    """frl_create picks 32-row chunks for small populations and 64-row chunks (4x2 / 2x4 register blocks, two workgroups
+    per CU) for the bench-sized ones; FRL_RC forces a size so the single-learner golden cases cover those kernels too."""
+    monkeypatch.setenv("FRL_RC", rows)
+    from freerl_amd.engine import Engine
+    e = Engine(N.ALGO_TD3, 8, 2, 512, twin_critic=True, batch_max=256)
+    assert e.lds_bytes()[1] == int(rows)
+    e.close()
+    test_dqn_learn_matches_oracle_and_reference(N)
+    test_td3_learn(N, "td3")
+    test_td3_learn(N, "td3_pendulum")
+    test_sac_learn(N)
+    test_maddpg_learn(N)
+    test_matd3_learn(N)
