@@ -23,6 +23,7 @@ namespace frl {
 constexpr int kPhaseMax = 64, kPhaseBlocks = 8, kPhaseWords = 5 * kPhaseMax;   // 4 waves' arrivals + wave 0's releases
 __device__ int g_phase_clock[kPhaseBlocks][kPhaseWords];
 __device__ int g_phase_stride = 509;
+__device__ int g_phase_kernel = 0;         // which kernel dumps its stamps: 0 ac_critic_kernel, 1 ac_actor_kernel
 __device__ __forceinline__ FRL_LDS int* phase_buf() {
     __shared__ int buf[kPhaseWords + 8];
     return (FRL_LDS int*)buf;
@@ -48,10 +49,10 @@ __device__ __forceinline__ FRL_LDS int* phase_buf() {
         __syncthreads();                                                                           \
         if (threadIdx.x == 0) FRL_STAMP_(4, 4);                                                    \
     } while (0)
-#define FRL_PHASE_DUMP(S)                                                                          \
+#define FRL_PHASE_DUMP(S, kernel_id)                                                               \
     do {                                                                                           \
         __syncthreads();                                                                           \
-        if (blockIdx.x % g_phase_stride == 0 && blockIdx.x / g_phase_stride < kPhaseBlocks)        \
+        if (g_phase_kernel == (kernel_id) && blockIdx.x % g_phase_stride == 0 && blockIdx.x / g_phase_stride < kPhaseBlocks) \
             for (int i_ = threadIdx.x; i_ < kPhaseWords; i_ += kWG)                                \
                 g_phase_clock[blockIdx.x / g_phase_stride][i_] = phase_buf()[i_];                  \
     } while (0)
@@ -59,7 +60,7 @@ __device__ __forceinline__ FRL_LDS int* phase_buf() {
 #define FRL_PHASE(S) lds_barrier()
 #define FRL_MARK() do {} while (0)
 #define FRL_PHASE_INIT(S) do {} while (0)
-#define FRL_PHASE_DUMP(S) do {} while (0)
+#define FRL_PHASE_DUMP(S, kernel_id) do {} while (0)
 #endif
 
 struct Lds {

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         FRL_PHASE(S);
         mlp_bwd(NC, h * ql, ql, thC, slab, S, true, false, 0, 0);
     }
-    FRL_PHASE_DUMP(S);
+    FRL_PHASE_DUMP(S, 0);
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[(((size_t)p * n + ag) * D.S + sl) * 4] = ls;
 }
