@@ -174,3 +174,98 @@ class Buffer_for_PPO(_RingView):
         step = 16 * self._e.batch_max
         chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
         return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))
+
+
+# ------------------------------------------------------------------------------------ PER / N-step (DQN_file/Buffer.py:66-399)
+class SumTreeView:
+    """What callers read on `PER_Buffer.sumtree` (DQN_file/Buffer.py:187-194): `sum()` and `max()`."""
+
+    def __init__(self, engine, learner=0):
+        self._e, self._learner = engine, learner
+
+    def sum(self):
+        return self._e.per_state(self._learner)["sum"]
+
+    def max(self):
+        return self._e.per_state(self._learner)["max"]
+
+
+class PER_Buffer:
+    """PER_Buffer (DQN_file/Buffer.py:66-129): the sum-tree lives next to the ring in HBM; `add` gives a new row the
+    current maximum priority, `sample(batch_size)` -> (indices int64 [B], is_weight float32 tensor [B]),
+    `update_priorities(indices, td_error)`.  `.buffer` is the plain ring view (`.buffer.sample(indices)`, :230)."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device, alpha=0.5, beta=0.4, beta_increment=0.001, epsilon=0.01, *,
+                 batch_max=1024, _engine=None):
+        self.capacity, self.alpha, self.beta_increment, self.epsilon = int(capacity), alpha, beta_increment, epsilon
+        self.buffer = Buffer(capacity, obs_dim, act_dim, device, batch_max=batch_max, _engine=_engine)
+        self.device = self.buffer.device
+        self._e = self.buffer._e
+        self._e.per_enable(alpha, beta, beta_increment, epsilon)
+        self.sumtree = SumTreeView(self._e)
+
+    @property
+    def beta(self):
+        return self._e.per_state(0)["beta"]
+
+    def add(self, obs, action, reward, next_obs, done):
+        self.buffer.add(obs, action, reward, next_obs, done)
+
+    def sample(self, batch_size):
+        """The stratified draws are np.random.uniform's own arithmetic on np.random.random_sample() (a + (b-a)*u), so a
+        seeded run consumes NumPy's global stream exactly like the reference's loop (:107-114)."""
+        u = np.array([np.random.random_sample() for _ in range(batch_size)])
+        idx, w = self._e.per_sample(batch_size, uniforms=u)
+        return idx[0], torch.as_tensor(w[0], dtype=torch.float32).to(self.device)
+
+    def update_priorities(self, indices, td_error):
+        td = np.asarray(torch.as_tensor(td_error).detach().cpu().numpy(), dtype=F32).reshape(-1)
+        self._e.per_update(td.size, idx=np.asarray(indices, dtype=np.int64).reshape(1, -1), td_error=td.reshape(1, -1))
+
+    def __len__(self):
+        return len(self.buffer)
+
+
+def _n_step_info(window, gamma):
+    """_get_n_step_info (DQN_file/Buffer.py:240-275): the oldest (obs, action); the return folded from the newest entry
+    back; next_obs / done of the earliest terminal inside the window.  Host arithmetic in Python floats, like the reference."""
+    obs, action = window[0][0], window[0][1]
+    _, _, reward, next_obs, done = window[-1]
+    for i in range(len(window) - 2, -1, -1):
+        _, _, r, n_o, d = window[i]
+        reward = r + gamma * reward * (1 - d)
+        if d:
+            next_obs, done = n_o, d
+    return obs, action, reward, next_obs, done
+
+
+class N_Step_Buffer(Buffer):
+    """N_Step_Buffer (DQN_file/Buffer.py:199-296): a deque of the last n transitions; once full, every add stores the
+    n-step transition of the oldest entry.  `n_step_gamma` = gamma ** n_step is what learn() bootstraps with."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device, gamma, n_step=2, **kw):
+        from collections import deque
+        super().__init__(capacity, obs_dim, act_dim, device, **kw)
+        self.n_step, self.gamma, self.n_step_gamma = n_step, gamma, gamma ** n_step
+        self.n_step_deque = deque(maxlen=n_step)
+
+    def add(self, obs, action, reward, next_obs, done):
+        self.n_step_deque.append((obs, action, reward, next_obs, done))
+        if len(self.n_step_deque) == self.n_step:
+            super().add(*_n_step_info(list(self.n_step_deque), self.gamma))
+
+
+class N_Step_PER_Buffer(PER_Buffer):
+    """N_Step_PER_Buffer (DQN_file/Buffer.py:333-399): the n-step fold in front of the prioritised ring."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device, alpha=0.5, beta=0.4, beta_increment=0.001, epsilon=0.01,
+                 gamma=None, n_step=3, **kw):
+        from collections import deque
+        super().__init__(capacity, obs_dim, act_dim, device, alpha, beta, beta_increment, epsilon, **kw)
+        self.n_step, self.gamma, self.n_step_gamma = n_step, gamma, gamma ** n_step
+        self.n_step_deque = deque(maxlen=n_step)
+
+    def add(self, obs, action, reward, next_obs, done):
+        self.n_step_deque.append((obs, action, reward, next_obs, done))
+        if len(self.n_step_deque) == self.n_step:
+            super().add(*_n_step_info(list(self.n_step_deque), self.gamma))

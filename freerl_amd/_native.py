@@ -56,6 +56,7 @@ class LearnArgs(C.Structure):
                 ("alpha_lr", C.c_float), ("adam_eps", C.c_float), ("critic_weight_decay", C.c_float),
                 ("clip_norm", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
                 ("max_action", C.c_float), ("policy_noise_scale", C.c_float), ("target_entropy", C.c_float),
+                ("double_dqn", C.c_int), ("per", C.c_int),
                 ("idx", C.POINTER(C.c_int64)), ("noise", C.POINTER(C.c_float)), ("stats_out", C.POINTER(C.c_float))]
 
 
@@ -116,6 +117,10 @@ SIGNATURES = {
     "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "frl_learn": (_i, [_vp, _P(LearnArgs)]),
     "frl_stats_get": (_i, [_vp, _fp]),
+    "frl_per_enable": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "frl_per_sample": (_i, [_vp, _i, _P(C.c_double), _i64p, _fp]),
+    "frl_per_update": (_i, [_vp, _i, _i64p, _fp]),
+    "frl_per_state": (_i, [_vp, _i, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),

@@ -18,6 +18,7 @@
 #include "kernels_update.hip"
 #include "kernels_act.hip"
 #include "kernels_ppo.hip"
+#include "kernels_per.hip"
 
 using namespace frl;
 
@@ -78,6 +79,16 @@ struct frl_engine {
     int* d_perm = nullptr;
     size_t perm_cap = 0;
     bool has_nets = false;
+    // prioritised replay (frl_per_*): sum-tree + max-tree per learner, float64 like the reference's SumTree
+    bool per_on = false;
+    double* d_per_sum = nullptr;
+    double* d_per_max = nullptr;
+    float per_alpha = 0.5f, per_eps = 0.01f;
+    double per_beta = 0.4, per_beta_inc = 0.001;
+    std::vector<int> size_flushed;        // rows valid per learner as of the last flush (PER_Buffer.add's `len(self.buffer) == 0`)
+    int* d_size = nullptr;                // [2][P]: size before the flush being applied / current size
+    float* d_per_prio = nullptr;          // [P][batch_max] float32 priorities of the last sample
+    double* d_uniforms = nullptr;         // [P][batch_max]
     // optional per-kernel timing (frl_profile_*): event pairs recorded around each launch
     bool profile = false;
     std::vector<hipEvent_t> prof_ev;      // pool, pairs
@@ -195,7 +206,12 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (!e) return FRL_OK;
     hipSetDevice(e->cfg.device_id);
     if (e->stream) hipStreamSynchronize(e->stream);
-    float* dev[] = {e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
+    if (e->d_per_sum) hipFree(e->d_per_sum);
+    if (e->d_per_max) hipFree(e->d_per_max);
+    if (e->d_size) hipFree(e->d_size);
+    if (e->d_per_prio) hipFree(e->d_per_prio);
+    if (e->d_uniforms) hipFree(e->d_uniforms);
+    float* dev[] = {e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo};
     for (float* p : dev) if (p) hipFree(p);
     if (e->h.idx) hipFree(e->h.idx);
@@ -355,6 +371,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (int i = 0; i < h.n_nets; ++i) h.Gmax = std::max(h.Gmax, (h.net[i].size / 4 + 256 * kAdamVec - 1) / (256 * kAdamVec));
         CREATE_TRY(dalloc_zero(&h.gsq, P * (size_t)h.n_agents * h.Gmax, e->stream));
         e->idx_count = P * h.n_agents * h.batch_max;
+        CREATE_TRY(dalloc_zero(&h.isw, P * (size_t)h.batch_max, e->stream));
+        CREATE_TRY(dalloc_zero(&h.td_err, P * (size_t)h.batch_max, e->stream));
         h.noise_sets = std::max(2, h.n_agents);
         e->noise_count = P * h.n_agents * h.noise_sets * (size_t)h.batch_max * h.act_max;
         CREATE_TRY(dalloc_zero(&h.idx, e->idx_count, e->stream));
@@ -439,6 +457,16 @@ static int flush_stage(frl_engine* e) {
     hipLaunchKernelGGL(replay_scatter_kernel, dim3(blocks), dim3(256), 0, e->stream, e->h.replay, e->d_stage_rows,
                        e->d_stage_slots, n, R.width, R.stride);
     HIP_TRY(hipGetLastError());
+    if (e->per_on) {                 // PER_Buffer.add (Buffer.py:92-98): the new rows enter at the current maximum priority
+        HIP_TRY(hipMemcpyAsync(e->d_size, e->size_flushed.data(), (size_t)e->h.P * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        PerArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = e->h.capacity; pa.n = n;
+        hipLaunchKernelGGL(per_add_kernel, dim3(e->h.P), dim3(256), 0, e->stream, pa, (const long long*)e->d_stage_slots, (const int*)e->d_size);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));            // size_flushed is host memory reused below
+    }
+    e->size_flushed = e->size;
     HIP_TRY(hipEventRecord(e->ev_stage, e->stream));
     e->stage_inflight = true;
     e->stage_n = 0;
@@ -792,7 +820,9 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     int min_size = h.capacity;
     for (int p = 0; p < h.P; ++p) min_size = std::min(min_size, e->size[p]);
     if (min_size < args->batch) return fail(FRL_ERR_STATE, "a ring holds %d rows < batch %d", min_size, args->batch);
-    const bool dev_rng = (args->idx == nullptr);
+    if (args->per && (h.algo != ALGO_DQN || !e->per_on)) return fail(FRL_ERR_STATE, "per = 1 needs a DQN engine with frl_per_enable");
+    if (args->per && args->idx) return fail(FRL_ERR_INVALID, "per = 1 uses the rows of the last frl_per_sample; idx must be NULL");
+    const bool dev_rng = (args->idx == nullptr) && !args->per;
     if (dev_rng && min_size < 2 * args->batch)
         return fail(FRL_ERR_STATE, "device index draw needs len(buffer) >= 2*batch (have %d); pass idx", min_size);
     const bool td3_like = (h.algo == ALGO_TD3 || h.algo == ALGO_MADDPG);       // MADDPG + noise/delay = MATD3_simple.py
@@ -819,6 +849,8 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     a.policy_noise_scale = args->policy_noise_scale;
     a.use_policy_noise = (td3_like && args->use_policy_noise) ? 1 : 0;
     a.target_entropy = args->target_entropy;
+    a.double_dqn = (h.algo == ALGO_DQN && args->double_dqn) ? 1 : 0;
+    a.use_isw = (h.algo == ALGO_DQN && args->per) ? (args->per == 2 ? 2 : 1) : 0;
     a.rng_counter = e->rng_counter++;
     const int ns = (a.batch + h.rc - 1) / h.rc;
     const int units = h.P * h.n_agents;
@@ -964,6 +996,113 @@ extern "C" int frl_profile_read(frl_engine* e, double* ms_sum8, long long* count
     ENG(e);
     prof_collect(e);
     for (int k = 0; k < 8; ++k) { if (ms_sum8) ms_sum8[k] = e->prof_ms[k]; if (count8) count8[k] = e->prof_n[k]; }
+    return FRL_OK;
+}
+
+// ------------------------------------------------------------------------- prioritised replay
+extern "C" int frl_per_enable(frl_engine* e, double alpha, double beta, double beta_increment, double epsilon) {
+    ENG(e);
+    if (e->h.n_agents != 1) return fail(FRL_ERR_INVALID, "PER is a single-agent buffer (DQN_file/Buffer.py:66)");
+    if (e->per_on) return fail(FRL_ERR_STATE, "PER already enabled");
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    for (int p = 0; p < e->h.P; ++p)
+        if (e->size[p] != 0) return fail(FRL_ERR_STATE, "enable PER on an empty buffer (priorities are assigned by add)");
+    const size_t nn = 2 * (size_t)e->h.capacity - 1, P = e->h.P;
+    HIP_TRY(hipMalloc((void**)&e->d_per_sum, P * nn * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&e->d_per_max, P * nn * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(e->d_per_sum, 0, P * nn * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_per_max, 0, P * nn * sizeof(double), e->stream));
+    HIP_TRY(hipMalloc((void**)&e->d_size, 2 * P * sizeof(int)));
+    const size_t bm = (size_t)std::max(e->h.batch_max, 1);
+    HIP_TRY(hipMalloc((void**)&e->d_per_prio, P * bm * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->d_uniforms, P * bm * sizeof(double)));
+    if (!e->h.isw) {          // replay-only engine (Buffer.py's PER_Buffer on its own): sample rows, weights and TD errors still need a home
+        HIP_TRY(hipMalloc((void**)&e->h.isw, P * bm * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->h.td_err, P * bm * sizeof(float)));
+        e->idx_count = P * e->h.n_agents * bm;
+        HIP_TRY(hipMalloc((void**)&e->h.idx, e->idx_count * sizeof(int)));
+        HIP_TRY(hipHostMalloc((void**)&e->h_idx, e->idx_count * sizeof(int)));
+        HIP_TRY(hipMemcpy(e->d, &e->h, sizeof(EngineDesc), hipMemcpyHostToDevice));
+    }
+    e->per_alpha = (float)alpha; e->per_beta = beta; e->per_beta_inc = beta_increment; e->per_eps = (float)epsilon;
+    e->size_flushed.assign(P, 0);
+    e->per_on = true;
+    return FRL_OK;
+}
+
+extern "C" int frl_per_sample(frl_engine* e, int batch, const double* uniforms, int64_t* idx_out, float* is_weight_out) {
+    ENG(e);
+    if (!e->per_on) return fail(FRL_ERR_STATE, "frl_per_enable first");
+    if (batch < 1 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch %d outside [1,%d]", batch, e->h.batch_max);
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    const size_t P = e->h.P;
+    for (size_t p = 0; p < P; ++p)
+        if (e->size[p] < 1) return fail(FRL_ERR_STATE, "learner %zu's buffer is empty", p);
+    e->per_beta = std::min(1.0, e->per_beta + e->per_beta_inc);             // Buffer.py:105 (before the weights are computed)
+    HIP_TRY(hipMemcpyAsync(e->d_size + P, e->size.data(), P * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if (uniforms) HIP_TRY(hipMemcpyAsync(e->d_uniforms, uniforms, P * batch * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    PerArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = e->h.capacity; pa.n = batch;
+    pa.size = e->d_size + P; pa.uniforms = uniforms ? e->d_uniforms : nullptr; pa.isw = e->h.isw; pa.prio_out = e->d_per_prio;
+    pa.beta = e->per_beta; pa.rng_counter = e->rng_counter++;
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)P), dim3(256), 0, e->stream, e->d, pa);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (idx_out) {
+        std::vector<int> tmp((size_t)e->h.batch_max * P);
+        HIP_TRY(hipMemcpy(tmp.data(), e->h.idx, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < P; ++p)
+            for (int i = 0; i < batch; ++i) idx_out[p * batch + i] = tmp[p * e->h.batch_max + i];
+    }
+    if (is_weight_out)
+        for (size_t p = 0; p < P; ++p)
+            HIP_TRY(hipMemcpy(is_weight_out + p * batch, e->h.isw + p * e->h.batch_max, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost));
+    return FRL_OK;
+}
+
+extern "C" int frl_per_update(frl_engine* e, int batch, const int64_t* idx, const float* td_error) {
+    ENG(e);
+    if (!e->per_on) return fail(FRL_ERR_STATE, "frl_per_enable first");
+    if (batch < 1 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch %d outside [1,%d]", batch, e->h.batch_max);
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    const size_t P = e->h.P, bm = e->h.batch_max;
+    if (idx) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (size_t p = 0; p < P; ++p)
+            for (int i = 0; i < batch; ++i) {
+                const int64_t v = idx[p * batch + i];
+                if (v < 0 || v >= e->h.capacity) return fail(FRL_ERR_INVALID, "priority index %lld out of range", (long long)v);
+                e->h_idx[p * bm + i] = (int)v;
+            }
+        HIP_TRY(hipMemcpyAsync(e->h.idx, e->h_idx, P * bm * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    if (td_error)
+        for (size_t p = 0; p < P; ++p)
+            HIP_TRY(hipMemcpyAsync(e->h.td_err + p * bm, td_error + p * batch, (size_t)batch * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    PerArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = e->h.capacity; pa.n = batch;
+    pa.leaf = e->h.idx; pa.n_pitch = (int)bm; pa.td = e->h.td_err; pa.alpha = e->per_alpha; pa.eps = e->per_eps;
+    hipLaunchKernelGGL(per_set_kernel, dim3((unsigned)P), dim3(256), 0, e->stream, e->d, pa);
+    HIP_TRY(hipGetLastError());
+    return FRL_OK;
+}
+
+extern "C" int frl_per_state(frl_engine* e, int learner, double* sum_out, double* max_out, double* beta_out) {
+    ENG(e);
+    if (!e->per_on) return fail(FRL_ERR_STATE, "frl_per_enable first");
+    if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
+    int rc = flush_stage(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t nn = 2 * (size_t)e->h.capacity - 1;
+    if (sum_out) HIP_TRY(hipMemcpy(sum_out, e->d_per_sum + learner * nn, sizeof(double), hipMemcpyDeviceToHost));
+    if (max_out) HIP_TRY(hipMemcpy(max_out, e->d_per_max + learner * nn, sizeof(double), hipMemcpyDeviceToHost));
+    if (beta_out) *beta_out = e->per_beta;
     return FRL_OK;
 }
 

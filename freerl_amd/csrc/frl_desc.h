@@ -86,6 +86,8 @@ struct EngineDesc {
     // LDS carve parameters (must match between host lds_bytes() and device carve_lds())
     int lds_kin_pad, lds_out_pad, lds_batch_pad, lds_act_pad;
     int n_discrete;       // DQN: number of discrete actions (0 otherwise)
+    float* isw;           // [P][batch_max] PER importance weights of the current sample (DQN_with_tricks.py:276-279)
+    float* td_err;        // [P][batch_max] TD errors Q(s,a) - y left by the last DQN learn (PER priorities)
     int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner
     // [1 + 3*O] floats = {n, mean[O], S[O], std[O]}; obs_norm_on switches every gather / act to
@@ -109,6 +111,8 @@ struct LearnArgs {
     int use_policy_noise;
     float target_entropy; // SAC
     unsigned long long rng_counter;   // device_rng: Philox counter of this call (host increments)
+    int double_dqn;       // DQN trick['Double']: a* = argmax_a Q(s',a), y uses Q_target(s', a*) (DQN_with_tricks.py:263-265)
+    int use_isw;          // DQN trick['PER']: loss = mean(w * td^2) with the weights in desc.isw (:276-278)
 };
 
 }  // namespace frl

@@ -129,10 +129,25 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
+    if (a.double_dqn) {              // the online net picks the action, the target net values it (DQN_with_tricks.py:263-265)
+        mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            int best = 0;
+            float mx = S.outb[r * S.op];
+            for (int j = 1; j < nA; ++j)
+                if (S.outb[r * S.op + j] > mx) { mx = S.outb[r * S.op + j]; best = j; }     // first maximum, like argmax
+            S.abuf[r * S.ap] = (float)best;
+        }
+        lds_barrier();
+    }
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
     for (int r = threadIdx.x; r < nv; r += kWG) {
-        float mx = S.outb[r * S.op];
-        for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+        float mx;
+        if (a.double_dqn) mx = S.outb[r * S.op + (int)S.abuf[r * S.ap]];
+        else {
+            mx = S.outb[r * S.op];
+            for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+        }
         g_cf rec = ring + (size_t)idx[r] * R.stride;
         S.y[r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
     }
@@ -142,6 +157,16 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     lds_barrier();
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
     float lossp = 0.f;
+    g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
+    g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
+    // use_isw == 1: the reference's arithmetic — `(is_weight * td_error**2).mean()` multiplies a [B] by a [B,1] tensor
+    // (DQN_with_tricks.py:277-278), i.e. mean(w) * mean(td^2): every row carries the MEAN weight.  2: per-row weights.
+    float wbar = 1.f;
+    if (a.use_isw == 1) {
+        float ws = 0.f;
+        for (int i = threadIdx.x; i < B; i += kWG) ws += D.isw[(size_t)p * D.batch_max + i];
+        wbar = block_sum(ws, S.red) / (float)B;
+    }
     for (int e = threadIdx.x; e < rc * npad; e += kWG) {
         const int r = e / npad, j = e - r * npad;
         float d = 0.f;
@@ -149,8 +174,10 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
             const int ar = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];   // actions.long() (DQN.py:114)
             if (j == ar) {
                 const float diff = S.outb[r * S.op + j] - S.y[r];
-                d = 2.f * diff / (float)B;
-                lossp += diff * diff;
+                const float w = a.use_isw == 2 ? isw[r] : wbar;
+                d = 2.f * w * diff / (float)B;
+                lossp += w * diff * diff;
+                tde[r] = diff;
             }
         }
         S.outb[r * S.op + j] = d;

@@ -174,10 +174,12 @@ class Engine:
     # ------------------------------------------------------------------ learn
     def learn(self, batch, *, gamma, tau, actor_lr=0.0, critic_lr=0.0, alpha_lr=1e-4, adam_eps=1e-8,
               critic_weight_decay=0.0, clip_norm=0.5, do_actor=True, use_policy_noise=False, policy_noise=0.0,
-              noise_clip=0.0, max_action=1.0, policy_noise_scale=1.0, target_entropy=0.0, idx=None, noise=None,
+              noise_clip=0.0, max_action=1.0, policy_noise_scale=1.0, target_entropy=0.0, double_dqn=False, per=False,
+              idx=None, noise=None,
               want_stats=False):
         a = N.LearnArgs()
         a.batch, a.do_actor, a.use_policy_noise = int(batch), int(bool(do_actor)), int(bool(use_policy_noise))
+        a.double_dqn, a.per = int(bool(double_dqn)), int(per)
         a.gamma, a.tau = gamma, tau
         a.actor_lr, a.critic_lr, a.alpha_lr, a.adam_eps = actor_lr, critic_lr, alpha_lr, adam_eps
         a.critic_weight_decay, a.clip_norm = critic_weight_decay, clip_norm
@@ -208,6 +210,36 @@ class Engine:
         fl, by = C.c_double(0), C.c_double(0)
         N.check(self._L.frl_learn_work(self._h, int(batch), int(bool(do_actor)), C.byref(fl), C.byref(by)))
         return fl.value, by.value
+
+    # ------------------------------------------------------------------ prioritised replay
+    def per_enable(self, alpha=0.5, beta=0.4, beta_increment=0.001, epsilon=0.01):
+        N.check(self._L.frl_per_enable(self._h, alpha, beta, beta_increment, epsilon))
+
+    def per_sample(self, batch, uniforms=None):
+        """-> (idx int64 [P][batch], is_weight f32 [P][batch]); the rows become the current sample for learn(per=True)."""
+        idx = np.zeros((self.P, int(batch)), np.int64)
+        w = np.zeros((self.P, int(batch)), F32)
+        up = None
+        if uniforms is not None:
+            u = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.P, int(batch))
+            up = u.ctypes.data_as(C.POINTER(C.c_double))
+        N.check(self._L.frl_per_sample(self._h, int(batch), up, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(w)))
+        return idx, w
+
+    def per_update(self, batch, idx=None, td_error=None):
+        ip = tp = None
+        if idx is not None:
+            ix = np.ascontiguousarray(idx, dtype=np.int64).reshape(self.P, int(batch))
+            ip = ix.ctypes.data_as(C.POINTER(C.c_int64))
+        if td_error is not None:
+            td = np.ascontiguousarray(td_error, dtype=F32).reshape(self.P, int(batch))
+            tp = _fp(td)
+        N.check(self._L.frl_per_update(self._h, int(batch), ip, tp))
+
+    def per_state(self, learner=0):
+        s, m, b = C.c_double(0), C.c_double(0), C.c_double(0)
+        N.check(self._L.frl_per_state(self._h, int(learner), C.byref(s), C.byref(m), C.byref(b)))
+        return dict(sum=s.value, max=m.value, beta=b.value)
 
     def ppo_learn(self, horizon, minibatch, k_epochs, *, gamma, lmbda, clip, ent_coef, actor_lr, critic_lr,
                   adam_eps=1e-8, clip_norm=0.5, adv_norm=False, perms=None, want_trace=False, want_adv=False,

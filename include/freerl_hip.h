@@ -116,6 +116,10 @@ typedef struct frl_learn_args {
     float clip_norm;           /* clip_grad_norm_ max_norm 0.5 (TD3.py:140); <= 0: none (DQN.py:56-59) */
     float policy_noise, noise_clip, max_action, policy_noise_scale;   /* TD3.py:196-198 */
     float target_entropy;      /* SAC: -act_dim (SAC.py:160) */
+    int double_dqn;            /* DQN trick['Double'] (DQN_with_tricks.py:263-265) */
+    int per;                   /* DQN trick['PER'] (:276-279): rows and importance weights of the last frl_per_sample; the TD errors
+                                  stay on the device for frl_per_update.  1 = the reference's arithmetic: its [B] weights times
+                                  [B,1] squared errors broadcast to [B,B], so loss = mean(w) * mean(td^2); 2 = mean(w_i * td_i^2) */
     const int64_t* idx;        /* host [P][n_agents][batch] rows drawn by the caller (np.random.choice,
                                   DQN.py:97) for bit-identical sampling; NULL: drawn on the device */
     const float* noise;        /* host [P][n_agents][S][batch][act_max], S = max(2, n_agents): N(0,1) draws the reference
@@ -220,6 +224,21 @@ int frl_ppo_learn(frl_engine* e, const frl_ppo_args* args);
  * PPO_with_tricks.py:308-311 / PPO.py:229-231 */
 int frl_gae(frl_engine* e, const float* td_delta_dev, const float* adv_done_dev, int n_seq, int horizon,
             float gamma, float lmbda, float* adv_out_dev);
+
+/* ---------------------------------------------------------------- prioritised replay
+ * PER_Buffer + SumTree (DQN_file/Buffer.py:66-194) on the engine's ring: a float64 sum-tree and max-tree per learner in HBM.
+ * add (frl_buffer_add*) gives new rows the current maximum priority, 1.0 on an empty buffer (:92-98). */
+/* PER_Buffer.__init__ (:81-90).  beta and its increment stay doubles (the reference's Python floats); alpha and epsilon act
+ * on float32 TD errors. */
+int frl_per_enable(frl_engine* e, double alpha, double beta, double beta_increment, double epsilon);
+/* PER_Buffer.sample (:99-124): beta += increment; `batch` stratified descents with s = a + (b-a)*u.  uniforms: host
+ * [P][batch] draws of np.random.uniform's underlying random_sample(), or NULL (device Philox).  The sampled rows become the
+ * engine's current sample (frl_learn with per = 1); idx_out / is_weight_out: host [P][batch] or NULL. */
+int frl_per_sample(frl_engine* e, int batch, const double* uniforms, int64_t* idx_out, float* is_weight_out);
+/* PER_Buffer.update_priorities (:126-129): priority = (|td| + epsilon)^alpha in float32.  idx / td_error: host [P][batch],
+ * or NULL = the rows of the last frl_per_sample / the TD errors the last frl_learn(per = 1) left on the device. */
+int frl_per_update(frl_engine* e, int batch, const int64_t* idx, const float* td_error);
+int frl_per_state(frl_engine* e, int learner, double* sum_out, double* max_out, double* beta_out);   /* sumtree.sum(), .max(), beta */
 
 /* ---------------------------------------------------------------- env pool + rollout
  * The step BEFORE the path: the reference steps one Python env inline per update (DQN.py:316) and

@@ -50,21 +50,36 @@ class DQN:
     def learn(self, batch_size, gamma, tau):
         return self.learn_with(_choice(len(self.buffer), batch_size), gamma, tau)
 
-    def learn_with(self, idx, gamma, tau):              # DQN.py:104-118
+    def learn_with(self, idx, gamma, tau, double=False, is_weight=None):
+        """DQN.py:104-118; `double` / `is_weight`: DQN_with_tricks.py:263-265 / :276-279 (returns the TD errors too)."""
         obs, act, rew, nobs, done = self.buffer.sample(idx)
         B = obs.shape[0]
-        next_q = self.net.forward(self.q_t, nobs)[0].max(axis=1).reshape(-1, 1)
+        qt = self.net.forward(self.q_t, nobs)[0]
+        if double:
+            a_star = np.argmax(self.net.forward(self.q, nobs)[0], axis=1)
+            next_q = qt[np.arange(B), a_star].reshape(-1, 1)
+        else:
+            next_q = qt.max(axis=1).reshape(-1, 1)
         y = rew + F32(gamma) * next_q * (F32(1) - done)
         q, acts = self.net.forward(self.q, obs)
         a = act.astype(np.int64).reshape(-1)
         cur = q[np.arange(B), a].reshape(-1, 1)
-        loss, dcur = nn.mse(cur, y)
+        if is_weight is None:
+            loss, dcur = nn.mse(cur, y)
+        else:
+            # DQN_with_tricks.py:277-278: `is_weight` is a 1-D [B] tensor and `td_error ** 2` is [B,1], so their product
+            # broadcasts to [B,B] and `.mean()` = mean(w) * mean(td^2): every sample is weighted by the MEAN weight
+            w = nn.f32(is_weight).reshape(1, -1)
+            td = cur - y
+            loss = F32(np.mean(w * (td * td), dtype=F32))
+            dcur = (F32(2.0 / B) * F32(np.mean(w, dtype=F32)) * td).astype(F32)
         dq = np.zeros_like(q)
         dq[np.arange(B), a] = dcur.reshape(-1)
         _, g = self.net.backward(self.q, acts, dq, need_dx=False)
         self.opt.step(self.q, g)                        # Agent.update_Qnet: no clipping (DQN.py:56-59)
         nn.soft_update(self.q_t, self.q, tau)           # DQN.py:120-128
         self.losses.append(loss)
+        self.last_td = (cur - y).reshape(-1)
         return loss
 
 

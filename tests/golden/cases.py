@@ -29,6 +29,12 @@ CASES = {
     # Buffer ring + sample (TD3_file/Buffer.py:11-61)
     "buffer": dict(kind="buffer", obs_dim=5, act_dim=2, capacity=300, n_add=450, batch=64,
                    table_seed=11, idx_seed=12),
+    # PER_Buffer + SumTree (DQN_file/Buffer.py:66-194): add past the capacity, stratified samples, priority updates
+    "per_buffer": dict(kind="per_buffer", obs_dim=5, act_dim=1, capacity=300, n_add=450, batch=64, n_rounds=4,
+                       table_seed=15, u_seed=16, td_seed=17),
+    # DQN_with_tricks.learn with trick Double + PER + N_Step (DQN_with_tricks.py:242-284, N_Step_PER_Buffer Buffer.py:333-399)
+    "dqn_tricks": dict(kind="dqn_tricks", obs_dim=8, n_actions=4, capacity=2048, n_table=700, batch=128, n_learn=5,
+                       gamma=0.99, n_step=3, tau=0.01, lr=1e-3, table_seed=133, param_seed=1010, u_seed=2010),
     # DQN.learn (DQN_file/DQN.py:104-128); SYN-D shape of SURVEY §8(d)
     "dqn": dict(kind="dqn", obs_dim=8, n_actions=4, capacity=4096, n_table=1024, batch=256,
                 n_learn=5, gamma=0.99, tau=0.01, lr=1e-3, table_seed=123, param_seed=1000,
@@ -113,6 +119,23 @@ def dqn_inputs(c):
     params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("l2", c["n_actions"], H)])
     idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
     return dict(table=tab, params=dict(Qnet=params), idx=idx)
+
+
+def per_buffer_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_add"], c["obs_dim"], 1, n_discrete=3)
+    g = np.random.default_rng(c["u_seed"])
+    us = [g.random(c["batch"]) for _ in range(c["n_rounds"])]                    # float64 in [0,1)
+    g2 = np.random.default_rng(c["td_seed"])
+    tds = [(g2.standard_normal((c["batch"], 1)) * 2).astype(np.float32) for _ in range(c["n_rounds"])]
+    return dict(table=tab, uniforms=us, td=tds)
+
+
+def dqn_tricks_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_table"], c["obs_dim"], 1, n_discrete=c["n_actions"])
+    params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("l2", c["n_actions"], H)])
+    g = np.random.default_rng(c["u_seed"])
+    us = [g.random(c["batch"]) for _ in range(c["n_learn"])]
+    return dict(table=tab, params=dict(Qnet=params), uniforms=us)
 
 
 def ac_inputs(c, twin, gaussian=False):

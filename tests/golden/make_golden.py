@@ -148,6 +148,70 @@ def _ac_outputs(pol, out, rec, loss_names):
         out[net + "_step"] = np.int64(step)
 
 
+class _UniformFeeder:
+    """np.random.uniform(a, b) driven by injected random_sample() draws: a + (b - a) * u, NumPy's own formula."""
+
+    def __init__(self, us):
+        self._it = iter([u for batch in us for u in batch])
+
+    def __call__(self, a, b):
+        return a + (b - a) * next(self._it)
+
+
+def gen_per_buffer(out):
+    c = cases.CASES["per_buffer"]
+    inp = cases.per_buffer_inputs(c)
+    mod = import_reference("DQN_file", "Buffer")
+    buf = mod.PER_Buffer(c["capacity"], c["obs_dim"], 1, CPU)
+    tab = inp["table"]
+    half = c["n_add"] // 2
+    for i in range(half):
+        buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    out["sum_after_first_adds"] = np.float64(buf.sumtree.sum())
+    added = half
+    with inject(np.random, "uniform", _UniformFeeder(inp["uniforms"])):
+        for k in range(c["n_rounds"]):
+            idx, w = buf.sample(c["batch"])
+            out["idx/%d" % k] = idx
+            out["is_weight/%d" % k] = w.numpy()
+            buf.update_priorities(idx, inp["td"][k])
+            out["sum/%d" % k] = np.float64(buf.sumtree.sum())
+            out["max/%d" % k] = np.float64(buf.sumtree.max())
+            for i in range(added, min(added + 60, c["n_add"])):        # more adds between rounds: wraps the ring in round 2
+                buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+            added = min(added + 60, c["n_add"])
+            out["sum_after_adds/%d" % k] = np.float64(buf.sumtree.sum())
+    out["beta"] = np.float64(buf.beta)
+    out["leaves"] = buf.sumtree.tree[-c["capacity"]:].copy()
+    out["size"] = np.int64(len(buf))
+
+
+def gen_dqn_tricks(out):
+    c = cases.CASES["dqn_tricks"]
+    inp = cases.dqn_tricks_inputs(c)
+    mod = import_reference("DQN_file", "DQN_with_tricks")
+    trick = dict(Double=True, Dueling=False, PER=True, Noisy=False, N_Step=True, Categorical=False)
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU, trick=trick, gamma=c["gamma"], batch_size=c["batch"])
+    assert pol.buffer.n_step == c["n_step"]
+    load(pol.agent.Qnet, inp["params"]["Qnet"])
+    load(pol.agent.Qnet_target, inp["params"]["Qnet"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    out["size"] = np.int64(len(pol.buffer))
+    out["stored_rewards"] = pol.buffer.buffer.rewards[:len(pol.buffer)].astype(np.float32)
+    out["stored_dones"] = pol.buffer.buffer.dones[:len(pol.buffer)].copy()
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    with inject(np.random, "uniform", _UniformFeeder(inp["uniforms"])):
+        for k in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            out["tree_sum/%d" % k] = np.float64(pol.buffer.sumtree.sum())
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    out["beta"] = np.float64(pol.buffer.beta)
+    synth.pack_digest("Qnet", t2n(pol.agent.Qnet.state_dict()), out)
+    synth.pack_digest("Qnet_target", t2n(pol.agent.Qnet_target.state_dict()), out)
+
+
 def gen_ddpg(out):
     c = cases.CASES["ddpg"]
     inp = cases.ac_inputs(c, twin=False)
@@ -710,7 +774,7 @@ def survey_known_answers():
 
 def main():
     gens = {
-        "buffer": gen_buffer, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
+        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),

@@ -749,3 +749,75 @@ def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
     test_sac_learn(N)
     test_maddpg_learn(N)
     test_matd3_learn(N)
+
+
+# ------------------------------------------------------------------ PER / N-step / Double
+def test_per_buffer_sumtree_on_device(N):
+    """frl_per_*: new rows at the max priority, stratified descents with injected uniforms (bit-exact indices), IS
+    weights, float32 priorities from TD errors, ring wrap — against the golden of the reference's PER_Buffer/SumTree."""
+    from freerl_amd.engine import Engine
+    c = cases.CASES["per_buffer"]
+    inp = cases.per_buffer_inputs(c)
+    fx = gold("per_buffer")
+    e = Engine(N.ALGO_REPLAY_ONLY, c["obs_dim"], 1, c["capacity"], batch_max=c["batch"])
+    e.per_enable(0.5, 0.4, 0.001, 0.01)
+    tab = inp["table"]
+    recs = records([tab])
+    half = c["n_add"] // 2
+    e.add_batch(recs[:half])
+    np.testing.assert_allclose(e.per_state()["sum"], float(fx["sum_after_first_adds"]), rtol=1e-14)
+    added = half
+    for k in range(c["n_rounds"]):
+        idx, w = e.per_sample(c["batch"], uniforms=inp["uniforms"][k])
+        np.testing.assert_array_equal(idx[0], fx["idx/%d" % k])
+        np.testing.assert_allclose(w[0], fx["is_weight/%d" % k], rtol=2e-6)
+        e.per_update(c["batch"], idx=idx, td_error=inp["td"][k].reshape(1, -1))
+        st = e.per_state()
+        np.testing.assert_allclose(st["sum"], float(fx["sum/%d" % k]), rtol=1e-6)     # float32 pow: powf vs NumPy, 1 ulp
+        np.testing.assert_allclose(st["max"], float(fx["max/%d" % k]), rtol=1e-6)
+        stop = min(added + 60, c["n_add"])
+        if stop > added:
+            e.add_batch(recs[added:stop])
+        added = stop
+        np.testing.assert_allclose(e.per_state()["sum"], float(fx["sum_after_adds/%d" % k]), rtol=1e-6)
+    assert abs(e.per_state()["beta"] - float(fx["beta"])) < 1e-12 and e.cursor(0)[1] == int(fx["size"])
+    e.close()
+
+
+def test_dqn_with_tricks_double_per_nstep(N):
+    """DQN_with_tricks.learn (Double + PER + N_Step) through the class: n-step fold on add, PER sample -> fused update with
+    the reference's weight broadcasting -> priority update; vs the golden from the imported reference."""
+    from freerl_amd.DQN_with_tricks import DQN
+    import torch
+    c = cases.CASES["dqn_tricks"]
+    inp = cases.dqn_tricks_inputs(c)
+    fx = gold("dqn_tricks")
+    trick = dict(Double=True, Dueling=False, PER=True, Noisy=False, N_Step=True, Categorical=False)
+    pol = DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], "cuda", trick=trick, gamma=c["gamma"],
+              batch_size=c["batch"], batch_max=c["batch"])
+    sd = {k: torch.from_numpy(v.copy()) for k, v in inp["params"]["Qnet"].items()}
+    pol.agent.Qnet.load_state_dict(sd)
+    pol.agent.Qnet_target.load_state_dict(sd)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    assert len(pol.buffer) == int(fx["size"])
+    np.testing.assert_array_equal(pol.buffer.buffer.rewards[:len(pol.buffer)], fx["stored_rewards"])
+    np.testing.assert_array_equal(pol.buffer.buffer.dones[:len(pol.buffer)], fx["stored_dones"])
+    pol.track_loss = True
+    losses = []
+    us = iter([u for b in inp["uniforms"] for u in b])
+    orig = np.random.random_sample
+    np.random.random_sample = lambda *a: next(us)
+    try:
+        for k in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            losses.append(pol.last_loss)
+            np.testing.assert_allclose(pol.buffer.sumtree.sum(), float(fx["tree_sum/%d" % k]), rtol=2e-4)
+    finally:
+        np.random.random_sample = orig
+    np.testing.assert_allclose(losses, fx["loss"], rtol=5e-4)
+    got = {k: v.numpy() for k, v in pol.agent.Qnet.state_dict().items()}
+    synth.check_digest("Qnet", got, fx, 2e-3, 2e-5, "hip-vs-reference")
+    with pytest.raises(NotImplementedError):
+        DQN([4, 2], False, 1e-3, 64, "cuda", trick=dict(trick, Dueling=True), gamma=0.99)

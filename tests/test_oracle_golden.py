@@ -155,6 +155,59 @@ def test_maddpg_learn():
         synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, P_RTOL, P_ATOL)
 
 
+def test_per_buffer_and_sumtree():
+    """PER_Buffer (DQN_file/Buffer.py:66-194): priorities on add, stratified sampling, IS weights, priority updates."""
+    from oracle.buffer import PERBuffer
+    c = cases.CASES["per_buffer"]
+    inp = cases.per_buffer_inputs(c)
+    fx = gold("per_buffer")
+    buf = PERBuffer(c["capacity"], c["obs_dim"], 1)
+    tab = inp["table"]
+    half = c["n_add"] // 2
+    for i in range(half):
+        buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    assert buf.sumtree.sum() == float(fx["sum_after_first_adds"])
+    added = half
+    for k in range(c["n_rounds"]):
+        idx, w = buf.sample_with(inp["uniforms"][k])
+        np.testing.assert_array_equal(idx, fx["idx/%d" % k])
+        np.testing.assert_allclose(w, fx["is_weight/%d" % k], rtol=1e-6)
+        buf.update_priorities(idx, inp["td"][k])
+        assert buf.sumtree.sum() == float(fx["sum/%d" % k]) and buf.sumtree.max() == float(fx["max/%d" % k])
+        for i in range(added, min(added + 60, c["n_add"])):
+            buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+        added = min(added + 60, c["n_add"])
+        assert buf.sumtree.sum() == float(fx["sum_after_adds/%d" % k])
+    assert buf.beta == float(fx["beta"]) and len(buf) == int(fx["size"])
+    np.testing.assert_array_equal(buf.sumtree.tree[-c["capacity"]:], fx["leaves"])
+
+
+def test_dqn_with_tricks_double_per_nstep():
+    """DQN_with_tricks.learn with Double + PER + N_Step (DQN_with_tricks.py:242-284; N_Step_PER_Buffer Buffer.py:333-399)."""
+    from oracle.buffer import NStepWrapper, PERBuffer
+    c = cases.CASES["dqn_tricks"]
+    inp = cases.dqn_tricks_inputs(c)
+    fx = gold("dqn_tricks")
+    pol = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+    per = PERBuffer(c["capacity"], c["obs_dim"], 1)
+    pol.buffer = per.buffer
+    front = NStepWrapper(per, c["gamma"], c["n_step"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        front.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    assert len(per) == int(fx["size"]) == c["n_table"] - c["n_step"] + 1
+    np.testing.assert_array_equal(per.buffer.rewards[:len(per)].astype(np.float32), fx["stored_rewards"])
+    np.testing.assert_array_equal(per.buffer.dones[:len(per)], fx["stored_dones"])
+    for k in range(c["n_learn"]):
+        idx, w = per.sample_with(inp["uniforms"][k])
+        pol.learn_with(idx, front.n_step_gamma, c["tau"], double=True, is_weight=w)
+        per.update_priorities(idx, pol.last_td)
+        np.testing.assert_allclose(per.sumtree.sum(), float(fx["tree_sum/%d" % k]), rtol=1e-5)
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+
+
 def test_ppo_beta_actor():
     """PPO_with_tricks.py with beta=True (Actor_Beta :120-151): alpha/beta heads, Beta log-prob / entropy / mean."""
     c = cases.CASES["ppo_beta"]
