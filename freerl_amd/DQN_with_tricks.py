@@ -1,6 +1,6 @@
 """`DQN` of DQN_file/DQN_with_tricks.py (:160-308) with the tricks that live on the replay path: Double
-(:263-265), PER (PER_Buffer / N_Step_PER_Buffer, :276-279) and N_Step (:269-270).  The network-side Rainbow tricks
-(Dueling :60-79, Noisy Noisy_net.py, Categorical/C51 :82-158) are not ported and raise NotImplementedError.
+(:263-265), PER (PER_Buffer / N_Step_PER_Buffer, :276-279), N_Step (:269-270), plus the Dueling head (:60-79).  Noisy
+(Noisy_net.py) and Categorical/C51 (:82-158) are not ported and raise NotImplementedError.
 
     policy = DQN(dim_info, is_continue, Qnet_lr, buffer_size, device, trick=..., gamma=..., batch_size=...)
 
@@ -13,11 +13,55 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import Engine, draw_indices, resolve_device
+from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
 from .Buffer import Buffer, N_Step_Buffer, N_Step_PER_Buffer, PER_Buffer
 from .DQN import Agent
 
-_NETWORK_TRICKS = ("Dueling", "Noisy", "Categorical")
+_NETWORK_TRICKS = ("Noisy", "Categorical")
+
+
+class DuelingNet(DeviceNet):
+    """`agent.Qnet` of Dueling (DQN_with_tricks.py:60-79): state_dict keys l1 / V / A; the engine keeps V and A as one
+    (1 + n_actions)-wide head [V ; A].  Calling it returns Q = V + A - mean(A)."""
+
+    def __init__(self, engine, hidden, obs_dim, action_dim, kind=N.PARAM_ONLINE):
+        super().__init__(engine, 0, [("l1", hidden, obs_dim), ("head", 1 + action_dim, hidden)], kind=kind, act_mode=N.ACT_RAW)
+        self._nA = action_dim
+
+    def keys(self):
+        return ["l1.weight", "l1.bias", "V.weight", "V.bias", "A.weight", "A.bias"]
+
+    def _split(self, flat):
+        parts = super()._split(flat)
+        w, b = parts.pop("head.weight"), parts.pop("head.bias")
+        parts.update({"V.weight": w[:1], "V.bias": b[:1], "A.weight": w[1:], "A.bias": b[1:]})
+        return parts
+
+    def load_state_dict(self, sd, strict=True):
+        if strict and set(sd.keys()) != set(self.keys()):
+            raise RuntimeError("Error(s) in loading state_dict: expected keys %s, got %s" % (self.keys(), list(sd.keys())))
+        t = lambda k: np.asarray(torch.as_tensor(sd[k]).detach().cpu().numpy(), dtype=np.float32).reshape(-1)
+        flat = [t(k) for k in ("l1.weight", "l1.bias", "V.weight", "A.weight", "V.bias", "A.bias")]
+        self._e.set_params(self._net, np.concatenate(flat), self._kind, self._learner)
+
+    def __call__(self, obs):
+        h = super().__call__(obs)
+        return h[:, :1] + h[:, 1:] - h[:, 1:].mean(dim=1, keepdim=True)
+
+
+class DuelingAgent:
+    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden):
+        # torch RNG order of Dueling.__init__: l1, V, A (:67-74); the engine's flat order is l1, [V.w ; A.w], [V.b ; A.b]
+        f = init_layers([("l1", hidden, obs_dim), ("V", 1, hidden), ("A", action_dim, hidden)])
+        o = hidden * obs_dim + hidden
+        vw, vb = f[o:o + hidden], f[o + hidden:o + hidden + 1]
+        aw, ab = f[o + hidden + 1:o + hidden + 1 + action_dim * hidden], f[o + hidden + 1 + action_dim * hidden:]
+        flat = np.concatenate([f[:o], vw, aw, vb, ab])
+        engine.set_params(0, flat, N.PARAM_ONLINE)
+        engine.set_params(0, flat, N.PARAM_TARGET)
+        self.Qnet = DuelingNet(engine, hidden, obs_dim, action_dim)
+        self.Qnet_target = DuelingNet(engine, hidden, obs_dim, action_dim, kind=N.PARAM_TARGET)
+        self.Qnet_optimizer = OptimizerView(engine, 0, Qnet_lr)
 
 
 class DQN:
@@ -31,8 +75,8 @@ class DQN:
                 raise NotImplementedError("trick['%s'] (DQN_with_tricks.py) is not ported" % k)
         hip_id, self.device = resolve_device(device)
         self._e = Engine(N.ALGO_DQN, obs_dim, action_dim, max(int(buffer_size), 1), discrete=True, hidden=hidden,
-                         batch_max=batch_max, device_id=hip_id, seed=seed)
-        self.agent = Agent(self._e, obs_dim, action_dim, Qnet_lr, hidden)
+                         batch_max=batch_max, device_id=hip_id, seed=seed, dueling=bool(trick["Dueling"]))
+        self.agent = (DuelingAgent if trick["Dueling"] else Agent)(self._e, obs_dim, action_dim, Qnet_lr, hidden)
         kw = dict(_engine=self._e)
         if trick["PER"] and trick["N_Step"]:                                   # :176-183
             self.buffer = N_Step_PER_Buffer(buffer_size, obs_dim, 1, self.device, gamma=gamma, **kw)

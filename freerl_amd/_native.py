@@ -37,7 +37,7 @@ class Config(C.Structure):
     _fields_ = [("algo", C.c_int), ("n_learners", C.c_int), ("n_agents", C.c_int),
                 ("obs_dim", C.c_int * FRL_MAX_AGENTS), ("act_dim", C.c_int * FRL_MAX_AGENTS),
                 ("discrete", C.c_int), ("hidden", C.c_int), ("hidden_act", C.c_int), ("twin_critic", C.c_int),
-                ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("actor_dist", C.c_int),
+                ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("actor_dist", C.c_int), ("dueling", C.c_int),
                 ("device_id", C.c_int),
                 ("seed", C.c_uint64)]
 

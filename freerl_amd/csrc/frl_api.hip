@@ -282,7 +282,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->has_nets = c.algo != FRL_ALGO_REPLAY_ONLY;
     if (c.algo == FRL_ALGO_DQN) {
         h.n_nets = 1;
-        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);   // MLP, DQN.py:32-45
+        h.dueling = c.dueling ? 1 : 0;
+        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0] + (c.dueling ? 1 : 0), H}}, 1, ACT_RELU, ACT_NONE, 0);   // MLP, DQN.py:32-45
     } else if (c.algo == FRL_ALGO_PPO) {
         h.n_nets = 2;
         if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits

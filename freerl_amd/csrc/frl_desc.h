@@ -88,6 +88,7 @@ struct EngineDesc {
     int n_discrete;       // DQN: number of discrete actions (0 otherwise)
     float* isw;           // [P][batch_max] PER importance weights of the current sample (DQN_with_tricks.py:276-279)
     float* td_err;        // [P][batch_max] TD errors Q(s,a) - y left by the last DQN learn (PER priorities)
+    int dueling;          // DQN: head = [V ; A] (1 + n_discrete outputs), Q = V + A - mean(A) (DQN_with_tricks.py:60-79)
     int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner
     // [1 + 3*O] floats = {n, mean[O], S[O], std[O]}; obs_norm_on switches every gather / act to

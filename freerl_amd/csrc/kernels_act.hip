@@ -58,11 +58,16 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     mlp_fwd(N, l0, nl, theta, S, out_act);
     const int nout = N.L[l0 + nl - 1].n;
     if (a.mode == ACTM_ARGMAX) {
+        const bool duel = D.dueling && D.algo == ALGO_DQN;       // Q = V + A - mean(A) (DQN_with_tricks.py:79): head = [V ; A]
         for (int r = threadIdx.x; r < nv; r += kWG) {
+            lds_cf o = S.outb + r * S.op;
+            const int nq = duel ? nout - 1 : nout;
+            float mean = 0.f;
+            if (duel) { for (int j = 0; j < nq; ++j) mean += o[1 + j]; mean /= (float)nq; }
             int best = 0;
-            float mx = S.outb[r * S.op];
-            for (int j = 1; j < nout; ++j) {       // first maximum wins, like torch.argmax
-                const float v = S.outb[r * S.op + j];
+            float mx = duel ? (o[0] + o[1]) - mean : o[0];
+            for (int j = 1; j < nq; ++j) {         // first maximum wins, like torch.argmax
+                const float v = duel ? (o[0] + o[1 + j]) - mean : o[j];
                 if (v > mx) { mx = v; best = j; }
             }
             a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;

@@ -124,7 +124,15 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
-    const int O = R.obs_dim[0], nA = N.L[nl - 1].n, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
+    const int O = R.obs_dim[0], nA = D.n_discrete, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
+    const bool duel = D.dueling != 0;
+    // Q(s, j) of row r out of the head in outb: plain, or Dueling's V + A_j - mean(A) with the head laid out [V ; A]
+    auto q_of = [&](int r, int j, float mean) { lds_cf o = S.outb + r * S.op; return duel ? (o[0] + o[1 + j]) - mean : o[j]; };
+    auto a_mean = [&](int r) {
+        float m = 0.f;
+        if (duel) { for (int j = 0; j < nA; ++j) m += S.outb[r * S.op + 1 + j]; m /= (float)nA; }
+        return m;
+    };
 
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
@@ -132,21 +140,25 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     if (a.double_dqn) {              // the online net picks the action, the target net values it (DQN_with_tricks.py:263-265)
         mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
         for (int r = threadIdx.x; r < nv; r += kWG) {
+            const float mean = a_mean(r);
             int best = 0;
-            float mx = S.outb[r * S.op];
-            for (int j = 1; j < nA; ++j)
-                if (S.outb[r * S.op + j] > mx) { mx = S.outb[r * S.op + j]; best = j; }     // first maximum, like argmax
+            float mx = q_of(r, 0, mean);
+            for (int j = 1; j < nA; ++j) {
+                const float v = q_of(r, j, mean);
+                if (v > mx) { mx = v; best = j; }     // first maximum, like argmax
+            }
             S.abuf[r * S.ap] = (float)best;
         }
         lds_barrier();
     }
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
     for (int r = threadIdx.x; r < nv; r += kWG) {
+        const float mean = a_mean(r);
         float mx;
-        if (a.double_dqn) mx = S.outb[r * S.op + (int)S.abuf[r * S.ap]];
+        if (a.double_dqn) mx = q_of(r, (int)S.abuf[r * S.ap], mean);
         else {
-            mx = S.outb[r * S.op];
-            for (int j = 1; j < nA; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+            mx = q_of(r, 0, mean);
+            for (int j = 1; j < nA; ++j) mx = fmaxf(mx, q_of(r, j, mean));
         }
         g_cf rec = ring + (size_t)idx[r] * R.stride;
         S.y[r] = rec[R.rew_off] + a.gamma * mx * (1.f - rec[R.done_off]);
@@ -167,20 +179,26 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
         for (int i = threadIdx.x; i < B; i += kWG) ws += D.isw[(size_t)p * D.batch_max + i];
         wbar = block_sum(ws, S.red) / (float)B;
     }
-    for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-        const int r = e / npad, j = e - r * npad;
+    // head delta, one thread per row: d = 2 w (Q(s,a) - y) / B on the taken action; through Dueling's recombination
+    // dV = d, dA_j = d (delta_ja - 1/nA)
+    for (int r = threadIdx.x; r < rc; r += kWG) {
         float d = 0.f;
+        int ar = 0;
         if (r < nv) {
-            const int ar = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];   // actions.long() (DQN.py:114)
-            if (j == ar) {
-                const float diff = S.outb[r * S.op + j] - S.y[r];
-                const float w = a.use_isw == 2 ? isw[r] : wbar;
-                d = 2.f * w * diff / (float)B;
-                lossp += w * diff * diff;
-                tde[r] = diff;
-            }
+            ar = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];             // actions.long() (DQN.py:114)
+            const float diff = q_of(r, ar, a_mean(r)) - S.y[r];
+            const float w = a.use_isw == 2 ? isw[r] : wbar;
+            d = 2.f * w * diff / (float)B;
+            lossp += w * diff * diff;
+            tde[r] = diff;
         }
-        S.outb[r * S.op + j] = d;
+        lds_f o = S.outb + r * S.op;
+        for (int j = 0; j < npad; ++j) {
+            float v = 0.f;
+            if (duel) { if (j == 0) v = d; else if (j <= nA) v = d * ((j - 1 == ar ? 1.f : 0.f) - 1.f / (float)nA); }
+            else if (j == ar) v = d;
+            o[j] = v;
+        }
     }
     lds_barrier();
     mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);

@@ -86,6 +86,8 @@ typedef struct frl_config {
     int extra_cols;               /* extra record columns (PPO: act_dim log-probs + 1 adv_done) */
     int actor_dist;               /* PPO, continuous: 0 Gaussian `Actor` (PPO_with_tricks.py:79-108), 1 `Actor_Beta` (:120-151):
                                      the actor's head is [alpha_layer ; beta_layer] = 2*act_dim outputs, no log_std */
+    int dueling;                  /* DQN trick['Dueling'] (DQN_with_tricks.py:60-79): the head is [V ; A] = 1 + n_actions outputs and
+                                     Q = V + A - mean(A) */
     int device_id;
     uint64_t seed;                /* device Philox key (fast path only) */
 } frl_config;

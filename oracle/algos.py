@@ -27,13 +27,36 @@ def _choice(size, batch):
 
 
 # ---------------------------------------------------------------------------------------- DQN
-class DQN:
-    """DQN_file/DQN.py:62-128.  Q-net MLP obs->128->n_actions, target copy, Adam(lr)."""
+class DuelingNet:
+    """Dueling (DQN_file/DQN_with_tricks.py:60-79): a = relu(l1 s); Q = V(a) + A(a) - mean_j A_j(a).  Same forward /
+    backward interface as nn.MLP."""
 
-    def __init__(self, params, obs_dim, n_actions, lr, capacity):
+    def forward(self, p, x):
+        h = np.maximum(x @ p["l1.weight"].T + p["l1.bias"], 0).astype(F32)
+        V = h @ p["V.weight"].T + p["V.bias"]
+        A = h @ p["A.weight"].T + p["A.bias"]
+        q = ((V + A) - A.mean(axis=1, keepdims=True, dtype=F32)).astype(F32)
+        return q, [x, h]
+
+    def backward(self, p, acts, dq, need_dx=False):
+        x, h = acts
+        dV = dq.sum(axis=1, keepdims=True).astype(F32)
+        dA = (dq - dq.mean(axis=1, keepdims=True, dtype=F32)).astype(F32)
+        g = {"V.weight": dV.T @ h, "V.bias": dV.sum(axis=0), "A.weight": dA.T @ h, "A.bias": dA.sum(axis=0)}
+        dh = (dV @ p["V.weight"] + dA @ p["A.weight"]) * (h > 0)
+        g["l1.weight"] = dh.T @ x
+        g["l1.bias"] = dh.sum(axis=0)
+        return None, {k: g[k].astype(F32) for k in p}
+
+
+class DQN:
+    """DQN_file/DQN.py:62-128.  Q-net MLP obs->128->n_actions, target copy, Adam(lr).  dueling=True: DQN_with_tricks'
+    Dueling net (params l1, V, A)."""
+
+    def __init__(self, params, obs_dim, n_actions, lr, capacity, dueling=False):
         self.q = nn.copy_params(params)
         self.q_t = nn.copy_params(params)
-        self.net = MLP(["l1", "l2"])
+        self.net = DuelingNet() if dueling else MLP(["l1", "l2"])
         self.opt = Adam(self.q, lr)
         self.buffer = Buffer(capacity, obs_dim, 1)
         self.losses = []

@@ -35,6 +35,9 @@ CASES = {
     # DQN_with_tricks.learn with trick Double + PER + N_Step (DQN_with_tricks.py:242-284, N_Step_PER_Buffer Buffer.py:333-399)
     "dqn_tricks": dict(kind="dqn_tricks", obs_dim=8, n_actions=4, capacity=2048, n_table=700, batch=128, n_learn=5,
                        gamma=0.99, n_step=3, tau=0.01, lr=1e-3, table_seed=133, param_seed=1010, u_seed=2010),
+    # DQN_with_tricks.learn with trick Dueling + Double (DQN_with_tricks.py:60-79,263-265), uniform replay
+    "dqn_dueling": dict(kind="dqn_dueling", obs_dim=8, n_actions=4, capacity=2048, n_table=600, batch=128, n_learn=4,
+                        gamma=0.99, tau=0.01, lr=1e-3, table_seed=134, param_seed=1020, idx_seed=2020),
     # DQN.learn (DQN_file/DQN.py:104-128); SYN-D shape of SURVEY §8(d)
     "dqn": dict(kind="dqn", obs_dim=8, n_actions=4, capacity=4096, n_table=1024, batch=256,
                 n_learn=5, gamma=0.99, tau=0.01, lr=1e-3, table_seed=123, param_seed=1000,
@@ -128,6 +131,13 @@ def per_buffer_inputs(c):
     g2 = np.random.default_rng(c["td_seed"])
     tds = [(g2.standard_normal((c["batch"], 1)) * 2).astype(np.float32) for _ in range(c["n_rounds"])]
     return dict(table=tab, uniforms=us, td=tds)
+
+
+def dqn_dueling_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_table"], c["obs_dim"], 1, n_discrete=c["n_actions"])
+    params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("V", 1, H), ("A", c["n_actions"], H)])
+    idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
+    return dict(table=tab, params=dict(Qnet=params), idx=idx)
 
 
 def dqn_tricks_inputs(c):

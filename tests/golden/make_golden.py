@@ -212,6 +212,29 @@ def gen_dqn_tricks(out):
     synth.pack_digest("Qnet_target", t2n(pol.agent.Qnet_target.state_dict()), out)
 
 
+def gen_dqn_dueling(out):
+    c = cases.CASES["dqn_dueling"]
+    inp = cases.dqn_dueling_inputs(c)
+    mod = import_reference("DQN_file", "DQN_with_tricks")
+    trick = dict(Double=True, Dueling=True, PER=False, Noisy=False, N_Step=False, Categorical=False)
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU, trick=trick, gamma=c["gamma"], batch_size=c["batch"])
+    load(pol.agent.Qnet, inp["params"]["Qnet"])
+    load(pol.agent.Qnet_target, inp["params"]["Qnet"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    out["select_action"] = np.array([pol.select_action(tab["obs"][i]) for i in range(32)], dtype=np.int64)
+    with torch.no_grad():
+        out["q_values"] = pol.agent.Qnet(torch.as_tensor(tab["obs"][:8])).numpy()
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    synth.pack_digest("Qnet", t2n(pol.agent.Qnet.state_dict()), out)
+    synth.pack_digest("Qnet_target", t2n(pol.agent.Qnet_target.state_dict()), out)
+
+
 def gen_ddpg(out):
     c = cases.CASES["ddpg"]
     inp = cases.ac_inputs(c, twin=False)
@@ -774,7 +797,7 @@ def survey_known_answers():
 
 def main():
     gens = {
-        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
+        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),

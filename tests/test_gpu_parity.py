@@ -820,4 +820,42 @@ def test_dqn_with_tricks_double_per_nstep(N):
     got = {k: v.numpy() for k, v in pol.agent.Qnet.state_dict().items()}
     synth.check_digest("Qnet", got, fx, 2e-3, 2e-5, "hip-vs-reference")
     with pytest.raises(NotImplementedError):
-        DQN([4, 2], False, 1e-3, 64, "cuda", trick=dict(trick, Dueling=True), gamma=0.99)
+        DQN([4, 2], False, 1e-3, 64, "cuda", trick=dict(trick, Noisy=True), gamma=0.99)
+
+
+def test_dqn_dueling_double(N):
+    """Dueling + Double through the class (DQN_with_tricks.py:60-79,263-265): head [V ; A] in the engine, Q = V + A - mean(A)
+    in the act and update kernels, the reference's l1/V/A state_dict layout."""
+    from freerl_amd.DQN_with_tricks import DQN
+    import torch
+    c = cases.CASES["dqn_dueling"]
+    inp = cases.dqn_dueling_inputs(c)
+    fx = gold("dqn_dueling")
+    trick = dict(Double=True, Dueling=True, PER=False, Noisy=False, N_Step=False, Categorical=False)
+    pol = DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], "cuda", trick=trick, gamma=c["gamma"],
+              batch_size=c["batch"], batch_max=c["batch"])
+    assert list(pol.agent.Qnet.state_dict().keys()) == ["l1.weight", "l1.bias", "V.weight", "V.bias", "A.weight", "A.bias"]
+    sd = {k: torch.from_numpy(v.copy()) for k, v in inp["params"]["Qnet"].items()}
+    pol.agent.Qnet.load_state_dict(sd)
+    pol.agent.Qnet_target.load_state_dict(sd)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    np.testing.assert_array_equal([pol.select_action(tab["obs"][i]) for i in range(32)], fx["select_action"])
+    np.testing.assert_allclose(pol.agent.Qnet(torch.as_tensor(tab["obs"][:8])).numpy(), fx["q_values"], rtol=1e-5, atol=1e-6)
+    pol.track_loss = True
+    losses = []
+    it = iter(inp["idx"])
+    orig = np.random.choice
+    np.random.choice = lambda *a, **k: next(it)
+    try:
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            losses.append(pol.last_loss)
+    finally:
+        np.random.choice = orig
+    np.testing.assert_allclose(losses, fx["loss"], rtol=LOSS_RTOL)
+    got = {k: v.numpy() for k, v in pol.agent.Qnet.state_dict().items()}
+    synth.check_digest("Qnet", got, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    got_t = {k: v.numpy() for k, v in pol.agent.Qnet_target.state_dict().items()}
+    synth.check_digest("Qnet_target", got_t, fx, P_RTOL, P_ATOL, "hip-vs-reference")

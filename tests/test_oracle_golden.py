@@ -208,6 +208,24 @@ def test_dqn_with_tricks_double_per_nstep():
     synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
 
 
+def test_dqn_dueling_double():
+    """DQN_with_tricks.learn with Dueling + Double (DQN_with_tricks.py:60-79,263-265)."""
+    c = cases.CASES["dqn_dueling"]
+    inp = cases.dqn_dueling_inputs(c)
+    fx = gold("dqn_dueling")
+    pol = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"], dueling=True)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    np.testing.assert_array_equal([pol.select_action(tab["obs"][i]) for i in range(32)], fx["select_action"])
+    np.testing.assert_allclose(pol.q_values(tab["obs"][:8]), fx["q_values"], rtol=1e-5, atol=1e-6)
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"], double=True)
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+
+
 def test_ppo_beta_actor():
     """PPO_with_tricks.py with beta=True (Actor_Beta :120-151): alpha/beta heads, Beta log-prob / entropy / mean."""
     c = cases.CASES["ppo_beta"]
