@@ -112,6 +112,7 @@ struct LearnArgs {
     int use_policy_noise;
     float target_entropy; // SAC
     unsigned long long rng_counter;   // device_rng: Philox counter of this call (host increments)
+    int p0, p_count;      // this launch covers learners [p0, p0 + p_count): frl_learn pipelines two halves of a population
     int double_dqn;       // DQN trick['Double']: a* = argmax_a Q(s',a), y uses Q_target(s', a*) (DQN_with_tricks.py:263-265)
     int use_isw;          // DQN trick['PER']: loss = mean(w * td^2) with the weights in desc.isw (:276-278)
 };

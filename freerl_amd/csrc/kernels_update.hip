@@ -53,7 +53,7 @@ __device__ __forceinline__ UnitSlice unit_slice(int ns) {
 __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int want_noise) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
-    const int n = D.n_agents, p = blockIdx.x / n, ag = blockIdx.x - p * n, B = a.batch;
+    const int n = D.n_agents, p = a.p0 + blockIdx.x / n, ag = blockIdx.x % n, B = a.batch;
     g_i idx = (g_i)(D.idx + ((size_t)p * n + ag) * D.batch_max);
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
     draw_indices(idx, (FRL_LDS int*)smem, B, a.size, a.rng_counter, (unsigned)ag, key);
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
 // RunningMeanStd_batch_size.update (PPO_file/normalization.py:61-71; SAC.py:215, DDPG.py:191) with
 // the batch mean of the sampled observations: n += 1; first call: mean = std = xbar; afterwards a
 // Welford step on the batch means.  One workgroup per learner, before the gradient kernels.
-__global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows) {
+__global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows, int p0) {
     const EngineDesc& D = *Dp;
-    const int p = blockIdx.x, O = D.rec.obs_dim[0];
+    const int p = p0 + blockIdx.x, O = D.rec.obs_dim[0];
     const RecordDesc& R = D.rec;
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max);
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
-    const int p = us.unit, sl = us.slice;
-    if (p >= D.P) return;
+    if (us.unit >= a.p_count) return;
+    const int p = a.p0 + us.unit, sl = us.slice;
     const NetDesc& N = D.net[0];
     const RecordDesc& R = D.rec;
     const Lds S = carve(D, smem);
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
     const int n = D.n_agents;
-    if (us.unit >= D.P * n) return;
-    const int p = us.unit / n, ag = us.unit - p * n, sl = us.slice;
+    if (us.unit >= a.p_count * n) return;
+    const int p = a.p0 + us.unit / n, ag = us.unit % n, sl = us.slice;
     const RecordDesc& R = D.rec;
     const NetDesc& NC = D.net[2 * ag + 1];
     const Lds S = carve(D, smem);
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     const EngineDesc& D = *Dp;
     const UnitSlice us = unit_slice(ns);
     const int n = D.n_agents;
-    if (us.unit >= D.P * n) return;
-    const int p = us.unit / n, ag = us.unit - p * n, sl = us.slice;
+    if (us.unit >= a.p_count * n) return;
+    const int p = a.p0 + us.unit / n, ag = us.unit % n, sl = us.slice;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[2 * ag];
     const NetDesc& NC = D.net[2 * ag + 1];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
 //                  also publishes the losses and performs SAC's alpha step (SAC.py:154-169,257-260).
 // which = 0: critic / Q-net, 1: actor.
 struct AdamArgs {
-    int which, ns, batch, soft, sac_alpha, G;
+    int which, ns, batch, soft, sac_alpha, G, p0;
     float lr, eps, beta1, beta2, wd, clip, tau, alpha_lr, target_entropy;
 };
 
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restric
     __shared__ float red_s[8];
     lds_f red = (lds_f)red_s;
     const EngineDesc& D = *Dp;
-    const int n = D.n_agents, unit = blockIdx.x / a.G, wg = blockIdx.x - unit * a.G;
-    const int p = unit / n, ag = unit - p * n;
+    const int n = D.n_agents, wg = blockIdx.x % a.G;
+    const int p = a.p0 + (blockIdx.x / a.G) / n, ag = (blockIdx.x / a.G) % n, unit = p * n + ag;
     const int net = adam_net_index(D, a.which, ag);
     const NetDesc& N = D.net[net];
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restric
 
 __global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
     const EngineDesc& D = *Dp;
-    const int n = D.n_agents, unit = blockIdx.x / a.G, wg = blockIdx.x - unit * a.G;
-    const int p = unit / n, ag = unit - p * n;
+    const int n = D.n_agents, wg = blockIdx.x % a.G;
+    const int p = a.p0 + (blockIdx.x / a.G) / n, ag = (blockIdx.x / a.G) % n, unit = p * n + ag;
     const int net = adam_net_index(D, a.which, ag);
     const NetDesc& N = D.net[net];
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
@@ -610,9 +610,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict_
 }
 
 // MADDPG.update_target (MADDPG_simple.py:188-195): every agent's actor then critic.
-__global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau) {
+__global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau, int p0) {
     const EngineDesc& D = *Dp;
-    const int p = blockIdx.x / D.n_nets, net = blockIdx.x - p * D.n_nets;
+    const int p = p0 + blockIdx.x / D.n_nets, net = blockIdx.x % D.n_nets;
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
     soft_update_net(D.net[net].size, as_global(D.target + off), as_global(D.theta + off), tau);
 }
