@@ -131,3 +131,42 @@ def test_c3_ppo_halfcheetah_shape(N):
     np.testing.assert_allclose(got_c, want_c, rtol=2e-2)
     assert e.opt_step(0) == K * n_mb and e.cursor(0) == (0, 0)
     e.close()
+
+
+@pytest.mark.parametrize("hidden", [64, 256, 48])
+def test_other_hidden_widths(N, hidden):
+    """The reference hard-codes 128 hidden units; the engine takes `hidden` as a parameter.  64: one interleaved column
+    group per layer; 256: runtime-length k loops, 32-row chunks, no head fusion; 48: no 64-column groups at all (plain
+    tile path everywhere).  TD3 (twin critic, policy noise, actor step) vs the oracle on the same inputs."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    O, A, B, n_tab = 11, 3, 96, 400
+    tab = synth.transitions(201, n_tab, O, A)
+    actor = synth.mlp_params(211, cases.actor_layers(O, A, hidden=hidden))
+    critic = synth.mlp_params(213, cases.critic_layers(O + A, twin=True, hidden=hidden))
+    e = Engine(N.ALGO_TD3, O, A, 1024, twin_critic=True, batch_max=B, hidden=hidden)
+    for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+        e.set_params(0, flat_params(actor, AC), kind)
+        e.set_params(1, flat_params(critic, TWIN), kind)
+    e.add_batch(records([tab]))
+    orc = algos.TD3(actor, critic, O, A, 1e-3, 1e-3, 1024)
+    for i in range(n_tab):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    for k in range(4):
+        idx = synth.indices(220 + k, n_tab, B)
+        nz = synth.normal(230 + k, (B, A))
+        noise = np.zeros((1, 1, 2, B, A), np.float32)
+        noise[0, 0, 0] = nz
+        st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True,
+                     policy_noise=0.2, noise_clip=0.5, max_action=1.0, idx=idx, noise=noise, want_stats=True)
+        cl, al = orc.learn_with(idx, nz, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0)
+        np.testing.assert_allclose(st[0, 0, N.STAT_CRITIC_LOSS], cl, rtol=1e-4)
+        if al is not None:
+            np.testing.assert_allclose(st[0, 0, N.STAT_ACTOR_LOSS], al, rtol=1e-4, atol=1e-6)
+    ga = unflat_params(e.get_params(0), orc.actor, AC)
+    gc = unflat_params(e.get_params(1, N.PARAM_TARGET), orc.critic_t, TWIN)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    for k in orc.critic_t:
+        np.testing.assert_allclose(gc[k], orc.critic_t[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    e.close()
