@@ -170,3 +170,71 @@ def test_other_hidden_widths(N, hidden):
     for k in orc.critic_t:
         np.testing.assert_allclose(gc[k], orc.critic_t[k], rtol=1e-3, atol=1e-5, err_msg=k)
     e.close()
+
+
+@pytest.mark.parametrize("B", [1, 5, 17])
+def test_tiny_batches(N, B):
+    """`batch_size = min(len(buffer), batch_size)` (DQN.py:95-96): the first learn() calls of a run see batches far below
+    one 16-row tile.  DQN and TD3 vs the oracle."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    O, nA, n_tab = 6, 3, 40
+    tab = synth.transitions(301, n_tab, O, 1, n_discrete=nA)
+    q = synth.mlp_params(311, [("l1", 128, O), ("l2", nA, 128)])
+    e = Engine(N.ALGO_DQN, O, nA, 64, discrete=True, batch_max=32)
+    for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+        e.set_params(0, flat_params(q, ["l1", "l2"]), kind)
+    e.add_batch(records([tab]))
+    orc = algos.DQN(q, O, nA, 1e-3, 64)
+    for i in range(n_tab):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    for k in range(3):
+        idx = synth.indices(320 + k, n_tab, B)
+        st = e.learn(B, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0, idx=idx, want_stats=True)
+        np.testing.assert_allclose(st[0, 0, N.STAT_CRITIC_LOSS], orc.learn_with(idx, 0.99, 0.01), rtol=1e-4, atol=1e-7)
+    got = unflat_params(e.get_params(0), orc.q, ["l1", "l2"])
+    for k in orc.q:
+        np.testing.assert_allclose(got[k], orc.q[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    e.close()
+
+
+def test_per_tree_at_depth(N):
+    """Sum-tree index arithmetic on a deep, non-power-of-two tree (capacity 100003: leaves on two levels), ring wrap
+    included: stratified samples and priority updates against the oracle's SumTree."""
+    from freerl_amd.engine import Engine
+    from oracle.buffer import SumTree
+    cap, B = 100003, 256
+    e = Engine(N.ALGO_REPLAY_ONLY, 3, 1, cap, batch_max=B)
+    e.per_enable(0.6, 0.4, 0.001, 0.01)
+    tree = SumTree(cap)
+    g = np.random.default_rng(5)
+    rec = g.standard_normal((4096, e.width)).astype(np.float32)
+    size, index = 0, 0
+    def add(n):
+        nonlocal size, index
+        mx = 1.0 if size == 0 else float(tree.tree[-cap:].max())
+        for _ in range(n):
+            tree.add(index, mx)
+            index = (index + 1) % cap
+            size = min(size + 1, cap)
+        for s in range(0, n, 4096):
+            e.add_batch(np.resize(rec, (min(4096, n - s), e.width)))
+    add(70000)
+    for rnd in range(3):
+        u = g.random(B)
+        idx, w = e.per_sample(B, uniforms=u)
+        seg = tree.sum() / B
+        want = [tree.get(seg * i + (seg * (i + 1) - seg * i) * u[i])[1] for i in range(B)]
+        np.testing.assert_array_equal(idx[0], want)
+        td = (g.standard_normal(B) * 3).astype(np.float32)
+        e.per_update(B, idx=idx, td_error=td.reshape(1, -1))
+        pr = (np.abs(td) + np.float32(0.01)) ** np.float32(0.6)
+        for i, p in zip(want, pr):
+            tree.add(i, p)
+        st = e.per_state()
+        np.testing.assert_allclose(st["sum"], tree.sum(), rtol=1e-7)
+        np.testing.assert_allclose(st["max"], tree.max(), rtol=1e-6)
+        add(20000)                                   # wraps the ring in the second round
+        np.testing.assert_allclose(e.per_state()["sum"], tree.sum(), rtol=1e-7)
+    assert e.cursor(0) == (index, size)
+    e.close()
