@@ -290,13 +290,14 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         FRL_PHASE(S);
     }
     // ---- centralised target critic on [next_obs_all | a'_all]
-    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
+    // single agent: xin[:, 0:O) still holds the (normalised) next_obs the target actor has just read
+    if (n > 1) gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
     for (int e = threadIdx.x; e < rc * AT; e += kWG) {
         const int r = e / AT, c = e - r * AT;
         S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
     }
     zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+    if (bn && n > 1) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
     FRL_PHASE(S);
     mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
     float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
@@ -316,9 +317,11 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     // ---- critic heads: forward, MSE delta, backward
     float lossp = 0.f;
     for (int h = 0; h < heads; ++h) {
-        gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
-        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+        if (h == 0) {           // the second head reads the same [obs | act] rows: nothing in between writes xin
+            gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
+            zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+            if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+        }
         FRL_PHASE(S);
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
