@@ -1,6 +1,6 @@
 """`DQN` of DQN_file/DQN_with_tricks.py (:160-308) with the tricks that live on the replay path: Double
-(:263-265), PER (PER_Buffer / N_Step_PER_Buffer, :276-279), N_Step (:269-270), plus the Dueling head (:60-79).  Noisy
-(Noisy_net.py) and Categorical/C51 (:82-158) are not ported and raise NotImplementedError.
+(:263-265), PER (PER_Buffer / N_Step_PER_Buffer, :276-279), N_Step (:269-270), plus the Dueling head (:60-79) and NoisyLinear
+heads (Noisy_net.py:17-76).  Categorical/C51 (:82-158) is not ported and raises NotImplementedError.
 
     policy = DQN(dim_info, is_continue, Qnet_lr, buffer_size, device, trick=..., gamma=..., batch_size=...)
 
@@ -17,7 +17,93 @@ from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, 
 from .Buffer import Buffer, N_Step_Buffer, N_Step_PER_Buffer, PER_Buffer
 from .DQN import Agent
 
-_NETWORK_TRICKS = ("Noisy", "Categorical")
+_NETWORK_TRICKS = ("Categorical",)
+SIGMA_INIT = 0.05            # NoisyLinear's default (Noisy_net.py:18)
+
+
+def _scale_noise(size):
+    """NoisyLinear.scale_noise (Noisy_net.py:72-76) on torch's global generator."""
+    x = torch.randn(size)
+    return (x.sign() * torch.sqrt(abs(x))).numpy()
+
+
+class NoisyQNet(DeviceNet):
+    """`agent.Qnet` with NoisyLinear heads: MLP.l2 (DQN_with_tricks.py:50-51) or Dueling's V and A (:68-70).  The engine keeps
+    the heads' mu as its head layer [V ; A] and their sigma as a parameter-only shadow layer; the epsilon buffers of the
+    state_dict are the last noise this object drew."""
+
+    def __init__(self, engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_ONLINE):
+        rows = (1 + action_dim) if dueling else action_dim
+        super().__init__(engine, 0, [("l1", hidden, obs_dim), ("head", rows, hidden), ("sigma", rows, hidden)], kind=kind,
+                         act_mode=N.ACT_RAW)
+        self._nA, self._H, self._dueling = action_dim, hidden, dueling
+        self.heads = [("V", 0, 1), ("A", 1, rows)] if dueling else [("l2", 0, rows)]
+        self.eps = {h: (np.zeros(hidden, np.float32), np.zeros(b - a, np.float32)) for h, a, b in self.heads}
+        self.is_train = True
+
+    def keys(self):
+        ks = ["l1.weight", "l1.bias"]
+        for h, _, _ in self.heads:
+            ks += [h + s for s in (".weight_mu", ".weight_sigma", ".bias_mu", ".bias_sigma", ".weight_epsilon", ".bias_epsilon")]
+        return ks
+
+    def _split(self, flat):
+        parts = super()._split(flat)
+        out = {"l1.weight": parts["l1.weight"], "l1.bias": parts["l1.bias"]}
+        for h, a, b in self.heads:
+            out[h + ".weight_mu"], out[h + ".bias_mu"] = parts["head.weight"][a:b], parts["head.bias"][a:b]
+            out[h + ".weight_sigma"], out[h + ".bias_sigma"] = parts["sigma.weight"][a:b], parts["sigma.bias"][a:b]
+            ei, eo = self.eps[h]
+            out[h + ".weight_epsilon"], out[h + ".bias_epsilon"] = np.outer(eo, ei).astype(np.float32), eo.copy()
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        if strict and set(sd.keys()) != set(self.keys()):
+            raise RuntimeError("Error(s) in loading state_dict: expected keys %s, got %s" % (self.keys(), list(sd.keys())))
+        t = lambda k: np.asarray(torch.as_tensor(sd[k]).detach().cpu().numpy(), dtype=np.float32)
+        cat = lambda sfx: np.concatenate([t(h + sfx).reshape(b - a, -1) for h, a, b in self.heads]).reshape(-1)
+        flat = [t("l1.weight").reshape(-1), t("l1.bias").reshape(-1), cat(".weight_mu"), cat(".bias_mu"), cat(".weight_sigma"),
+                cat(".bias_sigma")]
+        self._e.set_params(self._net, np.concatenate(flat), self._kind, self._learner)
+
+    def draw(self):
+        """One forward's noise in the reference's order (V then A; eps_in then eps_out each), as the engine's flat array."""
+        flat = []
+        for h, a, b in self.heads:
+            ei, eo = _scale_noise(self._H), _scale_noise(b - a)
+            self.eps[h] = (ei, eo)
+            flat += [ei, eo]
+        return np.concatenate(flat).astype(np.float32)
+
+    def __call__(self, obs):
+        raise NotImplementedError("use policy.select_action / the engine's act for a noisy forward")
+
+
+class NoisyAgent:
+    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden, dueling):
+        # torch RNG order: l1 (nn.Linear default), then per NoisyLinear: weight_mu.uniform_, bias_mu.uniform_, reset_noise's two
+        # randn, and torch.manual_seed(100) (Noisy_net.py:30-33) — the seed reset is part of the reference's behaviour
+        from ._core import linear_init
+        l1w, l1b = linear_init(hidden, obs_dim)
+        heads = [("V", 1), ("A", action_dim)] if dueling else [("l2", action_dim)]
+        mu_w, mu_b, sg_w, sg_b, eps = [], [], [], [], {}
+        for name, rows in heads:
+            r = 1.0 / np.sqrt(hidden)
+            mu_w.append(torch.empty(rows, hidden).uniform_(-r, r).numpy())
+            mu_b.append(torch.empty(rows).uniform_(-r, r).numpy())
+            sg_w.append(np.full((rows, hidden), SIGMA_INIT / np.sqrt(hidden), np.float32))
+            sg_b.append(np.full(rows, SIGMA_INIT / np.sqrt(rows), np.float32))
+            eps[name] = (_scale_noise(hidden), _scale_noise(rows))
+            torch.manual_seed(100)
+        flat = np.concatenate([l1w.reshape(-1), l1b] + [np.concatenate(mu_w).reshape(-1), np.concatenate(mu_b)] +
+                              [np.concatenate(sg_w).reshape(-1), np.concatenate(sg_b)]).astype(np.float32)
+        engine.set_params(0, flat, N.PARAM_ONLINE)
+        engine.set_params(0, flat, N.PARAM_TARGET)
+        self.Qnet = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling)
+        self.Qnet_target = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_TARGET)
+        self.Qnet.eps = dict(eps)
+        self.Qnet_target.eps = dict(eps)              # deepcopy copies the buffers too
+        self.Qnet_optimizer = OptimizerView(engine, 0, Qnet_lr)
 
 
 class DuelingNet(DeviceNet):
@@ -75,8 +161,11 @@ class DQN:
                 raise NotImplementedError("trick['%s'] (DQN_with_tricks.py) is not ported" % k)
         hip_id, self.device = resolve_device(device)
         self._e = Engine(N.ALGO_DQN, obs_dim, action_dim, max(int(buffer_size), 1), discrete=True, hidden=hidden,
-                         batch_max=batch_max, device_id=hip_id, seed=seed, dueling=bool(trick["Dueling"]))
-        self.agent = (DuelingAgent if trick["Dueling"] else Agent)(self._e, obs_dim, action_dim, Qnet_lr, hidden)
+                         batch_max=batch_max, device_id=hip_id, seed=seed, dueling=bool(trick["Dueling"]), noisy=bool(trick["Noisy"]))
+        if trick["Noisy"]:
+            self.agent = NoisyAgent(self._e, obs_dim, action_dim, Qnet_lr, hidden, bool(trick["Dueling"]))
+        else:
+            self.agent = (DuelingAgent if trick["Dueling"] else Agent)(self._e, obs_dim, action_dim, Qnet_lr, hidden)
         kw = dict(_engine=self._e)
         if trick["PER"] and trick["N_Step"]:                                   # :176-183
             self.buffer = N_Step_PER_Buffer(buffer_size, obs_dim, 1, self.device, gamma=gamma, **kw)
@@ -90,7 +179,11 @@ class DQN:
         self.last_loss = None
 
     def select_action(self, obs):
-        a = self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1))
+        use = False
+        if self.trick["Noisy"] and self.agent.Qnet.is_train:      # every forward of a training NoisyLinear redraws its noise
+            self._e.noisy_resample(self.agent.Qnet.draw())
+            use = 2
+        a = self._e.act(0, N.ACT_ARGMAX, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), use_target=use)
         return np.int64(a[0, 0, 0])
 
     def evaluate_action(self, obs):
@@ -115,8 +208,12 @@ class DQN:
             self.buffer.sample(batch)                 # the rows and weights stay on the device for the update below
         else:
             idx = draw_indices(len(self.buffer), batch_size)
+        noisy_eps = None
+        if self.trick["Noisy"]:        # the reference's forwards in program order: [Qnet(s') if Double,] Qnet_target(s'), Qnet(s)
+            draws = ([self.agent.Qnet.draw()] if self.trick["Double"] else []) + [self.agent.Qnet_target.draw(), self.agent.Qnet.draw()]
+            noisy_eps = np.stack(draws)[None]
         st = self._e.learn(batch, gamma=gamma, tau=tau, critic_lr=self.agent.Qnet_optimizer.lr, clip_norm=0.0, idx=idx,
-                           double_dqn=bool(self.trick["Double"]), per=1 if self.trick["PER"] else 0,
+                           noisy_eps=noisy_eps, double_dqn=bool(self.trick["Double"]), per=1 if self.trick["PER"] else 0,
                            want_stats=getattr(self, "track_loss", False))
         if self.trick["PER"]:
             self._e.per_update(batch)                 # priorities from the TD errors the kernel left behind (:279)
@@ -134,4 +231,6 @@ class DQN:
     def load(dim_info, is_continue, model_dir, trick=None):
         policy = DQN(dim_info, is_continue, 0, 0, device=torch.device("cpu"), trick=trick, gamma=0.99)
         policy.agent.Qnet.load_state_dict(torch.load(os.path.join(model_dir, "DQN.pt")))
+        if trick["Noisy"]:
+            policy.agent.Qnet.is_train = False                                     # :304-307
         return policy

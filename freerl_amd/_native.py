@@ -37,7 +37,7 @@ class Config(C.Structure):
     _fields_ = [("algo", C.c_int), ("n_learners", C.c_int), ("n_agents", C.c_int),
                 ("obs_dim", C.c_int * FRL_MAX_AGENTS), ("act_dim", C.c_int * FRL_MAX_AGENTS),
                 ("discrete", C.c_int), ("hidden", C.c_int), ("hidden_act", C.c_int), ("twin_critic", C.c_int),
-                ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("actor_dist", C.c_int), ("dueling", C.c_int),
+                ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("actor_dist", C.c_int), ("dueling", C.c_int), ("noisy", C.c_int),
                 ("device_id", C.c_int),
                 ("seed", C.c_uint64)]
 
@@ -56,7 +56,7 @@ class LearnArgs(C.Structure):
                 ("alpha_lr", C.c_float), ("adam_eps", C.c_float), ("critic_weight_decay", C.c_float),
                 ("clip_norm", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
                 ("max_action", C.c_float), ("policy_noise_scale", C.c_float), ("target_entropy", C.c_float),
-                ("double_dqn", C.c_int), ("per", C.c_int),
+                ("double_dqn", C.c_int), ("per", C.c_int), ("noisy_eps", C.POINTER(C.c_float)),
                 ("idx", C.POINTER(C.c_int64)), ("noise", C.POINTER(C.c_float)), ("stats_out", C.POINTER(C.c_float))]
 
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "frl_learn": (_i, [_vp, _P(LearnArgs)]),
     "frl_stats_get": (_i, [_vp, _fp]),
+    "frl_noisy_eps_size": (_i, [_vp, _ip]),
+    "frl_noisy_resample": (_i, [_vp, _fp]),
     "frl_per_enable": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double]),
     "frl_per_sample": (_i, [_vp, _i, _P(C.c_double), _i64p, _fp]),
     "frl_per_update": (_i, [_vp, _i, _i64p, _fp]),

@@ -19,6 +19,7 @@
 #include "kernels_act.hip"
 #include "kernels_ppo.hip"
 #include "kernels_per.hip"
+#include "kernels_noisy.hip"
 
 using namespace frl;
 
@@ -79,6 +80,8 @@ struct frl_engine {
     int* d_perm = nullptr;
     size_t perm_cap = 0;
     bool has_nets = false;
+    int noisy_per_set = 0;                // floats of device noise per (learner, forward): 2 * (k_pad + n_pad) of the head
+    float* h_noisy = nullptr;             // pinned staging for uploaded noise
     // prioritised replay (frl_per_*): sum-tree + max-tree per learner, float64 like the reference's SumTree
     bool per_on = false;
     double* d_per_sum = nullptr;
@@ -129,9 +132,11 @@ static void prof_collect(frl_engine* e) {
 }
 
 // ------------------------------------------------------------------------------ descriptors
-static int build_net(NetDesc& N, const std::vector<std::pair<int, int>>& layers /* (out,in) */, int heads,
-                     int hidden_act, int out_act, int extra_n) {
+static int build_net(NetDesc& N, const std::vector<std::pair<int, int>>& layers_in /* (out,in) */, int heads,
+                     int hidden_act, int out_act, int extra_n, int n_shadow = 0) {
     memset(&N, 0, sizeof N);
+    std::vector<std::pair<int, int>> layers = layers_in;
+    for (int i = 0; i < n_shadow; ++i) layers.push_back(layers_in.back());       // sigma of a NoisyLinear head: same shape as the head
     N.n_layers = (int)layers.size();
     N.heads = heads;
     N.hidden_act = hidden_act;
@@ -158,6 +163,8 @@ static int build_net(NetDesc& N, const std::vector<std::pair<int, int>>& layers 
     }
     N.size = pad32(off);
     N.n_params = np;
+    N.n_layers -= n_shadow;
+    N.n_shadow = n_shadow;
     return 0;
 }
 
@@ -211,7 +218,8 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_size) hipFree(e->d_size);
     if (e->d_per_prio) hipFree(e->d_per_prio);
     if (e->d_uniforms) hipFree(e->d_uniforms);
-    float* dev[] = {e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
+    if (e->h_noisy) hipHostFree(e->h_noisy);
+    float* dev[] = {e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo};
     for (float* p : dev) if (p) hipFree(p);
     if (e->h.idx) hipFree(e->h.idx);
@@ -283,7 +291,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     if (c.algo == FRL_ALGO_DQN) {
         h.n_nets = 1;
         h.dueling = c.dueling ? 1 : 0;
-        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0] + (c.dueling ? 1 : 0), H}}, 1, ACT_RELU, ACT_NONE, 0);   // MLP, DQN.py:32-45
+        h.noisy = c.noisy ? 1 : 0;
+        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0] + (c.dueling ? 1 : 0), H}}, 1, ACT_RELU, ACT_NONE, 0,
+                  c.noisy ? 1 : 0);                                                                      // MLP, DQN.py:32-45
+        h.noisy_split = c.dueling ? 1 : h.net[0].L[1].n_pad;
     } else if (c.algo == FRL_ALGO_PPO) {
         h.n_nets = 2;
         if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits
@@ -372,6 +383,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (int i = 0; i < h.n_nets; ++i) h.Gmax = std::max(h.Gmax, (h.net[i].size / 4 + 256 * kAdamVec - 1) / (256 * kAdamVec));
         CREATE_TRY(dalloc_zero(&h.gsq, P * (size_t)h.n_agents * h.Gmax, e->stream));
         e->idx_count = P * h.n_agents * h.batch_max;
+        if (h.noisy) {
+            const LayerDesc& HL = h.net[0].L[h.net[0].n_layers - 1];
+            e->noisy_per_set = 2 * (HL.k_pad + HL.n_pad);
+            CREATE_TRY(dalloc_zero(&h.theta_eff, P * 3 * ls, e->stream));
+            CREATE_TRY(dalloc_zero(&h.noisy_eps, P * 3 * (size_t)e->noisy_per_set, e->stream));
+            CREATE_TRY(hipHostMalloc((void**)&e->h_noisy, P * 3 * (size_t)e->noisy_per_set * sizeof(float)));
+        }
         CREATE_TRY(dalloc_zero(&h.isw, P * (size_t)h.batch_max, e->stream));
         CREATE_TRY(dalloc_zero(&h.td_err, P * (size_t)h.batch_max, e->stream));
         h.noise_sets = std::max(2, h.n_agents);
@@ -642,7 +660,7 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!to_device) HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
     size_t o = 0;
-    for (int i = 0; i < N.n_layers; ++i) {
+    for (int i = 0; i < N.n_layers + N.n_shadow; ++i) {       // shadow layers (a noisy head's sigma) follow the forward ones
         const LayerDesc& L = N.L[i];
         for (int r = 0; r < L.n; ++r)
             for (int c = 0; c < L.k; ++c) {
@@ -811,6 +829,56 @@ extern "C" int frl_stats_get(frl_engine* e, float* out_host) {
     return FRL_OK;
 }
 
+// Host noise of `n_sets` forwards -> the device layout of kernels_noisy.hip.  Host order per forward (frl_noisy_eps_size
+// floats): per NoisyLinear eps_in[hidden] then eps_out[rows], V before A for a Dueling head.
+static int noisy_upload(frl_engine* e, const float* eps_host, int set0, int n_sets) {
+    const EngineDesc& h = e->h;
+    const LayerDesc& H = h.net[0].L[h.net[0].n_layers - 1];
+    const int per = e->noisy_per_set, K = H.k, kp = H.k_pad, np_ = H.n_pad;
+    const int rows0 = h.dueling ? h.noisy_split : H.n, rows1 = h.dueling ? H.n - h.noisy_split : 0;
+    const int host_per = K + rows0 + (rows1 ? K + rows1 : 0);
+    HIP_TRY(hipStreamSynchronize(e->stream));                       // pinned staging reuse
+    for (int p = 0; p < h.P; ++p)
+        for (int s = 0; s < n_sets; ++s) {
+            const float* src = eps_host + ((size_t)p * n_sets + s) * host_per;
+            float* dst = e->h_noisy + ((size_t)p * 3 + set0 + s) * per;
+            memset(dst, 0, (size_t)per * sizeof(float));
+            memcpy(dst, src, (size_t)K * sizeof(float));                                   // eps_in of sub-layer 0
+            memcpy(dst + kp, src + K, (size_t)rows0 * sizeof(float));                      // eps_out of sub-layer 0: rows [0, rows0)
+            if (rows1) {
+                memcpy(dst + kp + np_, src + K + rows0, (size_t)K * sizeof(float));        // eps_in of sub-layer 1
+                memcpy(dst + kp + np_ + kp + rows0, src + K + rows0 + K, (size_t)rows1 * sizeof(float));   // rows [rows0, n)
+            }
+        }
+    for (int p = 0; p < h.P; ++p)
+        HIP_TRY(hipMemcpyAsync(h.noisy_eps + ((size_t)p * 3 + set0) * per, e->h_noisy + ((size_t)p * 3 + set0) * per,
+                               (size_t)n_sets * per * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return FRL_OK;
+}
+
+extern "C" int frl_noisy_eps_size(const frl_engine* e, int* n_out) {
+    if (!e || !n_out) return fail(FRL_ERR_INVALID, "NULL argument");
+    *n_out = 0;
+    if (!e->h.noisy) return FRL_OK;
+    const EngineDesc& h = e->h;
+    const LayerDesc& H = h.net[0].L[h.net[0].n_layers - 1];
+    const int rows0 = h.dueling ? h.noisy_split : H.n, rows1 = h.dueling ? H.n - h.noisy_split : 0;
+    *n_out = H.k + rows0 + (rows1 ? H.k + rows1 : 0);
+    return FRL_OK;
+}
+
+// A forward of the online net with fresh noise (select_action on a noisy net, DQN_with_tricks.py:213-216 with
+// Noisy_net.py:41-44): materialises effective set 0; frl_act(..., use_target = 2, ...) then reads it.
+extern "C" int frl_noisy_resample(frl_engine* e, const float* eps_host) {
+    ENG(e);
+    if (!e->h.noisy) return fail(FRL_ERR_STATE, "engine has no NoisyLinear head");
+    if (eps_host) { int rc = noisy_upload(e, eps_host, 0, 1); if (rc) return rc; }
+    else hipLaunchKernelGGL(noisy_draw_kernel, dim3(e->h.P, 1), dim3(256), 0, e->stream, e->d, 0, 1, e->rng_counter++);
+    hipLaunchKernelGGL(noisy_materialise_kernel, dim3(e->h.P, 1), dim3(256), 0, e->stream, e->d, 0, 1, 0);
+    HIP_TRY(hipGetLastError());
+    return FRL_OK;
+}
+
 // One stage of learn() for learners [p0, p0 + pc) on `st`: stage 0 = [draw, obsnorm,] grad(critic | Q) + reduce + adam;
 // stage 1 = grad(actor) + reduce + adam; stage 2 = MADDPG's soft update.
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
@@ -832,6 +900,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (h.obs_norm_on && h.algo != ALGO_DQN && h.n_agents == 1)      // sample(): norm(obs) updates the statistics first
             hipLaunchKernelGGL(obsnorm_kernel, dim3(pc), blk, 0, st, e->d, a.batch, 0, p0);
+        if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
+            hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
         prof_begin(e, PK_GRAD_CRITIC);
         if (h.algo == ALGO_DQN) hipLaunchKernelGGL(dqn_grad_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
         else hipLaunchKernelGGL(ac_critic_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
@@ -840,6 +910,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         ad.soft = (h.algo == ALGO_DQN) ? 1 : ((!maddpg && a.do_actor) ? 1 : 0);
         prof_begin(e, PK_ADAM_CRITIC);
         hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);
+        if (h.noisy) hipLaunchKernelGGL(noisy_sigma_grad_kernel, dim3(h.P), blk, 0, st, e->d);
         hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
         prof_end(e);
     } else if (stage == 1) {
@@ -905,6 +976,12 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     // +2.7 %, with the gradient kernels chained across the streams -8 %: the Adam workgroups do not get co-resident with
     // the gradient kernel's (2 x 80 KB of LDS and 448 of 512 VGPRs per SIMD are taken).
     const bool actor_stage = (h.algo != ALGO_DQN && a.do_actor), soft_stage = (h.algo == ALGO_MADDPG && a.do_actor);
+    if (h.noisy) {
+        // the reference draws noise per forward in program order: [online(s') if Double,] target(s'), online(s)
+        const int first = a.double_dqn ? 0 : 1;
+        if (args->noisy_eps) { rc = noisy_upload(e, args->noisy_eps, first, 3 - first); if (rc) return rc; }
+        else hipLaunchKernelGGL(noisy_draw_kernel, dim3(h.P, 3), dim3(256), 0, e->stream, e->d, 0, 3, e->rng_counter++);
+    }
     launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise);
     if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise);
     if (soft_stage) launch_learn_stage(e, e->stream, a, 2, 0, h.P, dev_rng, needs_noise);

@@ -30,6 +30,7 @@ struct NetDesc {
     int extra_off;       // state-independent log_std [extra_n] (Gaussian actors), else -1
     int extra_n;
     int heads;           // 1, or 2 for a twin critic (layers [0,n_layers/2) and [n_layers/2,n_layers))
+    int n_shadow;        // parameter-only layers behind the forward ones: L[n_layers] = the sigma of a NoisyLinear head
     LayerDesc L[kMaxLayers];
 };
 
@@ -88,6 +89,14 @@ struct EngineDesc {
     int n_discrete;       // DQN: number of discrete actions (0 otherwise)
     float* isw;           // [P][batch_max] PER importance weights of the current sample (DQN_with_tricks.py:276-279)
     float* td_err;        // [P][batch_max] TD errors Q(s,a) - y left by the last DQN learn (PER priorities)
+    // NoisyLinear head (DQN_file/Noisy_net.py:17-76): head layer = mu, shadow layer = sigma; every forward of the reference
+    // draws fresh factorised noise, so learn() materialises up to three effective parameter sets (online on s', target on
+    // s', online on s) into theta_eff before the gradient kernel; noisy_eps[P][3][2*(k_pad + n_pad)] holds, per set,
+    // eps_in / eps_out of sub-layer 0 then of sub-layer 1 (Dueling: V then A)
+    int noisy;
+    int noisy_split;      // head rows [0, noisy_split) belong to sub-layer 0 (Dueling's V), the rest to sub-layer 1
+    float* theta_eff;     // [P][3][learner_stride]
+    float* noisy_eps;
     int dueling;          // DQN: head = [V ; A] (1 + n_discrete outputs), Q = V + A - mean(A) (DQN_with_tricks.py:60-79)
     int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner

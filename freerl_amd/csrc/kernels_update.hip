@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     const Lds S = carve(D, smem);
     const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
     const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
-    g_cf theta = as_global(D.theta + base);
-    g_cf target = as_global(D.target + base);
+    // noisy head: the three forwards read the effective parameter sets frl_learn has materialised (kernels_noisy.hip)
+    g_cf eff = D.noisy ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[0]) : nullptr;
+    g_cf theta_next = D.noisy ? eff : as_global(D.theta + base);                              // online net on s' (Double)
+    g_cf target = D.noisy ? eff + D.learner_stride : as_global(D.target + base);              // target net on s'
+    g_cf theta = D.noisy ? eff + 2 * (size_t)D.learner_stride : as_global(D.theta + base);    // online net on s (differentiated)
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
     if (a.double_dqn) {              // the online net picks the action, the target net values it (DQN_with_tricks.py:263-265)
-        mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
+        mlp_fwd(N, 0, nl, theta_next, S, ACT_NONE);
         for (int r = threadIdx.x; r < nv; r += kWG) {
             const float mean = a_mean(r);
             int best = 0;

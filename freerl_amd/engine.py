@@ -18,7 +18,7 @@ def _fp(a):
 
 class Engine:
     def __init__(self, algo, obs_dim, act_dim, capacity, *, n_learners=1, discrete=False, hidden=128,
-                 hidden_act=N.ACT_RELU, twin_critic=False, batch_max=256, extra_cols=0, device_id=0, seed=0, actor_dist=0, dueling=False):
+                 hidden_act=N.ACT_RELU, twin_critic=False, batch_max=256, extra_cols=0, device_id=0, seed=0, actor_dist=0, dueling=False, noisy=False):
         obs_dim = list(obs_dim) if isinstance(obs_dim, (list, tuple)) else [int(obs_dim)]
         act_dim = list(act_dim) if isinstance(act_dim, (list, tuple)) else [int(act_dim)]
         assert len(obs_dim) == len(act_dim)
@@ -29,7 +29,7 @@ class Engine:
         cfg.discrete, cfg.hidden, cfg.hidden_act = int(bool(discrete)), int(hidden), int(hidden_act)
         cfg.twin_critic, cfg.capacity, cfg.batch_max = int(bool(twin_critic)), int(capacity), int(batch_max)
         cfg.extra_cols, cfg.device_id, cfg.seed = int(extra_cols), int(device_id), int(seed) & (2 ** 64 - 1)
-        cfg.actor_dist, cfg.dueling = int(actor_dist), int(bool(dueling))
+        cfg.actor_dist, cfg.dueling, cfg.noisy = int(actor_dist), int(bool(dueling)), int(bool(noisy))
         self._L = N.lib()
         h = C.c_void_p()
         N.check(self._L.frl_create(C.byref(cfg), C.byref(h)))
@@ -167,7 +167,7 @@ class Engine:
             eps = np.ascontiguousarray(eps, dtype=F32).reshape(P, n_rows, -1)
             ep = _fp(eps)
         flags = int(mode) | (0 if normalize else N.ACT_NO_OBSNORM)
-        N.check(self._L.frl_act(self._h, int(net), flags, int(head), int(bool(use_target)), n_rows, in_dim,
+        N.check(self._L.frl_act(self._h, int(net), flags, int(head), int(use_target), n_rows, in_dim,      # 2: noisy effective set 0
                                 _fp(obs), ep, _fp(out), _fp(logp) if want_logp else None))
         return (out, logp) if want_logp else out
 
@@ -175,7 +175,7 @@ class Engine:
     def learn(self, batch, *, gamma, tau, actor_lr=0.0, critic_lr=0.0, alpha_lr=1e-4, adam_eps=1e-8,
               critic_weight_decay=0.0, clip_norm=0.5, do_actor=True, use_policy_noise=False, policy_noise=0.0,
               noise_clip=0.0, max_action=1.0, policy_noise_scale=1.0, target_entropy=0.0, double_dqn=False, per=False,
-              idx=None, noise=None,
+              noisy_eps=None, idx=None, noise=None,
               want_stats=False):
         a = N.LearnArgs()
         a.batch, a.do_actor, a.use_policy_noise = int(batch), int(bool(do_actor)), int(bool(use_policy_noise))
@@ -186,6 +186,10 @@ class Engine:
         a.policy_noise, a.noise_clip, a.max_action, a.policy_noise_scale = policy_noise, noise_clip, max_action, policy_noise_scale
         a.target_entropy = target_entropy
         keep = []
+        if noisy_eps is not None:
+            ne = np.ascontiguousarray(noisy_eps, dtype=F32).reshape(self.P, -1)
+            keep.append(ne)
+            a.noisy_eps = _fp(ne)
         if idx is not None:
             ix = np.ascontiguousarray(idx, dtype=np.int64).reshape(self.P, self.n_agents, int(batch))
             keep.append(ix)
@@ -210,6 +214,19 @@ class Engine:
         fl, by = C.c_double(0), C.c_double(0)
         N.check(self._L.frl_learn_work(self._h, int(batch), int(bool(do_actor)), C.byref(fl), C.byref(by)))
         return fl.value, by.value
+
+    # ------------------------------------------------------------------ noisy head
+    def noisy_eps_size(self):
+        n = C.c_int(0)
+        N.check(self._L.frl_noisy_eps_size(self._h, C.byref(n)))
+        return n.value
+
+    def noisy_resample(self, eps=None):
+        if eps is None:
+            N.check(self._L.frl_noisy_resample(self._h, None))
+        else:
+            ne = np.ascontiguousarray(eps, dtype=F32).reshape(self.P, -1)
+            N.check(self._L.frl_noisy_resample(self._h, _fp(ne)))
 
     # ------------------------------------------------------------------ prioritised replay
     def per_enable(self, alpha=0.5, beta=0.4, beta_increment=0.001, epsilon=0.01):

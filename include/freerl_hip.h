@@ -88,6 +88,8 @@ typedef struct frl_config {
                                      the actor's head is [alpha_layer ; beta_layer] = 2*act_dim outputs, no log_std */
     int dueling;                  /* DQN trick['Dueling'] (DQN_with_tricks.py:60-79): the head is [V ; A] = 1 + n_actions outputs and
                                      Q = V + A - mean(A) */
+    int noisy;                    /* DQN trick['Noisy'] (Noisy_net.py:17-76): the head (l2, or Dueling's V and A) is NoisyLinear: parameters
+                                     mu + sigma, fresh factorised noise at every forward */
     int device_id;
     uint64_t seed;                /* device Philox key (fast path only) */
 } frl_config;
@@ -122,6 +124,10 @@ typedef struct frl_learn_args {
     int per;                   /* DQN trick['PER'] (:276-279): rows and importance weights of the last frl_per_sample; the TD errors
                                   stay on the device for frl_per_update.  1 = the reference's arithmetic: its [B] weights times
                                   [B,1] squared errors broadcast to [B,B], so loss = mean(w) * mean(td^2); 2 = mean(w_i * td_i^2) */
+    const float* noisy_eps;    /* noisy engines: host [P][3][S] factorised noise of the three forwards of learn() in the reference's
+                                  order (online on s' when double_dqn, target on s', online on s); S = frl_noisy_eps_size(): per
+                                  NoisyLinear eps_in[hidden] then eps_out[rows] = f(randn) (Noisy_net.py:66-76), V before A.  NULL:
+                                  drawn on the device */
     const int64_t* idx;        /* host [P][n_agents][batch] rows drawn by the caller (np.random.choice,
                                   DQN.py:97) for bit-identical sampling; NULL: drawn on the device */
     const float* noise;        /* host [P][n_agents][S][batch][act_max], S = max(2, n_agents): N(0,1) draws the reference
@@ -187,7 +193,8 @@ int frl_obsnorm_set(frl_engine* e, int learner, const float* stats);
 
 /* ---------------------------------------------------------------- forward (select_action)
  * in_host [P][n_rows][in_dim], eps_host [P][n_rows][out_dim] or NULL, out_host [P][n_rows][out_dim]
- * (ARGMAX: [P][n_rows] indices as float), logp_host like out or NULL.  Synchronous. */
+ * (ARGMAX: [P][n_rows] indices as float), logp_host like out or NULL.  Synchronous.
+ * use_target: 0 online parameters, 1 target parameters, 2 the noisy net's effective set of the last frl_noisy_resample. */
 int frl_act(frl_engine* e, int net, int mode, int head, int use_target, int n_rows, int in_dim, const float* in_host,
             const float* eps_host, float* out_host, float* logp_host);
 /* same with DEVICE pointers, asynchronous on the engine stream (vectorised env pool path) */
@@ -226,6 +233,12 @@ int frl_ppo_learn(frl_engine* e, const frl_ppo_args* args);
  * PPO_with_tricks.py:308-311 / PPO.py:229-231 */
 int frl_gae(frl_engine* e, const float* td_delta_dev, const float* adv_done_dev, int n_seq, int horizon,
             float gamma, float lmbda, float* adv_out_dev);
+
+/* floats of factorised noise ONE forward of a noisy net consumes (0 for other engines) */
+int frl_noisy_eps_size(const frl_engine* e, int* n_out);
+/* one forward's worth of fresh noise for select_action (DQN_with_tricks.py:213-216 through Noisy_net.py:41-44): eps_host
+ * [P][frl_noisy_eps_size] or NULL (device draw); afterwards frl_act(..., use_target = 2, ...) runs the net with it */
+int frl_noisy_resample(frl_engine* e, const float* eps_host);
 
 /* ---------------------------------------------------------------- prioritised replay
  * PER_Buffer + SumTree (DQN_file/Buffer.py:66-194) on the engine's ring: a float64 sum-tree and max-tree per learner in HBM.

@@ -49,14 +49,57 @@ class DuelingNet:
         return None, {k: g[k].astype(F32) for k in p}
 
 
+class NoisyNet:
+    """MLP / Dueling of DQN_with_tricks.py (:40-79) with NoisyLinear heads (Noisy_net.py:17-76): head weight = weight_mu +
+    weight_sigma * (eps_out (x) eps_in), bias = bias_mu + bias_sigma * eps_out, fresh eps at every forward.  `eps` = {head
+    name: (eps_in, eps_out)} for heads "l2" or "V" and "A"; None = is_train False (mu only)."""
+
+    def __init__(self, dueling):
+        self.heads = ["V", "A"] if dueling else ["l2"]
+        self.dueling = dueling
+
+    def _eff(self, p, name, eps):
+        w, b = p[name + ".weight_mu"], p[name + ".bias_mu"]
+        if eps is None:
+            return w, b
+        ei, eo = nn.f32(eps[name][0]), nn.f32(eps[name][1])
+        return (w + p[name + ".weight_sigma"] * np.outer(eo, ei)).astype(F32), (b + p[name + ".bias_sigma"] * eo).astype(F32)
+
+    def forward(self, p, x, eps=None):
+        h = np.maximum(x @ p["l1.weight"].T + p["l1.bias"], 0).astype(F32)
+        outs, effs = {}, {}
+        for name in self.heads:
+            w, b = self._eff(p, name, eps)
+            effs[name] = w
+            outs[name] = (h @ w.T + b).astype(F32)
+        q = ((outs["V"] + outs["A"]) - outs["A"].mean(axis=1, keepdims=True, dtype=F32)).astype(F32) if self.dueling else outs["l2"]
+        return q, [x, h, effs, eps]
+
+    def backward(self, p, acts, dq, need_dx=False):
+        x, h, effs, eps = acts
+        d = {"l2": dq} if not self.dueling else {"V": dq.sum(axis=1, keepdims=True).astype(F32),
+                                                 "A": (dq - dq.mean(axis=1, keepdims=True, dtype=F32)).astype(F32)}
+        g, dh = {}, 0
+        for name in self.heads:
+            dW, db = d[name].T @ h, d[name].sum(axis=0)
+            g[name + ".weight_mu"], g[name + ".bias_mu"] = dW, db
+            ei, eo = nn.f32(eps[name][0]), nn.f32(eps[name][1])
+            g[name + ".weight_sigma"], g[name + ".bias_sigma"] = dW * np.outer(eo, ei), db * eo
+            dh = dh + d[name] @ effs[name]
+        dh = dh * (h > 0)
+        g["l1.weight"], g["l1.bias"] = dh.T @ x, dh.sum(axis=0)
+        return None, {k: g[k].astype(F32) for k in p}
+
+
 class DQN:
     """DQN_file/DQN.py:62-128.  Q-net MLP obs->128->n_actions, target copy, Adam(lr).  dueling=True: DQN_with_tricks'
-    Dueling net (params l1, V, A)."""
+    Dueling net (params l1, V, A); noisy=True: NoisyLinear heads (learn_with takes the per-forward noise)."""
 
-    def __init__(self, params, obs_dim, n_actions, lr, capacity, dueling=False):
+    def __init__(self, params, obs_dim, n_actions, lr, capacity, dueling=False, noisy=False):
         self.q = nn.copy_params(params)
         self.q_t = nn.copy_params(params)
-        self.net = DuelingNet() if dueling else MLP(["l1", "l2"])
+        self.noisy = noisy
+        self.net = NoisyNet(dueling) if noisy else (DuelingNet() if dueling else MLP(["l1", "l2"]))
         self.opt = Adam(self.q, lr)
         self.buffer = Buffer(capacity, obs_dim, 1)
         self.losses = []
@@ -73,18 +116,20 @@ class DQN:
     def learn(self, batch_size, gamma, tau):
         return self.learn_with(_choice(len(self.buffer), batch_size), gamma, tau)
 
-    def learn_with(self, idx, gamma, tau, double=False, is_weight=None):
-        """DQN.py:104-118; `double` / `is_weight`: DQN_with_tricks.py:263-265 / :276-279 (returns the TD errors too)."""
+    def learn_with(self, idx, gamma, tau, double=False, is_weight=None, noisy_eps=None):
+        """DQN.py:104-118; `double` / `is_weight`: DQN_with_tricks.py:263-265 / :276-279 (returns the TD errors too).
+        noisy_eps = [eps of Qnet(next_obs) (Double only, else None), eps of Qnet_target(next_obs), eps of Qnet(obs)]."""
         obs, act, rew, nobs, done = self.buffer.sample(idx)
         B = obs.shape[0]
-        qt = self.net.forward(self.q_t, nobs)[0]
+        fwd = (lambda p, x, j: self.net.forward(p, x, noisy_eps[j])) if self.noisy else (lambda p, x, j: self.net.forward(p, x))
+        a_star = np.argmax(fwd(self.q, nobs, 0)[0], axis=1) if double else None       # program order of the reference
+        qt = fwd(self.q_t, nobs, 1)[0]
         if double:
-            a_star = np.argmax(self.net.forward(self.q, nobs)[0], axis=1)
             next_q = qt[np.arange(B), a_star].reshape(-1, 1)
         else:
             next_q = qt.max(axis=1).reshape(-1, 1)
         y = rew + F32(gamma) * next_q * (F32(1) - done)
-        q, acts = self.net.forward(self.q, obs)
+        q, acts = fwd(self.q, obs, 2)
         a = act.astype(np.int64).reshape(-1)
         cur = q[np.arange(B), a].reshape(-1, 1)
         if is_weight is None:

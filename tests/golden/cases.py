@@ -38,6 +38,9 @@ CASES = {
     # DQN_with_tricks.learn with trick Dueling + Double (DQN_with_tricks.py:60-79,263-265), uniform replay
     "dqn_dueling": dict(kind="dqn_dueling", obs_dim=8, n_actions=4, capacity=2048, n_table=600, batch=128, n_learn=4,
                         gamma=0.99, tau=0.01, lr=1e-3, table_seed=134, param_seed=1020, idx_seed=2020),
+    # DQN_with_tricks.learn with Noisy + Dueling + Double (Noisy_net.py:17-76; DQN_with_tricks.py:60-79,263-265)
+    "dqn_noisy": dict(kind="dqn_noisy", obs_dim=8, n_actions=4, capacity=2048, n_table=600, batch=128, n_learn=4,
+                      gamma=0.99, tau=0.01, lr=1e-3, table_seed=135, param_seed=1030, idx_seed=2030, noise_seed=3030),
     # DQN.learn (DQN_file/DQN.py:104-128); SYN-D shape of SURVEY §8(d)
     "dqn": dict(kind="dqn", obs_dim=8, n_actions=4, capacity=4096, n_table=1024, batch=256,
                 n_learn=5, gamma=0.99, tau=0.01, lr=1e-3, table_seed=123, param_seed=1000,
@@ -138,6 +141,40 @@ def dqn_dueling_inputs(c):
     params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("V", 1, H), ("A", c["n_actions"], H)])
     idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
     return dict(table=tab, params=dict(Qnet=params), idx=idx)
+
+
+def noisy_f(x):
+    """scale_noise (Noisy_net.py:72-76): sign(x) * sqrt(|x|) in float32."""
+    x = np.asarray(x, dtype=np.float32)
+    return (np.sign(x) * np.sqrt(np.abs(x))).astype(np.float32)
+
+
+def dqn_noisy_inputs(c):
+    """Noisy + Dueling: params l1, V (NoisyLinear hidden->1), A (NoisyLinear hidden->n_actions).  raw[k][j][head] = the
+    (randn(in), randn(out)) pair of forward j of learn call k (j: Qnet(next_obs), Qnet_target(next_obs), Qnet(obs)), plus one
+    pair set for a select_action probe."""
+    nA, O = c["n_actions"], c["obs_dim"]
+    tab = synth.transitions(c["table_seed"], c["n_table"], O, 1, n_discrete=nA)
+    g = np.random.default_rng(c["param_seed"])
+    p = dict(synth.mlp_params(c["param_seed"], [("l1", H, O)]))
+    for name, rows in (("V", 1), ("A", nA)):
+        r = 1 / np.sqrt(H)
+        p[name + ".weight_mu"] = g.uniform(-r, r, (rows, H)).astype(np.float32)
+        p[name + ".weight_sigma"] = g.uniform(0.02, 0.08, (rows, H)).astype(np.float32)      # distinct values: exercises d/d sigma
+        p[name + ".bias_mu"] = g.uniform(-r, r, rows).astype(np.float32)
+        p[name + ".bias_sigma"] = g.uniform(0.02, 0.08, rows).astype(np.float32)
+    idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
+    gn = np.random.default_rng(c["noise_seed"])
+    draw = lambda: {"V": (gn.standard_normal(H).astype(np.float32), gn.standard_normal(1).astype(np.float32)),
+                    "A": (gn.standard_normal(H).astype(np.float32), gn.standard_normal(nA).astype(np.float32))}
+    raw = [[draw() for _ in range(3)] for _ in range(c["n_learn"])]
+    probe = draw()
+    return dict(table=tab, params=dict(Qnet=p), idx=idx, raw=raw, probe=probe)
+
+
+def noisy_eps(raw_one):
+    """{head: (randn_in, randn_out)} -> {head: (eps_in, eps_out)}"""
+    return {h: (noisy_f(a), noisy_f(b)) for h, (a, b) in raw_one.items()}
 
 
 def dqn_tricks_inputs(c):

@@ -820,7 +820,7 @@ def test_dqn_with_tricks_double_per_nstep(N):
     got = {k: v.numpy() for k, v in pol.agent.Qnet.state_dict().items()}
     synth.check_digest("Qnet", got, fx, 2e-3, 2e-5, "hip-vs-reference")
     with pytest.raises(NotImplementedError):
-        DQN([4, 2], False, 1e-3, 64, "cuda", trick=dict(trick, Noisy=True), gamma=0.99)
+        DQN([4, 2], False, 1e-3, 64, "cuda", trick=dict(trick, Categorical=True), gamma=0.99)
 
 
 def test_dqn_dueling_double(N):
@@ -859,3 +859,55 @@ def test_dqn_dueling_double(N):
     synth.check_digest("Qnet", got, fx, P_RTOL, P_ATOL, "hip-vs-reference")
     got_t = {k: v.numpy() for k, v in pol.agent.Qnet_target.state_dict().items()}
     synth.check_digest("Qnet_target", got_t, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+
+
+def test_dqn_noisy_dueling_double(N):
+    """NoisyLinear heads (Noisy_net.py:17-76) under Dueling + Double through the class: the reference's state_dict keys,
+    per-forward noise drawn from torch's generator in the reference's order, mu / sigma gradients."""
+    from freerl_amd.DQN_with_tricks import DQN
+    import torch
+    c = cases.CASES["dqn_noisy"]
+    inp = cases.dqn_noisy_inputs(c)
+    fx = gold("dqn_noisy")
+    trick = dict(Double=True, Dueling=True, PER=False, Noisy=True, N_Step=False, Categorical=False)
+    pol = DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], "cuda", trick=trick, gamma=c["gamma"],
+              batch_size=c["batch"], batch_max=c["batch"])
+    assert list(pol.agent.Qnet.state_dict().keys()) == list(fx["state_dict_keys"])
+    assert torch.initial_seed() == 100                                   # NoisyLinear.__init__ reseeds (Noisy_net.py:33)
+    sd = pol.agent.Qnet.state_dict()
+    for k, v in inp["params"]["Qnet"].items():
+        sd[k] = torch.from_numpy(v.copy())
+    pol.agent.Qnet.load_state_dict(sd)
+    pol.agent.Qnet_target.load_state_dict(sd)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    order = lambda one: [torch.from_numpy(t.copy()) for h in ("V", "A") for t in one[h]]
+    seq = iter(order(inp["probe"]) + [t for per_call in inp["raw"] for one in per_call for t in order(one)])
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(seq)
+    pol.track_loss = True
+    losses = []
+    it = iter(inp["idx"])
+    orig_choice = np.random.choice
+    np.random.choice = lambda *a, **k: next(it)
+    try:
+        # a noisy forward with the probe noise: Q = V + A - mean(A) from the raw head of effective set 0
+        pol._e.noisy_resample(pol.agent.Qnet.draw())
+        raw = pol._e.act(0, N.ACT_RAW, tab["obs"][:8], out_dim=1 + c["n_actions"], use_target=2)[0]
+        q = raw[:, :1] + raw[:, 1:] - raw[:, 1:].mean(axis=1, keepdims=True)
+        np.testing.assert_allclose(q, fx["q_probe"], rtol=1e-5, atol=1e-6)
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            losses.append(pol.last_loss)
+    finally:
+        torch.randn = orig
+        np.random.choice = orig_choice
+    np.testing.assert_allclose(losses, fx["loss"], rtol=LOSS_RTOL)
+    got = {k: v.numpy() for k, v in pol.agent.Qnet.state_dict().items() if "epsilon" not in k}
+    synth.check_digest("Qnet", got, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    got_t = {k: v.numpy() for k, v in pol.agent.Qnet_target.state_dict().items() if "epsilon" not in k}
+    synth.check_digest("Qnet_target", got_t, fx, P_RTOL, P_ATOL, "hip-vs-reference")
+    # the epsilon buffers are the last noise drawn (the online net's: Qnet(obs) of the last learn)
+    last = cases.noisy_eps(inp["raw"][-1][2])
+    np.testing.assert_allclose(pol.agent.Qnet.state_dict()["A.bias_epsilon"].numpy(), last["A"][1], rtol=1e-6)

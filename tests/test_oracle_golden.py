@@ -226,6 +226,27 @@ def test_dqn_dueling_double():
     synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
 
 
+def test_dqn_noisy_dueling_double():
+    """NoisyLinear heads (Noisy_net.py:17-76) under Dueling + Double: per-forward factorised noise, d/d mu and d/d sigma."""
+    c = cases.CASES["dqn_noisy"]
+    inp = cases.dqn_noisy_inputs(c)
+    fx = gold("dqn_noisy")
+    assert list(fx["state_dict_keys"]) == ["l1.weight", "l1.bias", "V.weight_mu", "V.weight_sigma", "V.bias_mu", "V.bias_sigma",
+                                           "V.weight_epsilon", "V.bias_epsilon", "A.weight_mu", "A.weight_sigma", "A.bias_mu",
+                                           "A.bias_sigma", "A.weight_epsilon", "A.bias_epsilon"]
+    pol = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"], dueling=True, noisy=True)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    q = pol.net.forward(pol.q, tab["obs"][:8].astype(np.float32), cases.noisy_eps(inp["probe"]))[0]
+    np.testing.assert_allclose(q, fx["q_probe"], rtol=1e-5, atol=1e-6)
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"], double=True, noisy_eps=[cases.noisy_eps(o) for o in inp["raw"][k]])
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+
+
 def test_ppo_beta_actor():
     """PPO_with_tricks.py with beta=True (Actor_Beta :120-151): alpha/beta heads, Beta log-prob / entropy / mean."""
     c = cases.CASES["ppo_beta"]
