@@ -1,6 +1,7 @@
 """`DQN` of DQN_file/DQN_with_tricks.py (:160-308) with the tricks that live on the replay path: Double
 (:263-265), PER (PER_Buffer / N_Step_PER_Buffer, :276-279), N_Step (:269-270), plus the Dueling head (:60-79) and NoisyLinear
-heads (Noisy_net.py:17-76).  Categorical/C51 (:82-158) is not ported and raises NotImplementedError.
+heads (Noisy_net.py:17-76) and the Categorical / C51 distributional head (:82-158): all six tricks, i.e. the reference's
+default configuration (:416), run as one fused update.
 
     policy = DQN(dim_info, is_continue, Qnet_lr, buffer_size, device, trick=..., gamma=..., batch_size=...)
 
@@ -17,7 +18,7 @@ from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, 
 from .Buffer import Buffer, N_Step_Buffer, N_Step_PER_Buffer, PER_Buffer
 from .DQN import Agent
 
-_NETWORK_TRICKS = ("Categorical",)
+ATOMS, V_MIN, V_MAX = 51, -100.0, 100.0       # Categorical's defaults (DQN_with_tricks.py:88)
 SIGMA_INIT = 0.05            # NoisyLinear's default (Noisy_net.py:18)
 
 
@@ -32,12 +33,12 @@ class NoisyQNet(DeviceNet):
     the heads' mu as its head layer [V ; A] and their sigma as a parameter-only shadow layer; the epsilon buffers of the
     state_dict are the last noise this object drew."""
 
-    def __init__(self, engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_ONLINE):
-        rows = (1 + action_dim) if dueling else action_dim
+    def __init__(self, engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_ONLINE, per_out=1):
+        rows = ((1 + action_dim) if dueling else action_dim) * per_out
         super().__init__(engine, 0, [("l1", hidden, obs_dim), ("head", rows, hidden), ("sigma", rows, hidden)], kind=kind,
                          act_mode=N.ACT_RAW)
         self._nA, self._H, self._dueling = action_dim, hidden, dueling
-        self.heads = [("V", 0, 1), ("A", 1, rows)] if dueling else [("l2", 0, rows)]
+        self.heads = [("V", 0, per_out), ("A", per_out, rows)] if dueling else [("l2", 0, rows)]
         self.eps = {h: (np.zeros(hidden, np.float32), np.zeros(b - a, np.float32)) for h, a, b in self.heads}
         self.is_train = True
 
@@ -80,12 +81,12 @@ class NoisyQNet(DeviceNet):
 
 
 class NoisyAgent:
-    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden, dueling):
+    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden, dueling, per_out=1):
         # torch RNG order: l1 (nn.Linear default), then per NoisyLinear: weight_mu.uniform_, bias_mu.uniform_, reset_noise's two
         # randn, and torch.manual_seed(100) (Noisy_net.py:30-33) — the seed reset is part of the reference's behaviour
         from ._core import linear_init
         l1w, l1b = linear_init(hidden, obs_dim)
-        heads = [("V", 1), ("A", action_dim)] if dueling else [("l2", action_dim)]
+        heads = [("V", per_out), ("A", action_dim * per_out)] if dueling else [("l2", action_dim * per_out)]
         mu_w, mu_b, sg_w, sg_b, eps = [], [], [], [], {}
         for name, rows in heads:
             r = 1.0 / np.sqrt(hidden)
@@ -99,8 +100,8 @@ class NoisyAgent:
                               [np.concatenate(sg_w).reshape(-1), np.concatenate(sg_b)]).astype(np.float32)
         engine.set_params(0, flat, N.PARAM_ONLINE)
         engine.set_params(0, flat, N.PARAM_TARGET)
-        self.Qnet = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling)
-        self.Qnet_target = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_TARGET)
+        self.Qnet = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling, per_out=per_out)
+        self.Qnet_target = NoisyQNet(engine, hidden, obs_dim, action_dim, dueling, kind=N.PARAM_TARGET, per_out=per_out)
         self.Qnet.eps = dict(eps)
         self.Qnet_target.eps = dict(eps)              # deepcopy copies the buffers too
         self.Qnet_optimizer = OptimizerView(engine, 0, Qnet_lr)
@@ -110,9 +111,10 @@ class DuelingNet(DeviceNet):
     """`agent.Qnet` of Dueling (DQN_with_tricks.py:60-79): state_dict keys l1 / V / A; the engine keeps V and A as one
     (1 + n_actions)-wide head [V ; A].  Calling it returns Q = V + A - mean(A)."""
 
-    def __init__(self, engine, hidden, obs_dim, action_dim, kind=N.PARAM_ONLINE):
-        super().__init__(engine, 0, [("l1", hidden, obs_dim), ("head", 1 + action_dim, hidden)], kind=kind, act_mode=N.ACT_RAW)
-        self._nA = action_dim
+    def __init__(self, engine, hidden, obs_dim, action_dim, kind=N.PARAM_ONLINE, per_out=1):
+        super().__init__(engine, 0, [("l1", hidden, obs_dim), ("head", (1 + action_dim) * per_out, hidden)], kind=kind,
+                         act_mode=N.ACT_RAW)
+        self._nA, self._v = action_dim, per_out            # per_out = atoms for the Categorical head (:96-97)
 
     def keys(self):
         return ["l1.weight", "l1.bias", "V.weight", "V.bias", "A.weight", "A.bias"]
@@ -120,7 +122,8 @@ class DuelingNet(DeviceNet):
     def _split(self, flat):
         parts = super()._split(flat)
         w, b = parts.pop("head.weight"), parts.pop("head.bias")
-        parts.update({"V.weight": w[:1], "V.bias": b[:1], "A.weight": w[1:], "A.bias": b[1:]})
+        v = self._v
+        parts.update({"V.weight": w[:v], "V.bias": b[:v], "A.weight": w[v:], "A.bias": b[v:]})
         return parts
 
     def load_state_dict(self, sd, strict=True):
@@ -132,21 +135,39 @@ class DuelingNet(DeviceNet):
 
     def __call__(self, obs):
         h = super().__call__(obs)
+        if self._v > 1:
+            raise NotImplementedError("the Categorical net returns (action, dist); use select_action")
         return h[:, :1] + h[:, 1:] - h[:, 1:].mean(dim=1, keepdim=True)
 
 
 class DuelingAgent:
-    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden):
-        # torch RNG order of Dueling.__init__: l1, V, A (:67-74); the engine's flat order is l1, [V.w ; A.w], [V.b ; A.b]
-        f = init_layers([("l1", hidden, obs_dim), ("V", 1, hidden), ("A", action_dim, hidden)])
+    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden, per_out=1):
+        # torch RNG order of Dueling.__init__ / Categorical.__init__: l1, V, A (:67-74, :90-97); the engine's flat order is
+        # l1, [V.w ; A.w], [V.b ; A.b]
+        rv, ra = per_out, action_dim * per_out
+        f = init_layers([("l1", hidden, obs_dim), ("V", rv, hidden), ("A", ra, hidden)])
         o = hidden * obs_dim + hidden
-        vw, vb = f[o:o + hidden], f[o + hidden:o + hidden + 1]
-        aw, ab = f[o + hidden + 1:o + hidden + 1 + action_dim * hidden], f[o + hidden + 1 + action_dim * hidden:]
+        vw, vb = f[o:o + rv * hidden], f[o + rv * hidden:o + rv * hidden + rv]
+        o2 = o + rv * hidden + rv
+        aw, ab = f[o2:o2 + ra * hidden], f[o2 + ra * hidden:]
         flat = np.concatenate([f[:o], vw, aw, vb, ab])
         engine.set_params(0, flat, N.PARAM_ONLINE)
         engine.set_params(0, flat, N.PARAM_TARGET)
-        self.Qnet = DuelingNet(engine, hidden, obs_dim, action_dim)
-        self.Qnet_target = DuelingNet(engine, hidden, obs_dim, action_dim, kind=N.PARAM_TARGET)
+        self.Qnet = DuelingNet(engine, hidden, obs_dim, action_dim, per_out=per_out)
+        self.Qnet_target = DuelingNet(engine, hidden, obs_dim, action_dim, kind=N.PARAM_TARGET, per_out=per_out)
+        self.Qnet_optimizer = OptimizerView(engine, 0, Qnet_lr)
+
+
+class PlainC51Agent:
+    """Categorical with a plain nn.Linear head l2: hidden -> action_dim * atoms (:98-99)."""
+
+    def __init__(self, engine, obs_dim, action_dim, Qnet_lr, hidden, atoms):
+        layers = [("l1", hidden, obs_dim), ("l2", action_dim * atoms, hidden)]
+        flat = init_layers(layers)
+        engine.set_params(0, flat, N.PARAM_ONLINE)
+        engine.set_params(0, flat, N.PARAM_TARGET)
+        self.Qnet = DeviceNet(engine, 0, layers)
+        self.Qnet_target = DeviceNet(engine, 0, layers, kind=N.PARAM_TARGET)
         self.Qnet_optimizer = OptimizerView(engine, 0, Qnet_lr)
 
 
@@ -156,16 +177,23 @@ class DQN:
         obs_dim, action_dim = dim_info
         if is_continue:
             raise ValueError("DQN is not suitable for continuous action spaces (DQN_with_tricks.py:207-210)")
-        for k in _NETWORK_TRICKS:
-            if trick[k]:
-                raise NotImplementedError("trick['%s'] (DQN_with_tricks.py) is not ported" % k)
+        cat = bool(trick["Categorical"])
+        if cat and trick["Noisy"] and not trick["Dueling"]:
+            # the reference builds NoisyLinear(hidden, action_dim) there (:94-95) and fails reshaping it to [B, nA, atoms] (:122)
+            raise RuntimeError("shape '[-1, %d, %d]' is invalid for input of size %d" % (action_dim, ATOMS, action_dim))
         hip_id, self.device = resolve_device(device)
         self._e = Engine(N.ALGO_DQN, obs_dim, action_dim, max(int(buffer_size), 1), discrete=True, hidden=hidden,
-                         batch_max=batch_max, device_id=hip_id, seed=seed, dueling=bool(trick["Dueling"]), noisy=bool(trick["Noisy"]))
+                         batch_max=batch_max, device_id=hip_id, seed=seed, dueling=bool(trick["Dueling"]), noisy=bool(trick["Noisy"]),
+                         c51=(ATOMS, V_MIN, V_MAX) if cat else None)
+        per_out = ATOMS if cat else 1
         if trick["Noisy"]:
-            self.agent = NoisyAgent(self._e, obs_dim, action_dim, Qnet_lr, hidden, bool(trick["Dueling"]))
+            self.agent = NoisyAgent(self._e, obs_dim, action_dim, Qnet_lr, hidden, bool(trick["Dueling"]), per_out=per_out)
+        elif trick["Dueling"]:
+            self.agent = DuelingAgent(self._e, obs_dim, action_dim, Qnet_lr, hidden, per_out=per_out)
+        elif cat:
+            self.agent = PlainC51Agent(self._e, obs_dim, action_dim, Qnet_lr, hidden, ATOMS)
         else:
-            self.agent = (DuelingAgent if trick["Dueling"] else Agent)(self._e, obs_dim, action_dim, Qnet_lr, hidden)
+            self.agent = Agent(self._e, obs_dim, action_dim, Qnet_lr, hidden)
         kw = dict(_engine=self._e)
         if trick["PER"] and trick["N_Step"]:                                   # :176-183
             self.buffer = N_Step_PER_Buffer(buffer_size, obs_dim, 1, self.device, gamma=gamma, **kw)

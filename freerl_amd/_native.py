@@ -38,6 +38,7 @@ class Config(C.Structure):
                 ("obs_dim", C.c_int * FRL_MAX_AGENTS), ("act_dim", C.c_int * FRL_MAX_AGENTS),
                 ("discrete", C.c_int), ("hidden", C.c_int), ("hidden_act", C.c_int), ("twin_critic", C.c_int),
                 ("capacity", C.c_int), ("batch_max", C.c_int), ("extra_cols", C.c_int), ("actor_dist", C.c_int), ("dueling", C.c_int), ("noisy", C.c_int),
+                ("c51_atoms", C.c_int), ("c51_vmin", C.c_float), ("c51_vmax", C.c_float),
                 ("device_id", C.c_int),
                 ("seed", C.c_uint64)]
 

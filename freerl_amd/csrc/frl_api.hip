@@ -20,6 +20,7 @@
 #include "kernels_ppo.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
+#include "kernels_c51.hip"
 
 using namespace frl;
 
@@ -292,9 +293,12 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         h.n_nets = 1;
         h.dueling = c.dueling ? 1 : 0;
         h.noisy = c.noisy ? 1 : 0;
-        build_net(h.net[0], {{H, c.obs_dim[0]}, {c.act_dim[0] + (c.dueling ? 1 : 0), H}}, 1, ACT_RELU, ACT_NONE, 0,
+        h.c51_atoms = c.c51_atoms > 1 ? c.c51_atoms : 0;
+        h.c51_vmin = c.c51_vmin; h.c51_vmax = c.c51_vmax;
+        const int per_out = h.c51_atoms ? h.c51_atoms : 1;        // head rows: [V (per_out) ;] A (act_dim x per_out)
+        build_net(h.net[0], {{H, c.obs_dim[0]}, {(c.act_dim[0] + (c.dueling ? 1 : 0)) * per_out, H}}, 1, ACT_RELU, ACT_NONE, 0,
                   c.noisy ? 1 : 0);                                                                      // MLP, DQN.py:32-45
-        h.noisy_split = c.dueling ? 1 : h.net[0].L[1].n_pad;
+        h.noisy_split = c.dueling ? per_out : h.net[0].L[1].n_pad;
     } else if (c.algo == FRL_ALGO_PPO) {
         h.n_nets = 2;
         if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits
@@ -337,6 +341,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.lds_act_pad = (std::max(R.act_total, 1) + 3) / 4 * 4; // abuf / dabuf are scalar-accessed: no tile padding
     if (c.algo == FRL_ALGO_PPO && c.discrete) h.lds_act_pad = std::max(h.lds_act_pad, pad16(c.act_dim[0]));   // logits' delta staging
     if (c.algo == FRL_ALGO_PPO && c.actor_dist == 1) h.lds_act_pad = std::max(h.lds_act_pad, pad16(2 * c.act_dim[0]));
+    if (h.c51_atoms) h.lds_act_pad = std::max(h.lds_act_pad, (h.c51_atoms + 3) / 4 * 4);      // projected distribution / probabilities per row
     // row chunk: the largest of {64,32,16} whose LDS footprint still lets TWO workgroups share a CU.  Measured
     // (profiles/README.md v4): 64 rows x 2 workgroups beats 32 x 3, 32 x 4 and 128 x 1 — more rows per weight fragment
     // fetched and half the gradient slabs, while two workgroups still overlap each other's barrier phases
@@ -903,7 +908,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
             hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
         prof_begin(e, PK_GRAD_CRITIC);
-        if (h.algo == ALGO_DQN) hipLaunchKernelGGL(dqn_grad_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
+        if (h.algo == ALGO_DQN && h.c51_atoms) hipLaunchKernelGGL(c51_grad_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
+        else if (h.algo == ALGO_DQN) hipLaunchKernelGGL(dqn_grad_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
         else hipLaunchKernelGGL(ac_critic_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
         prof_end(e);
         ad.which = 0; ad.lr = a.critic_lr; ad.wd = a.critic_wd;

@@ -97,6 +97,8 @@ struct EngineDesc {
     int noisy_split;      // head rows [0, noisy_split) belong to sub-layer 0 (Dueling's V), the rest to sub-layer 1
     float* theta_eff;     // [P][3][learner_stride]
     float* noisy_eps;
+    int c51_atoms;        // > 0: Categorical DQN head (DQN_with_tricks.py:82-158): action_dim x atoms logits (+ atoms for Dueling's V)
+    float c51_vmin, c51_vmax;
     int dueling;          // DQN: head = [V ; A] (1 + n_discrete outputs), Q = V + A - mean(A) (DQN_with_tricks.py:60-79)
     int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner

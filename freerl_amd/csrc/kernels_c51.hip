@@ -1,0 +1,153 @@
+// Categorical DQN (C51) update for one row chunk — DQN_with_tricks.py:82-158 (Categorical net, projection_dist) and
+// :248-260 (cross-entropy loss, PER error).  Head rows: [a * atoms + i] (plain) or [V_i ; atoms + a * atoms + i] (Dueling:
+// logits = V + A - mean_a A).  Forwards and backward are the shared MFMA layer code; the distribution arithmetic between
+// them is vector work, one thread per (row, action) pair or per row.
+#include <hip/hip_runtime.h>
+
+#include "device/c51.hpp"
+#include "device/net.hpp"
+
+namespace frl {
+
+__global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int group = 8 * ns, gq = blockIdx.x / group, lq = blockIdx.x - gq * group;
+    const int unit = gq * 8 + (lq & 7), sl = lq >> 3;
+    if (unit >= a.p_count) return;
+    const int p = a.p0 + unit;
+    const NetDesc& N = D.net[0];
+    const RecordDesc& R = D.rec;
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
+    const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
+    g_cf eff = D.noisy ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[0]) : nullptr;
+    g_cf theta_next = D.noisy ? eff : as_global(D.theta + base);
+    g_cf target = D.noisy ? eff + D.learner_stride : as_global(D.target + base);
+    g_cf theta = D.noisy ? eff + 2 * (size_t)D.learner_stride : as_global(D.theta + base);
+    g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
+    const int O = R.obs_dim[0], nA = D.n_discrete, atoms = D.c51_atoms, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
+    const bool duel = D.dueling != 0;
+    const float vmin = D.c51_vmin, vmax = D.c51_vmax, dz = (vmax - vmin) / (float)(atoms - 1);
+    lds_f m = S.abuf;                    // [rc][ap] projected target distribution
+    lds_f qb = S.dabuf;                  // [rc][ap] q values / scratch
+    const int ap = S.ap;
+
+    // ---- next action: argmax_a q(s', a) by the online net (Double, :141-143) or by the target net itself (:145)
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
+    zero_cols(S.xin, S.xp, rc, O, k0pad);
+    lds_barrier();
+    if (a.double_dqn) {
+        mlp_fwd(N, 0, nl, theta_next, S, ACT_NONE);
+        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
+            const int r = e / nA, act = e - r * nA;
+            qb[r * ap + act] = c51_q(S.outb + r * S.op, nA, atoms, duel, act, vmin, dz, nullptr);
+        }
+        lds_barrier();
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            int best = 0;
+            for (int j = 1; j < nA; ++j) if (qb[r * ap + j] > qb[r * ap + best]) best = j;
+            S.y[r] = (float)best;
+        }
+        lds_barrier();
+    }
+    mlp_fwd(N, 0, nl, target, S, ACT_NONE);
+    if (!a.double_dqn) {
+        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
+            const int r = e / nA, act = e - r * nA;
+            qb[r * ap + act] = c51_q(S.outb + r * S.op, nA, atoms, duel, act, vmin, dz, nullptr);
+        }
+        lds_barrier();
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            int best = 0;
+            for (int j = 1; j < nA; ++j) if (qb[r * ap + j] > qb[r * ap + best]) best = j;
+            S.y[r] = (float)best;
+        }
+        lds_barrier();
+    }
+    // ---- projection of the target distribution (projection_dist :147-158), one thread per row; qb row = next_dist
+    for (int r = threadIdx.x; r < nv; r += kWG) {
+        float* nd = nullptr;
+        lds_f ndl = qb + r * ap;
+        {   // probabilities of the chosen next action into LDS
+            const int act = (int)S.y[r];
+            lds_cf o = S.outb + r * S.op;
+            float mx = -3.4e38f;
+            for (int i = 0; i < atoms; ++i) mx = fmaxf(mx, c51_logit(o, nA, atoms, duel, act, i));
+            float sum = 0.f;
+            for (int i = 0; i < atoms; ++i) sum += expf(c51_logit(o, nA, atoms, duel, act, i) - mx);
+            for (int i = 0; i < atoms; ++i) ndl[i] = expf(c51_logit(o, nA, atoms, duel, act, i) - mx) / sum;
+        }
+        (void)nd;
+        g_cf rec = ring + (size_t)idx[r] * R.stride;
+        const float rew = rec[R.rew_off], done = rec[R.done_off];
+        lds_f mr = m + r * ap;
+        for (int i = 0; i < atoms; ++i) mr[i] = 0.f;
+        for (int pass = 0; pass < 2; ++pass)               // index_add_ of all lower bins first, then of all upper bins (:155-156)
+            for (int i = 0; i < atoms; ++i) {
+                const float z = vmin + dz * (float)i;
+                const float tz = fminf(fmaxf(rew + a.gamma * z * (1.f - done), vmin), vmax);
+                const float b = (tz - vmin) / dz;
+                const float lf = floorf(b), uf = ceilf(b);
+                const int l = (int)lf, u = (int)uf;
+                if (pass == 0) mr[l] += (uf + (l == u ? 1.f : 0.f) - b) * ndl[i];
+                else mr[u] += (b - lf) * ndl[i];
+            }
+    }
+    lds_barrier();
+    // ---- current distribution of the taken action, cross-entropy against m, head delta
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], O, 0);
+    zero_cols(S.xin, S.xp, rc, O, k0pad);
+    lds_barrier();
+    mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
+    float lossp = 0.f;
+    g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
+    g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
+    for (int r = threadIdx.x; r < rc; r += kWG) {
+        lds_f o = S.outb + r * S.op;
+        lds_f pr = qb + r * ap;               // probabilities of the taken action, then its logit delta
+        int at = 0;
+        if (r < nv) {
+            at = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
+            float mx = -3.4e38f;
+            for (int i = 0; i < atoms; ++i) mx = fmaxf(mx, c51_logit(o, nA, atoms, duel, at, i));
+            float sum = 0.f;
+            for (int i = 0; i < atoms; ++i) sum += expf(c51_logit(o, nA, atoms, duel, at, i) - mx);
+            const float w = a.use_isw ? isw[r] : 1.f;              // `is_weight.reshape(-1,1)`: per-row weights here (:256)
+            float ce = 0.f, gp = 0.f;
+            for (int i = 0; i < atoms; ++i) {
+                const float pi = expf(c51_logit(o, nA, atoms, duel, at, i) - mx) / sum;
+                const float mi = m[r * ap + i];
+                const bool inside = pi > 1e-5f && pi < 1.f - 1e-5f;
+                ce += mi * logf(fminf(fmaxf(pi, 1e-5f), 1.f - 1e-5f));
+                const float gi = inside ? -(mi * w / (float)B) / pi : 0.f;     // d loss / d p_i
+                pr[i] = pi;
+                m[r * ap + i] = gi;                                             // m_i is not needed any more
+                gp += gi * pi;
+            }
+            lossp += -w * ce;
+            tde[r] = ce;                                                        // `error` of :255 (PER priorities use |error|)
+            for (int i = 0; i < atoms; ++i) pr[i] = pr[i] * (m[r * ap + i] - gp);       // softmax backward: d loss / d logit_i
+        }
+        for (int j = 0; j < npad; ++j) {
+            float v = 0.f;
+            if (r < nv) {
+                if (!duel) { if (j >= at * atoms && j < (at + 1) * atoms) v = pr[j - at * atoms]; }
+                else if (j < atoms) v = pr[j];                                                   // dV_i = d_i
+                else if (j < atoms + nA * atoms) {
+                    const int b = (j - atoms) / atoms, i = (j - atoms) - b * atoms;
+                    v = pr[i] * ((b == at ? 1.f : 0.f) - 1.f / (float)nA);                       // dA_b,i = d_i (delta - 1/nA)
+                }
+            }
+            o[j] = v;
+        }
+    }
+    lds_barrier();
+    mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);
+    const float ls = block_sum(lossp, S.red);
+    if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
+}
+
+}  // namespace frl

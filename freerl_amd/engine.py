@@ -18,7 +18,7 @@ def _fp(a):
 
 class Engine:
     def __init__(self, algo, obs_dim, act_dim, capacity, *, n_learners=1, discrete=False, hidden=128,
-                 hidden_act=N.ACT_RELU, twin_critic=False, batch_max=256, extra_cols=0, device_id=0, seed=0, actor_dist=0, dueling=False, noisy=False):
+                 hidden_act=N.ACT_RELU, twin_critic=False, batch_max=256, extra_cols=0, device_id=0, seed=0, actor_dist=0, dueling=False, noisy=False, c51=None):
         obs_dim = list(obs_dim) if isinstance(obs_dim, (list, tuple)) else [int(obs_dim)]
         act_dim = list(act_dim) if isinstance(act_dim, (list, tuple)) else [int(act_dim)]
         assert len(obs_dim) == len(act_dim)
@@ -30,6 +30,8 @@ class Engine:
         cfg.twin_critic, cfg.capacity, cfg.batch_max = int(bool(twin_critic)), int(capacity), int(batch_max)
         cfg.extra_cols, cfg.device_id, cfg.seed = int(extra_cols), int(device_id), int(seed) & (2 ** 64 - 1)
         cfg.actor_dist, cfg.dueling, cfg.noisy = int(actor_dist), int(bool(dueling)), int(bool(noisy))
+        if c51 is not None:                     # (atoms, v_min, v_max)
+            cfg.c51_atoms, cfg.c51_vmin, cfg.c51_vmax = int(c51[0]), float(c51[1]), float(c51[2])
         self._L = N.lib()
         h = C.c_void_p()
         N.check(self._L.frl_create(C.byref(cfg), C.byref(h)))

@@ -90,6 +90,8 @@ typedef struct frl_config {
                                      Q = V + A - mean(A) */
     int noisy;                    /* DQN trick['Noisy'] (Noisy_net.py:17-76): the head (l2, or Dueling's V and A) is NoisyLinear: parameters
                                      mu + sigma, fresh factorised noise at every forward */
+    int c51_atoms;                /* DQN trick['Categorical'] (DQN_with_tricks.py:82-158): atoms of the value distribution (51), 0 = off */
+    float c51_vmin, c51_vmax;     /* its support [v_min, v_max] (-100, 100) */
     int device_id;
     uint64_t seed;                /* device Philox key (fast path only) */
 } frl_config;

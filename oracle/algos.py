@@ -91,6 +91,126 @@ class NoisyNet:
         return None, {k: g[k].astype(F32) for k in p}
 
 
+class C51Net:
+    """Categorical (DQN_with_tricks.py:82-132): logits [B, nA, atoms] from l2 (plain) or V + A - mean_a A (Dueling, V: atoms
+    rows, A: nA*atoms rows); dist = softmax over atoms; q = sum_i z_i dist_i.  Heads are nn.Linear or NoisyLinear."""
+
+    def __init__(self, n_actions, atoms, vmin, vmax, dueling, noisy):
+        self.nA, self.atoms, self.vmin, self.vmax = n_actions, atoms, vmin, vmax
+        self.dueling, self.noisy = dueling, noisy
+        self.heads = ["V", "A"] if dueling else ["l2"]
+        self.z = np.linspace(vmin, vmax, atoms, dtype=np.float64).astype(F32)       # torch.linspace in float32
+        self.delta_z = (vmax - vmin) / (atoms - 1)
+
+    def _eff(self, p, name, eps):
+        if not self.noisy:
+            return p[name + ".weight"], p[name + ".bias"]
+        w, b = p[name + ".weight_mu"], p[name + ".bias_mu"]
+        if eps is None:
+            return w, b
+        ei, eo = nn.f32(eps[name][0]), nn.f32(eps[name][1])
+        return (w + p[name + ".weight_sigma"] * np.outer(eo, ei)).astype(F32), (b + p[name + ".bias_sigma"] * eo).astype(F32)
+
+    def forward(self, p, x, eps=None):
+        h = np.maximum(x @ p["l1.weight"].T + p["l1.bias"], 0).astype(F32)
+        outs, effs = {}, {}
+        for name in self.heads:
+            w, b = self._eff(p, name, eps)
+            effs[name] = w
+            outs[name] = (h @ w.T + b).astype(F32)
+        B = x.shape[0]
+        if self.dueling:
+            V = outs["V"].reshape(B, 1, self.atoms)
+            A = outs["A"].reshape(B, self.nA, self.atoms)
+            logits = ((V + A) - A.mean(axis=1, keepdims=True, dtype=F32)).astype(F32)
+        else:
+            logits = outs["l2"].reshape(B, self.nA, self.atoms)
+        e = np.exp(logits - logits.max(axis=2, keepdims=True))
+        dist = (e / e.sum(axis=2, keepdims=True)).astype(F32)
+        q = (dist * self.z).sum(axis=2).astype(F32)
+        return dist, q, [x, h, effs, eps]
+
+    def backward(self, p, acts, dlogits):
+        x, h, effs, eps = acts
+        B = x.shape[0]
+        if self.dueling:
+            d = {"V": dlogits.sum(axis=1).astype(F32),
+                 "A": (dlogits - dlogits.mean(axis=1, keepdims=True, dtype=F32)).reshape(B, -1).astype(F32)}
+        else:
+            d = {"l2": dlogits.reshape(B, -1)}
+        g, dh = {}, 0
+        for name in self.heads:
+            dW, db = d[name].T @ h, d[name].sum(axis=0)
+            if self.noisy:
+                ei, eo = nn.f32(eps[name][0]), nn.f32(eps[name][1])
+                g[name + ".weight_mu"], g[name + ".bias_mu"] = dW, db
+                g[name + ".weight_sigma"], g[name + ".bias_sigma"] = dW * np.outer(eo, ei), db * eo
+            else:
+                g[name + ".weight"], g[name + ".bias"] = dW, db
+            dh = dh + d[name] @ effs[name]
+        dh = dh * (h > 0)
+        g["l1.weight"], g["l1.bias"] = dh.T @ x, dh.sum(axis=0)
+        return {k: g[k].astype(F32) for k in p}
+
+
+class C51DQN:
+    """DQN_with_tricks.learn, Categorical branch (:248-260) with projection_dist (:134-158); buffer/PER handled by the caller."""
+
+    def __init__(self, params, obs_dim, n_actions, lr, capacity, atoms=51, vmin=-100, vmax=100, dueling=False, noisy=False):
+        self.q = nn.copy_params(params)
+        self.q_t = nn.copy_params(params)
+        self.net = C51Net(n_actions, atoms, vmin, vmax, dueling, noisy)
+        self.opt = Adam(self.q, lr)
+        self.buffer = Buffer(capacity, obs_dim, 1)
+        self.losses = []
+
+    def add(self, *a):
+        self.buffer.add(*a)
+
+    def select_action(self, obs, eps=None):
+        return int(np.argmax(self.net.forward(self.q, nn.f32(obs).reshape(1, -1), eps)[1], axis=1)[0])
+
+    def learn_with(self, idx, gamma, tau, double=False, is_weight=None, noisy_eps=(None, None, None)):
+        net = self.net
+        obs, act, rew, nobs, done = self.buffer.sample(idx)
+        B, atoms = obs.shape[0], net.atoms
+        if double:
+            next_a = np.argmax(net.forward(self.q, nobs, noisy_eps[0])[1], axis=1)
+            dist_t, _, _ = net.forward(self.q_t, nobs, noisy_eps[1])
+        else:
+            dist_t, q_t, _ = net.forward(self.q_t, nobs, noisy_eps[1])
+            next_a = np.argmax(q_t, axis=1)
+        next_dist = dist_t[np.arange(B), next_a]                                     # [B, atoms]
+        t_z = np.clip(rew + F32(gamma) * net.z * (F32(1) - done), net.vmin, net.vmax).astype(F32)
+        b = ((t_z - F32(net.vmin)) / F32(net.delta_z)).astype(F32)
+        l, u = np.floor(b).astype(np.int64), np.ceil(b).astype(np.int64)
+        dl = ((u + (l == u) - b) * next_dist).astype(F32)
+        du = ((b - l) * next_dist).astype(F32)
+        m = np.zeros((B, atoms), dtype=F32)
+        for r in range(B):                               # index_add_: sequential in source order, lower bins first
+            for i in range(atoms):
+                m[r, l[r, i]] += dl[r, i]
+            for i in range(atoms):
+                m[r, u[r, i]] += du[r, i]
+        dist, _, acts = net.forward(self.q, obs, noisy_eps[2])
+        a = act.astype(np.int64).reshape(-1)
+        p = dist[np.arange(B), a]
+        logp = np.log(np.clip(p, 1e-5, 1 - 1e-5)).astype(F32)
+        w = np.ones((B, 1), F32) if is_weight is None else nn.f32(is_weight).reshape(-1, 1)
+        loss = F32(np.mean(-(m * logp * w).sum(axis=1), dtype=F32))
+        self.last_td = (m * logp).sum(axis=1).astype(F32)                            # `error` (:255)
+        inside = (p > 1e-5) & (p < 1 - 1e-5)
+        gp_ = np.where(inside, -(m * w / F32(B)) / p, F32(0)).astype(F32)            # d loss / d p
+        dlog_a = (p * (gp_ - (gp_ * p).sum(axis=1, keepdims=True))).astype(F32)      # softmax backward
+        dlogits = np.zeros((B, net.nA, atoms), dtype=F32)
+        dlogits[np.arange(B), a] = dlog_a
+        g = net.backward(self.q, acts, dlogits)
+        self.opt.step(self.q, g)
+        nn.soft_update(self.q_t, self.q, tau)
+        self.losses.append(loss)
+        return loss
+
+
 class DQN:
     """DQN_file/DQN.py:62-128.  Q-net MLP obs->128->n_actions, target copy, Adam(lr).  dueling=True: DQN_with_tricks'
     Dueling net (params l1, V, A); noisy=True: NoisyLinear heads (learn_with takes the per-forward noise)."""

@@ -41,6 +41,14 @@ CASES = {
     # DQN_with_tricks.learn with Noisy + Dueling + Double (Noisy_net.py:17-76; DQN_with_tricks.py:60-79,263-265)
     "dqn_noisy": dict(kind="dqn_noisy", obs_dim=8, n_actions=4, capacity=2048, n_table=600, batch=128, n_learn=4,
                       gamma=0.99, tau=0.01, lr=1e-3, table_seed=135, param_seed=1030, idx_seed=2030, noise_seed=3030),
+    # full Rainbow = the reference's default trick set: Double + Dueling + PER + Noisy + N_Step + Categorical
+    "dqn_rainbow": dict(kind="dqn_rainbow", obs_dim=8, n_actions=4, capacity=2048, n_table=500, batch=64, n_learn=4,
+                        gamma=0.99, n_step=3, tau=0.01, lr=1e-3, atoms=51, vmin=-100.0, vmax=100.0,
+                        table_seed=136, param_seed=1040, u_seed=2040, noise_seed=3040),
+    # Categorical alone (plain l2 head, uniform replay, no Double): DQN_with_tricks.py:82-158,248-260
+    "dqn_c51": dict(kind="dqn_c51", obs_dim=8, n_actions=3, capacity=2048, n_table=500, batch=64, n_learn=4,
+                    gamma=0.99, tau=0.01, lr=1e-3, atoms=51, vmin=-100.0, vmax=100.0,
+                    table_seed=137, param_seed=1050, idx_seed=2050),
     # DQN.learn (DQN_file/DQN.py:104-128); SYN-D shape of SURVEY §8(d)
     "dqn": dict(kind="dqn", obs_dim=8, n_actions=4, capacity=4096, n_table=1024, batch=256,
                 n_learn=5, gamma=0.99, tau=0.01, lr=1e-3, table_seed=123, param_seed=1000,
@@ -175,6 +183,34 @@ def dqn_noisy_inputs(c):
 def noisy_eps(raw_one):
     """{head: (randn_in, randn_out)} -> {head: (eps_in, eps_out)}"""
     return {h: (noisy_f(a), noisy_f(b)) for h, (a, b) in raw_one.items()}
+
+
+def dqn_c51_inputs(c):
+    tab = synth.transitions(c["table_seed"], c["n_table"], c["obs_dim"], 1, n_discrete=c["n_actions"])
+    tab["rew"] = (tab["rew"] * 30).astype(np.float32)          # spread the projected targets over the [-100, 100] support
+    params = synth.mlp_params(c["param_seed"], [("l1", H, c["obs_dim"]), ("l2", c["n_actions"] * c["atoms"], H)])
+    idx = [synth.indices(c["idx_seed"] + k, c["n_table"], c["batch"]) for k in range(c["n_learn"])]
+    return dict(table=tab, params=dict(Qnet=params), idx=idx)
+
+
+def dqn_rainbow_inputs(c):
+    nA, O, atoms = c["n_actions"], c["obs_dim"], c["atoms"]
+    tab = synth.transitions(c["table_seed"], c["n_table"], O, 1, n_discrete=nA)
+    tab["rew"] = (tab["rew"] * 30).astype(np.float32)
+    g = np.random.default_rng(c["param_seed"])
+    p = dict(synth.mlp_params(c["param_seed"], [("l1", H, O)]))
+    rows = dict(V=atoms, A=nA * atoms)
+    for name in ("V", "A"):
+        r = 1 / np.sqrt(H)
+        p[name + ".weight_mu"] = g.uniform(-r, r, (rows[name], H)).astype(np.float32)
+        p[name + ".weight_sigma"] = g.uniform(0.02, 0.08, (rows[name], H)).astype(np.float32)
+        p[name + ".bias_mu"] = g.uniform(-r, r, rows[name]).astype(np.float32)
+        p[name + ".bias_sigma"] = g.uniform(0.02, 0.08, rows[name]).astype(np.float32)
+    us = [np.random.default_rng(c["u_seed"] + k).random(c["batch"]) for k in range(c["n_learn"])]
+    gn = np.random.default_rng(c["noise_seed"])
+    draw = lambda: {h: (gn.standard_normal(H).astype(np.float32), gn.standard_normal(rows[h]).astype(np.float32)) for h in ("V", "A")}
+    raw = [[draw() for _ in range(3)] for _ in range(c["n_learn"])]
+    return dict(table=tab, params=dict(Qnet=p), uniforms=us, raw=raw, probe=draw())
 
 
 def dqn_tricks_inputs(c):

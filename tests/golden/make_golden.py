@@ -264,6 +264,57 @@ def gen_dqn_noisy(out):
     synth.pack_digest("Qnet_target", params_only(pol.agent.Qnet_target), out)
 
 
+def gen_dqn_c51(out):
+    c = cases.CASES["dqn_c51"]
+    inp = cases.dqn_c51_inputs(c)
+    mod = import_reference("DQN_file", "DQN_with_tricks")
+    trick = dict(Double=False, Dueling=False, PER=False, Noisy=False, N_Step=False, Categorical=True)
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU, trick=trick, gamma=c["gamma"], batch_size=c["batch"])
+    load(pol.agent.Qnet, inp["params"]["Qnet"])
+    load(pol.agent.Qnet_target, inp["params"]["Qnet"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    out["select_action"] = np.array([pol.select_action(tab["obs"][i]) for i in range(32)], dtype=np.int64)
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    synth.pack_digest("Qnet", t2n(pol.agent.Qnet.state_dict()), out, full_limit=0)
+    synth.pack_digest("Qnet_target", t2n(pol.agent.Qnet_target.state_dict()), out, full_limit=0)
+
+
+def gen_dqn_rainbow(out):
+    """The reference's default trick set (DQN_with_tricks.py:416): all six."""
+    c = cases.CASES["dqn_rainbow"]
+    inp = cases.dqn_rainbow_inputs(c)
+    mod = import_reference("DQN_file", "DQN_with_tricks")
+    trick = dict(Double=True, Dueling=True, PER=True, Noisy=True, N_Step=True, Categorical=True)
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU, trick=trick, gamma=c["gamma"], batch_size=c["batch"])
+    out["state_dict_keys"] = np.array(list(pol.agent.Qnet.state_dict().keys()))
+    for net in (pol.agent.Qnet, pol.agent.Qnet_target):
+        with torch.no_grad():
+            for name, prm in net.named_parameters():
+                prm.copy_(torch.from_numpy(inp["params"]["Qnet"][name]))
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    order = lambda one: [torch.from_numpy(t.copy()) for h in ("V", "A") for t in one[h]]
+    with inject(torch, "randn", feeder(order(inp["probe"]))):
+        out["select_action_probe"] = np.int64(pol.select_action(tab["obs"][3]))
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    seq = [t for per_call in inp["raw"] for one in per_call for t in order(one)]
+    with inject(np.random, "uniform", _UniformFeeder(inp["uniforms"])), inject(torch, "randn", feeder(seq)):
+        for k in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            out["tree_sum/%d" % k] = np.float64(pol.buffer.sumtree.sum())
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    params_only = lambda net: {k: v for k, v in t2n(net.state_dict()).items() if "epsilon" not in k}
+    synth.pack_digest("Qnet", params_only(pol.agent.Qnet), out, full_limit=0)
+    synth.pack_digest("Qnet_target", params_only(pol.agent.Qnet_target), out, full_limit=0)
+
+
 def gen_ddpg(out):
     c = cases.CASES["ddpg"]
     inp = cases.ac_inputs(c, twin=False)
@@ -826,7 +877,7 @@ def survey_known_answers():
 
 def main():
     gens = {
-        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn_noisy": gen_dqn_noisy, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
+        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn_noisy": gen_dqn_noisy, "dqn_c51": gen_dqn_c51, "dqn_rainbow": gen_dqn_rainbow, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),

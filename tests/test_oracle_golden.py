@@ -247,6 +247,48 @@ def test_dqn_noisy_dueling_double():
     synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
 
 
+def test_dqn_categorical():
+    """Categorical DQN alone (DQN_with_tricks.py:82-158,248-260): softmax heads, projection of the target distribution."""
+    c = cases.CASES["dqn_c51"]
+    inp = cases.dqn_c51_inputs(c)
+    fx = gold("dqn_c51")
+    pol = algos.C51DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"], c["atoms"], c["vmin"], c["vmax"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    np.testing.assert_array_equal([pol.select_action(tab["obs"][i]) for i in range(32)], fx["select_action"])
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+
+
+def test_dqn_rainbow_all_six_tricks():
+    """The reference's default trick set: Double + Dueling + PER + Noisy + N_Step + Categorical."""
+    from oracle.buffer import NStepWrapper, PERBuffer
+    c = cases.CASES["dqn_rainbow"]
+    inp = cases.dqn_rainbow_inputs(c)
+    fx = gold("dqn_rainbow")
+    pol = algos.C51DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"], c["atoms"], c["vmin"], c["vmax"],
+                       dueling=True, noisy=True)
+    per = PERBuffer(c["capacity"], c["obs_dim"], 1)
+    pol.buffer = per.buffer
+    front = NStepWrapper(per, c["gamma"], c["n_step"])
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        front.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    assert pol.select_action(tab["obs"][3], cases.noisy_eps(inp["probe"])) == int(fx["select_action_probe"])
+    for k in range(c["n_learn"]):
+        idx, w = per.sample_with(inp["uniforms"][k])
+        pol.learn_with(idx, front.n_step_gamma, c["tau"], double=True, is_weight=w, noisy_eps=[cases.noisy_eps(o) for o in inp["raw"][k]])
+        per.update_priorities(idx, pol.last_td)
+        np.testing.assert_allclose(per.sumtree.sum(), float(fx["tree_sum/%d" % k]), rtol=1e-5)
+    np.testing.assert_allclose(np.array(pol.losses), fx["loss"], rtol=LOSS_RTOL)
+    synth.check_digest("Qnet", pol.q, fx, P_RTOL, P_ATOL)
+    synth.check_digest("Qnet_target", pol.q_t, fx, P_RTOL, P_ATOL)
+
+
 def test_ppo_beta_actor():
     """PPO_with_tricks.py with beta=True (Actor_Beta :120-151): alpha/beta heads, Beta log-prob / entropy / mean."""
     c = cases.CASES["ppo_beta"]
