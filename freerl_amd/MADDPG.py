@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import DeviceNet, Engine, OptimizerView, F32, init_layers, init_layers_ddpg, resolve_device
+from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, F32, init_layers, init_layers_ddpg, resolve_device
 from .Buffer import Buffer
 from .TD3 import actor_layers, critic_layers
 
@@ -39,8 +39,6 @@ class MADDPG:
         if not is_continue:
             raise ValueError("only continuous actions are implemented in the reference (MADDPG_simple.py:126)")
         sup = dict(supplement or {})
-        if sup.get("Batch_ObsNorm"):
-            raise NotImplementedError("MADDPG.py supplement['Batch_ObsNorm'] (per-agent Normalization_batch_size) is not ported")
         self.supplement = supplement
         self._wd = 1e-3 if sup.get("weight_decay") else 0.0      # MADDPG.py:118-121: critic Adam weight_decay
         self.agent_ids = list(dim_info.keys())
@@ -55,6 +53,9 @@ class MADDPG:
             self.agents[aid] = Agent(self._e, j, od[j], ad[j], total, actor_lr, critic_lr, hidden, twin=self._twin,
                                      net_init=bool(sup.get("net_init")), weight_decay=self._wd)
             self.buffers[aid] = Buffer(buffer_size, od[j], ad[j], self.device, _engine=self._e, _agent=j)
+        if sup.get("Batch_ObsNorm"):                       # MADDPG.py:155-156: one Normalization_batch_size per agent
+            self._e.obsnorm_enable(True)
+            self.batch_size_obs_norm = {aid: BatchObsNormView(self._e, j) for j, aid in enumerate(self.agent_ids)}
         self.is_continue = is_continue
         self.agent_x = self.agent_ids[0]
         self.regular = False
@@ -70,8 +71,12 @@ class MADDPG:
             actions[aid] = self._e.act(2 * j, N.ACT_TANHHEAD, o, out_dim=self._ad[j])[0, 0]
         return actions
 
-    def evaluate_action(self, obs):
-        return self.select_action(obs)
+    def evaluate_action(self, obs):                     # no Batch_ObsNorm here (MADDPG.py:173-180), unlike select_action (:162-163)
+        actions = {}
+        for j, aid in enumerate(self.agent_ids):
+            o = np.asarray(obs[aid], dtype=np.float32).reshape(1, 1, -1)
+            actions[aid] = self._e.act(2 * j, N.ACT_TANHHEAD, o, out_dim=self._ad[j], normalize=False)[0, 0]
+        return actions
 
     def add(self, obs, action, reward, next_obs, done):
         """Every agent's buffer is written in lock-step (MADDPG_simple.py:143-145): one joint record."""

@@ -166,21 +166,21 @@ class BatchObsNormView:
     """`policy.batch_size_obs_norm.running_ms.{mean,std}` (SAC.py:586, DDPG.py:160): reads the engine's
     device-side Normalization_batch_size statistics."""
 
-    def __init__(self, engine):
-        self._e = engine
+    def __init__(self, engine, agent=0):
+        self._e, self._agent = engine, agent
         self.running_ms = self
 
     @property
     def n(self):
-        return self._e.obsnorm_stats()["n"]
+        return self._e.obsnorm_stats(agent=self._agent)["n"]
 
     @property
     def mean(self):
-        return torch.from_numpy(self._e.obsnorm_stats()["mean"].reshape(1, -1))
+        return torch.from_numpy(self._e.obsnorm_stats(agent=self._agent)["mean"].reshape(1, -1))
 
     @property
     def std(self):
-        return torch.from_numpy(self._e.obsnorm_stats()["std"].reshape(1, -1))
+        return torch.from_numpy(self._e.obsnorm_stats(agent=self._agent)["std"].reshape(1, -1))
 
 
 def as_f32(x, n):

@@ -404,7 +404,12 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
-        CREATE_TRY(dalloc_zero(&h.obsnorm, P * (size_t)(1 + 3 * c.obs_dim[0]), e->stream));
+        {
+            int omax = 1;
+            for (int j = 0; j < c.n_agents; ++j) omax = std::max(omax, c.obs_dim[j]);
+            h.obsnorm_w = 1 + 3 * omax;
+            CREATE_TRY(dalloc_zero(&h.obsnorm, P * (size_t)c.n_agents * c.n_agents * h.obsnorm_w, e->stream));
+        }
         CREATE_TRY(hipHostMalloc((void**)&e->h_idx, e->idx_count * sizeof(int)));
         CREATE_TRY(hipHostMalloc((void**)&e->h_noise, e->noise_count * sizeof(float)));
     }
@@ -742,7 +747,8 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     const bool no_norm = (mode_flags & FRL_ACT_NO_OBSNORM) != 0;
     ActArgs a;
     a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
-    a.normalize = (!no_norm && e->h.obs_norm_on && e->h.n_agents == 1 && in_dim == e->h.rec.obs_dim[0]) ? 1 : 0;
+    const int agent = e->h.n_agents > 1 ? net / 2 : 0;            // MADDPG: only the actors (even nets) take a single agent's obs
+    a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
     dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
     hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
@@ -903,7 +909,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)a.batch * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
             prof_end(e);
         }
-        if (h.obs_norm_on && h.algo != ALGO_DQN && h.n_agents == 1)      // sample(): norm(obs) updates the statistics first
+        if (h.obs_norm_on && h.algo != ALGO_DQN)                         // sample(): norm(obs) updates the statistics first
             hipLaunchKernelGGL(obsnorm_kernel, dim3(pc), blk, 0, st, e->d, a.batch, 0, p0);
         if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
             hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
@@ -1059,26 +1065,30 @@ extern "C" int frl_timer_stop(frl_engine* e, float* ms_out) {
 // Batch_ObsNorm (Normalization_batch_size): switch + statistics {n, mean[O], S[O], std[O]} per learner
 extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
     ENG(e);
-    if (!e->has_nets || e->h.n_agents != 1) return fail(FRL_ERR_STATE, "Batch_ObsNorm is implemented for the single-agent engines");
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
     e->h.obs_norm_on = on ? 1 : 0;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d, &e->h, sizeof e->h, hipMemcpyHostToDevice));
     return FRL_OK;
 }
+// stats of one learner: n_agents blocks of (1 + 3*max obs_dim) floats, block j = {n, mean[O_j], S[O_j], std[O_j]} of agent j
+// (the version the next select_action / learn starts from); single agent: one block of 1 + 3*O floats
+static float* obsnorm_final(frl_engine* e, int learner) {
+    const size_t n = e->h.n_agents, w = e->h.obsnorm_w;
+    return e->h.obsnorm + (((size_t)learner * n + (n - 1)) * n) * w;
+}
 extern "C" int frl_obsnorm_get(frl_engine* e, int learner, float* stats_out) {
     ENG(e);
     if (!e->has_nets || learner < 0 || learner >= e->h.P || !stats_out) return fail(FRL_ERR_INVALID, "bad argument");
-    const size_t w = 1 + 3 * (size_t)e->h.rec.obs_dim[0];
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(stats_out, e->h.obsnorm + learner * w, w * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stats_out, obsnorm_final(e, learner), (size_t)e->h.n_agents * e->h.obsnorm_w * sizeof(float), hipMemcpyDeviceToHost));
     return FRL_OK;
 }
 extern "C" int frl_obsnorm_set(frl_engine* e, int learner, const float* stats) {
     ENG(e);
     if (!e->has_nets || learner < 0 || learner >= e->h.P || !stats) return fail(FRL_ERR_INVALID, "bad argument");
-    const size_t w = 1 + 3 * (size_t)e->h.rec.obs_dim[0];
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->h.obsnorm + learner * w, stats, w * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(obsnorm_final(e, learner), stats, (size_t)e->h.n_agents * e->h.obsnorm_w * sizeof(float), hipMemcpyHostToDevice));
     return FRL_OK;
 }
 

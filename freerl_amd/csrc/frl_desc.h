@@ -106,6 +106,11 @@ struct EngineDesc {
     // (x - mean) / (std + 1e-8)
     float* obsnorm;
     int obs_norm_on;
+    // multi-agent (MADDPG.py:155-156,194-196): statistics per agent, and one VERSION per updating agent — inside one learn()
+    // agent i's sample() updates every agent's statistics before agent i's update reads them.  Address of (learner p,
+    // version i, agent j) = obsnorm + ((p*n + i)*n + j) * obsnorm_w, obsnorm_w = 1 + 3*max obs_dim; the last version is the
+    // state carried to the next call (and what select_action reads).  n = 1: exactly the single-agent layout.
+    int obsnorm_w;
 };
 
 // Hyper-parameters of one learn() call (passed by value to the kernels).

@@ -50,10 +50,11 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
         const int r = e / kpad, c = e - r * kpad;
         S.xin[r * S.xp + c] = (r < nv && c < K) ? in[(size_t)r * K + c] : 0.f;
     }
-    if (D.obs_norm_on && a.normalize) {          // select_action: norm(obs, update=False) (SAC.py:194-195)
+    if (D.obs_norm_on && a.normalize) {          // select_action: norm(obs, update=False) (SAC.py:194-195, MADDPG.py:162-163)
         __syncthreads();
-        normalize_cols(S.xin, S.xp, nv, 0, D.rec.obs_dim[0], as_global(D.obsnorm + (size_t)p * (1 + 3 * D.rec.obs_dim[0])),
-                       D.rec.obs_dim[0]);
+        const int nag = D.n_agents, j = nag > 1 ? a.net / 2 : 0;           // MADDPG: net 2j is agent j's actor
+        normalize_cols(S.xin, S.xp, nv, 0, D.rec.obs_dim[j],
+                       as_global(D.obsnorm + (((size_t)p * nag + (nag - 1)) * nag + j) * D.obsnorm_w), D.rec.obs_dim[j]);
     }
     __syncthreads();
     const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;

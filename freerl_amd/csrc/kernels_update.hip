@@ -78,31 +78,44 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
 // Welford step on the batch means.  One workgroup per learner, before the gradient kernels.
 __global__ __launch_bounds__(256) void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows, int p0) {
     const EngineDesc& D = *Dp;
-    const int p = p0 + blockIdx.x, O = D.rec.obs_dim[0];
+    const int p = p0 + blockIdx.x, n = D.n_agents, W = D.obsnorm_w;
     const RecordDesc& R = D.rec;
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
-    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max);
-    g_f st = as_global(D.obsnorm + (size_t)p * (1 + 3 * O));
-    const float n = st[0] + 1.f;
-    for (int c = threadIdx.x; c < O; c += kWG) {
-        float s = 0.f;
-        for (int r = 0; r < batch; ++r) s += ring[(size_t)(all_rows ? r : idx[r]) * R.stride + R.obs_off[0] + c];
-        const float xbar = s / (float)batch;
-        g_f mean = st + 1 + c, S = st + 1 + O + c, sd = st + 1 + 2 * O + c;
-        if (n == 1.f) {
-            *mean = xbar;
-            *sd = xbar;
-        } else {
-            const float old = *mean;
-            const float m2 = old + (xbar - old) / n;
-            const float S2 = *S + (xbar - old) * (xbar - m2);
-            *mean = m2;
-            *S = S2;
-            *sd = sqrtf(S2 / n);
+    g_f base = as_global(D.obsnorm + (size_t)p * n * n * W);
+    // version i = the statistics after updating agent i's sample() (MADDPG.py:189-197: one index draw per updating agent,
+    // every agent's running mean/std updated with the batch mean of ITS observations over those rows); n = 1: in place
+    for (int i = 0; i < n; ++i) {
+        g_ci idx = as_global_i(D.idx + ((size_t)p * n + i) * D.batch_max);
+        g_cf prev = base + (size_t)(i == 0 ? n - 1 : i - 1) * n * W;
+        g_f cur = base + (size_t)i * n * W;
+        for (int e = threadIdx.x; e < n * W; e += kWG) {
+            const int j = e / W, c = e - j * W - 1;              // c = -1: the count slot
+            const int O = R.obs_dim[j];
+            g_cf ps = prev + (size_t)j * W;
+            g_f cs = cur + (size_t)j * W;
+            const float cnt = ps[0] + 1.f;
+            if (c < 0) { if (n > 1) cs[0] = cnt; continue; }
+            if (c >= O) continue;
+            float s = 0.f;
+            for (int r = 0; r < batch; ++r) s += ring[(size_t)(all_rows ? r : idx[r]) * R.stride + R.obs_off[j] + c];
+            const float xbar = s / (float)batch;
+            if (cnt == 1.f) {
+                cs[1 + c] = xbar;
+                cs[1 + O + c] = ps[1 + O + c];
+                cs[1 + 2 * O + c] = xbar;                      // the reference's first update sets std = x (normalization.py:63-65)
+            } else {
+                const float old = ps[1 + c];
+                const float m2 = old + (xbar - old) / cnt;
+                const float S2 = ps[1 + O + c] + (xbar - old) * (xbar - m2);
+                cs[1 + c] = m2;
+                cs[1 + O + c] = S2;
+                cs[1 + 2 * O + c] = sqrtf(S2 / cnt);
+            }
         }
+        __syncthreads();
+        if (n == 1 && threadIdx.x == 0) cur[0] = cur[0] + 1.f;     // in place: the count moves after every column has read it
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) st[0] = n;
 }
 
 // ------------------------------------------------------------------------------------- DQN
@@ -236,7 +249,12 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
-    g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
+    // Batch_ObsNorm statistics as of THIS agent's sample() (version ag), one block of obsnorm_w per agent
+    g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + ((size_t)p * n + ag) * n * D.obsnorm_w) : nullptr;
+    auto normalize_joint = [&](int nvalid) {      // every agent's segment of a joint [obs_0 | obs_1 | ...] block in xin[:, 0:OT)
+        for (int j = 0; j < n; ++j)
+            normalize_cols(S.xin, S.xp, nvalid, R.obs_off[j] - R.obs_off[0], R.obs_dim[j], bn + (size_t)j * D.obsnorm_w, R.obs_dim[j]);
+    };
     FRL_PHASE_INIT(S);
 #ifdef FRL_EXP_TOUCH      // experiment: pull every weight line this kernel will read into L2 up front
     {
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         g_cf noise0 = noise_u + (size_t)j * D.batch_max * am;     // set j (n = 1: set 0); MATD3_simple.py:199-201
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[j], Oj, 0);
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
-        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn, Oj); }
+        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn + (size_t)j * D.obsnorm_w, Oj); }
         FRL_PHASE(S);
         mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
         if (sac) {                                  // SAC.py:70-97 on actor_target (SAC.py:227)
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
     }
     zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-    if (bn && n > 1) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+    if (bn && n > 1) { lds_barrier(); normalize_joint(nv); }
     FRL_PHASE(S);
     mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
     float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         if (h == 0) {           // the second head reads the same [obs | act] rows: nothing in between writes xin
             gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
             zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-            if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+            if (bn) { lds_barrier(); normalize_joint(nv); }
         }
         FRL_PHASE(S);
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
@@ -378,12 +396,17 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     const int ct0 = (OT + acol) / 16, ct1 = (OT + acol + Aa + 15) / 16;
     const int nq = sac ? heads : 1;                 // SAC: mean of the twins (SAC.py:250); TD3: Q1 only (TD3.py:227)
     const float dq = sac ? -0.5f * invB : -invB;
-    g_cf bn = (D.obs_norm_on && n == 1) ? as_global(D.obsnorm + (size_t)p * (1 + 3 * OT)) : nullptr;
+    g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + ((size_t)p * n + ag) * n * D.obsnorm_w) : nullptr;
+    g_cf bn_own = bn ? bn + (size_t)ag * D.obsnorm_w : nullptr;
+    auto normalize_joint = [&](int nvalid) {
+        for (int j = 0; j < n; ++j)
+            normalize_cols(S.xin, S.xp, nvalid, R.obs_off[j] - R.obs_off[0], R.obs_dim[j], bn + (size_t)j * D.obsnorm_w, R.obs_dim[j]);
+    };
 
     // -- a = actor(obs)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
+    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
     lds_barrier();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     float lp = 0.f;
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     for (int h = 0; h < nq; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, OT, bn, OT); }
+        if (bn) { lds_barrier(); normalize_joint(nv); }
         lds_barrier();
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     // -- actor forward again (activations for its backward), head delta, backward
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
-    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn, Oa); }
+    if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
     lds_barrier();
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     const int napad = NA.L[NA.n_layers - 1].n_pad;

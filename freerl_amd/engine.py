@@ -308,9 +308,10 @@ class Engine:
     def obsnorm_enable(self, on=True):
         N.check(self._L.frl_obsnorm_enable(self._h, int(bool(on))))
 
-    def obsnorm_stats(self, learner=0):
-        """-> dict(n, mean[O], S[O], std[O]) of the Batch_ObsNorm running statistics."""
-        O = self.layout.obs_dim[0]
-        buf = np.zeros(1 + 3 * O, dtype=F32)
+    def obsnorm_stats(self, learner=0, agent=0):
+        """-> dict(n, mean[O], S[O], std[O]) of the Batch_ObsNorm running statistics (of one agent of a MADDPG engine)."""
+        w = 1 + 3 * max(self.layout.obs_dim[j] for j in range(self.n_agents))
+        buf = np.zeros(self.n_agents * w, dtype=F32)
         N.check(self._L.frl_obsnorm_get(self._h, int(learner), _fp(buf)))
-        return dict(n=int(buf[0]), mean=buf[1:1 + O].copy(), S=buf[1 + O:1 + 2 * O].copy(), std=buf[1 + 2 * O:].copy())
+        O, b = self.layout.obs_dim[agent], buf[agent * w:(agent + 1) * w]
+        return dict(n=int(b[0]), mean=b[1:1 + O].copy(), S=b[1 + O:1 + 2 * O].copy(), std=b[1 + 2 * O:1 + 3 * O].copy())

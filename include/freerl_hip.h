@@ -188,7 +188,8 @@ int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int step);
  * DDPG.py:160-161,190-192; PPO_with_tricks.py:225-226,297-299): when enabled, every learn call first
  * updates the running statistics with the batch mean of the sampled observations, then obs and
  * next_obs are normalised wherever the path reads them; select_action normalises without updating.
- * stats = {n, mean[O], S[O], std[O]} */
+ * stats = {n, mean[O], S[O], std[O]}; a MADDPG engine (MADDPG.py:155-156,194-196) keeps one such block per agent, each 1 +
+ * 3*max(obs_dim) floats wide, and get/set move all n_agents blocks. */
 int frl_obsnorm_enable(frl_engine* e, int on);
 int frl_obsnorm_get(frl_engine* e, int learner, float* stats_out);
 int frl_obsnorm_set(frl_engine* e, int learner, const float* stats);

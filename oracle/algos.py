@@ -508,9 +508,12 @@ class MADDPG:
     `learn` re-samples per agent, steps critic then actor, one soft update of every agent's
     actor then critic at the end."""
 
-    def __init__(self, params, dims, actor_lr, critic_lr, capacity):
+    def __init__(self, params, dims, actor_lr, critic_lr, capacity, critic_weight_decay=0.0, batch_obs_norm=False):
+        """critic_weight_decay / batch_obs_norm: MADDPG.py's supplements (:118-121, :155-156,162-163,194-196)."""
         self.ids = list(dims.keys())
         self.dims = dims
+        self.bn = {a: NormalizationBatch(dims[a][0]) for a in self.ids} if batch_obs_norm else None
+        self._wd = critic_weight_decay
         self.pi = MLP(["l1", "l2", "l3"], out_act="tanh")
         self.q = MLP(["l1", "l2", "l3"])
         self.actor = {a: nn.copy_params(params[a]["actor"]) for a in self.ids}
@@ -518,13 +521,28 @@ class MADDPG:
         self.critic = {a: nn.copy_params(params[a]["critic"]) for a in self.ids}
         self.critic_t = {a: nn.copy_params(params[a]["critic"]) for a in self.ids}
         self.actor_opt = {a: Adam(self.actor[a], actor_lr) for a in self.ids}
-        self.critic_opt = {a: Adam(self.critic[a], critic_lr) for a in self.ids}
+        self.critic_opt = {a: Adam(self.critic[a], critic_lr, weight_decay=critic_weight_decay) for a in self.ids}
         self.buffers = {a: Buffer(capacity, dims[a][0], dims[a][1]) for a in self.ids}
         self.critic_losses = {a: [] for a in self.ids}
         self.actor_losses = {a: [] for a in self.ids}
 
-    def select_action(self, obs):                       # MADDPG_simple.py:122-132
-        return {a: self.pi.forward(self.actor[a], nn.f32(obs[a]).reshape(1, -1))[0][0] for a in self.ids}
+    def select_action(self, obs):                       # MADDPG_simple.py:122-132; MADDPG.py:162-163 normalises, no update
+        out = {}
+        for a in self.ids:
+            o = nn.f32(obs[a]).reshape(1, -1)
+            if self.bn is not None:
+                o = self.bn[a](o, update=False)
+            out[a] = self.pi.forward(self.actor[a], o)[0][0]
+        return out
+
+    def _sample(self, idx):
+        """MADDPG.py:189-197: every agent's rows; obs normalised with an update, next_obs without."""
+        batch = {a: list(self.buffers[a].sample(idx)) for a in self.ids}
+        if self.bn is not None:
+            for a in self.ids:
+                batch[a][0] = self.bn[a](batch[a][0])
+                batch[a][3] = self.bn[a](batch[a][3], update=False)
+        return batch
 
     def add(self, obs, action, reward, next_obs, done):
         for a in self.ids:
@@ -533,7 +551,7 @@ class MADDPG:
     def learn_with(self, idx_per_agent, gamma, tau):    # MADDPG_simple.py:165-186
         for j, aid in enumerate(self.ids):
             idx = idx_per_agent[j]
-            batch = {a: self.buffers[a].sample(idx) for a in self.ids}
+            batch = self._sample(idx)
             next_act = {a: self.pi.forward(self.actor_t[a], batch[a][3])[0] for a in self.ids}
             x_next = np.concatenate([batch[a][3] for a in self.ids] + [next_act[a] for a in self.ids], axis=1)
             next_q = self.q.forward(self.critic_t[aid], x_next)[0]

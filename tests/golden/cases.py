@@ -77,6 +77,10 @@ CASES = {
     "maddpg": dict(kind="maddpg", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
                    capacity=512, n_table=256, batch=64, n_learn=2, gamma=0.95, tau=0.01,
                    actor_lr=1e-3, critic_lr=1e-3, table_seed=125, param_seed=1400, idx_seed=2400),
+    # MADDPG.py with its default supplements (weight_decay, net_init, per-agent Batch_ObsNorm; MADDPG.py:60-228)
+    "maddpg_full": dict(kind="maddpg", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
+                        capacity=512, n_table=256, batch=64, n_learn=3, gamma=0.95, tau=0.01,
+                        actor_lr=1e-3, critic_lr=1e-3, table_seed=125, param_seed=1470, idx_seed=2470),
     # MATD3_simple.learn (MADDPG_file/MATD3_simple.py:217-262): twin critics, per-agent target smoothing, delayed policy
     "matd3": dict(kind="matd3", dims={"agent_0": [6, 2], "agent_1": [5, 3], "agent_2": [7, 2]},
                   capacity=512, n_table=256, batch=64, n_learn=4, gamma=0.95, tau=0.01,

@@ -466,6 +466,43 @@ def gen_maddpg(out):
             synth.pack_digest(a + "/" + net, t2n(getattr(ag, net).state_dict()), out)
 
 
+def gen_maddpg_full(out):
+    c = cases.CASES["maddpg_full"]
+    inp = cases.maddpg_inputs(c)
+    ids = inp["ids"]
+    mod = import_reference("MADDPG_file", "MADDPG")
+    sup = {"weight_decay": True, "OUNoise": True, "ObsNorm": False, "net_init": True, "Batch_ObsNorm": True}
+    pol = mod.MADDPG(copy.deepcopy(c["dims"]), True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, None, sup)
+    for aid in ids:
+        ag = pol.agents[aid]
+        for net in ("actor", "critic"):
+            load(getattr(ag, net), inp["params"][aid][net])
+            load(getattr(ag, net + "_target"), inp["params"][aid][net])
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    flat_idx = [ix for per_call in inp["idx"] for ix in per_call]
+    with inject(np.random, "choice", feeder(flat_idx)):
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    acts = pol.select_action({a: inp["tables"][a]["obs"][0] for a in ids})          # normalised, no update
+    evs = pol.evaluate_action({a: inp["tables"][a]["obs"][0] for a in ids})         # not normalised
+    for a in ids:
+        ag = pol.agents[a]
+        out["select_action/" + a] = acts[a]
+        out["evaluate_action/" + a] = evs[a]
+        out["bn_mean/" + a] = pol.batch_size_obs_norm[a].running_ms.mean.numpy()
+        out["bn_std/" + a] = pol.batch_size_obs_norm[a].running_ms.std.numpy()
+        out["bn_n/" + a] = np.int64(pol.batch_size_obs_norm[a].running_ms.n)
+        out["loss_critic/" + a] = np.array(recs[a]["update_critic"], dtype=np.float32)
+        out["loss_actor/" + a] = np.array(recs[a]["update_actor"], dtype=np.float32)
+        for net in ("actor", "critic", "actor_target", "critic_target"):
+            synth.pack_digest(a + "/" + net, t2n(getattr(ag, net).state_dict()), out)
+
+
 def gen_matd3(out):
     c = cases.CASES["matd3"]
     inp = cases.maddpg_inputs(c, twin=True)
@@ -879,7 +916,7 @@ def main():
     gens = {
         "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn_noisy": gen_dqn_noisy, "dqn_c51": gen_dqn_c51, "dqn_rainbow": gen_dqn_rainbow, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
-        "sac": gen_sac, "maddpg": gen_maddpg, "matd3": gen_matd3,
+        "sac": gen_sac, "maddpg": gen_maddpg, "maddpg_full": gen_maddpg_full, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
         "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_beta": gen_ppo_beta,
         "norm": gen_norm,

@@ -329,3 +329,50 @@ def test_ppo_beta_class():
     got = sd2np(pol.agent.actor.state_dict())
     for k in orc.actor:
         np.testing.assert_allclose(got[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_maddpg_py_default_supplements():
+    """MADDPG.py's default supplement set (weight_decay, net_init, per-agent Batch_ObsNorm) through the class, vs the golden
+    of the imported reference: statistics versions per updating agent, normalised select_action, raw evaluate_action."""
+    from freerl_amd.MADDPG import MADDPG
+    c = cases.CASES["maddpg_full"]
+    inp = cases.maddpg_inputs(c)
+    fx = gold("maddpg_full")
+    ids = inp["ids"]
+    sup = {"weight_decay": True, "OUNoise": True, "ObsNorm": False, "net_init": True, "Batch_ObsNorm": True}
+    pol = MADDPG(dict(c["dims"]), True, c["actor_lr"], c["critic_lr"], c["capacity"], CUDA, None, sup, batch_max=c["batch"])
+    for a in ids:
+        for net in ("actor", "critic"):
+            sd = {k: torch.from_numpy(v.copy()) for k, v in inp["params"][a][net].items()}
+            getattr(pol.agents[a], net).load_state_dict(sd)
+            getattr(pol.agents[a], net + "_target").load_state_dict(sd)
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    pol.track_loss = True
+    cl = {a: [] for a in ids}
+    al = {a: [] for a in ids}
+    it = iter([ix for per_call in inp["idx"] for ix in per_call])
+    orig = np.random.choice
+    np.random.choice = lambda *a, **k: next(it)
+    try:
+        for _ in range(c["n_learn"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+            for a in ids:
+                cl[a].append(pol.last_losses[a][0]); al[a].append(pol.last_losses[a][1])
+    finally:
+        np.random.choice = orig
+    acts = pol.select_action({a: inp["tables"][a]["obs"][0] for a in ids})
+    evs = pol.evaluate_action({a: inp["tables"][a]["obs"][0] for a in ids})
+    for a in ids:
+        bn = pol.batch_size_obs_norm[a].running_ms
+        assert bn.n == int(fx["bn_n/" + a])
+        np.testing.assert_allclose(bn.mean.numpy().reshape(-1), fx["bn_mean/" + a].reshape(-1), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(bn.std.numpy().reshape(-1), fx["bn_std/" + a].reshape(-1), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(acts[a], fx["select_action/" + a], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(evs[a], fx["evaluate_action/" + a], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(cl[a], fx["loss_critic/" + a], rtol=2e-4)
+        np.testing.assert_allclose(al[a], fx["loss_actor/" + a], rtol=5e-4, atol=2e-5)
+        synth.check_digest(a + "/actor", sd2np(pol.agents[a].actor.state_dict()), fx, 5e-3, 5e-5)
+        synth.check_digest(a + "/critic_target", sd2np(pol.agents[a].critic_target.state_dict()), fx, 5e-3, 5e-5)

@@ -337,6 +337,33 @@ def test_ppo_py_cautious_adamw():
     assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
 
 
+def test_maddpg_py_supplements():
+    """MADDPG.py with weight_decay + per-agent Batch_ObsNorm: every agent's statistics move once per updating agent."""
+    c = cases.CASES["maddpg_full"]
+    inp = cases.maddpg_inputs(c)
+    fx = gold("maddpg_full")
+    ids = inp["ids"]
+    pol = algos.MADDPG(inp["params"], c["dims"], c["actor_lr"], c["critic_lr"], c["capacity"], critic_weight_decay=1e-3,
+                       batch_obs_norm=True)
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids},
+                {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    for k in range(c["n_learn"]):
+        pol.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    acts = pol.select_action({a: inp["tables"][a]["obs"][0] for a in ids})
+    for a in ids:
+        assert pol.bn[a].running_ms.n == int(fx["bn_n/" + a]) == c["n_learn"] * len(ids)
+        np.testing.assert_allclose(pol.bn[a].running_ms.mean.reshape(-1), fx["bn_mean/" + a].reshape(-1), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(pol.bn[a].running_ms.std.reshape(-1), fx["bn_std/" + a].reshape(-1), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(acts[a], fx["select_action/" + a], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(np.array(pol.critic_losses[a]), fx["loss_critic/" + a], rtol=2e-4)
+        np.testing.assert_allclose(np.array(pol.actor_losses[a]), fx["loss_actor/" + a], rtol=5e-4, atol=2e-5)
+        synth.check_digest(a + "/actor", pol.actor[a], fx, 5e-3, 5e-5)
+        synth.check_digest(a + "/critic_target", pol.critic_t[a], fx, 5e-3, 5e-5)
+
+
 def test_matd3_learn():
     """MATD3_simple.learn: twin critics, per-target-agent policy noise, delayed actor + target updates."""
     c = cases.CASES["matd3"]
