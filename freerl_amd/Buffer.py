@@ -215,6 +215,9 @@ class PER_Buffer:
         """The stratified draws are np.random.uniform's own arithmetic on np.random.random_sample() (a + (b-a)*u), so a
         seeded run consumes NumPy's global stream exactly like the reference's loop (:107-114)."""
         u = np.array([np.random.random_sample() for _ in range(batch_size)])
+        if getattr(self, "_device_only", False):       # learn(): rows and weights are consumed on the device, nothing read back
+            self._e.per_sample(batch_size, uniforms=u, want_outputs=False)
+            return None, None
         idx, w = self._e.per_sample(batch_size, uniforms=u)
         return idx[0], torch.as_tensor(w[0], dtype=torch.float32).to(self.device)
 

@@ -233,7 +233,11 @@ class DQN:
             gamma = self.buffer.n_step_gamma                                   # :269-270
         idx = None
         if self.trick["PER"]:
-            self.buffer.sample(batch)                 # the rows and weights stay on the device for the update below
+            self.buffer._device_only = True           # the rows and weights stay on the device for the update below
+            try:
+                self.buffer.sample(batch)
+            finally:
+                self.buffer._device_only = False
         else:
             idx = draw_indices(len(self.buffer), batch_size)
         noisy_eps = None

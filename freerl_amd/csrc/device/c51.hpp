@@ -4,24 +4,33 @@
 
 namespace frl {
 
-// combined logit (row r, action a, atom i) out of the head outputs in outb
-__device__ __forceinline__ float c51_logit(lds_cf o, int nA, int atoms, bool duel, int a, int i) {
-    if (!duel) return o[a * atoms + i];
-    float mean = 0.f;
-    for (int b = 0; b < nA; ++b) mean += o[atoms + b * atoms + i];
-    mean /= (float)nA;
-    return (o[i] + o[atoms + a * atoms + i]) - mean;
+// Turn the head outputs of `rows` rows in outb into the logits [a][i] the reference forms (:113-120): plain head: as is
+// (offset 0); Dueling: logit[a][i] = (V_i + A_a,i) - mean_a A_a,i written over the A block (offset `atoms`).  Returns the
+// column offset of logit[0][0].  Ends with a barrier.
+__device__ __forceinline__ int c51_combine(lds_f outb, int op, int rows, int nA, int atoms, bool duel) {
+    if (!duel) return 0;
+    for (int e = threadIdx.x; e < rows * atoms; e += kWG) {
+        const int r = e / atoms, i = e - r * atoms;
+        lds_f o = outb + r * op;
+        float mean = 0.f;
+        for (int b = 0; b < nA; ++b) mean += o[atoms + b * atoms + i];
+        mean /= (float)nA;
+        const float v = o[i];
+        for (int b = 0; b < nA; ++b) o[atoms + b * atoms + i] = (v + o[atoms + b * atoms + i]) - mean;
+    }
+    lds_barrier();
+    return atoms;
 }
 
-// expected value q = sum_i z_i softmax(logits)_i of (row, action); also usable to fetch the probabilities
-__device__ __forceinline__ float c51_q(lds_cf o, int nA, int atoms, bool duel, int a, float vmin, float dz, float* p_out /* [atoms] or null */) {
-    float mx = -3.4e38f;
-    for (int i = 0; i < atoms; ++i) mx = fmaxf(mx, c51_logit(o, nA, atoms, duel, a, i));
+// softmax over the atoms of one action's logits lg[0..atoms): expected value q = sum_i z_i p_i; p_out (may be null) gets p
+__device__ __forceinline__ float c51_q(lds_cf lg, int atoms, float vmin, float dz, lds_f p_out) {
+    float mx = lg[0];
+    for (int i = 1; i < atoms; ++i) mx = fmaxf(mx, lg[i]);
     float sum = 0.f;
-    for (int i = 0; i < atoms; ++i) sum += expf(c51_logit(o, nA, atoms, duel, a, i) - mx);
+    for (int i = 0; i < atoms; ++i) sum += expf(lg[i] - mx);
     float q = 0.f;
     for (int i = 0; i < atoms; ++i) {
-        const float p = expf(c51_logit(o, nA, atoms, duel, a, i) - mx) / sum;
+        const float p = expf(lg[i] - mx) / sum;
         if (p_out) p_out[i] = p;
         q += p * (vmin + dz * (float)i);
     }

@@ -487,13 +487,12 @@ static int flush_stage(frl_engine* e) {
                        e->d_stage_slots, n, R.width, R.stride);
     HIP_TRY(hipGetLastError());
     if (e->per_on) {                 // PER_Buffer.add (Buffer.py:92-98): the new rows enter at the current maximum priority
-        HIP_TRY(hipMemcpyAsync(e->d_size, e->size_flushed.data(), (size_t)e->h.P * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpy(e->d_size, e->size_flushed.data(), (size_t)e->h.P * sizeof(int), hipMemcpyHostToDevice));   // pageable source: synchronous copy
         PerArgs pa;
         memset(&pa, 0, sizeof pa);
         pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = e->h.capacity; pa.n = n;
         hipLaunchKernelGGL(per_add_kernel, dim3(e->h.P), dim3(256), 0, e->stream, pa, (const long long*)e->d_stage_slots, (const int*)e->d_size);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(e->stream));            // size_flushed is host memory reused below
     }
     e->size_flushed = e->size;
     HIP_TRY(hipEventRecord(e->ev_stage, e->stream));
@@ -1157,16 +1156,20 @@ extern "C" int frl_per_sample(frl_engine* e, int batch, const double* uniforms, 
     pa.beta = e->per_beta; pa.rng_counter = e->rng_counter++;
     hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)P), dim3(256), 0, e->stream, e->d, pa);
     HIP_TRY(hipGetLastError());
+    if (!idx_out && !is_weight_out) return FRL_OK;            // device-resident use (frl_learn with per = 1): asynchronous
     HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t bm = e->h.batch_max;
     if (idx_out) {
-        std::vector<int> tmp((size_t)e->h.batch_max * P);
+        std::vector<int> tmp(bm * P);
         HIP_TRY(hipMemcpy(tmp.data(), e->h.idx, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (size_t p = 0; p < P; ++p)
-            for (int i = 0; i < batch; ++i) idx_out[p * batch + i] = tmp[p * e->h.batch_max + i];
+            for (int i = 0; i < batch; ++i) idx_out[p * batch + i] = tmp[p * bm + i];
     }
-    if (is_weight_out)
-        for (size_t p = 0; p < P; ++p)
-            HIP_TRY(hipMemcpy(is_weight_out + p * batch, e->h.isw + p * e->h.batch_max, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost));
+    if (is_weight_out) {
+        std::vector<float> tmp(bm * P);
+        HIP_TRY(hipMemcpy(tmp.data(), e->h.isw, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < P; ++p) memcpy(is_weight_out + p * batch, tmp.data() + p * bm, (size_t)batch * sizeof(float));
+    }
     return FRL_OK;
 }
 

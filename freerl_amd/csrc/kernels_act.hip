@@ -62,11 +62,12 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     const int nout = N.L[l0 + nl - 1].n;
     if (a.mode == ACTM_ARGMAX && D.c51_atoms && D.algo == ALGO_DQN) {      // argmax_a sum_i z_i p_i(s, a) (DQN_with_tricks.py:122-130)
         const float dz = (D.c51_vmax - D.c51_vmin) / (float)(D.c51_atoms - 1);
+        const int lb = c51_combine(S.outb, S.op, nv, D.n_discrete, D.c51_atoms, D.dueling != 0);
         for (int r = threadIdx.x; r < nv; r += kWG) {
             int best = 0;
             float mx = 0.f;
             for (int j = 0; j < D.n_discrete; ++j) {
-                const float q = c51_q(S.outb + r * S.op, D.n_discrete, D.c51_atoms, D.dueling != 0, j, D.c51_vmin, dz, nullptr);
+                const float q = c51_q(S.outb + r * S.op + lb + j * D.c51_atoms, D.c51_atoms, D.c51_vmin, dz, nullptr);
                 if (j == 0 || q > mx) { mx = q; best = j; }
             }
             a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;

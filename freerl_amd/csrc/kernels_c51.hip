@@ -35,52 +35,36 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     lds_f qb = S.dabuf;                  // [rc][ap] q values / scratch
     const int ap = S.ap;
 
+    // q[r][a] of the logits in outb -> qb, then argmax into S.y (one thread per (row, action), then per row)
+    auto pick_action = [&]() {
+        const int lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
+        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
+            const int r = e / nA, act = e - r * nA;
+            qb[r * ap + act] = c51_q(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz, nullptr);
+        }
+        lds_barrier();
+        for (int r = threadIdx.x; r < nv; r += kWG) {
+            int best = 0;
+            for (int jj = 1; jj < nA; ++jj) if (qb[r * ap + jj] > qb[r * ap + best]) best = jj;
+            S.y[r] = (float)best;
+        }
+        lds_barrier();
+        return lb;
+    };
     // ---- next action: argmax_a q(s', a) by the online net (Double, :141-143) or by the target net itself (:145)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
     if (a.double_dqn) {
         mlp_fwd(N, 0, nl, theta_next, S, ACT_NONE);
-        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
-            const int r = e / nA, act = e - r * nA;
-            qb[r * ap + act] = c51_q(S.outb + r * S.op, nA, atoms, duel, act, vmin, dz, nullptr);
-        }
-        lds_barrier();
-        for (int r = threadIdx.x; r < nv; r += kWG) {
-            int best = 0;
-            for (int j = 1; j < nA; ++j) if (qb[r * ap + j] > qb[r * ap + best]) best = j;
-            S.y[r] = (float)best;
-        }
-        lds_barrier();
+        pick_action();
     }
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
-    if (!a.double_dqn) {
-        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
-            const int r = e / nA, act = e - r * nA;
-            qb[r * ap + act] = c51_q(S.outb + r * S.op, nA, atoms, duel, act, vmin, dz, nullptr);
-        }
-        lds_barrier();
-        for (int r = threadIdx.x; r < nv; r += kWG) {
-            int best = 0;
-            for (int j = 1; j < nA; ++j) if (qb[r * ap + j] > qb[r * ap + best]) best = j;
-            S.y[r] = (float)best;
-        }
-        lds_barrier();
-    }
+    int lb = a.double_dqn ? c51_combine(S.outb, S.op, nv, nA, atoms, duel) : pick_action();
     // ---- projection of the target distribution (projection_dist :147-158), one thread per row; qb row = next_dist
     for (int r = threadIdx.x; r < nv; r += kWG) {
-        float* nd = nullptr;
         lds_f ndl = qb + r * ap;
-        {   // probabilities of the chosen next action into LDS
-            const int act = (int)S.y[r];
-            lds_cf o = S.outb + r * S.op;
-            float mx = -3.4e38f;
-            for (int i = 0; i < atoms; ++i) mx = fmaxf(mx, c51_logit(o, nA, atoms, duel, act, i));
-            float sum = 0.f;
-            for (int i = 0; i < atoms; ++i) sum += expf(c51_logit(o, nA, atoms, duel, act, i) - mx);
-            for (int i = 0; i < atoms; ++i) ndl[i] = expf(c51_logit(o, nA, atoms, duel, act, i) - mx) / sum;
-        }
-        (void)nd;
+        c51_q(S.outb + r * S.op + lb + (int)S.y[r] * atoms, atoms, vmin, dz, ndl);
         g_cf rec = ring + (size_t)idx[r] * R.stride;
         const float rew = rec[R.rew_off], done = rec[R.done_off];
         lds_f mr = m + r * ap;
@@ -102,6 +86,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
+    lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
     float lossp = 0.f;
     g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
@@ -111,19 +96,14 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
         int at = 0;
         if (r < nv) {
             at = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
-            float mx = -3.4e38f;
-            for (int i = 0; i < atoms; ++i) mx = fmaxf(mx, c51_logit(o, nA, atoms, duel, at, i));
-            float sum = 0.f;
-            for (int i = 0; i < atoms; ++i) sum += expf(c51_logit(o, nA, atoms, duel, at, i) - mx);
+            c51_q(o + lb + at * atoms, atoms, vmin, dz, pr);
             const float w = a.use_isw ? isw[r] : 1.f;              // `is_weight.reshape(-1,1)`: per-row weights here (:256)
             float ce = 0.f, gp = 0.f;
             for (int i = 0; i < atoms; ++i) {
-                const float pi = expf(c51_logit(o, nA, atoms, duel, at, i) - mx) / sum;
-                const float mi = m[r * ap + i];
+                const float pi = pr[i], mi = m[r * ap + i];
                 const bool inside = pi > 1e-5f && pi < 1.f - 1e-5f;
                 ce += mi * logf(fminf(fmaxf(pi, 1e-5f), 1.f - 1e-5f));
                 const float gi = inside ? -(mi * w / (float)B) / pi : 0.f;     // d loss / d p_i
-                pr[i] = pi;
                 m[r * ap + i] = gi;                                             // m_i is not needed any more
                 gp += gi * pi;
             }
@@ -131,18 +111,25 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
             tde[r] = ce;                                                        // `error` of :255 (PER priorities use |error|)
             for (int i = 0; i < atoms; ++i) pr[i] = pr[i] * (m[r * ap + i] - gp);       // softmax backward: d loss / d logit_i
         }
-        for (int j = 0; j < npad; ++j) {
-            float v = 0.f;
-            if (r < nv) {
-                if (!duel) { if (j >= at * atoms && j < (at + 1) * atoms) v = pr[j - at * atoms]; }
-                else if (j < atoms) v = pr[j];                                                   // dV_i = d_i
-                else if (j < atoms + nA * atoms) {
-                    const int b = (j - atoms) / atoms, i = (j - atoms) - b * atoms;
-                    v = pr[i] * ((b == at ? 1.f : 0.f) - 1.f / (float)nA);                       // dA_b,i = d_i (delta - 1/nA)
-                }
+        if (r < nv) S.y[r] = (float)at;
+    }
+    lds_barrier();
+    // head delta from the per-atom logit deltas in qb, all threads: plain head: the taken action's block; Dueling:
+    // dV_i = d_i, dA_b,i = d_i (delta_b,at - 1/nA)
+    for (int e = threadIdx.x; e < rc * npad; e += kWG) {
+        const int r = e / npad, j = e - r * npad;
+        float v = 0.f;
+        if (r < nv) {
+            const int at = (int)S.y[r];
+            lds_cf pr = qb + r * ap;
+            if (!duel) { if (j >= at * atoms && j < (at + 1) * atoms) v = pr[j - at * atoms]; }
+            else if (j < atoms) v = pr[j];
+            else if (j < atoms + nA * atoms) {
+                const int b = (j - atoms) / atoms, i = (j - atoms) - b * atoms;
+                v = pr[i] * ((b == at ? 1.f : 0.f) - 1.f / (float)nA);
             }
-            o[j] = v;
         }
+        S.outb[r * S.op + j] = v;
     }
     lds_barrier();
     mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);

@@ -234,14 +234,18 @@ class Engine:
     def per_enable(self, alpha=0.5, beta=0.4, beta_increment=0.001, epsilon=0.01):
         N.check(self._L.frl_per_enable(self._h, alpha, beta, beta_increment, epsilon))
 
-    def per_sample(self, batch, uniforms=None):
-        """-> (idx int64 [P][batch], is_weight f32 [P][batch]); the rows become the current sample for learn(per=True)."""
-        idx = np.zeros((self.P, int(batch)), np.int64)
-        w = np.zeros((self.P, int(batch)), F32)
+    def per_sample(self, batch, uniforms=None, want_outputs=True):
+        """-> (idx int64 [P][batch], is_weight f32 [P][batch]); the rows become the current sample for learn(per=True).
+        want_outputs=False: nothing is read back and the call is asynchronous (returns None)."""
         up = None
         if uniforms is not None:
             u = np.ascontiguousarray(uniforms, dtype=np.float64).reshape(self.P, int(batch))
             up = u.ctypes.data_as(C.POINTER(C.c_double))
+        if not want_outputs:
+            N.check(self._L.frl_per_sample(self._h, int(batch), up, None, None))
+            return None
+        idx = np.zeros((self.P, int(batch)), np.int64)
+        w = np.zeros((self.P, int(batch)), F32)
         N.check(self._L.frl_per_sample(self._h, int(batch), up, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(w)))
         return idx, w
 
