@@ -102,12 +102,14 @@ enum WMode : int { W_IL = 0, W_ROWS = 1, W_COLS = 2 };
 template <int BN, int MODE>
 __device__ __forceinline__ void fetch_w(f32x4 (&b)[BN], g_cf mp, int ld, int k) {
     if constexpr (MODE == W_IL) {        // mp -> row 4q, column c0 + 4i
-        static_assert(BN == 4, "interleaved weight fragments come four tiles at a time");
+        static_assert(BN % 4 == 0, "interleaved weight fragments come four tiles (64 columns) at a time");
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x4 t = ld4(mp + (size_t)(k + e) * ld);
-            b[0][e] = t.x; b[1][e] = t.y; b[2][e] = t.z; b[3][e] = t.w;
-        }
+        for (int g = 0; g < BN / 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = ld4(mp + (size_t)(k + e) * ld + 64 * g);
+                b[4 * g][e] = t.x; b[4 * g + 1][e] = t.y; b[4 * g + 2][e] = t.z; b[4 * g + 3][e] = t.w;
+            }
     } else if constexpr (MODE == W_ROWS) {   // mp -> row 4q, column c0 + i
 #pragma unroll
         for (int y = 0; y < BN; ++y)
@@ -142,10 +144,37 @@ __device__ __forceinline__ void mma_w(f32x4 (&acc)[BM][BN], lds_cf A, int lda, i
         for (int j = 0; j < kDepth - 1 && j < KB; ++j) fetch(a[j], b[j], 16 * j);
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            if (j + kDepth - 1 < KB) fetch(a[(j + kDepth - 1) % kDepth], b[(j + kDepth - 1) % kDepth], 16 * (j + kDepth - 1));
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step4<BM, BN>(acc, a[j % kDepth], b[j % kDepth]);
-            __builtin_amdgcn_sched_barrier(0);
+            constexpr int ahead = kDepth - 1;
+            f32x4 (&an)[BM] = a[(j + ahead) % kDepth];
+            f32x4 (&bn)[BN] = b[(j + ahead) % kDepth];
+            const int kn = 16 * (j + ahead);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // one slice of the fetch of block j+ahead in front of each quarter of block j's MFMAs: a wave that
+                // issues its loads in one bunch sits in the (CU-shared) address queue while its MFMA pipe drains
+                if (j + ahead < KB) {
+                    if constexpr (MODE == W_IL) {
+#pragma unroll
+                        for (int g = 0; g < BN / 4; ++g) {
+                            const f32x4 t = ld4(mp + (size_t)(kn + e) * ld + 64 * g);
+                            bn[4 * g][e] = t.x; bn[4 * g + 1][e] = t.y; bn[4 * g + 2][e] = t.z; bn[4 * g + 3][e] = t.w;
+                        }
+                    } else if constexpr (MODE == W_ROWS) {
+#pragma unroll
+                        for (int y = 0; y < BN; ++y) bn[y][e] = mp[(size_t)(kn + e) * ld + y * 16];
+                    } else {
+                        if (e < BN) bn[e] = ld4(mp + (size_t)e * 16 * ld + kn);
+                    }
+                    if (e < BM) an[e] = ld4(ap + e * 16 * lda + kn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int x = 0; x < BM; ++x)
+#pragma unroll
+                    for (int y = 0; y < BN; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j % kDepth][y][e], a[j % kDepth][x][e], acc[x][y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
         f32x4 a0[BM], b0[BN], a1[BM], b1[BN];
@@ -178,8 +207,11 @@ __device__ __forceinline__ void tile_epilogue(const f32x4 (&acc)[BM][BN], int m0
     for (int x = 0; x < BM; ++x) {
         if constexpr (MODE == W_IL) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                f(m0 + x * 16 + row, c0 + 16 * q + 4 * r, f32x4{acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]}, r);
+            for (int g = 0; g < BN / 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    f(m0 + x * 16 + row, c0 + 64 * g + 16 * q + 4 * r,
+                      f32x4{acc[x][4 * g][r], acc[x][4 * g + 1][r], acc[x][4 * g + 2][r], acc[x][4 * g + 3][r]}, 4 * g + r);
         } else {
 #pragma unroll
             for (int y = 0; y < BN; ++y) f(m0 + x * 16 + row, c0 + y * 16 + 4 * q, acc[x][y], y);

@@ -220,7 +220,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_per_prio) hipFree(e->d_per_prio);
     if (e->d_uniforms) hipFree(e->d_uniforms);
     if (e->h_noisy) hipHostFree(e->h_noisy);
-    float* dev[] = {e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
+    float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo};
     for (float* p : dev) if (p) hipFree(p);
     if (e->h.idx) hipFree(e->h.idx);
@@ -384,6 +384,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.grad, P * ls, e->stream));
         CREATE_TRY(dalloc_zero(&h.slab, P * (size_t)h.S * ls, e->stream));
         CREATE_TRY(dalloc_zero(&h.part, P * (size_t)h.n_agents * h.S * 4, e->stream));
+        if (c.algo != FRL_ALGO_DQN && c.algo != FRL_ALGO_PPO)
+            CREATE_TRY(dalloc_zero(&h.act_spill, P * (size_t)h.n_agents * h.S * 2 * h.rc * (h.hidden + 4), e->stream));
         h.Gmax = 1;
         for (int i = 0; i < h.n_nets; ++i) h.Gmax = std::max(h.Gmax, (h.net[i].size / 4 + 256 * kAdamVec - 1) / (256 * kAdamVec));
         CREATE_TRY(dalloc_zero(&h.gsq, P * (size_t)h.n_agents * h.Gmax, e->stream));
@@ -1219,6 +1221,7 @@ extern "C" int frl_per_state(frl_engine* e, int learner, double* sum_out, double
 #ifdef FRL_PHASE_TIMING
 // developer build only (tools/phase_timing.py): not part of include/freerl_hip.h
 extern "C" int frl_debug_phase_clocks(int* out, int stride) {
+    if (stride < 0) { const int k = -stride - 1; return (int)hipMemcpyToSymbol(HIP_SYMBOL(frl::g_phase_kernel), &k, sizeof(int), 0, hipMemcpyHostToDevice); }
     if (stride > 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(frl::g_phase_stride), &stride, sizeof(int), 0, hipMemcpyHostToDevice);
     hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(frl::g_phase_clock), sizeof(int) * frl::kPhaseBlocks * frl::kPhaseWords, 0,

@@ -70,6 +70,8 @@ struct EngineDesc {
     float* v;
     float* grad;          // reduced gradients (sum of the partial slabs)
     float* slab;          // [P][S][learner_stride] per-row-chunk partial gradients
+    float* act_spill;     // [P][n_agents][S][2][rc][hidden + 4] the actor's hidden activations of a row chunk, parked in HBM while
+                          // the critic pass of ac_actor_kernel reuses h1 / h2 (instead of a second actor forward)
     float* part;          // [P][n_agents][S][4] per-row-chunk partial sums {loss, entropy, -, -}
     int S;                // row chunks per batch_max = ceil(batch_max / rc)
     float* gsq;           // [P][n_agents][Gmax] per-workgroup sum of squared gradients (reduce -> adam)

@@ -403,12 +403,18 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
             normalize_cols(S.xin, S.xp, nvalid, R.obs_off[j] - R.obs_off[0], R.obs_dim[j], bn + (size_t)j * D.obsnorm_w, R.obs_dim[j]);
     };
 
+    FRL_PHASE_INIT(S);
     // -- a = actor(obs)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
     if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
-    lds_barrier();
+    FRL_PHASE(S);
     mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
+    // park the actor's hidden activations in HBM: the critic pass below reuses h1 / h2, the actor's backward needs them
+    // again, and a second actor forward cost 16 % of this kernel (tools/phase_timing.py actor)
+    const int spill_n4 = 2 * rc * S.hp / 4;                 // h1 and h2 are adjacent in LDS
+    FRL_GLB f32x4* spill = (FRL_GLB f32x4*)(D.act_spill + (((size_t)p * n + ag) * D.S + sl) * 2 * rc * S.hp);
+    for (int i = threadIdx.x; i < spill_n4; i += kWG) spill[i] = ld4((lds_cf)(S.h1 + 4 * i));
     float lp = 0.f;
     if (sac) {
         const int r = threadIdx.x;
@@ -435,34 +441,34 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
         const int r = e / Aa, c = e - r * Aa;
         S.dabuf[r * S.ap + c] = 0.f;
     }
-    lds_barrier();
+    FRL_PHASE(S);
     // -- dQ/da through the critic head(s)
     float qsum = 0.f;
     for (int h = 0; h < nq; ++h) {
         gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
         zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
         if (bn) { lds_barrier(); normalize_joint(nv); }
-        lds_barrier();
+        FRL_PHASE(S);
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
             S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
         }
-        lds_barrier();
+        FRL_PHASE(S);
         mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         if (threadIdx.x < nv) qsum += S.outb[threadIdx.x * S.op];
-        lds_barrier();
+        FRL_PHASE(S);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
         for (int e = threadIdx.x; e < rc * npad; e += kWG) {
             const int r = e / npad, c = e - r * npad;
             S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
         }
-        lds_barrier();
+        FRL_PHASE(S);
         mlp_bwd(NC, h * ql, ql, thC, nullptr, S, false, true, ct0, ct1);
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
             S.dabuf[r * S.ap + c] += S.xin[r * S.xp + OT + acol + c];
         }
-        lds_barrier();
+        FRL_PHASE(S);
     }
     float alossp = 0.f, entp = 0.f;
     if (threadIdx.x < nv) {
@@ -473,12 +479,12 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
             alossp = -qsum;
         }
     }
-    // -- actor forward again (activations for its backward), head delta, backward
-    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
+    // -- the actor's activations back from HBM (same thread, same addresses as the spill), its input back in xin
+    for (int i = threadIdx.x; i < spill_n4; i += kWG) st4(S.h1 + 4 * i, spill[i]);
+    gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);    // (the critic's dX1 landed on xin)
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
     if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
-    lds_barrier();
-    mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
+    FRL_PHASE(S);
     const int napad = NA.L[NA.n_layers - 1].n_pad;
     for (int e = threadIdx.x; e < rc * napad; e += kWG) {
         const int r = e / napad, c = e - r * napad;
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
                 const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
                 S.dabuf[r * S.ap + c] = d * expf(ls) * noise1[(size_t)r * am + c] - alpha * invB;   // d/d log_std
             } else {
-                const float av = S.outb[r * S.op + c];      // tanh output
+                const float av = S.abuf[r * S.ap + c];      // the actor's tanh output (kept from the forward)
                 d = S.dabuf[r * S.ap + c] * (1.f - av * av);
             }
         } else if (sac && c < Aa) {
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
         }
         S.outb[r * S.op + c] = d;
     }
-    lds_barrier();
+    FRL_PHASE(S);
     if (sac && threadIdx.x < Aa) {
         float gls = 0.f;
         for (int r = 0; r < rc; ++r) gls += S.dabuf[r * S.ap + threadIdx.x];
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
         slab[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? gls : 0.f;
     }
     mlp_bwd(NA, 0, NA.n_layers, thA, slab, S, true, false, 0, 0);
+    FRL_PHASE_DUMP(S, 1);
     const float la = block_sum(alossp, S.red);
     const float le = sac ? block_sum(entp, S.red) : 0.f;
     if (threadIdx.x == 0) {

@@ -24,8 +24,14 @@ LABELS_TD3 = (["gather s'"] + FWD("pi'") + ["a' = clip(pi'+noise)", "gather [s'|
               ["y = r + g min q", "gather [s|a]"] + FWD("Q1") + BWD + ["gather [s|a]"] + FWD("Q2") + BWD)
 
 
+LABELS_TD3_ACTOR = (["gather s"] + FWD("pi") + ["a -> abuf", "gather [s|a]", "a -> xin"] + FWD("Q1") + ["q read", "dq"] +
+                    ["head bwd (dX3)", "dX2", "dX1 (action columns)", "da += dx"] + ["reload h1,h2 + gather s", "head delta"] +
+                    ["head bwd (dW3,dX3)", "dW2", "dX2", "dW1"])
+
+
 def main():
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    actor = len(sys.argv) > 2 and sys.argv[2] == "actor"
     N.build()
     from freerl_amd.engine import Engine
     L = N.lib()
@@ -40,9 +46,11 @@ def main():
     buf = (C.c_int * (8 * 5 * KMAX))()
     stride = max(1, nblk // 8 - 3)
     assert fn(buf, stride) == 0
+    assert fn(buf, -2 if actor else -1) == 0            # which kernel dumps its stamps
     for it in range(6):
-        e.learn(B, **bench.td3_kwargs(0))
+        e.learn(B, **bench.td3_kwargs(1 if actor else 0))
     assert fn(buf, 0) == 0
+    labels = LABELS_TD3_ACTOR if actor else LABELS_TD3
     raw = np.array(buf[:], dtype=np.int64).reshape(8, 5, KMAX)
     if os.environ.get("FRL_RAW_MARKS"):        # wave 0's stamp row as-is (FRL_MARK() experiments)
         row = raw[:, 4, :].astype(np.float64)
@@ -50,7 +58,7 @@ def main():
         print("wave-0 stamp-to-stamp cycles, mean over sampled workgroups:")
         print(np.round(d.mean(axis=0)).astype(int).tolist())
         return
-    nb = len(LABELS_TD3)
+    nb = len(labels)
     arrive = raw[:, :4, :nb].astype(np.float64)                              # [block][wave][barrier]
     rel0 = raw[:, 4, :nb + 1].astype(np.float64)                             # init stamp, then wave 0's release of each barrier
     t0 = rel0[:, :1]
@@ -65,7 +73,7 @@ def main():
     total = (rel0[:, -1] - rel0[:, 0]).mean()
     print("P=%d, %d rows per workgroup, sampled every %d blocks; mean cycles per workgroup %.0f" % (P, rc, stride, total))
     print("%-24s %9s %9s %9s %9s %7s" % ("phase (ends at barrier)", "work mean", "work max", "work min", "wait mean", "share"))
-    for k, lab in enumerate(LABELS_TD3):
+    for k, lab in enumerate(labels):
         w = work[:, :, k]
         print("%-24s %9.0f %9.0f %9.0f %9.0f %6.1f%%" % (lab, w.mean(), w.max(axis=1).mean(), w.min(axis=1).mean(),
               wait[:, :, k].mean(), 100 * (w.mean() + wait[:, :, k].mean()) / total))
