@@ -128,6 +128,8 @@ class Buffer_for_PPO(_RingView):
     """PPO rollout storage (PPO_file/Buffer.py:266-323): transition + per-dimension old
     log-probs + adv_done; `all()` returns the WHOLE arrays, `clear()` resets the counters only."""
 
+    _tail_cols = 1           # columns after the log-probs: adv_done
+
     def __init__(self, capacity, obs_dim, act_dim, device, trick=None, *, batch_max=256, _engine=None, _learner=0):
         self.capacity = capacity = int(capacity)
         if trick is not None and trick.get("decaystd"):
@@ -136,7 +138,7 @@ class Buffer_for_PPO(_RingView):
         if _engine is None:
             hip_id, dev = resolve_device(device)
             eng = Engine(N.ALGO_REPLAY_ONLY, int(obs_dim), int(act_dim), max(capacity, 1), device_id=hip_id,
-                         batch_max=batch_max, extra_cols=int(act_dim) + 1)
+                         batch_max=batch_max, extra_cols=int(act_dim) + self._tail_cols)
             self._attach(eng, 0, 0, dev)
             self._own = True
         else:
@@ -171,6 +173,49 @@ class Buffer_for_PPO(_RingView):
         fields = [self._obs, self._act, self._rew, self._nobs, self._done, (self._extra[0], self._act_dim),
                   (self._extra[0] + self._act_dim, 1)]
         # one gather per <= 16*batch_max rows (C ABI limit)
+        step = 16 * self._e.batch_max
+        chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
+        return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))
+
+
+class Buffer_for_PPO_2(Buffer_for_PPO):
+    """PPO_advance/Buffer.py:435-533: Buffer_for_PPO + the critic's value of every step, stored at rollout time
+    (`add(..., value)`, `all()` returns it as an eighth tensor).  `compute_returns_and_advantage` (:480-507) is not a
+    host loop here: `PPO.learn(..., last_value)` runs it on the device over the ring (frl_ppo_learn, gae_mode 1) and leaves
+    its float32 results in `.advantages` / `.returns`."""
+    _tail_cols = 2           # value, adv_done (adv_done stays the last extra column)
+
+    def __init__(self, capacity, obs_dim, act_dim, device, trick=None, **kw):
+        super().__init__(capacity, obs_dim, act_dim, device, trick, **kw)
+        self.advantages = np.zeros(self.capacity, dtype=F32)
+        self.returns = np.zeros(self.capacity, dtype=F32)
+
+    def add(self, obs, action, reward, next_obs, done, action_log_probs, adv_done, value):
+        r = self._rec
+        r[self._obs[0]:self._obs[0] + self._obs[1]] = np.asarray(obs, dtype=F32).reshape(-1)
+        r[self._act[0]:self._act[0] + self._act[1]] = np.asarray(action, dtype=F32).reshape(-1)
+        r[self._rew[0]] = reward
+        r[self._nobs[0]:self._nobs[0] + self._nobs[1]] = np.asarray(next_obs, dtype=F32).reshape(-1)
+        r[self._done[0]] = float(done)
+        x0 = self._extra[0]
+        r[x0:x0 + self._act_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
+        r[x0 + self._act_dim] = float(np.asarray(value).reshape(-1)[0])
+        r[x0 + self._act_dim + 1] = float(adv_done)
+        self._e.add(self._learner, r)
+
+    @property
+    def values(self):
+        return self._column((self._extra[0] + self._act_dim, 1), squeeze=True)
+
+    @property
+    def adv_dones(self):
+        return self._column((self._extra[0] + self._act_dim + 1, 1), squeeze=True, dtype=bool)
+
+    def all(self):
+        idx = np.arange(self.capacity, dtype=np.int64)
+        x0 = self._extra[0]
+        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (x0, self._act_dim),
+                  (x0 + self._act_dim + 1, 1), (x0 + self._act_dim, 1)]
         step = 16 * self._e.batch_max
         chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
         return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))

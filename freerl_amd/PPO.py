@@ -103,6 +103,8 @@ class Agent:
 
 
 class PPO:
+    _buffer_cls = Buffer_for_PPO          # PPO_2 swaps in Buffer_for_PPO_2 (one more stored column: the rollout-time value)
+
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, horizon, device, trick=None, beta=False, *,
                  rng="host", hidden=128, minibatch_max=256, seed=0):
         obs_dim, action_dim = dim_info
@@ -118,10 +120,10 @@ class PPO:
         self.horizon = int(horizon)
         stored = action_dim if is_continue else 1            # Buffer act_dim (Buffer.py:3-9)
         self._e = Engine(N.ALGO_PPO, obs_dim, action_dim, max(self.horizon, 2), hidden=hidden, batch_max=minibatch_max,
-                         extra_cols=stored + 1, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
+                         extra_cols=stored + self._buffer_cls._tail_cols, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
                          discrete=not is_continue, device_id=hip_id, seed=seed, actor_dist=1 if beta else 0)
         self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue, beta=bool(beta))
-        self.buffer = Buffer_for_PPO(self.horizon, obs_dim, stored, self.device, _engine=self._e)
+        self.buffer = self._buffer_cls(self.horizon, obs_dim, stored, self.device, _engine=self._e)
         if self.trick["Batch_ObsNorm"]:                                   # PPO_with_tricks.py:225-226
             self._e.obsnorm_enable(True)
             self.batch_size_obs_norm = BatchObsNormView(self._e)

@@ -66,7 +66,8 @@ class PpoArgs(C.Structure):
                 ("gamma", C.c_float), ("lmbda", C.c_float), ("clip", C.c_float), ("ent_coef", C.c_float),
                 ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("adam_eps", C.c_float), ("clip_norm", C.c_float),
                 ("optimizer", C.c_int), ("perms", C.POINTER(C.c_int64)), ("loss_trace_out", C.POINTER(C.c_float)),
-                ("adv_out", C.POINTER(C.c_float)), ("vtarget_out", C.POINTER(C.c_float))]
+                ("adv_out", C.POINTER(C.c_float)), ("vtarget_out", C.POINTER(C.c_float)),
+                ("gae_mode", C.c_int), ("last_value", C.POINTER(C.c_float)), ("gae_gamma", C.c_double), ("gae_lmbda", C.c_double)]
 
 
 class RolloutArgs(C.Structure):

@@ -347,6 +347,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     // fetched and half the gradient slabs, while two workgroups still overlap each other's barrier phases
     h.rc = 64;
     while (h.rc > 16 && lds_bytes_for(h, h.rc) > 80 * 1024) h.rc /= 2;   // two workgroups per CU (160 KB LDS)
+    // wide inputs (SAC on Humanoid: 393 input columns): 16 rows re-read every weight 16x per batch; 32 rows at ONE
+    // workgroup per CU measured +8 % over 16 rows at three (tools/config_bench.py, SAC C4)
+    if (h.rc == 16 && lds_bytes_for(h, 32) <= 160 * 1024) h.rc = 32;
     // small populations cannot fill 256 CUs with 64-row chunks (one learner = batch/64 workgroups): 32-row chunks double
     // the workgroup count and measured +19 % (P = 1) / +13 % (P = 8) updates/s.  PPO's persistent kernel is one workgroup
     // per net whatever rc is, and prefers the whole minibatch in one chunk.

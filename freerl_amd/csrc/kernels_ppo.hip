@@ -23,6 +23,8 @@ struct PpoArgs {
     float* vtarget;   // [P][T]
     float* trace;     // [P][k_epochs * n_mb][2] per-minibatch (actor, critic) losses
     const int* perm;  // [P][k_epochs][T]
+    const float* last_value;   // [P] (gae_mode 1)
+    double gamma_d, lmbda_d;   // the float64 scan's discount and lambda (gae_mode 1)
 };
 
 // ---- td_delta = r + gamma*(1-done)*V(s') - V(s) for every stored row (PPO_with_tricks.py:304-306)
@@ -136,6 +138,77 @@ __global__ __launch_bounds__(256) void ppo_gae_kernel(const EngineDesc* __restri
     }
     const float sd = sqrtf(block_sum(s2, lds + 8) / (float)(T - 1));
     for (int i = threadIdx.x; i < T; i += kWG) adv[i] = (adv_raw[i] - mean) / (sd + 1e-8f);
+}
+
+// ---- PPO_advance/Buffer.py:480-507 `compute_returns_and_advantage` (stable-baselines3's form): the values were stored
+// at rollout time; float64 throughout (the reference scans float64 NumPy arrays with Python-float gamma / lambda), one
+// cast to float32 at the end (PPO_2.py:223-224).  Same affine suffix scan as gae_scan, in double.
+struct AffineD { double a, b; };
+__device__ __forceinline__ AffineD compose(AffineD f, AffineD g) { return AffineD{f.a * g.a, f.a * g.b + f.b}; }
+
+__global__ __launch_bounds__(256) void ppo_gae_sb3_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
+    __shared__ double lds_d[8];
+    __shared__ float lds_s[16];
+    lds_f lds = (lds_f)lds_s;
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.x, T = a.horizon, t = threadIdx.x;
+    const RecordDesc& R = D.rec;
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_f adv_raw = as_global(a.adv_raw + (size_t)p * T);
+    g_f adv = as_global(a.adv + (size_t)p * T);
+    g_f vt = as_global(a.vtarget + (size_t)p * T);
+    const int ad_col = R.extra_off + R.extra - 1, v_col = ad_col - 1;
+    const double gam = a.gamma_d, c = a.gamma_d * a.lmbda_d, last = (double)a.last_value[p];
+    auto step = [&](int i, double& g, double& delta) {
+        g_cf rec = ring + (size_t)i * R.stride;
+        const double nv = (i == T - 1) ? last : (double)rec[R.stride + v_col];
+        delta = (double)rec[R.rew_off] + gam * nv * (1.0 - (double)rec[R.done_off]) - (double)rec[v_col];
+        g = c * (1.0 - (double)rec[ad_col]);
+    };
+    const int L = (T + kWG - 1) / kWG, s0 = min(t * L, T), s1 = min(s0 + L, T);
+    AffineD f{1.0, 0.0};
+    for (int i = s1 - 1; i >= s0; --i) {
+        double g, d;
+        step(i, g, d);
+        f = AffineD{g * f.a, d + g * f.b};
+    }
+    const int lane = t & 63, w = t >> 6;
+    AffineD s = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        AffineD o{__shfl_down(s.a, off, 64), __shfl_down(s.b, off, 64)};
+        if (lane + off < 64) s = compose(s, o);
+    }
+    if (lane == 0) { lds_d[2 * w] = s.a; lds_d[2 * w + 1] = s.b; }
+    __syncthreads();
+    double right = 0.0;
+    for (int ww = kWaves - 1; ww > w; --ww) right = lds_d[2 * ww] * right + lds_d[2 * ww + 1];
+    const double mine = s.a * right + s.b;
+    double x = __shfl_down(mine, 1, 64);
+    if (lane == 63) x = right;
+    float s1f = 0.f;
+    for (int i = s1 - 1; i >= s0; --i) {
+        double g, d;
+        step(i, g, d);
+        x = d + g * x;
+        const float xf = (float)x;
+        adv_raw[i] = xf;
+        vt[i] = (float)(x + (double)ring[(size_t)i * R.stride + v_col]);
+        s1f += xf;
+    }
+    __syncthreads();
+    if (!a.adv_norm) {
+        for (int i = t; i < T; i += kWG) adv[i] = adv_raw[i];
+        return;
+    }
+    const float mean = block_sum(s1f, lds + 8) / (float)T;
+    float s2 = 0.f;
+    for (int i = t; i < T; i += kWG) {
+        const float d = adv_raw[i] - mean;
+        s2 += d * d;
+    }
+    const float sd = sqrtf(block_sum(s2, lds + 8) / (float)(T - 1));
+    for (int i = t; i < T; i += kWG) adv[i] = (adv_raw[i] - mean) / (sd + 1e-8f);
 }
 
 // stand-alone K3 entry (frl_gae): adv_done given as a dense array

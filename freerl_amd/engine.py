@@ -266,7 +266,9 @@ class Engine:
 
     def ppo_learn(self, horizon, minibatch, k_epochs, *, gamma, lmbda, clip, ent_coef, actor_lr, critic_lr,
                   adam_eps=1e-8, clip_norm=0.5, adv_norm=False, perms=None, want_trace=False, want_adv=False,
-                  optimizer=0):
+                  optimizer=0, last_value=None):
+        """last_value (one float per learner): PPO_advance/PPO_2.py's learn — advantages and returns from the values the
+        ring stored at rollout time (extra column before adv_done), no value pass."""
         a = N.PpoArgs()
         a.horizon, a.minibatch, a.k_epochs, a.adv_norm = int(horizon), int(minibatch), int(k_epochs), int(bool(adv_norm))
         a.gamma, a.lmbda, a.clip, a.ent_coef = gamma, lmbda, clip, ent_coef
@@ -277,6 +279,10 @@ class Engine:
             pm = np.ascontiguousarray(perms, dtype=np.int64).reshape(self.P, int(k_epochs), int(horizon))
             keep.append(pm)
             a.perms = pm.ctypes.data_as(C.POINTER(C.c_int64))
+        if last_value is not None:
+            lv = np.ascontiguousarray(np.broadcast_to(np.asarray(last_value, dtype=F32).reshape(-1), (self.P,)))
+            keep.append(lv)
+            a.gae_mode, a.last_value, a.gae_gamma, a.gae_lmbda = 1, _fp(lv), float(gamma), float(lmbda)
         n_mb = (int(horizon) + int(minibatch) - 1) // int(minibatch)
         out = {}
         if want_trace:

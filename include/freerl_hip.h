@@ -230,6 +230,14 @@ typedef struct frl_ppo_args {
     float* loss_trace_out;     /* host [P][k_epochs*n_mb][2] (actor, critic) losses or NULL */
     float* adv_out;            /* host [P][horizon] raw GAE advantages or NULL */
     float* vtarget_out;        /* host [P][horizon] or NULL */
+    int gae_mode;              /* 0: the value pass + TD-delta scan described above.
+                                  1: PPO_advance/PPO_2.py:213-224 — no value pass: V(s_t) was stored at rollout time in the
+                                     extra column before adv_done (Buffer_for_PPO_2.add, PPO_advance/Buffer.py:462-478) and
+                                     the advantages / returns come from stable-baselines3's scan (:480-507) in float64:
+                                     delta = r + gamma*next_value*(1-done) - V, A = delta + gamma*lambda*(1-adv_done)*A',
+                                     returns = A + V, both cast to float32 once */
+    const float* last_value;   /* gae_mode 1: host [P], the critic's value of the state after the last stored step */
+    double gae_gamma, gae_lmbda; /* gae_mode 1: the scan's gamma / lambda as the caller's doubles (0: use gamma / lmbda) */
 } frl_ppo_args;
 int frl_ppo_learn(frl_engine* e, const frl_ppo_args* args);
 /* stand-alone GAE scan (K3) on device arrays [n_seq][horizon]: replaces the host loop at

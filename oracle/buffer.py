@@ -66,6 +66,30 @@ class BufferForPPO(Buffer):
                 self.action_log_probs.astype(F32), self.adv_dones.astype(F32).reshape(-1, 1))
 
 
+class BufferForPPO2(BufferForPPO):
+    """PPO_advance/Buffer.py:435-533 `Buffer_for_PPO_2`: + the critic's value of every stored step, written at rollout time,
+    and stable-baselines3's `compute_returns_and_advantage` (:480-507) — a float64 scan over the stored rows."""
+
+    def __init__(self, capacity, obs_dim, act_dim):
+        super().__init__(capacity, obs_dim, act_dim)
+        self.values = np.zeros(self.capacity)
+        self.advantages = np.zeros(self.capacity)
+        self.returns = np.zeros(self.capacity)
+
+    def add(self, obs, action, reward, next_obs, done, action_log_probs, adv_done, value):
+        self.values[self._index] = value
+        super().add(obs, action, reward, next_obs, done, action_log_probs, adv_done)
+
+    def compute_returns_and_advantage(self, gamma, gae_lambda, last_value):
+        last = 0
+        for step in reversed(range(self._size)):
+            next_value = last_value if step == self._size - 1 else self.values[step + 1]
+            delta = self.rewards[step] + gamma * next_value * (1.0 - self.dones[step]) - self.values[step]
+            last = delta + gamma * gae_lambda * (1.0 - self.adv_dones[step]) * last
+            self.advantages[step] = last
+        self.returns = self.advantages + self.values
+
+
 # --------------------------------------------------------------------------------------------- PER / N-step
 class SumTree:
     """DQN_file/Buffer.py:131-194: float64 array heap of 2*capacity - 1 nodes, leaves last; `update` walks to the root

@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 from . import nn
-from .buffer import BufferForPPO
+from .buffer import BufferForPPO, BufferForPPO2
 from .nn import F32, MLP, Adam
 
 HALF_LOG_2PI = 0.5 * math.log(2 * math.pi)
@@ -37,8 +37,11 @@ F32_EPS = float(np.finfo(np.float32).eps)
 
 class PPO:
     def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False,
-                 optimizer="adam", beta=False):
-        """optimizer="c_adamw": PPO_file/PPO.py:109-152,213-286 — the same clipped-surrogate learn with no tricks and ONE
+                 optimizer="adam", beta=False, rollout_values=False):
+        """rollout_values=True: PPO_advance/PPO_2.py:152-292 — values stored at rollout time, advantages and returns from the
+        buffer's stable-baselines3-style float64 scan, `learn_with(..., last_value=...)`; otherwise that file's learn is
+        PPO_file/PPO.py's with two torch Adams.
+        optimizer="c_adamw": PPO_file/PPO.py:109-152,213-286 — the same clipped-surrogate learn with no tricks and ONE
         cautious AdamW (lr = actor_lr) over actor + critic parameters, each net's gradients clipped to 0.5 on its own."""
         self.trick = trick
         self.discrete = discrete
@@ -62,7 +65,8 @@ class PPO:
             self.actor_opt = Adam(self.actor, actor_lr, eps=eps)
             self.critic_opt = Adam(self.critic, critic_lr, eps=eps)
         self.horizon = int(horizon)
-        self.buffer = BufferForPPO(horizon, obs_dim, 1 if discrete else act_dim)
+        self.rollout_values = rollout_values
+        self.buffer = (BufferForPPO2 if rollout_values else BufferForPPO)(horizon, obs_dim, 1 if discrete else act_dim)
         self.actor_losses, self.critic_losses = [], []
         self.adv_raw = self.v_target = None
 
@@ -153,14 +157,19 @@ class PPO:
     def add(self, *a):
         self.buffer.add(*a)
 
-    def learn_with(self, perms, minibatch_size, gamma, lmbda, clip_param, k_epochs, ent_coef):
+    def learn_with(self, perms, minibatch_size, gamma, lmbda, clip_param, k_epochs, ent_coef, last_value=None):
         obs, action, reward, nobs, done, logp_old, adv_dones = self.buffer.all()
         T = self.horizon
-        vs = self.v.forward(self.critic, obs)[0]
-        vs_ = self.v.forward(self.critic, nobs)[0]
-        td = reward + F32(gamma) * (F32(1.0) - done) * vs_ - vs                      # :306
-        adv = gae(td.reshape(-1), adv_dones.reshape(-1), gamma, lmbda).reshape(-1, 1)
-        v_target = adv + vs                                                          # :313
+        if self.rollout_values:                                                      # PPO_2.py:214,223-224
+            self.buffer.compute_returns_and_advantage(gamma, lmbda, last_value)
+            adv = self.buffer.advantages.astype(F32).reshape(-1, 1)
+            v_target = self.buffer.returns.astype(F32).reshape(-1, 1)
+        else:
+            vs = self.v.forward(self.critic, obs)[0]
+            vs_ = self.v.forward(self.critic, nobs)[0]
+            td = reward + F32(gamma) * (F32(1.0) - done) * vs_ - vs                  # :306
+            adv = gae(td.reshape(-1), adv_dones.reshape(-1), gamma, lmbda).reshape(-1, 1)
+            v_target = adv + vs                                                      # :313
         self.adv_raw, self.v_target = adv.copy(), v_target.copy()
         if self.trick.get("adv_norm"):                                               # :314-315
             std = np.sqrt(np.sum((adv - adv.mean(dtype=F32)) ** 2, dtype=F32) / F32(T - 1))   # unbiased

@@ -100,6 +100,13 @@ CASES = {
                               orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
                               Batch_ObsNorm=False),
                    table_seed=129, param_seed=1530, perm_seed=2530),
+    # PPO_advance/PPO_2.py:152-292: values stored at rollout time, stable-baselines3-style float64 GAE, two torch Adams
+    "ppo_2": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
+                  gamma=0.99, lmbda=0.95, clip=0.2, ent=0.005, actor_lr=1e-3, critic_lr=2e-3, last_value=0.37,
+                  trick=dict(adv_norm=False, ObsNorm=False, reward_norm=False, reward_scaling=False,
+                             orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
+                             Batch_ObsNorm=False),
+                  table_seed=133, param_seed=1560, perm_seed=2560),
     # PPO with Actor_Beta (PPO_with_tricks.py:120-151,240-251,325-332): actions in (0,1), alpha/beta heads, adv_norm
     "ppo_beta": dict(kind="ppo_beta", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
                      gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3,
@@ -280,6 +287,8 @@ def ppo_inputs(c):
     actor = dict([("log_std", g.uniform(-0.5, 0.3, (1, A)).astype(np.float32))] + list(actor.items()))
     critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
     perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
+    if "last_value" in c:                      # PPO_2: the critic's value of each step as select_action returned it
+        tab["value"] = (0.8 * g.standard_normal(T)).astype(np.float32)
     return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)
 
 

@@ -669,6 +669,36 @@ def gen_ppo_py(out):
     out["buffer_size_after"] = np.int64(len(pol.buffer))
 
 
+def gen_ppo_2(out):
+    """PPO_advance/PPO_2.py: add(..., value), learn(..., last_value) with Buffer_for_PPO_2.compute_returns_and_advantage."""
+    c = cases.CASES["ppo_2"]
+    inp = cases.ppo_inputs(c)
+    mod = import_reference("PPO_advance", "PPO_2")
+    pol = mod.PPO([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["horizon"], CPU)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    torch.manual_seed(77)
+    sel = [pol.select_action(tab["obs"][i]) for i in range(8)]          # (action, log_pi, value)
+    out["select_value"] = np.array([float(np.asarray(v).reshape(-1)[0]) for _, _, v in sel], dtype=np.float32)
+    out["select_action"] = np.stack([a for a, _, _ in sel]).astype(np.float32)
+    out["select_logp"] = np.stack([lp for _, lp, _ in sel]).astype(np.float32)
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]), float(tab["value"][i]))
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+    out["evaluate_action"] = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    with inject(np.random, "permutation", feeder(inp["perms"])):
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"], c["last_value"])
+    out["adv_raw"] = pol.buffer.advantages.astype(np.float32)
+    out["v_target"] = pol.buffer.returns.astype(np.float32)
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+    out["buffer_size_after"] = np.int64(len(pol.buffer))
+
+
 def gen_ppo_discrete(out):
     c = cases.CASES["ppo_discrete"]
     inp = cases.ppo_discrete_inputs(c)
@@ -918,7 +948,7 @@ def main():
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "maddpg_full": gen_maddpg_full, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
-        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_beta": gen_ppo_beta,
+        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_2": gen_ppo_2, "ppo_beta": gen_ppo_beta,
         "norm": gen_norm,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),

@@ -288,6 +288,53 @@ def test_buffer_module_standalone():
     assert len(pb) == 0 and pb._index == 0
 
 
+def test_ppo_2_class_against_reference_golden():
+    """freerl_amd.PPO_2.PPO (PPO_advance/PPO_2.py): select_action's value, add(..., value), learn(..., last_value) — the
+    device's float64 stable-baselines3 scan over the stored values and the update kernel, against the reference's outputs."""
+    from freerl_amd.PPO_2 import PPO
+    from freerl_amd.Buffer import Buffer_for_PPO_2
+    c = cases.CASES["ppo_2"]
+    inp = cases.ppo_inputs(c)
+    fx = gold("ppo_2")
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    pol = PPO([O, A], True, c["actor_lr"], c["critic_lr"], T, CUDA)
+    assert isinstance(pol.buffer, Buffer_for_PPO_2)
+    pol.agent.actor.load_state_dict({k: torch.as_tensor(v) for k, v in inp["params"]["actor"].items()})
+    pol.agent.critic.load_state_dict({k: torch.as_tensor(v) for k, v in inp["params"]["critic"].items()})
+    tab = inp["table"]
+    torch.manual_seed(77)
+    sel = [pol.select_action(tab["obs"][i]) for i in range(8)]
+    np.testing.assert_allclose(np.array([v[0] for _, _, v in sel]), fx["select_value"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.stack([a for a, _, _ in sel]), fx["select_action"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.stack([lp for _, lp, _ in sel]), fx["select_logp"], rtol=1e-4, atol=1e-5)
+    assert sel[0][2].shape == (1,)
+    for i in range(T):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]), tab["value"][i:i + 1])
+    np.testing.assert_array_equal(pol.buffer.values, tab["value"])
+    np.testing.assert_array_equal(pol.buffer.adv_dones, tab["adv_done"])
+    assert len(pol.buffer.all()) == 8 and tuple(pol.buffer.all()[7].shape) == (T, 1)
+    ev = np.stack([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+    np.testing.assert_allclose(ev, fx["evaluate_action"], rtol=1e-4, atol=1e-5)
+    pol.track_loss = True
+    perms = iter(inp["perms"])
+    orig = np.random.permutation
+    np.random.permutation = lambda n: next(perms)
+    try:
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"], c["last_value"])
+    finally:
+        np.random.permutation = orig
+    # the scan runs in float64 from float32-stored rewards / values (the reference's are float64 copies of the same float32
+    # numbers here): equal to the last float32 bit but for the reassociation of the parallel scan
+    np.testing.assert_allclose(pol.buffer.advantages, fx["adv_raw"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(pol.buffer.returns, fx["v_target"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(pol.last_trace[0, :, 0], fx["loss_actor"], rtol=5e-4, atol=5e-6)
+    np.testing.assert_allclose(pol.last_trace[0, :, 1], fx["loss_critic"], rtol=5e-4)
+    synth.check_digest("actor", sd2np(pol.agent.actor.state_dict()), fx, 2e-3, 2e-5, "hip-vs-reference")
+    synth.check_digest("critic", sd2np(pol.agent.critic.state_dict()), fx, 2e-3, 2e-5, "hip-vs-reference")
+    assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
+
+
 def test_ppo_beta_class():
     """PPO(beta=True): Actor_Beta state_dict layout, default-init RNG order, mean / sample / learn through the class."""
     from freerl_amd.PPO import PPO

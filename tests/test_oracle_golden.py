@@ -337,6 +337,30 @@ def test_ppo_py_cautious_adamw():
     assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
 
 
+def test_ppo_2_rollout_values_and_sb3_gae():
+    """PPO_advance/PPO_2.py: add(..., value); learn(..., last_value) takes advantages / returns from the buffer's float64 scan."""
+    c = cases.CASES["ppo_2"]
+    inp = cases.ppo_inputs(c)
+    fx = gold("ppo_2")
+    pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"],
+                  c["actor_lr"], c["critic_lr"], c["horizon"], c["trick"], rollout_values=True)
+    tab = inp["table"]
+    v8 = pol.v.forward(pol.critic, tab["obs"][:8])[0].reshape(-1)          # select_action's third return (PPO_2.py:167,180)
+    np.testing.assert_allclose(v8, fx["select_value"], rtol=1e-5, atol=1e-6)
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]), float(tab["value"][i]))
+    pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"],
+                   last_value=c["last_value"])
+    np.testing.assert_array_equal(pol.adv_raw.reshape(-1), fx["adv_raw"])         # float64 scan, then one cast
+    np.testing.assert_array_equal(pol.v_target.reshape(-1), fx["v_target"])
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=1e-4)
+    synth.check_digest("actor", pol.actor, fx, 2e-3, 2e-5)
+    synth.check_digest("critic", pol.critic, fx, 2e-3, 2e-5)
+    assert len(pol.buffer) == int(fx["buffer_size_after"]) == 0
+
+
 def test_maddpg_py_supplements():
     """MADDPG.py with weight_decay + per-agent Batch_ObsNorm: every agent's statistics move once per updating agent."""
     c = cases.CASES["maddpg_full"]

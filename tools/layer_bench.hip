@@ -28,9 +28,15 @@ __global__ __launch_bounds__(256, 2) void k(const float* theta_all, float* slab_
     for (int e = threadIdx.x; e < RC * S.hp; e += kWG) { S.h1[e] = 0.001f * (e % 97); S.h2[e] = 0.002f * (e % 89); }
     __syncthreads();
 #ifdef STAGGER
-    // half a layer of head start for every other workgroup of a CU: do two co-resident workgroups overlap each
-    // other's prologue / epilogue / barrier with MFMA work once they are out of lockstep?
-    if ((blockIdx.x >> STAGGER_SHIFT) & 1) { const long long s0 = clock64(); while (clock64() - s0 < STAGGER) {} }
+    // head start for the workgroup whose wave 0 sits in an odd wave slot of its SIMD (HW_ID bits 3:0): do two
+    // co-resident workgroups overlap each other's prologue / epilogue / barrier with MFMA work once out of lockstep?
+    {
+        __shared__ int slot;
+        if (threadIdx.x == 0) slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;   // HW_REG_HW_ID[3:0]
+        __syncthreads();
+        if (slot) { const long long s0 = clock64(); while (clock64() - s0 < STAGGER) {} }
+        if (threadIdx.x == 0 && slot) atomicAdd((int*)(cyc + 8000), 1);
+    }
 #endif
     long long st[3] = {0, 0, 0};
     const long long t0 = clock64();
@@ -105,7 +111,7 @@ int main() {
     const int maxwg = 1024;
     hipMalloc(&theta, (size_t)(maxwg / 8) * 32768 * 4);
     hipMalloc(&slab, (size_t)maxwg * 32768 * 4);
-    hipMalloc(&cyc, maxwg * 8 * 4);
+    hipMalloc(&cyc, maxwg * 8 * 8); hipMemset(cyc, 0, maxwg * 64);
     std::vector<float> h((size_t)(maxwg / 8) * 32768);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.01f * ((i * 7919) % 13) - 0.06f;
     hipMemcpy(theta, h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -133,6 +139,9 @@ int main() {
             for (auto v : c) s += v;
             printf("%-12s %4d workgroups (%d per CU): %8.0f cycles per call  (MFMA floor %d)\n", names[mode], wg, wg / 256,
                    s / wg / reps, (mode < 3 || mode > 4 ? 128 : 16) * 32 * (wg / 256) * (RC / 32));
+#ifdef STAGGER
+            { long long ns = 0; hipMemcpy(&ns, cyc + 8000, 8, hipMemcpyDeviceToHost); printf("    staggered workgroups so far: %lld\n", ns); }
+#endif
             if (mode == 7) {
                 std::vector<long long> d(wg * 3);
                 hipMemcpy(d.data(), cyc + 1024, wg * 24, hipMemcpyDeviceToHost);
