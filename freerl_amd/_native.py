@@ -75,6 +75,10 @@ class RolloutArgs(C.Structure):
                 ("policy_freq", C.c_int), ("epsilon", C.c_float), ("explore_sigma", C.c_float), ("learn", LearnArgs)]
 
 
+class PpoRolloutArgs(C.Structure):
+    _fields_ = [("n_iters", C.c_int), ("envs_per_learner", C.c_int), ("steps_per_env", C.c_int), ("learn", PpoArgs)]
+
+
 class RolloutStats(C.Structure):
     _fields_ = [("env_steps", C.c_longlong), ("updates", C.c_longlong), ("episodes", C.c_longlong),
                 ("return_sum", C.c_double), ("seconds", C.c_double)]
@@ -135,6 +139,7 @@ SIGNATURES = {
     "frl_envpool_set_state": (_i, [_vp, _i, _P(C.c_double)]),
     "frl_envpool_step": (_i, [_vp, _fp, _fp, _fp, _P(C.c_uint8), _P(C.c_uint8), _fp]),
     "frl_rollout": (_i, [_vp, _vp, _P(RolloutArgs), _P(RolloutStats)]),
+    "frl_ppo_rollout": (_i, [_vp, _vp, _P(PpoRolloutArgs), _P(RolloutStats)]),
     "frl_timer_start": (_i, [_vp]),
     "frl_timer_stop": (_i, [_vp, _fp]),
     "frl_profile_enable": (_i, [_vp, _i]),

@@ -88,3 +88,21 @@ def rollout(engine, pool, n_steps, *, envs_per_learner=1, start_steps=500, learn
     N.check(engine._L.frl_rollout(engine._h, pool._h, C.byref(a), C.byref(st)))
     return dict(env_steps=st.env_steps, updates=st.updates, episodes=st.episodes, return_sum=st.return_sum,
                 seconds=st.seconds)
+
+
+def ppo_rollout(engine, pool, n_iters, *, envs_per_learner, steps_per_env, minibatch=64, k_epochs=10, gamma=0.99, lmbda=0.95,
+                clip=0.2, ent_coef=0.01, actor_lr=3e-4, critic_lr=3e-4, adam_eps=1e-8, clip_norm=0.5, adv_norm=False,
+                optimizer=0):
+    """`n_iters` cycles of (collect envs_per_learner x steps_per_env transitions per learner, then PPO.learn) on the device:
+    the on-policy counterpart of `rollout` (frl_ppo_rollout)."""
+    a = N.PpoRolloutArgs()
+    a.n_iters, a.envs_per_learner, a.steps_per_env = int(n_iters), int(envs_per_learner), int(steps_per_env)
+    la = a.learn
+    la.horizon, la.minibatch, la.k_epochs = int(envs_per_learner) * int(steps_per_env), int(minibatch), int(k_epochs)
+    la.adv_norm, la.optimizer = int(bool(adv_norm)), int(optimizer)
+    la.gamma, la.lmbda, la.clip, la.ent_coef = gamma, lmbda, clip, ent_coef
+    la.actor_lr, la.critic_lr, la.adam_eps, la.clip_norm = actor_lr, critic_lr, adam_eps, clip_norm
+    st = N.RolloutStats()
+    N.check(engine._L.frl_ppo_rollout(engine._h, pool._h, C.byref(a), C.byref(st)))
+    return dict(env_steps=st.env_steps, updates=st.updates, episodes=st.episodes, return_sum=st.return_sum,
+                seconds=st.seconds)

@@ -302,6 +302,20 @@ typedef struct frl_rollout_stats {
     double return_sum, seconds;
 } frl_rollout_stats;
 int frl_rollout(frl_engine* e, frl_envpool* p, const frl_rollout_args* args, frl_rollout_stats* out);
+/* On-policy counterpart for PPO engines (BASELINE config 3, PPO with vectorised envs): the reference steps one env for
+ * `horizon` steps and calls learn() (PPO_with_tricks.py:524-569); here every learner steps E env instances for
+ * horizon / E vector steps per cycle — select_action (:234-255) batched over all envs, action_ = clip(action *
+ * max_action) (:529-530), add(obs, action, reward, next_obs, terminated, log_pi, terminated or truncated) (:541-545) —
+ * then frl_ppo_learn.  Env j's steps fill ring rows [j*steps_per_env, (j+1)*steps_per_env); the last row of each
+ * segment is marked adv_done so that the GAE scan restarts there as it does at the end of the reference's horizon.
+ * stats: updates = minibatch steps (one actor + one critic step each). */
+typedef struct frl_ppo_rollout_args {
+    int n_iters;             /* collect + learn cycles */
+    int envs_per_learner;    /* E; the pool must hold P*E envs */
+    int steps_per_env;       /* vector steps per cycle; learn.horizon must equal E * steps_per_env */
+    frl_ppo_args learn;      /* perms / outputs NULL (device-side permutations), gae_mode 0 */
+} frl_ppo_rollout_args;
+int frl_ppo_rollout(frl_engine* e, frl_envpool* p, const frl_ppo_rollout_args* args, frl_rollout_stats* out);
 
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);

@@ -628,6 +628,51 @@ def test_rollout_collector_fills_the_ring_consistently(N):
     pool.close(); e.close()
 
 
+def test_ppo_rollout_collector_lays_out_env_segments(N):
+    """frl_ppo_rollout: every env's steps form one contiguous time-ordered segment of the learner's ring, the stored
+    log-probs are those of the stored actions under the collecting policy, the segment ends carry adv_done, and a
+    cycle performs K_epochs x n_minibatch steps per learner."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, ppo_rollout
+    P, E, Tseg, O, A = 2, 4, 16, 3, 1
+    T = E * Tseg
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=32, n_learners=P, extra_cols=A + 1, seed=3)
+    rng = np.random.default_rng(2)
+    for p in range(P):
+        fa = (rng.standard_normal(e.num_params(0)) * 0.1).astype(np.float32)
+        fa[-A:] = -0.3                                           # log_std
+        e.set_params(0, fa, learner=p)
+        e.set_params(1, (rng.standard_normal(e.num_params(1)) * 0.1).astype(np.float32), learner=p)
+    pool = EnvPool("PendulumShort-v1", P * E, n_threads=2, seed=4)          # 40-step episodes, max_action 2
+    out = ppo_rollout(e, pool, 1, envs_per_learner=E, steps_per_env=Tseg, minibatch=32, k_epochs=2, actor_lr=0.0, critic_lr=0.0)
+    assert out["env_steps"] == P * T and out["updates"] == P * 2 * (T // 32)
+    lay = e.layout
+    for p in range(P):
+        assert e.cursor(p) == (0, 0)                             # learn() cleared the buffer (PPO_with_tricks.py:354)
+        rows = e.read_rows(p, 0, T)
+        obs = rows[:, lay.obs_off[0]:lay.obs_off[0] + O]
+        nobs = rows[:, lay.next_obs_off[0]:lay.next_obs_off[0] + O]
+        act, logp, adv_done = rows[:, lay.act_off[0]], rows[:, lay.extra_off], rows[:, lay.extra_off + A]
+        for env in range(E):
+            seg = slice(env * Tseg, (env + 1) * Tseg)
+            cont = np.all(np.abs(nobs[seg][:-1] - obs[seg][1:]) < 1e-6, axis=1)
+            assert cont.all()                                    # 16 steps of a 40-step episode: no boundary inside
+            assert adv_done[seg][-1] == 1 and np.all(adv_done[seg][:-1] == 0) and np.all(rows[seg, lay.done_off] == 0)
+        # lr = 0: the parameters are still the collecting policy's -> recompute the Gaussian log-prob of the stored actions
+        full = np.zeros((P, T, O), np.float32)
+        full[p] = obs
+        mean = e.act(0, N.ACT_TANHHEAD, full, out_dim=A)[p][:, 0]
+        ls = -0.3
+        want = -((act - mean) ** 2) / (2 * np.exp(2 * ls)) - ls - 0.9189385332
+        np.testing.assert_allclose(logp, want, rtol=2e-4, atol=2e-5)
+    before = e.get_params(0, learner=1).copy()
+    out = ppo_rollout(e, pool, 3, envs_per_learner=E, steps_per_env=Tseg, minibatch=32, k_epochs=2, actor_lr=1e-3, critic_lr=1e-3)
+    assert out["updates"] == 3 * P * 2 * 2 and out["env_steps"] == 3 * P * T and out["episodes"] >= P * E
+    assert not np.allclose(before, e.get_params(0, learner=1))
+    assert e.opt_step(0, learner=0) == 2 * 2 + 3 * 2 * 2 and np.all(np.isfinite(e.get_params(1, learner=0)))
+    pool.close(); e.close()
+
+
 def test_ppo_discrete_learn(N):
     """Actor_discrete + Categorical (PPO_with_tricks.py:110-121, 249-251, 333-336)."""
     import torch

@@ -1,6 +1,9 @@
 """PPO.learn() timing at BASELINE config C3's shape (HalfCheetah-v4: obs 17, act 6, horizon 2048, minibatch 64,
 K_epochs 10 -> 320 actor + 320 critic steps per learn): P learners, one persistent workgroup each.
-    python tools/ppo_bench.py [P ...]"""
+    python tools/ppo_bench.py [P ...]
+and the whole collect + learn cycle (frl_ppo_rollout) with 64 vectorised envs per learner (config C3's "64 vec-envs") on the
+synthetic linear-Gaussian env (obs 8, act 2): 64 envs x 32 steps = horizon 2048 per cycle.
+    python tools/ppo_bench.py rollout [P ...]"""
 import os
 import sys
 import time
@@ -50,6 +53,30 @@ def run(P):
     e.close()
 
 
+def run_rollout(P, E=64, Tseg=32, iters=3):
+    from freerl_amd.envpool import EnvPool, ppo_rollout
+    o, a = 8, 2
+    e = Engine(N.ALGO_PPO, o, a, E * Tseg, n_learners=P, batch_max=MB, extra_cols=a + 1, seed=1)
+    rng = np.random.default_rng(0)
+    for p in range(P):
+        fa = (rng.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
+        fa[-a:] = 0.0
+        e.set_params(0, fa, learner=p)
+        e.set_params(1, (rng.standard_normal(e.num_params(1)) * 0.05).astype(np.float32), learner=p)
+    pool = EnvPool("SynLinear-v0", P * E, n_threads=min(8, max(1, os.cpu_count() or 1)), seed=3)
+    kw = dict(envs_per_learner=E, steps_per_env=Tseg, minibatch=MB, k_epochs=K, adv_norm=True)
+    ppo_rollout(e, pool, 1, **kw)
+    out = ppo_rollout(e, pool, iters, **kw)
+    print("P=%4d  %d envs/learner: %.1f ms per cycle (collect %d x %d + learn) -> %.0f env-steps/s, %.0f minibatch steps/s"
+          % (P, E, out["seconds"] / iters * 1e3, E, Tseg, out["env_steps"] / out["seconds"], out["updates"] / out["seconds"]),
+          flush=True)
+    pool.close(); e.close()
+
+
 if __name__ == "__main__":
-    for P in [int(x) for x in sys.argv[1:]] or [1, 64, 256]:
-        run(P)
+    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+        for P in [int(x) for x in sys.argv[2:]] or [1, 16, 64]:
+            run_rollout(P)
+    else:
+        for P in [int(x) for x in sys.argv[1:]] or [1, 64, 256]:
+            run(P)
