@@ -180,33 +180,53 @@ __device__ __forceinline__ void linear_bwd_dx(const LayerDesc& L, g_cf theta, ld
 }
 
 // G.Wk[k_pad][n_pad] (=|+=) X^T * dY ;  G.b (=|+=) column sums of dY
+// How a gradient tile reaches its slab: GS_STREAM the slab is written once and read once by reduce_kernel (non-temporal
+// store), GS_STORE first of several row chunks (plain store: the next chunk reads it back), GS_ADD a later chunk.
+enum GradStore : int { GS_STREAM = 0, GS_STORE = 1, GS_ADD = 2 };
+
 __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf dY, int ldy, lds_cf X, int ldx, int rc,
-                                              bool first) {
+                                              int gs) {
     g_f GW = G + L.w_off;
     const int kpad = L.k_pad, npad = L.n_pad;
+    const bool first = gs != GS_ADD;
     auto finish = [&](int k, int n4, f32x4 v) {
         g_f g = GW + (size_t)k * npad + n4;
-        if (first) { st4_stream(g, v); return; }           // a slab is written once and read once by reduce_kernel
+        if (gs == GS_STREAM) { st4_stream(g, v); return; }
+        if (gs == GS_STORE) { st4(g, v); return; }
         st4(g, v + ld4((g_cf)g));
+    };
+    // the interleaved blocks fetch the running sums BEFORE their MFMA loop (GS_ADD), so the loads' latency hides
+    // behind it; as part of the epilogue it was +13 % on the critic kernel
+    auto run_il = [&](auto bn_c, int g, int kt0) {
+        constexpr int BN = decltype(bn_c)::value;
+        const int l = lane_id(), i = l & 15, q = l >> 4;
+        f32x4 acc[4][BN], old[BN][4];
+        acc_zero(acc);
+        if (gs == GS_ADD) {
+#pragma unroll
+            for (int y = 0; y < BN; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[y][r] = ld4((g_cf)(GW + (size_t)(kt0 * 16 + 16 * y + 4 * q + r) * npad + g * 64 + 4 * i));
+        }
+        mma_dw_il<BN>(acc, dY, ldy, g * 64, X, ldx, kt0 * 16, rc);
+#pragma unroll
+        for (int y = 0; y < BN; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = {acc[0][y][r], acc[1][y][r], acc[2][y][r], acc[3][y][r]};
+                g_f gp = GW + (size_t)(kt0 * 16 + 16 * y + 4 * q + r) * npad + g * 64 + 4 * i;
+                if (gs == GS_ADD) v += old[y][r];
+                if (gs == GS_STREAM) st4_stream(gp, v); else st4(gp, v);
+            }
     };
     if (npad % 64 == 0) {
         const int w = wave_id(), groups = npad / 64, tk = kpad / 16;
         if (tk % 2 == 0 && groups * (tk / 2) >= kWaves) {
-            for (int blk = w; blk < groups * (tk / 2); blk += kWaves) {
-                const int g = blk % groups, kt0 = (blk / groups) * 2;
-                f32x4 acc[4][2];
-                acc_zero(acc);
-                mma_dw_il<2>(acc, dY, ldy, g * 64, X, ldx, kt0 * 16, rc);
-                dw_il_epilogue<2>(acc, g * 64, kt0 * 16, finish);
-            }
+            for (int blk = w; blk < groups * (tk / 2); blk += kWaves)
+                run_il(std::integral_constant<int, 2>{}, blk % groups, (blk / groups) * 2);
         } else {
-            for (int blk = w; blk < groups * tk; blk += kWaves) {
-                const int g = blk % groups, kt0 = blk / groups;
-                f32x4 acc[4][1];
-                acc_zero(acc);
-                mma_dw_il<1>(acc, dY, ldy, g * 64, X, ldx, kt0 * 16, rc);
-                dw_il_epilogue<1>(acc, g * 64, kt0 * 16, finish);
-            }
+            for (int blk = w; blk < groups * tk; blk += kWaves)
+                run_il(std::integral_constant<int, 1>{}, blk % groups, blk / groups);
         }
     } else {
         for_tile_blocks(kpad / 16, npad / 16, [&](auto bm, auto bn, int kt0, int nt0) {
@@ -222,13 +242,14 @@ __device__ __forceinline__ void linear_bwd_dw(const LayerDesc& L, g_f G, lds_cf 
     // chain of rc reads this loop was the longest thing in every dW phase.
     g_f Gb = G + L.b_off;
     for (int n = kWG - 1 - threadIdx.x; n < L.n_pad; n += kWG) {
+        const float oldb = first ? 0.f : Gb[n];             // in flight during the column sum
         float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int r = 0; r < rc; r += 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) p[j] += dY[(r + j) * ldy + n];
         }
         const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        Gb[n] = first ? s : (Gb[n] + s);
+        Gb[n] = oldb + s;
     }
 }
 
@@ -324,12 +345,14 @@ __device__ __forceinline__ void head_finalize(const LayerDesc& LH, g_cf theta, l
 // and h[r][k] <- (d[r] . WH[k]) * act'(h[r][k]) in place (the delta of the hidden layer).  The last 16 threads also
 // sum the bias gradient.  G == nullptr: input gradient only.  k_pad <= 128 (32 units per wave).
 __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G, lds_cf outb, int op, lds_f H, int ldh,
-                                         int act_prev, int rc, bool first) {
+                                         int act_prev, int rc, int gs) {
+    const bool first = gs != GS_ADD;
     const int l = lane_id(), half = l >> 5, k = (threadIdx.x >> 6) * 32 + (l & 31);
     const int hr = rc / 2, r_lo = half * hr;
     if (k < LH.k_pad) {
         const f32x4 w = ld4(theta + LH.w_off + k * 16);
-        f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+        f32x4 gw = {0.f, 0.f, 0.f, 0.f}, gold = {0.f, 0.f, 0.f, 0.f};
+        if (G && !first && half == 0) gold = ld4((g_cf)(G + LH.w_off + k * 16));     // running sum, in flight during the row loop
         for (int r = r_lo; r < r_lo + hr; r += 4) {
             float h[4];
             f32x4 d[4];
@@ -347,12 +370,14 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
         if (G && half == 0) {
             g_f g = G + LH.w_off + k * 16;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (first) { st4_stream(g, gw); st4_stream(g + 4, z); st4_stream(g + 8, z); st4_stream(g + 12, z); }
-            else st4(g, gw + ld4((g_cf)g));
+            if (gs == GS_STREAM) { st4_stream(g, gw); st4_stream(g + 4, z); st4_stream(g + 8, z); st4_stream(g + 12, z); }
+            else if (first) { st4(g, gw); st4(g + 4, z); st4(g + 8, z); st4(g + 12, z); }
+            else st4(g, gw + gold);
         }
     }
     const int t = kWG - 1 - threadIdx.x;
     if (G && t < 16) {
+        const float oldb = first ? 0.f : G[LH.b_off + t];
         float p[4] = {0.f, 0.f, 0.f, 0.f};
         if (t < 4)
             for (int r = 0; r < rc; r += 4) {
@@ -361,7 +386,7 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
             }
         const float s = (p[0] + p[1]) + (p[2] + p[3]);
         g_f gb = G + LH.b_off + t;
-        *gb = first ? s : (*gb + s);
+        *gb = oldb + s;
     }
 }
 
@@ -390,9 +415,9 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
 }
 
 // Backward of layers [l0, l0+nl): head delta in outb (zero in padded columns and invalid rows).
-// G != nullptr accumulates weight/bias gradients (first: overwrite).  want_dx0 leaves
+// G != nullptr: weight/bias gradients go to G the way `gs` (GradStore) says.  want_dx0 leaves
 // d loss / d xin in xin for column tiles [ct0, ct1).  Ends with a barrier.
-__device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf theta, g_f G, const Lds& S, bool first,
+__device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf theta, g_f G, const Lds& S, int gs,
                                         bool want_dx0, int ct0, int ct1) {
     const bool fuse = head_fusable(N, l0, nl);
     for (int i = nl - 1; i >= 0; --i) {
@@ -403,12 +428,12 @@ __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf t
         const int ldx = (i == 0) ? S.xp : S.hp;
         const LayerDesc& L = N.L[l0 + i];
         if (last && fuse) {
-            head_bwd(L, theta, G, D, ldd, X, ldx, N.hidden_act, S.rc, first);
+            head_bwd(L, theta, G, D, ldd, X, ldx, N.hidden_act, S.rc, gs);
             FRL_PHASE(S);
             continue;
         }
         if (G) {
-            linear_bwd_dw(L, G, D, ldd, X, ldx, S.rc, first);
+            linear_bwd_dw(L, G, D, ldd, X, ldx, S.rc, gs);
             FRL_PHASE(S);
         }
         if (i > 0) {

@@ -242,17 +242,6 @@ __device__ __forceinline__ void mma_dw_il(f32x4 (&acc)[4][BN], lds_cf dY, int ld
         mma_step4<4, BN>(acc, a, b);
     }
 }
-// f(k, n4, value4): value4[j] belongs to G[k][n4 + j]
-template <int BN, class F>
-__device__ __forceinline__ void dw_il_epilogue(const f32x4 (&acc)[4][BN], int n0, int k0, F f) {
-    const int l = lane_id(), i = l & 15, q = l >> 4;
-#pragma unroll
-    for (int y = 0; y < BN; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            f(k0 + 16 * y + 4 * q + r, n0 + 4 * i, f32x4{acc[0][y][r], acc[1][y][r], acc[2][y][r], acc[3][y][r]});
-}
-
 // Plain variant (n_pad not a multiple of 64, i.e. the heads): C[k][n] tiles, a-side = X (k), b-side = dY (n).
 template <int BM, int BN>
 __device__ __forceinline__ void mma_tn(f32x4 (&acc)[BM][BN], lds_cf A, int lda, int m0, lds_cf B, int ldb, int n0, int K) {

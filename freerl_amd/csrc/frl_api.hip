@@ -360,7 +360,33 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     }
     if (lds_bytes_for(h, h.rc) > 160 * 1024) { delete e; return fail(FRL_ERR_INVALID, "network too wide for LDS (%d B at 16 rows)", lds_bytes_for(h, h.rc)); }
     e->lds_bytes = lds_bytes_for(h, h.rc);
-    h.S = (h.batch_max + h.rc - 1) / h.rc;
+    // Row chunks per gradient workgroup.  With `units` (learner, agent) pairs and n_chunks chunks each, s slabs per unit cost
+    // ceil(units * s / slots) rounds of n_chunks / s chunk-times on the chip's resident-workgroup slots, and the reduce
+    // pass streams s slabs: take the fewest slabs (but two) among the cheapest schedules.  512 learners x 4 chunks of 64
+    // rows on 512 slots: two workgroups per learner walk 2 chunks each (2 slabs) instead of 4 workgroups writing 4 slabs.
+    {
+        const int n_chunks = (h.batch_max + h.rc - 1) / h.rc;
+        // resident gradient workgroups: 256 CUs x (2 by registers — the kernels are built for FRL_GRAD_WGS = 2 — or 1 by LDS)
+        const long long slots = 256LL * std::max(1, std::min(2, (160 * 1024) / std::max(1, e->lds_bytes)));
+        const long long units = (long long)h.P * h.n_agents;
+        long long best_cost = -1;
+        h.cps = 1;
+        for (int cps = n_chunks; cps >= 1; --cps) {
+            if (n_chunks % cps) continue;
+            const int s = n_chunks / cps;
+            // measured (P = 512, 4 chunks): 2 slabs 529 k updates/s, 1 slab 524 k, 4 slabs 495 k — with a single slab every
+            // workgroup of the launch starts at once and they stay in step (gather bursts, barrier phases coincide)
+            if (s < 2 && n_chunks >= 2) continue;
+            const long long cost = ((units * s + slots - 1) / slots) * cps;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; h.cps = cps; }
+        }
+        if (c.algo == FRL_ALGO_PPO) h.cps = 1;
+        if (const char* force = getenv("FRL_CPS")) {        // developer knob
+            const int v = atoi(force);
+            if (v >= 1 && n_chunks % v == 0) h.cps = v;
+        }
+        h.S = n_chunks / h.cps;
+    }
 
 #define CREATE_TRY(expr)                                                                           \
     do {                                                                                           \
@@ -899,7 +925,7 @@ extern "C" int frl_noisy_resample(frl_engine* e, const float* eps_host) {
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
-    const int ns = (a.batch + h.rc - 1) / h.rc;
+    const int ns = ((a.batch + h.rc - 1) / h.rc + h.cps - 1) / h.cps;      // workgroups (= slabs) per unit
     const int units = pc * h.n_agents;
     const dim3 grid_chunks(((units + 7) / 8) * 8 * ns), grid_units(units), blk(256), grid_adam(units * h.Gmax);
     const bool sac = h.algo == ALGO_SAC, maddpg = h.algo == ALGO_MADDPG;

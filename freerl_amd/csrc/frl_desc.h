@@ -73,7 +73,8 @@ struct EngineDesc {
     float* act_spill;     // [P][n_agents][S][2][rc][hidden + 4] the actor's hidden activations of a row chunk, parked in HBM while
                           // the critic pass of ac_actor_kernel reuses h1 / h2 (instead of a second actor forward)
     float* part;          // [P][n_agents][S][4] per-row-chunk partial sums {loss, entropy, -, -}
-    int S;                // row chunks per batch_max = ceil(batch_max / rc)
+    int S;                // gradient slabs per unit = workgroups per unit = ceil(ceil(batch_max / rc) / cps)
+    int cps;              // consecutive row chunks one gradient workgroup works through (summing into its slab)
     float* gsq;           // [P][n_agents][Gmax] per-workgroup sum of squared gradients (reduce -> adam)
     int Gmax;             // workgroups per net in the reduce/adam launches
     float* replay;        // [P][capacity][rec.stride]

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     const NetDesc& N = D.net[0];
     const RecordDesc& R = D.rec;
     const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
-    const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
+    const int rc = D.rc, B = a.batch, nl = N.n_layers;
+    const int nchunks = (B + rc - 1) / rc, ck0 = sl * D.cps, ck1 = min(ck0 + D.cps, nchunks);
     const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
     g_cf eff = D.noisy ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[0]) : nullptr;
     g_cf theta_next = D.noisy ? eff : as_global(D.theta + base);
@@ -27,13 +28,19 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     g_cf theta = D.noisy ? eff + 2 * (size_t)D.learner_stride : as_global(D.theta + base);
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
-    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
     const int O = R.obs_dim[0], nA = D.n_discrete, atoms = D.c51_atoms, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
     const bool duel = D.dueling != 0;
     const float vmin = D.c51_vmin, vmax = D.c51_vmax, dz = (vmax - vmin) / (float)(atoms - 1);
     lds_f m = S.abuf;                    // [rc][ap] projected target distribution
     lds_f qb = S.dabuf;                  // [rc][ap] q values / scratch
     const int ap = S.ap;
+    float lossp = 0.f;
+    for (int ck = ck0; ck < ck1; ++ck) {            // the row chunks of this workgroup, their gradients summed in its slab
+    const bool first = (ck == ck0);
+    const int gs = first ? (D.cps > 1 ? GS_STORE : GS_STREAM) : GS_ADD;
+    const int r0 = ck * rc, nv = min(rc, B - r0);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
+    if (!first) lds_barrier();
 
     // q[r][a] of the logits in outb -> qb, then argmax into S.y (one thread per (row, action), then per row)
     auto pick_action = [&]() {
@@ -87,7 +94,6 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     lds_barrier();
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
     lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
-    float lossp = 0.f;
     g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
     for (int r = threadIdx.x; r < rc; r += kWG) {
@@ -132,7 +138,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
         S.outb[r * S.op + j] = v;
     }
     lds_barrier();
-    mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);
+    mlp_bwd(N, 0, nl, theta, slab, S, gs, false, 0, 0);
+    }
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
 }

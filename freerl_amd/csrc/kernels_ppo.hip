@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                         for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
                     }
                     __syncthreads();
-                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
                     continue;
                 }
                 if (discrete) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                         for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
                     }
                     __syncthreads();
-                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
                     continue;
                 }
                 // per-row ratio and d loss / d sum(logp)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 __syncthreads();
                 if (threadIdx.x < A)
                     for (int r = 0; r < rc; ++r) gls += S.abuf[r * S.ap + threadIdx.x];
-                mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0, false, 0, 0);
+                mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
             }
             if (!discrete && !beta && threadIdx.x < A) {
                 const float raw = thA[NA.extra_off + threadIdx.x];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                     S.outb[r * S.op + c] = d;
                 }
                 __syncthreads();
-                mlp_bwd(NC, 0, NC.n_layers, thC, gC, S, r0 == 0, false, 0, 0);
+                mlp_bwd(NC, 0, NC.n_layers, thC, gC, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
             }
             const float closs = block_sum(closs_p, S.red) * invm;
             __syncthreads();

@@ -45,6 +45,15 @@ __device__ __forceinline__ UnitSlice unit_slice(int ns) {
     return UnitSlice{g * 8 + (l & 7), l >> 3};
 }
 
+// A workgroup owns `cps` consecutive row chunks of its unit (frl_create picks cps so that one round of workgroups fills
+// the chip): chunk 0 stores its weight gradients in the workgroup's slab, the others add to them — one slab per
+// workgroup instead of one per chunk for reduce_kernel to stream.
+struct ChunkRange { int c0, c1; };
+__device__ __forceinline__ ChunkRange chunk_range(const EngineDesc& D, int batch, int slab) {
+    const int nchunks = (batch + D.rc - 1) / D.rc, c0 = slab * D.cps;
+    return ChunkRange{c0, min(c0 + D.cps, nchunks)};
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------- draw
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     const NetDesc& N = D.net[0];
     const RecordDesc& R = D.rec;
     const Lds S = carve(D, smem);
-    const int rc = D.rc, B = a.batch, nl = N.n_layers, r0 = sl * rc, nv = min(rc, B - r0);
+    const int rc = D.rc, B = a.batch, nl = N.n_layers;
+    const ChunkRange cr = chunk_range(D, B, sl);
     const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
     // noisy head: the three forwards read the effective parameter sets frl_learn has materialised (kernels_noisy.hip)
     g_cf eff = D.noisy ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[0]) : nullptr;
@@ -139,7 +149,6 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     g_cf theta = D.noisy ? eff + 2 * (size_t)D.learner_stride : as_global(D.theta + base);    // online net on s (differentiated)
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[0]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
-    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
     const int O = R.obs_dim[0], nA = D.n_discrete, npad = N.L[nl - 1].n_pad, k0pad = N.L[0].k_pad;
     const bool duel = D.dueling != 0;
     // Q(s, j) of row r out of the head in outb: plain, or Dueling's V + A_j - mean(A) with the head laid out [V ; A]
@@ -150,6 +159,21 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
         return m;
     };
 
+    // use_isw == 1: the reference's arithmetic — `(is_weight * td_error**2).mean()` multiplies a [B] by a [B,1] tensor
+    // (DQN_with_tricks.py:277-278), i.e. mean(w) * mean(td^2): every row carries the MEAN weight.  2: per-row weights.
+    float wbar = 1.f;
+    if (a.use_isw == 1) {
+        float ws = 0.f;
+        for (int i = threadIdx.x; i < B; i += kWG) ws += D.isw[(size_t)p * D.batch_max + i];
+        wbar = block_sum(ws, S.red) / (float)B;
+    }
+    float lossp = 0.f;
+    for (int ck = cr.c0; ck < cr.c1; ++ck) {       // the row chunks of this workgroup, their gradients summed in its slab
+    const bool first = (ck == cr.c0);
+    const int gs = first ? (D.cps > 1 ? GS_STORE : GS_STREAM) : GS_ADD;
+    const int r0 = ck * rc, nv = min(rc, B - r0);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
+    if (!first) lds_barrier();
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
@@ -184,17 +208,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
     zero_cols(S.xin, S.xp, rc, O, k0pad);
     lds_barrier();
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
-    float lossp = 0.f;
     g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
-    // use_isw == 1: the reference's arithmetic — `(is_weight * td_error**2).mean()` multiplies a [B] by a [B,1] tensor
-    // (DQN_with_tricks.py:277-278), i.e. mean(w) * mean(td^2): every row carries the MEAN weight.  2: per-row weights.
-    float wbar = 1.f;
-    if (a.use_isw == 1) {
-        float ws = 0.f;
-        for (int i = threadIdx.x; i < B; i += kWG) ws += D.isw[(size_t)p * D.batch_max + i];
-        wbar = block_sum(ws, S.red) / (float)B;
-    }
     // head delta, one thread per row: d = 2 w (Q(s,a) - y) / B on the taken action; through Dueling's recombination
     // dV = d, dA_j = d (delta_ja - 1/nA)
     for (int r = threadIdx.x; r < rc; r += kWG) {
@@ -217,7 +232,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
         }
     }
     lds_barrier();
-    mlp_bwd(N, 0, nl, theta, slab, S, true, false, 0, 0);
+    mlp_bwd(N, 0, nl, theta, slab, S, gs, false, 0, 0);
+    }
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
 }
@@ -235,16 +251,15 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     const RecordDesc& R = D.rec;
     const NetDesc& NC = D.net[2 * ag + 1];
     const Lds S = carve(D, smem);
-    const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
+    const int rc = D.rc, B = a.batch;
+    const ChunkRange cr = chunk_range(D, B, sl);
     const bool sac = (D.algo == ALGO_SAC);
     const size_t lbase = (size_t)p * D.learner_stride;
     g_cf thC = as_global(D.theta + lbase + D.net_off[2 * ag + 1]);
     g_cf tgC = as_global(D.target + lbase + D.net_off[2 * ag + 1]);
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag + 1]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
-    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    g_cf noise_u = as_global(D.noise + ((size_t)p * n + ag) * D.noise_sets * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
@@ -267,6 +282,14 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     }
 #endif
 
+    float lossp = 0.f;
+    for (int ck = cr.c0; ck < cr.c1; ++ck) {       // the row chunks of this workgroup, their gradients summed in its slab
+    const bool first = (ck == cr.c0);
+    const int gs = first ? (D.cps > 1 ? GS_STORE : GS_STREAM) : GS_ADD;
+    const int r0 = ck * rc, nv = min(rc, B - r0);
+    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
+    g_cf noise_u = as_global(D.noise + ((size_t)p * n + ag) * D.noise_sets * D.batch_max * am + (size_t)r0 * am);
+    if (!first) lds_barrier();
     // ---- a' = actor_target_j(s'_j) for every agent j (MADDPG_simple.py:155; n = 1 otherwise)
     float lp_next = 0.f;                            // SAC: log pi(a'|s') of row threadIdx.x
     for (int j = 0; j < n; ++j) {
@@ -336,7 +359,6 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     FRL_PHASE(S);
 
     // ---- critic heads: forward, MSE delta, backward
-    float lossp = 0.f;
     for (int h = 0; h < heads; ++h) {
         if (h == 0) {           // the second head reads the same [obs | act] rows: nothing in between writes xin
             gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
@@ -357,7 +379,8 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
             S.outb[r * S.op + c] = d;
         }
         FRL_PHASE(S);
-        mlp_bwd(NC, h * ql, ql, thC, slab, S, true, false, 0, 0);
+        mlp_bwd(NC, h * ql, ql, thC, slab, S, gs, false, 0, 0);
+    }
     }
     FRL_PHASE_DUMP(S, 0);
     const float ls = block_sum(lossp, S.red);
@@ -378,16 +401,15 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     const NetDesc& NA = D.net[2 * ag];
     const NetDesc& NC = D.net[2 * ag + 1];
     const Lds S = carve(D, smem);
-    const int rc = D.rc, B = a.batch, r0 = sl * rc, nv = min(rc, B - r0);
+    const int rc = D.rc, B = a.batch;
+    const ChunkRange cr = chunk_range(D, B, sl);
     const bool sac = (D.algo == ALGO_SAC);
     const size_t lbase = (size_t)p * D.learner_stride;
     g_cf thA = as_global(D.theta + lbase + D.net_off[2 * ag]);
     g_cf thC = as_global(D.theta + lbase + D.net_off[2 * ag + 1]);
     g_f slab = as_global(D.slab + ((size_t)p * D.S + sl) * D.learner_stride + D.net_off[2 * ag]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
-    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
     const int am = D.act_max;
-    g_cf noise1 = as_global(D.noise + (((size_t)p * n + ag) * D.noise_sets + 1) * D.batch_max * am + (size_t)r0 * am);
     const int heads = NC.heads, ql = NC.n_layers / heads;
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const int Oa = R.obs_dim[ag], Aa = R.act_dim[ag], acol = R.act_off[ag] - R.act_off[0];
@@ -404,6 +426,14 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     };
 
     FRL_PHASE_INIT(S);
+    float alossp = 0.f, entp = 0.f;
+    for (int ck = cr.c0; ck < cr.c1; ++ck) {       // the row chunks of this workgroup, their gradients summed in its slab
+    const bool first = (ck == cr.c0);
+    const int gs = first ? (D.cps > 1 ? GS_STORE : GS_STREAM) : GS_ADD;
+    const int r0 = ck * rc, nv = min(rc, B - r0);
+    g_ci idx = as_global_i(D.idx + ((size_t)p * n + ag) * D.batch_max + r0);
+    g_cf noise1 = as_global(D.noise + (((size_t)p * n + ag) * D.noise_sets + 1) * D.batch_max * am + (size_t)r0 * am);
+    if (!first) lds_barrier();
     // -- a = actor(obs)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
@@ -463,20 +493,19 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
             S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
         }
         FRL_PHASE(S);
-        mlp_bwd(NC, h * ql, ql, thC, nullptr, S, false, true, ct0, ct1);
+        mlp_bwd(NC, h * ql, ql, thC, nullptr, S, GS_ADD, true, ct0, ct1);
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
             S.dabuf[r * S.ap + c] += S.xin[r * S.xp + OT + acol + c];
         }
         FRL_PHASE(S);
     }
-    float alossp = 0.f, entp = 0.f;
     if (threadIdx.x < nv) {
         if (sac) {
-            alossp = -(qsum * 0.5f) - alpha * (-lp);      // (-Q_pi - alpha*entropy), SAC.py:251
-            entp = -lp;
+            alossp += -(qsum * 0.5f) - alpha * (-lp);     // (-Q_pi - alpha*entropy), SAC.py:251
+            entp += -lp;
         } else {
-            alossp = -qsum;
+            alossp += -qsum;
         }
     }
     // -- the actor's activations back from HBM (same thread, same addresses as the spill), its input back in xin
@@ -509,9 +538,11 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
         float gls = 0.f;
         for (int r = 0; r < rc; ++r) gls += S.dabuf[r * S.ap + threadIdx.x];
         const float raw = thA[NA.extra_off + threadIdx.x];
-        slab[NA.extra_off + threadIdx.x] = (raw >= -20.f && raw <= 2.f) ? gls : 0.f;
+        const float gl = (raw >= -20.f && raw <= 2.f) ? gls : 0.f;
+        slab[NA.extra_off + threadIdx.x] = first ? gl : slab[NA.extra_off + threadIdx.x] + gl;
     }
-    mlp_bwd(NA, 0, NA.n_layers, thA, slab, S, true, false, 0, 0);
+    mlp_bwd(NA, 0, NA.n_layers, thA, slab, S, gs, false, 0, 0);
+    }
     FRL_PHASE_DUMP(S, 1);
     const float la = block_sum(alossp, S.red);
     const float le = sac ? block_sum(entp, S.red) : 0.f;

@@ -796,6 +796,20 @@ def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
     test_matd3_learn(N)
 
 
+@pytest.mark.parametrize("rows,cps", [("16", "2"), ("16", "4"), ("32", "2")])
+def test_workgroups_walking_several_row_chunks_give_the_same_answers(N, rows, cps, monkeypatch):
+    """Bench-sized populations give one gradient workgroup several consecutive row chunks (first chunk stores its slab, the
+    others add to it; frl_create's schedule).  FRL_CPS forces that for the single-learner golden cases, Rainbow included."""
+    monkeypatch.setenv("FRL_RC", rows)
+    monkeypatch.setenv("FRL_CPS", cps)
+    test_dqn_learn_matches_oracle_and_reference(N)
+    test_td3_learn(N, "td3")
+    test_sac_learn(N)
+    test_maddpg_learn(N)
+    test_matd3_learn(N)
+    test_dqn_rainbow_all_six_tricks(N)
+
+
 # ------------------------------------------------------------------ PER / N-step / Double (SURVEY §8f-2)
 def test_per_buffer_sumtree_on_device(N):
     """frl_per_*: new rows at the max priority, stratified descents with injected uniforms (bit-exact indices), IS
