@@ -922,6 +922,23 @@ extern "C" int frl_noisy_resample(frl_engine* e, const float* eps_host) {
 
 // One stage of learn() for learners [p0, p0 + pc) on `st`: stage 0 = [draw, obsnorm,] grad(critic | Q) + reduce + adam;
 // stage 1 = grad(actor) + reduce + adam; stage 2 = MADDPG's soft update.
+// reduce + clip + Adam (+ soft update) of every unit's net `ad.which`: one fused launch when each net's gradient fits the
+// registers of one workgroup, else the two streaming passes
+static void launch_adam(frl_engine* e, hipStream_t st, const AdamArgs& ad, int units, dim3 grid_adam) {
+    const EngineDesc& h = e->h;
+    int max_n4 = 0;
+    for (int ag = 0; ag < h.n_agents; ++ag) {
+        const int net = (h.algo == ALGO_DQN) ? 0 : (ad.which == 0 ? 2 * ag + 1 : 2 * ag);
+        max_n4 = std::max(max_n4, h.net[net].size / 4);
+    }
+    if (max_n4 <= kFusedThreads * kFusedVec && !getenv("FRL_ADAM_TWO_PASS")) {
+        hipLaunchKernelGGL(adam_fused_kernel, dim3(units), dim3(kFusedThreads), 0, st, e->d, ad);
+    } else {
+        hipLaunchKernelGGL(reduce_kernel, grid_adam, dim3(256), 0, st, e->d, ad);
+        hipLaunchKernelGGL(adam_kernel, grid_adam, dim3(256), 0, st, e->d, ad);
+    }
+}
+
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
@@ -951,9 +968,13 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         ad.which = 0; ad.lr = a.critic_lr; ad.wd = a.critic_wd;
         ad.soft = (h.algo == ALGO_DQN) ? 1 : ((!maddpg && a.do_actor) ? 1 : 0);
         prof_begin(e, PK_ADAM_CRITIC);
-        hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);
-        if (h.noisy) hipLaunchKernelGGL(noisy_sigma_grad_kernel, dim3(h.P), blk, 0, st, e->d);
-        hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
+        if (h.noisy) {        // the sigma gradients are derived from the reduced gradient between the two passes
+            hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);
+            hipLaunchKernelGGL(noisy_sigma_grad_kernel, dim3(h.P), blk, 0, st, e->d);
+            hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
+        } else {
+            launch_adam(e, st, ad, units, grid_adam);
+        }
         prof_end(e);
     } else if (stage == 1) {
         prof_begin(e, PK_GRAD_ACTOR);
@@ -961,8 +982,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         prof_end(e);
         ad.which = 1; ad.lr = a.actor_lr; ad.wd = 0.f; ad.soft = maddpg ? 0 : 1; ad.sac_alpha = sac ? 1 : 0;
         prof_begin(e, PK_ADAM_ACTOR);
-        hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);
-        hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
+        launch_adam(e, st, ad, units, grid_adam);
         prof_end(e);
     } else {                                          // MATD3_simple.py:245-246: targets move with the delayed policy step
         prof_begin(e, PK_SOFT);

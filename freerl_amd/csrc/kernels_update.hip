@@ -572,6 +572,39 @@ __device__ __forceinline__ int adam_net_index(const EngineDesc& D, int which, in
     return (D.algo == ALGO_DQN) ? 0 : (which == 0 ? 2 * ag + 1 : 2 * ag);
 }
 
+// thread 0 of a unit's first Adam workgroup: losses of the step, SAC's alpha update (SAC.py:154-169,257-260)
+__device__ __forceinline__ void adam_publish(const EngineDesc& D, const AdamArgs& a, int p, int ag, float total, int* steps) {
+    const int n = D.n_agents;
+    const float* pt = D.part + ((size_t)p * n + ag) * D.S * 4;
+    float l0 = 0.f, l1 = 0.f;
+    for (int k = 0; k < a.ns; ++k) { l0 += pt[4 * k]; l1 += pt[4 * k + 1]; }
+    float* st = D.stats + ((size_t)p * n + ag) * ST_COUNT;
+    const float invB = 1.f / (float)a.batch;
+    st[a.which == 0 ? ST_CRITIC_LOSS : ST_ACTOR_LOSS] = l0 * invB;
+    st[a.which == 0 ? ST_CRITIC_GNORM : ST_ACTOR_GNORM] = total;
+    if (a.sac_alpha) {
+        float* al = D.alpha + p * 4;
+        const float alpha = al[3];
+        const float ent_mean = l1 * invB;
+        const float mean_term = ent_mean - a.target_entropy;
+        const float gl = alpha * mean_term;            // d alpha_loss / d log_alpha
+        const int ta = steps[kMaxNets] + 1;
+        float mi = al[1], vi = al[2];
+        mi = mi + (gl - mi) * (1.f - a.beta1);
+        vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
+        const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
+        const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
+        al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
+        al[1] = mi;
+        al[2] = vi;
+        al[3] = expf(al[0]);
+        steps[kMaxNets] = ta;
+        st[ST_ALPHA_LOSS] = alpha * mean_term;
+        st[ST_ALPHA] = al[3];
+        st[ST_ENTROPY] = ent_mean;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
     __shared__ float red_s[8];
     lds_f red = (lds_f)red_s;
@@ -644,35 +677,75 @@ __global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict_
             if (a.soft) tg[i] = tg[i] * tk + thi * a.tau;
         }
     }
-    if (wg == 0 && threadIdx.x == 0) {
-        const float* pt = D.part + ((size_t)p * n + ag) * D.S * 4;
-        float l0 = 0.f, l1 = 0.f;
-        for (int k = 0; k < a.ns; ++k) { l0 += pt[4 * k]; l1 += pt[4 * k + 1]; }
-        float* st = D.stats + ((size_t)p * n + ag) * ST_COUNT;
-        const float invB = 1.f / (float)a.batch;
-        st[a.which == 0 ? ST_CRITIC_LOSS : ST_ACTOR_LOSS] = l0 * invB;
-        st[a.which == 0 ? ST_CRITIC_GNORM : ST_ACTOR_GNORM] = total;
-        if (a.sac_alpha) {
-            float* al = D.alpha + p * 4;
-            const float alpha = al[3];
-            const float ent_mean = l1 * invB;
-            const float mean_term = ent_mean - a.target_entropy;
-            const float gl = alpha * mean_term;            // d alpha_loss / d log_alpha
-            const int ta = steps[kMaxNets] + 1;
-            float mi = al[1], vi = al[2];
-            mi = mi + (gl - mi) * (1.f - a.beta1);
-            vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
-            const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
-            const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
-            al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
-            al[1] = mi;
-            al[2] = vi;
-            al[3] = expf(al[0]);
-            steps[kMaxNets] = ta;
-            st[ST_ALPHA_LOSS] = alpha * mean_term;
-            st[ST_ALPHA] = al[3];
-            st[ST_ENTROPY] = ent_mean;
+    if (wg == 0 && threadIdx.x == 0) adam_publish(D, a, p, ag, total, steps);
+}
+
+// One launch instead of reduce_kernel + adam_kernel when a net's gradient fits in the registers of ONE 1024-thread
+// workgroup (<= kFusedVec float4 per thread: every 128-wide net of the reference): the slabs are summed into registers,
+// the norm is a block reduction, and the Adam pass takes its gradient from the registers — the reduced gradient is
+// never written, the norm partials never leave the workgroup.  11 -> 9 floats of traffic per parameter at 2 slabs.
+constexpr int kFusedThreads = 1024, kFusedVec = 12;
+__global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
+    __shared__ float red[kFusedThreads / 64];
+    const EngineDesc& D = *Dp;
+    const int n = D.n_agents;
+    const int p = a.p0 + blockIdx.x / n, ag = blockIdx.x % n;
+    const int net = adam_net_index(D, a.which, ag);
+    const NetDesc& N = D.net[net];
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
+    const int n4 = N.size / 4;
+    const FRL_GLB f32x4* slab = (const FRL_GLB f32x4*)(D.slab + (size_t)p * D.S * D.learner_stride + D.net_off[net]);
+    const size_t ls4 = (size_t)D.learner_stride / 4;
+    f32x4 g[kFusedVec];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kFusedVec; ++j) {
+        const int i = j * kFusedThreads + threadIdx.x;
+        g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            f32x4 s = slab[i];
+            for (int k = 1; k < a.ns; ++k) s += slab[(size_t)k * ls4 + i];       // fixed order: deterministic
+            g[j] = s;
+            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
         }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
+    const float total = sqrtf(tot);
+    float coef = 1.f;
+    if (a.clip > 0.f) coef = fminf(a.clip / (total + 1e-6f), 1.f);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t = steps[net] + 1;
+    const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
+    const float step = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
+    FRL_GLB f32x4* th = (FRL_GLB f32x4*)(D.theta + off);
+    FRL_GLB f32x4* m = (FRL_GLB f32x4*)(D.m + off);
+    FRL_GLB f32x4* v = (FRL_GLB f32x4*)(D.v + off);
+    FRL_GLB f32x4* tg = (FRL_GLB f32x4*)(D.target + off);
+#pragma unroll
+    for (int j = 0; j < kFusedVec; ++j) {
+        const int i = j * kFusedThreads + threadIdx.x;
+        if (i < n4) {
+            f32x4 gi = g[j] * coef, thi = th[i], mi = m[i], vi = v[i];
+            if (a.wd != 0.f) gi += a.wd * thi;
+            mi = mi + (gi - mi) * w1;
+            vi = vi * a.beta2 + (w2 * gi) * gi;
+            f32x4 denom;
+            denom.x = sqrtf(vi.x) / bc2s + a.eps; denom.y = sqrtf(vi.y) / bc2s + a.eps;
+            denom.z = sqrtf(vi.z) / bc2s + a.eps; denom.w = sqrtf(vi.w) / bc2s + a.eps;
+            thi = thi - step * (mi / denom);
+            m[i] = mi; v[i] = vi; th[i] = thi;
+            if (a.soft) tg[i] = tg[i] * tk + thi * a.tau;
+        }
+    }
+    if (threadIdx.x == 0) {
+        steps[net] = t;
+        adam_publish(D, a, p, ag, total, steps);
     }
 }
 

@@ -43,7 +43,9 @@ enum frl_algo {
 
 enum frl_activation { FRL_ACT_NONE = 0, FRL_ACT_RELU = 1, FRL_ACT_TANH = 2 };
 
-/* which copy of a net's parameters frl_params_get/set addresses */
+/* which copy of a net's parameters frl_params_get/set addresses.  FRL_PARAM_GRAD is a debugging view of the reduced
+ * gradient block: PPO engines, noisy DQN engines and nets wider than the fused Adam kernel materialise it; the other
+ * off-policy updates keep the reduced gradient in registers and leave this block untouched. */
 enum frl_param_kind { FRL_PARAM_ONLINE = 0, FRL_PARAM_TARGET = 1, FRL_PARAM_ADAM_M = 2, FRL_PARAM_ADAM_V = 3, FRL_PARAM_GRAD = 4 };
 
 /* frl_act modes */
