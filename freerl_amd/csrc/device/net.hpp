@@ -579,28 +579,40 @@ __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta
 // Draw `batch` distinct row indices in [0,size) into idx (global, this learner's slice) using
 // `lidx` (LDS int[batch]) for the duplicate check: rejection keeps the draw uniform over
 // subsets, like np.random.choice(size, batch, replace=False) (DQN.py:97).
+// lidx: 2 * round_up(batch, 4) ints of LDS
 __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
                                              unsigned stream, unsigned long long key) {
     for (int i = threadIdx.x; i < batch; i += kWG)
         lidx[i] = (int)uniform_index(philox4x32_10(counter, stream, (unsigned)i, key), (unsigned)size);
     __syncthreads();
+    // does an earlier slot hold the same row?  four slots per LDS read (as a dependent chain of single reads this
+    // check was most of the 33 us the kernel took)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto dup_before = [&](int i) {
+        const int mine = lidx[i];
+        bool d = false;
+        const FRL_LDS i32x4* l4 = (const FRL_LDS i32x4*)lidx;
+        const int full = i >> 2;
+#pragma unroll 4
+        for (int j4 = 0; j4 < full; ++j4) {
+            const i32x4 v = l4[j4];
+            d |= (v.x == mine) | (v.y == mine) | (v.z == mine) | (v.w == mine);
+        }
+        for (int j = full * 4; j < i; ++j) d |= (lidx[j] == mine);
+        return d;
+    };
     for (unsigned round = 1; round < 64; ++round) {
         int dup = 0;
-        for (int i = threadIdx.x; i < batch; i += kWG) {
-            const int mine = lidx[i];
-            bool d = false;
-            for (int j = 0; j < i; ++j) d |= (lidx[j] == mine);
-            if (d) dup = 1;
-        }
+        for (int i = threadIdx.x; i < batch; i += kWG)
+            if (dup_before(i)) dup = 1;
         // redraw AFTER everyone has finished comparing against the old values
         const int any = __syncthreads_or(dup);
         if (!any) break;
-        for (int i = threadIdx.x; i < batch; i += kWG) {
-            const int mine = lidx[i];
-            bool d = false;
-            for (int j = 0; j < i; ++j) d |= (lidx[j] == mine);
-            if (d) lidx[i] = -1 - i;          // mark; distinct negative so marks never collide
-        }
+        FRL_LDS int* lmark = lidx + ((batch + 3) & ~3);     // second half of the caller's 2 x batch ints of LDS
+        for (int i = threadIdx.x; i < batch; i += kWG) lmark[i] = dup_before(i) ? 1 : 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < batch; i += kWG)
+            if (lmark[i]) lidx[i] = -1 - i;
         __syncthreads();
         for (int i = threadIdx.x; i < batch; i += kWG)
             if (lidx[i] < 0)

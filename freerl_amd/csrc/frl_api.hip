@@ -953,7 +953,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     if (stage == 0) {
         if (dev_rng) {
             prof_begin(e, PK_DRAW);
-            hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)a.batch * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
+            hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)2 * ((a.batch + 3) & ~3) * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
             prof_end(e);
         }
         if (h.obs_norm_on && h.algo != ALGO_DQN)                         // sample(): norm(obs) updates the statistics first
