@@ -123,6 +123,7 @@ SIGNATURES = {
     "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "frl_learn": (_i, [_vp, _P(LearnArgs)]),
     "frl_stats_get": (_i, [_vp, _fp]),
+    "frl_last_indices": (_i, [_vp, _i, _i64p]),
     "frl_noisy_eps_size": (_i, [_vp, _ip]),
     "frl_noisy_resample": (_i, [_vp, _fp]),
     "frl_per_enable": (_i, [_vp, C.c_double, C.c_double, C.c_double, C.c_double]),

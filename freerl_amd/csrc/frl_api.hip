@@ -870,6 +870,18 @@ extern "C" int frl_stats_get(frl_engine* e, float* out_host) {
     return FRL_OK;
 }
 
+extern "C" int frl_last_indices(frl_engine* e, int batch, int64_t* out_host) {
+    ENG(e);
+    if (!e->has_nets || !out_host || batch < 1 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "bad argument");
+    const size_t units = (size_t)e->h.P * e->h.n_agents;
+    std::vector<int> tmp(units * e->h.batch_max);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(tmp.data(), e->h.idx, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t u = 0; u < units; ++u)
+        for (int i = 0; i < batch; ++i) out_host[u * batch + i] = tmp[u * e->h.batch_max + i];
+    return FRL_OK;
+}
+
 // Host noise of `n_sets` forwards -> the device layout of kernels_noisy.hip.  Host order per forward (frl_noisy_eps_size
 // floats): per NoisyLinear eps_in[hidden] then eps_out[rows], V before A for a Dueling head.
 static int noisy_upload(frl_engine* e, const float* eps_host, int set0, int n_sets) {

@@ -212,6 +212,12 @@ class Engine:
         N.check(self._L.frl_stats_get(self._h, _fp(out)))
         return out
 
+    def last_indices(self, batch):
+        """int64 [P][n_agents][batch]: the ring rows the last learn() trained on."""
+        out = np.zeros((self.P, self.n_agents, int(batch)), dtype=np.int64)
+        N.check(self._L.frl_last_indices(self._h, int(batch), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
     def learn_work(self, batch, do_actor=True):
         fl, by = C.c_double(0), C.c_double(0)
         N.check(self._L.frl_learn_work(self._h, int(batch), int(bool(do_actor)), C.byref(fl), C.byref(by)))

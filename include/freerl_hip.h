@@ -209,6 +209,9 @@ int frl_act_device(frl_engine* e, int net, int mode, int head, int use_target, i
 /* ---------------------------------------------------------------- learn (the hot path) */
 int frl_learn(frl_engine* e, const frl_learn_args* args);
 int frl_stats_get(frl_engine* e, float* out_host);          /* [P][n_agents][FRL_STAT_COUNT] */
+/* the ring rows the last frl_learn trained on — `indices` of `<ALGO>.sample` (DQN.py:97): uploaded, device-drawn or (per = 1)
+ * the last frl_per_sample's — as host int64 [P][n_agents][batch] */
+int frl_last_indices(frl_engine* e, int batch, int64_t* out_host);
 /* algorithmic work of one frl_learn launch (for the roofline figure): flops and HBM bytes */
 int frl_learn_work(const frl_engine* e, int batch, int do_actor, double* flops_out, double* bytes_out);
 

@@ -589,6 +589,35 @@ def test_full_size_device_rng_properties(N):
     np.testing.assert_array_equal(r1["c"], r1["ct"])
 
 
+def test_device_index_draw_is_a_uniform_subset_without_replacement(N):
+    """The device-side stand-in for `np.random.choice(len(buffer), B, replace=False)` (DQN.py:97) at its hardest point,
+    len(buffer) == 2 * B (every second draw collides and is redrawn): distinct rows, all in range, every row equally
+    likely, a fresh subset per call, the same subsets from the same seed, different ones per learner."""
+    from freerl_amd.engine import Engine
+    B, size, P, calls = 256, 512, 3, 60
+
+    def run(seed):
+        e = Engine(N.ALGO_DQN, 4, 3, size, discrete=True, batch_max=B, n_learners=P, seed=seed)
+        e.fill_synthetic(size, seed=1)
+        got = []
+        for _ in range(calls):
+            e.learn(B, gamma=0.99, tau=0.01, critic_lr=0.0, clip_norm=0.0)
+            got.append(e.last_indices(B)[:, 0])
+        e.close()
+        return np.stack(got)                     # [calls][P][B]
+    a, b = run(7), run(7)
+    np.testing.assert_array_equal(a, b)
+    assert a.min() >= 0 and a.max() < size
+    for k in range(calls):
+        for p in range(P):
+            assert len(np.unique(a[k, p])) == B
+    assert not np.array_equal(a[0, 0], a[1, 0]) and not np.array_equal(a[0, 0], a[0, 1])
+    counts = np.bincount(a[:, 0].reshape(-1), minlength=size)          # each row ~ Binomial(calls, 1/2)
+    assert abs(counts.mean() - calls / 2) < 1e-9 and counts.min() > 8 and counts.max() < 52
+    assert 2.8 < counts.std() < 5.0                                        # sqrt(60 / 4) = 3.87
+    assert not np.array_equal(run(8)[0], a[0])
+
+
 def test_rollout_collector_fills_the_ring_consistently(N):
     """frl_rollout on a population: collect-only first (transitions land in the right rings, next_obs
     of step t is obs of step t+1 unless the episode ended), then with learning (updates counted,
