@@ -494,11 +494,15 @@ __device__ __forceinline__ double powi_d(double b, int t) {
 __device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_cf g, g_f target, float lr, float eps,
                                           float b1, float b2, float wd, float clip_norm, int t_new, float tau,
                                           lds_f red) {
+    // float4 lanes (the block is 16-byte aligned: net offsets are multiples of 32 floats), scalar tail for log_std
+    const int n4 = size >> 2;
+    const FRL_GLB f32x4* g4 = (const FRL_GLB f32x4*)g;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < size; i += kWG) {
-        const float x = g[i];
-        ss += x * x;
+    for (int i = threadIdx.x; i < n4; i += kWG) {
+        const f32x4 x = g4[i];
+        ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
     }
+    for (int i = 4 * n4 + threadIdx.x; i < size; i += kWG) ss += g[i] * g[i];
     const float total = sqrtf(block_sum(ss, red));
     float coef = 1.f;
     if (clip_norm > 0.f) coef = fminf(clip_norm / (total + 1e-6f), 1.f);
@@ -507,7 +511,23 @@ __device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_c
     const float step = (float)((double)lr / bc1);
     const float bc2s = (float)sqrt(bc2);
     const float w1 = 1.f - b1, w2 = 1.f - b2, tk = 1.f - tau;
-    for (int i = threadIdx.x; i < size; i += kWG) {
+    FRL_GLB f32x4* th4 = (FRL_GLB f32x4*)theta;
+    FRL_GLB f32x4* m4 = (FRL_GLB f32x4*)m;
+    FRL_GLB f32x4* v4 = (FRL_GLB f32x4*)v;
+    FRL_GLB f32x4* t4 = (FRL_GLB f32x4*)target;
+    for (int i = threadIdx.x; i < n4; i += kWG) {
+        f32x4 gi = g4[i] * coef, th = th4[i], mi = m4[i], vi = v4[i];
+        if (wd != 0.f) gi += wd * th;
+        mi = mi + (gi - mi) * w1;
+        vi = vi * b2 + (w2 * gi) * gi;
+        f32x4 denom;
+        denom.x = sqrtf(vi.x) / bc2s + eps; denom.y = sqrtf(vi.y) / bc2s + eps;
+        denom.z = sqrtf(vi.z) / bc2s + eps; denom.w = sqrtf(vi.w) / bc2s + eps;
+        th = th - step * (mi / denom);
+        m4[i] = mi; v4[i] = vi; th4[i] = th;
+        if (target) t4[i] = t4[i] * tk + th * tau;
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < size; i += kWG) {
         float gi = g[i] * coef;
         float th = theta[i];
         if (wd != 0.f) gi += wd * th;

@@ -19,7 +19,7 @@ using namespace frl;
 constexpr int H = 128, RC = RC_ROWS;
 
 template <int mode>
-__global__ __launch_bounds__(256, 2) void k(const float* theta_all, float* slab_all, long long* cyc, int reps, LayerDesc L) {
+__global__ __launch_bounds__(256, RC_ROWS > 64 ? 1 : 2) void k(const float* theta_all, float* slab_all, long long* cyc, int reps, LayerDesc L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Lds S = carve_lds(smem, RC, H, 16, 16, 64, 4);
     g_cf theta = as_global(theta_all) + (size_t)(blockIdx.x / WSHARE) * 32768;
@@ -115,8 +115,11 @@ int main() {
     std::vector<float> h((size_t)(maxwg / 8) * 32768);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.01f * ((i * 7919) % 13) - 0.06f;
     hipMemcpy(theta, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    const int lds = (RC * (20 + 2 * 132 + 20 + 8) + 64 + 8) * 4;   // 80 KB at 64 rows: two workgroups per CU
+    const int lds = (RC * (20 + 2 * 132 + 20 + 8) + 64 + 8) * 4;   // 80 KB at 64 rows: two workgroups per CU; 160 KB at 128: one
     const int reps = 64;
+    hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const char* names[9] = {"fwd 128x128", "dX 128x128", "dW 128x128", "fwd 16->128", "fwd 128->16", "mma 8x(K=128)", "mma K=1024", "fwd stamped", "fwd wave rows"};
     LayerDesc L1{H, 10, H, 16, 0, 16 * H}, L3{1, H, 16, H, 0, 16 * H};
     for (int mode = 0; mode < 9; ++mode)
