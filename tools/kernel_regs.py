@@ -18,7 +18,7 @@ for blk in md.split("  - .agpr_count:")[1:]:
     g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
     print("%-28s agpr %3s vgpr %3s spill %3s scratch %4s" % (re.sub(r"^_ZN3frl\d+", "", g("name"))[:28], blk.split()[0],
           g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size")))
-for f in glob.glob(os.path.join(N.LIB_DIR, "frl_api-*")) + [N.LIB_PATH]:      # leave nothing for gpurun to ship
+for f in glob.glob(os.path.join(N.LIB_DIR, "frl_api-*")) + glob.glob(os.path.join(N.LIB_DIR, "frl_api.hip-*")) + [N.LIB_PATH]:      # leave nothing for gpurun to ship
     if os.environ.get("FRL_KEEP_ASM") and f.endswith(".s"):
         continue
     os.remove(f)
