@@ -498,7 +498,8 @@ __device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_c
     const int n4 = size >> 2;
     const FRL_GLB f32x4* g4 = (const FRL_GLB f32x4*)g;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < n4; i += kWG) {
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += kWG) {              // unrolled: one workgroup, latency-bound — keep loads in flight
         const f32x4 x = g4[i];
         ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
     }
@@ -515,6 +516,7 @@ __device__ __forceinline__ float adam_net(int size, g_f theta, g_f m, g_f v, g_c
     FRL_GLB f32x4* m4 = (FRL_GLB f32x4*)m;
     FRL_GLB f32x4* v4 = (FRL_GLB f32x4*)v;
     FRL_GLB f32x4* t4 = (FRL_GLB f32x4*)target;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n4; i += kWG) {
         f32x4 gi = g4[i] * coef, th = th4[i], mi = m4[i], vi = v4[i];
         if (wd != 0.f) gi += wd * th;

@@ -319,10 +319,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                         for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
                     }
                     __syncthreads();
-                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
-                    continue;
-                }
-                if (discrete) {
+                } else if (discrete) {
                     // Categorical(probs = softmax(l3)) (:333-336): one thread per row does the softmax,
                     // log-prob of the stored action, entropy, ratio and the logits' delta
                     if (threadIdx.x < rc) {
@@ -364,9 +361,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                         for (int c = 0; c < napad; ++c) S.outb[r * S.op + c] = S.abuf[r * S.ap + c];
                     }
                     __syncthreads();
-                    mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
-                    continue;
-                }
+                } else {
                 // per-row ratio and d loss / d sum(logp)
                 if (threadIdx.x < rc) {
                     const int r = threadIdx.x;
@@ -410,6 +405,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 __syncthreads();
                 if (threadIdx.x < A)
                     for (int r = 0; r < rc; ++r) gls += S.abuf[r * S.ap + threadIdx.x];
+                }
+                // one call site for the three policy distributions (every inlined copy of the backward pass is ~20 k
+                // instructions of a kernel that walks its whole code once per minibatch step)
                 mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
             }
             if (!discrete && !beta && threadIdx.x < A) {
