@@ -702,6 +702,38 @@ def test_ppo_rollout_collector_lays_out_env_segments(N):
     pool.close(); e.close()
 
 
+def test_ppo_rollout_collector_discrete_policy(N):
+    """frl_ppo_rollout with a Categorical policy on CartPole: stored actions are valid action indices, stored log-probs are
+    log-softmax values of the collecting policy (lr = 0 keeps it), episodes terminate inside the segments and carry
+    done / adv_done accordingly."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, ppo_rollout
+    P, E, Tseg, O, nA = 2, 4, 32, 4, 2
+    T = E * Tseg
+    e = Engine(N.ALGO_PPO, O, nA, T, batch_max=32, n_learners=P, discrete=True, extra_cols=2, seed=5)
+    rng = np.random.default_rng(3)
+    for p in range(P):
+        e.set_params(0, (rng.standard_normal(e.num_params(0)) * 0.03).astype(np.float32), learner=p)      # near-uniform policy
+        e.set_params(1, (rng.standard_normal(e.num_params(1)) * 0.1).astype(np.float32), learner=p)
+    pool = EnvPool("CartPole-v1", P * E, n_threads=2, seed=6)
+    out = ppo_rollout(e, pool, 1, envs_per_learner=E, steps_per_env=Tseg, minibatch=32, k_epochs=1, actor_lr=0.0, critic_lr=0.0)
+    assert out["env_steps"] == P * T and out["episodes"] >= 1          # a random policy drops the pole within 32 steps somewhere
+    lay = e.layout
+    for p in range(P):
+        rows = e.read_rows(p, 0, T)
+        act, logp, adv_done, done = rows[:, lay.act_off[0]], rows[:, lay.extra_off], rows[:, lay.extra_off + 1], rows[:, lay.done_off]
+        assert set(np.unique(act)) <= {0.0, 1.0}
+        assert np.all(adv_done >= done) and np.all(adv_done.reshape(E, Tseg)[:, -1] == 1)
+        assert done.sum() >= 1 or p > 0
+        full = np.zeros((P, T, O), np.float32)
+        full[p] = rows[:, lay.obs_off[0]:lay.obs_off[0] + O]
+        logits = e.act(0, N.ACT_RAW, full, out_dim=nA)[p]
+        lsm = logits - np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True)) - logits.max(1, keepdims=True)
+        np.testing.assert_allclose(logp, lsm[np.arange(T), act.astype(int)], rtol=2e-4, atol=2e-5)
+        assert 0.1 < act.mean() < 0.9                                    # both actions get sampled
+    pool.close(); e.close()
+
+
 def test_ppo_discrete_learn(N):
     """Actor_discrete + Categorical (PPO_with_tricks.py:110-121, 249-251, 333-336)."""
     import torch
