@@ -285,14 +285,13 @@ __device__ __forceinline__ void for_tile_blocks(int tm, int tn, Body body) {
 }
 
 // Interleaved blocks: tm row tiles x (tn / 4) groups of four column tiles.  BM = 2 when every wave still
-// gets a block (4 for 128-row chunks), else 1.  body(integral_constant<BM>, tile_row0, group)
+// gets a block, else 1.  body(integral_constant<BM>, tile_row0, group)
+// (a BM = 4 variant for 128-row chunks was measured: -4 % on the forward layer, but its extra instantiation in every
+// call site cost the 64-row kernels 50-100 spilled VGPRs and 8 % of their speed)
 template <class Body>
 __device__ __forceinline__ void for_il_blocks(int tm, int groups, Body body) {
     const int w = wave_id();
-    if ((tm % 4 == 0) && (tm / 4) * groups >= kWaves) {          // 128-row chunks: 64 rows x 64 columns per wave
-        const int nbm = tm / 4, nb = nbm * groups;
-        for (int blk = w; blk < nb; blk += kWaves) body(std::integral_constant<int, 4>{}, (blk % nbm) * 4, blk / nbm);
-    } else if ((tm % 2 == 0) && (tm / 2) * groups >= kWaves) {
+    if ((tm % 2 == 0) && (tm / 2) * groups >= kWaves) {
         const int nbm = tm / 2, nb = nbm * groups;
         for (int blk = w; blk < nb; blk += kWaves) body(std::integral_constant<int, 2>{}, (blk % nbm) * 2, blk / nbm);
     } else {
