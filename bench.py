@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--learners", type=int, default=int(os.environ.get("FRL_BENCH_LEARNERS", "512")),
                     help="independent learners (seeds) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling runs: only the P-learner engine (no P = 1 engine, no CPU baseline), so that rocprofv3's "
+                         "per-kernel averages are averages over the headline launches")
     args = ap.parse_args()
 
     import torch
@@ -186,17 +189,19 @@ def main():
         lds, rc = e.lds_bytes()
         # single-learner latency (P = 1): the reference-compatible drop-in case
         e.close()
-        e1 = make_engine(N, Engine, 1, local_rank, seed=7)
-        for k in range(10):
-            e1.learn(BATCH, **td3_kwargs(k))
-        e1.sync()
-        t1 = time.perf_counter()
-        n1 = 200
-        for k in range(n1):
-            e1.learn(BATCH, **td3_kwargs(k))
-        e1.sync()
-        single = n1 / (time.perf_counter() - t1)
-        e1.close()
+        single = None
+        if not args.headline_only:
+            e1 = make_engine(N, Engine, 1, local_rank, seed=7)
+            for k in range(10):
+                e1.learn(BATCH, **td3_kwargs(k))
+            e1.sync()
+            t1 = time.perf_counter()
+            n1 = 200
+            for k in range(n1):
+                e1.learn(BATCH, **td3_kwargs(k))
+            e1.sync()
+            single = n1 / (time.perf_counter() - t1)
+            e1.close()
         traffic = None
         pf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(pf):
@@ -227,7 +232,7 @@ def main():
                          "step_ms_avg": step_s * 1e3,
                          "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "kernels": kern},
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
         }
         print(json.dumps(line))
     if dist is not None:

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 2 --headline-only"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 i=0
