@@ -37,4 +37,18 @@ __device__ __forceinline__ float c51_q(lds_cf lg, int atoms, float vmin, float d
     return q;
 }
 
+// The same softmax by one WAVE (lane i = atom i, atoms <= 64): every lane gets q, `p_lane` is this lane's probability
+// (0 beyond the support).  Sums run as shuffle trees instead of ascending chains: last-bit differences to c51_q.
+__device__ __forceinline__ float c51_softmax_wave(lds_cf lg, int atoms, float vmin, float dz, float& p_lane) {
+    const int l = lane_id();
+    const float x = l < atoms ? lg[l] : -3.0e38f;
+    float mx = x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float e = l < atoms ? expf(x - mx) : 0.f;
+    const float sum = wave_sum(e);
+    p_lane = e / sum;
+    return wave_sum(p_lane * (vmin + dz * (float)l));
+}
+
 }  // namespace frl

@@ -294,6 +294,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         h.dueling = c.dueling ? 1 : 0;
         h.noisy = c.noisy ? 1 : 0;
         h.c51_atoms = c.c51_atoms > 1 ? c.c51_atoms : 0;
+        if (h.c51_atoms > 64) { delete e; return fail(FRL_ERR_INVALID, "c51_atoms %d: the distribution arithmetic runs one wave lane per atom (<= 64; the reference uses 51)", h.c51_atoms); }
         h.c51_vmin = c.c51_vmin; h.c51_vmax = c.c51_vmax;
         const int per_out = h.c51_atoms ? h.c51_atoms : 1;        // head rows: [V (per_out) ;] A (act_dim x per_out)
         build_net(h.net[0], {{H, c.obs_dim[0]}, {(c.act_dim[0] + (c.dueling ? 1 : 0)) * per_out, H}}, 1, ACT_RELU, ACT_NONE, 0,

@@ -35,48 +35,58 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     lds_f qb = S.dabuf;                  // [rc][ap] q values / scratch
     const int ap = S.ap;
     float lossp = 0.f;
+    FRL_PHASE_INIT(S);
     for (int ck = ck0; ck < ck1; ++ck) {            // the row chunks of this workgroup, their gradients summed in its slab
     const bool first = (ck == ck0);
     const int gs = first ? (D.cps > 1 ? GS_STORE : GS_STREAM) : GS_ADD;
     const int r0 = ck * rc, nv = min(rc, B - r0);
     g_ci idx = as_global_i(D.idx + (size_t)p * D.n_agents * D.batch_max + r0);
-    if (!first) lds_barrier();
+    if (!first) FRL_PHASE(S);
 
     // q[r][a] of the logits in outb -> qb, then argmax into S.y (one thread per (row, action), then per row)
     auto pick_action = [&]() {
         const int lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
-        for (int e = threadIdx.x; e < nv * nA; e += kWG) {
+        for (int e = wave_id(); e < nv * nA; e += kWaves) {          // one wave per (row, action): lane = atom
             const int r = e / nA, act = e - r * nA;
-            qb[r * ap + act] = c51_q(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz, nullptr);
+            float pl;
+            const float q = c51_softmax_wave(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz, pl);
+            if (lane_id() == 0) qb[r * ap + act] = q;
         }
-        lds_barrier();
+        FRL_PHASE(S);
         for (int r = threadIdx.x; r < nv; r += kWG) {
             int best = 0;
             for (int jj = 1; jj < nA; ++jj) if (qb[r * ap + jj] > qb[r * ap + best]) best = jj;
             S.y[r] = (float)best;
         }
-        lds_barrier();
+        FRL_PHASE(S);
         return lb;
     };
     // ---- next action: argmax_a q(s', a) by the online net (Double, :141-143) or by the target net itself (:145)
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
-    lds_barrier();
+    FRL_PHASE(S);
     if (a.double_dqn) {
         mlp_fwd(N, 0, nl, theta_next, S, ACT_NONE);
         pick_action();
     }
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
     int lb = a.double_dqn ? c51_combine(S.outb, S.op, nv, nA, atoms, duel) : pick_action();
-    // ---- projection of the target distribution (projection_dist :147-158), one thread per row; qb row = next_dist
+    // ---- projection of the target distribution (projection_dist :147-158).  qb row = next_dist (one wave per row), then
+    // one thread per row walks the support: every lower-bin index_add_ in atom order, then every upper-bin one (:155-156).
+    // (One thread per (row, target bin) scanning all sources was measured: 51x the arithmetic, slower than this chain.)
+    for (int r = wave_id(); r < nv; r += kWaves) {
+        float pl;
+        c51_softmax_wave(S.outb + r * S.op + lb + (int)S.y[r] * atoms, atoms, vmin, dz, pl);
+        if (lane_id() < atoms) qb[r * ap + lane_id()] = pl;
+    }
+    FRL_PHASE(S);
     for (int r = threadIdx.x; r < nv; r += kWG) {
-        lds_f ndl = qb + r * ap;
-        c51_q(S.outb + r * S.op + lb + (int)S.y[r] * atoms, atoms, vmin, dz, ndl);
+        lds_cf ndl = qb + r * ap;
         g_cf rec = ring + (size_t)idx[r] * R.stride;
         const float rew = rec[R.rew_off], done = rec[R.done_off];
         lds_f mr = m + r * ap;
         for (int i = 0; i < atoms; ++i) mr[i] = 0.f;
-        for (int pass = 0; pass < 2; ++pass)               // index_add_ of all lower bins first, then of all upper bins (:155-156)
+        for (int pass = 0; pass < 2; ++pass)
             for (int i = 0; i < atoms; ++i) {
                 const float z = vmin + dz * (float)i;
                 const float tz = fminf(fmaxf(rew + a.gamma * z * (1.f - done), vmin), vmax);
@@ -87,59 +97,56 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
                 else mr[u] += (b - lf) * ndl[i];
             }
     }
-    lds_barrier();
+    FRL_PHASE(S);
     // ---- current distribution of the taken action, cross-entropy against m, head delta
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], O, 0);
     zero_cols(S.xin, S.xp, rc, O, k0pad);
-    lds_barrier();
+    FRL_PHASE(S);
     mlp_fwd(N, 0, nl, theta, S, ACT_NONE);
     lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
     g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
-    for (int r = threadIdx.x; r < rc; r += kWG) {
-        lds_f o = S.outb + r * S.op;
-        lds_f pr = qb + r * ap;               // probabilities of the taken action, then its logit delta
-        int at = 0;
-        if (r < nv) {
-            at = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
-            c51_q(o + lb + at * atoms, atoms, vmin, dz, pr);
-            const float w = a.use_isw ? isw[r] : 1.f;              // `is_weight.reshape(-1,1)`: per-row weights here (:256)
-            float ce = 0.f, gp = 0.f;
-            for (int i = 0; i < atoms; ++i) {
-                const float pi = pr[i], mi = m[r * ap + i];
-                const bool inside = pi > 1e-5f && pi < 1.f - 1e-5f;
-                ce += mi * logf(fminf(fmaxf(pi, 1e-5f), 1.f - 1e-5f));
-                const float gi = inside ? -(mi * w / (float)B) / pi : 0.f;     // d loss / d p_i
-                m[r * ap + i] = gi;                                             // m_i is not needed any more
-                gp += gi * pi;
-            }
+    for (int r = wave_id(); r < nv; r += kWaves) {             // one wave per row: lane = atom
+        const int l = lane_id();
+        const int at = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
+        float pi;
+        c51_softmax_wave(S.outb + r * S.op + lb + at * atoms, atoms, vmin, dz, pi);
+        const float w = a.use_isw ? isw[r] : 1.f;              // `is_weight.reshape(-1,1)`: per-row weights here (:256)
+        const float mi = l < atoms ? m[r * ap + l] : 0.f;
+        const bool inside = pi > 1e-5f && pi < 1.f - 1e-5f;
+        const float ce = wave_sum(l < atoms ? mi * logf(fminf(fmaxf(pi, 1e-5f), 1.f - 1e-5f)) : 0.f);
+        const float gi = (l < atoms && inside) ? -(mi * w / (float)B) / pi : 0.f;       // d loss / d p_i
+        const float gp = wave_sum(gi * pi);
+        if (l < atoms) qb[r * ap + l] = pi * (gi - gp);        // softmax backward: d loss / d logit_i
+        if (l == 0) {
             lossp += -w * ce;
-            tde[r] = ce;                                                        // `error` of :255 (PER priorities use |error|)
-            for (int i = 0; i < atoms; ++i) pr[i] = pr[i] * (m[r * ap + i] - gp);       // softmax backward: d loss / d logit_i
+            tde[r] = ce;                                        // `error` of :255 (PER priorities use |error|)
+            S.y[r] = (float)at;
         }
-        if (r < nv) S.y[r] = (float)at;
     }
-    lds_barrier();
+    FRL_PHASE(S);
     // head delta from the per-atom logit deltas in qb, all threads: plain head: the taken action's block; Dueling:
     // dV_i = d_i, dA_b,i = d_i (delta_b,at - 1/nA)
-    for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-        const int r = e / npad, j = e - r * npad;
-        float v = 0.f;
-        if (r < nv) {
-            const int at = (int)S.y[r];
-            lds_cf pr = qb + r * ap;
-            if (!duel) { if (j >= at * atoms && j < (at + 1) * atoms) v = pr[j - at * atoms]; }
-            else if (j < atoms) v = pr[j];
-            else if (j < atoms + nA * atoms) {
-                const int b = (j - atoms) / atoms, i = (j - atoms) - b * atoms;
-                v = pr[i] * ((b == at ? 1.f : 0.f) - 1.f / (float)nA);
+    for (int j = threadIdx.x; j < npad; j += kWG) {             // a head column per thread: its (action, atom) once, then down the rows
+        const int jj = duel ? j - atoms : j;
+        const int b = jj >= 0 ? jj / atoms : -1, i = jj >= 0 ? jj - b * atoms : j;
+        const bool live = duel ? (j < atoms + nA * atoms) : (j < nA * atoms);
+        for (int r = 0; r < rc; ++r) {
+            float v = 0.f;
+            if (r < nv && live) {
+                const int at = (int)S.y[r];
+                const float d = qb[r * ap + i];
+                if (!duel) v = (b == at) ? d : 0.f;
+                else if (b < 0) v = d;                                                   // dV_i
+                else v = d * ((b == at ? 1.f : 0.f) - 1.f / (float)nA);                 // dA_b,i
             }
+            S.outb[r * S.op + j] = v;
         }
-        S.outb[r * S.op + j] = v;
     }
-    lds_barrier();
+    FRL_PHASE(S);
     mlp_bwd(N, 0, nl, theta, slab, S, gs, false, 0, 0);
     }
+    FRL_PHASE_DUMP(S, 2);
     const float ls = block_sum(lossp, S.red);
     if (threadIdx.x == 0) D.part[((size_t)p * D.n_agents * D.S + sl) * 4] = ls;
 }

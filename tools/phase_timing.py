@@ -29,7 +29,40 @@ LABELS_TD3_ACTOR = (["gather s"] + FWD("pi") + ["a -> abuf", "gather [s|a]", "a 
                     ["head bwd (dW3,dX3)", "dW2", "dX2", "dW1"])
 
 
+def c51(P):
+    """Wave 0's stamp-to-stamp cycles through c51_grad_kernel (the reference's default Rainbow set), first row chunk."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    N.build()
+    from freerl_amd.engine import Engine
+    L = N.lib()
+    fn = L.frl_debug_phase_clocks
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_int), C.c_int]
+    e = Engine(N.ALGO_DQN, 8, 4, 100_000, discrete=True, batch_max=256, n_learners=P, seed=1, dueling=True, noisy=True,
+               c51=(51, -100.0, 100.0))
+    rng = np.random.default_rng(0)
+    for p in range(P):
+        flat = (rng.standard_normal(e.get_params(0, learner=p).size) * 0.05).astype(np.float32)
+        e.set_params(0, flat, N.PARAM_ONLINE, learner=p)
+        e.set_params(0, flat, N.PARAM_TARGET, learner=p)
+    e.fill_synthetic(100_000, seed=5)
+    rc = e.lds_bytes()[1]
+    nblk = P * (256 // rc)
+    buf = (C.c_int * (8 * 5 * 64))()
+    assert fn(buf, max(1, nblk // 8 - 3)) == 0
+    assert fn(buf, -3) == 0
+    for it in range(4):
+        e.learn(256, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0, double_dqn=True)
+    assert fn(buf, 0) == 0
+    raw = np.array(buf[:], dtype=np.int64).reshape(8, 5, 64)
+    d = np.diff(raw[:, 4, :].astype(np.float64), axis=1)
+    d = d[:, :(d[0] > 0).sum()]
+    print("P=%d, %d rows per workgroup; wave 0 barrier-to-barrier cycles, mean over sampled workgroups (total %.0f):" % (P, rc, d.mean(axis=0).sum()))
+    print(np.round(d.mean(axis=0)).astype(int).tolist())
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c51":
+        return c51(int(sys.argv[2]) if len(sys.argv) > 2 else 512)
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     actor = len(sys.argv) > 2 and sys.argv[2] == "actor"
     N.build()
