@@ -696,19 +696,30 @@ __global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineD
     const int n4 = N.size / 4;
     const FRL_GLB f32x4* slab = (const FRL_GLB f32x4*)(D.slab + (size_t)p * D.S * D.learner_stride + D.net_off[net]);
     const size_t ls4 = (size_t)D.learner_stride / 4;
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t = steps[net] + 1;                             // in flight with the slab loads
+    // slab-major: all of a thread's loads of one slab in flight together (element-major, each element's slab sum was a
+    // dependent chain of waits: 57 us for 64 learners); per element the slabs are still added in index order
     f32x4 g[kFusedVec];
-    float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < kFusedVec; ++j) {
         const int i = j * kFusedThreads + threadIdx.x;
-        g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < n4) {
-            f32x4 s = slab[i];
-            for (int k = 1; k < a.ns; ++k) s += slab[(size_t)k * ls4 + i];       // fixed order: deterministic
-            g[j] = s;
-            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
-        }
+        g[j] = (i < n4) ? slab[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    for (int k = 1; k < a.ns; ++k) {
+        const FRL_GLB f32x4* sk = slab + (size_t)k * ls4;
+        f32x4 tmp[kFusedVec];
+#pragma unroll
+        for (int j = 0; j < kFusedVec; ++j) {
+            const int i = j * kFusedThreads + threadIdx.x;
+            tmp[j] = (i < n4) ? sk[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kFusedVec; ++j) g[j] += tmp[j];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kFusedVec; ++j) ss += g[j].x * g[j].x + g[j].y * g[j].y + g[j].z * g[j].z + g[j].w * g[j].w;
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
@@ -718,8 +729,6 @@ __global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineD
     const float total = sqrtf(tot);
     float coef = 1.f;
     if (a.clip > 0.f) coef = fminf(a.clip / (total + 1e-6f), 1.f);
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t = steps[net] + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     const float step = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
     const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
