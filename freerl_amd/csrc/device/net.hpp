@@ -268,7 +268,8 @@ __device__ __forceinline__ bool head_fusable(const NetDesc& N, int l0, int nl) {
 // Hidden layer L (as linear_fwd) + partial head outputs: outb[r][4*g + o] = sum over column group g of h[r][c] * WH[c][o]
 // ONE: single-output head (every critic): the 16 head weights a lane needs are scalars fetched with the layer's own
 // weights; otherwise they are float4s (4 outputs) fetched in the epilogue.
-template <bool ONE>
+// STORE = false: the hidden activations are not kept (target nets: nothing is differentiated through them).
+template <bool ONE, bool STORE = true>
 __device__ __forceinline__ void linear_fwd_head_t(const LayerDesc& L, const LayerDesc& LH, g_cf theta, lds_cf X, int ldx, lds_f Y,
                                                   int ldy, int act, int rc, lds_f outb, int op) {
     g_cf W = theta + L.w_off;
@@ -301,7 +302,7 @@ __device__ __forceinline__ void linear_fwd_head_t(const LayerDesc& L, const Laye
 #pragma unroll
             for (int x = 0; x < BM; ++x) {
                 const f32x4 v = act_apply4<ACT>(f32x4{acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]} + bias[r]);
-                st4(Y + (mt0 * 16 + x * 16 + row) * ldy + c4, v);
+                if constexpr (STORE) st4(Y + (mt0 * 16 + x * 16 + row) * ldy + c4, v);
                 if constexpr (ONE) part[x].x += (v.x * w1[4 * r] + v.y * w1[4 * r + 1]) + (v.z * w1[4 * r + 2] + v.w * w1[4 * r + 3]);
                 else part[x] += v.x * w0 + v.y * w1v + v.z * w2 + v.w * w3;
             }
@@ -412,6 +413,27 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
         in = out;
         ldin = ldo;
     }
+}
+
+// Twin single-output critics evaluated WITHOUT a backward pass (the target critics of TD3 / SAC / MATD3): both first
+// layers in one barrier phase (xin -> h1 / h2), both second layers with their head dot products in the next (their
+// activations never stored); the caller reads q_h(row) = twin_target_q(...).  Three phases instead of eight.
+__device__ __forceinline__ bool twin_target_fusable(const NetDesc& N) {
+    return N.heads == 2 && N.n_layers == 6 && head_fusable(N, 0, 3) && head_fusable(N, 3, 3) && N.L[2].n == 1 && N.L[5].n == 1 &&
+           N.L[0].n_pad == N.L[1].k_pad && N.L[3].n_pad == N.L[4].k_pad && N.L[1].n_pad == 128 && N.L[4].n_pad == 128;
+}
+__device__ __forceinline__ void twin_target_fwd(const NetDesc& N, g_cf theta, const Lds& S) {
+    linear_fwd(N.L[0], theta, S.xin, S.xp, S.h1, S.hp, N.hidden_act, S.rc);
+    linear_fwd(N.L[3], theta, S.xin, S.xp, S.h2, S.hp, N.hidden_act, S.rc);
+    FRL_PHASE(S);
+    linear_fwd_head_t<true, false>(N.L[1], N.L[2], theta, S.h1, S.hp, nullptr, 0, N.hidden_act, S.rc, S.outb, S.op);
+    linear_fwd_head_t<true, false>(N.L[4], N.L[5], theta, S.h2, S.hp, nullptr, 0, N.hidden_act, S.rc, S.outb + 8, S.op);
+    FRL_PHASE(S);
+}
+// head h's value of row r after twin_target_fwd: bias + the two 64-column groups' partial dot products (head_finalize's order)
+__device__ __forceinline__ float twin_target_q(const NetDesc& N, g_cf theta, const Lds& S, int r, int h) {
+    lds_cf o = S.outb + r * S.op + 8 * h;
+    return (theta[N.L[3 * h + 2].b_off] + o[0]) + o[4];
 }
 
 // Backward of layers [l0, l0+nl): head delta in outb (zero in padded columns and invalid rows).

@@ -343,12 +343,18 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
     if (bn && n > 1) { lds_barrier(); normalize_joint(nv); }
     FRL_PHASE(S);
-    mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
-    float q = (threadIdx.x < rc) ? S.outb[threadIdx.x * S.op] : 0.f;
-    if (heads == 2) {
-        FRL_PHASE(S);
-        mlp_fwd(NC, ql, ql, tgC, S, ACT_NONE);
-        if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
+    float q = 0.f;
+    if (twin_target_fusable(NC)) {
+        twin_target_fwd(NC, tgC, S);
+        if (threadIdx.x < rc) q = fminf(twin_target_q(NC, tgC, S, threadIdx.x, 0), twin_target_q(NC, tgC, S, threadIdx.x, 1));
+    } else {
+        mlp_fwd(NC, 0, ql, tgC, S, ACT_NONE);
+        if (threadIdx.x < rc) q = S.outb[threadIdx.x * S.op];
+        if (heads == 2) {
+            FRL_PHASE(S);
+            mlp_fwd(NC, ql, ql, tgC, S, ACT_NONE);
+            if (threadIdx.x < rc) q = fminf(q, S.outb[threadIdx.x * S.op]);
+        }
     }
     if (threadIdx.x < nv) {
         g_cf rec = ring + (size_t)idx[threadIdx.x] * R.stride;
