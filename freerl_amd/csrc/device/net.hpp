@@ -392,7 +392,13 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
 }
 
 // Forward of layers [l0, l0+nl) of net N: xin -> h1 [-> h2] -> outb.  Ends with a barrier.
-__device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act) {
+// rowf(r) runs on thread r (< rc) right after row r's head outputs are final in outb: the caller's per-row consumer of
+// the output (target action, TD delta, log-prob ...) rides on the last phase instead of costing a barrier phase of its
+// own (fused narrow heads; other heads get one extra phase for it).  rowf may read / rewrite outb row r and write other
+// LDS buffers.  mlp_fwd = no consumer.
+struct NoRowConsumer { __device__ __forceinline__ void operator()(int) const {} };
+template <class RowF>
+__device__ __forceinline__ void mlp_fwd_rows(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act, RowF rowf) {
     lds_cf in = S.xin;
     int ldin = S.xp;
     const bool fuse = head_fusable(N, l0, nl);
@@ -405,6 +411,7 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
             linear_fwd_head(N.L[l0 + i], LH, theta, in, ldin, out, ldo, N.hidden_act, S.rc, S.outb, S.op);
             FRL_PHASE(S);
             head_finalize(LH, theta, S.outb, S.op, S.rc, N.L[l0 + i].n_pad / 64, out_act);
+            if (threadIdx.x < S.rc) rowf((int)threadIdx.x);
             FRL_PHASE(S);
             return;
         }
@@ -413,6 +420,13 @@ __device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf t
         in = out;
         ldin = ldo;
     }
+    if constexpr (!std::is_same<RowF, NoRowConsumer>::value) {
+        if (threadIdx.x < S.rc) rowf((int)threadIdx.x);
+        FRL_PHASE(S);
+    }
+}
+__device__ __forceinline__ void mlp_fwd(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act) {
+    mlp_fwd_rows(N, l0, nl, theta, S, out_act, NoRowConsumer{});
 }
 
 // Twin single-output critics evaluated WITHOUT a backward pass (the target critics of TD3 / SAC / MATD3): both first

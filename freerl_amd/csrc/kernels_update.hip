@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
     const int OT = R.obs_total, AT = R.act_total, kc0 = NC.L[0].k_pad;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
+    const bool direct = (n == 1) && kc0 <= D.net[0].L[0].k_pad;      // a' can be written into the critic input in place
     // Batch_ObsNorm statistics as of THIS agent's sample() (version ag), one block of obsnorm_w per agent
     g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + ((size_t)p * n + ag) * n * D.obsnorm_w) : nullptr;
     auto normalize_joint = [&](int nvalid) {      // every agent's segment of a joint [obs_0 | obs_1 | ...] block in xin[:, 0:OT)
@@ -301,10 +302,10 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
         zero_cols(S.xin, S.xp, rc, Oj, NJ.L[0].k_pad);
         if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oj, bn + (size_t)j * D.obsnorm_w, Oj); }
         FRL_PHASE(S);
-        mlp_fwd(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH);
-        if (sac) {                                  // SAC.py:70-97 on actor_target (SAC.py:227)
-            const int r = threadIdx.x;
-            if (r < rc) {
+        // a'_j per row in the finalize phase of the target actor; single agent: straight into the critic's input row
+        // (xin[:, 0:O) still holds the normalised next_obs, the columns past the action are already zero)
+        mlp_fwd_rows(NJ, 0, NJ.n_layers, tgJ, S, sac ? ACT_NONE : ACT_TANH, [&](int r) {
+            if (sac) {                              // SAC.py:70-97 on actor_target (SAC.py:227)
                 float lp = 0.f;
                 for (int c = 0; c < Aj; ++c) {
                     const float mean = S.outb[r * S.op + c];
@@ -318,31 +319,33 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
                     S.abuf[r * S.ap + cj + c] = tanhf(u);
                 }
                 lp_next = lp;
-            }
-        } else {
-            for (int e = threadIdx.x; e < rc * Aj; e += kWG) {
-                const int r = e / Aj, c = e - r * Aj;
-                float v = S.outb[r * S.op + c];
-                if (a.use_policy_noise && r < nv) {   // TD3.py:196-198
-                    float nz = a.policy_noise_scale * (noise0[(size_t)r * am + c] * a.policy_noise);
-                    nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
-                    v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
+            } else {
+                for (int c = 0; c < Aj; ++c) {
+                    float v = S.outb[r * S.op + c];
+                    if (a.use_policy_noise && r < nv) {   // TD3.py:196-198
+                        float nz = a.policy_noise_scale * (noise0[(size_t)r * am + c] * a.policy_noise);
+                        nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
+                        v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
+                    }
+                    S.abuf[r * S.ap + cj + c] = v;
                 }
-                S.abuf[r * S.ap + cj + c] = v;
             }
-        }
-        FRL_PHASE(S);
+            if (direct)
+                for (int c = 0; c < Aj; ++c) S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
+        });
     }
     // ---- centralised target critic on [next_obs_all | a'_all]
     // single agent: xin[:, 0:O) still holds the (normalised) next_obs the target actor has just read
-    if (n > 1) gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
-    for (int e = threadIdx.x; e < rc * AT; e += kWG) {
-        const int r = e / AT, c = e - r * AT;
-        S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
+    if (!direct) {
+        if (n > 1) gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.nobs_off[0], OT, 0);
+        for (int e = threadIdx.x; e < rc * AT; e += kWG) {
+            const int r = e / AT, c = e - r * AT;
+            S.xin[r * S.xp + OT + c] = S.abuf[r * S.ap + c];
+        }
+        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+        if (bn && n > 1) { lds_barrier(); normalize_joint(nv); }
+        FRL_PHASE(S);
     }
-    zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-    if (bn && n > 1) { lds_barrier(); normalize_joint(nv); }
-    FRL_PHASE(S);
     float q = 0.f;
     if (twin_target_fusable(NC)) {
         twin_target_fwd(NC, tgC, S);
@@ -372,19 +375,18 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
             if (bn) { lds_barrier(); normalize_joint(nv); }
         }
         FRL_PHASE(S);
-        mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
-        for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-            const int r = e / npad, c = e - r * npad;
+        mlp_fwd_rows(NC, h * ql, ql, thC, S, ACT_NONE, [&](int r) {     // MSE delta of row r in the finalize phase
+            lds_f o = S.outb + r * S.op;
             float d = 0.f;
-            if (c == 0 && r < nv) {
-                const float diff = S.outb[r * S.op] - S.y[r];
+            if (r < nv) {
+                const float diff = o[0] - S.y[r];
                 d = 2.f * diff * invB;
                 lossp += diff * diff;
             }
-            S.outb[r * S.op + c] = d;
-        }
-        FRL_PHASE(S);
+            o[0] = d;
+            for (int c = 1; c < npad; ++c) o[c] = 0.f;
+        });
         mlp_bwd(NC, h * ql, ql, thC, slab, S, gs, false, 0, 0);
     }
     }
