@@ -396,9 +396,14 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
 // the output (target action, TD delta, log-prob ...) rides on the last phase instead of costing a barrier phase of its
 // own (fused narrow heads; other heads get one extra phase for it).  rowf may read / rewrite outb row r and write other
 // LDS buffers.  mlp_fwd = no consumer.
-struct NoRowConsumer { __device__ __forceinline__ void operator()(int) const {} };
-template <class RowF>
-__device__ __forceinline__ void mlp_fwd_rows(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act, RowF rowf) {
+struct NoRowConsumer {
+    __device__ __forceinline__ void operator()(int) const {}
+    __device__ __forceinline__ void operator()() const {}
+};
+// allf() runs on every thread in that same last phase (the hidden activations in h1 / h2 are final by then).
+template <class RowF, class AllF = NoRowConsumer>
+__device__ __forceinline__ void mlp_fwd_rows(const NetDesc& N, int l0, int nl, g_cf theta, const Lds& S, int out_act, RowF rowf,
+                                             AllF allf = AllF{}) {
     lds_cf in = S.xin;
     int ldin = S.xp;
     const bool fuse = head_fusable(N, l0, nl);
@@ -412,6 +417,7 @@ __device__ __forceinline__ void mlp_fwd_rows(const NetDesc& N, int l0, int nl, g
             FRL_PHASE(S);
             head_finalize(LH, theta, S.outb, S.op, S.rc, N.L[l0 + i].n_pad / 64, out_act);
             if (threadIdx.x < S.rc) rowf((int)threadIdx.x);
+            if constexpr (!std::is_same<AllF, NoRowConsumer>::value) allf();
             FRL_PHASE(S);
             return;
         }
@@ -422,6 +428,7 @@ __device__ __forceinline__ void mlp_fwd_rows(const NetDesc& N, int l0, int nl, g
     }
     if constexpr (!std::is_same<RowF, NoRowConsumer>::value) {
         if (threadIdx.x < S.rc) rowf((int)threadIdx.x);
+        if constexpr (!std::is_same<AllF, NoRowConsumer>::value) allf();
         FRL_PHASE(S);
     }
 }

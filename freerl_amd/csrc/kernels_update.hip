@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     const float invB = 1.f / (float)B;
     const int ct0 = (OT + acol) / 16, ct1 = (OT + acol + Aa + 15) / 16;
     const int nq = sac ? heads : 1;                 // SAC: mean of the twins (SAC.py:250); TD3: Q1 only (TD3.py:227)
+    const bool direct = (n == 1) && kc0 <= NA.L[0].k_pad;   // the action can be written into the critic's input row in place
     const float dq = sac ? -0.5f * invB : -invB;
     g_cf bn = D.obs_norm_on ? as_global(D.obsnorm + ((size_t)p * n + ag) * n * D.obsnorm_w) : nullptr;
     g_cf bn_own = bn ? bn + (size_t)ag * D.obsnorm_w : nullptr;
@@ -447,60 +448,54 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
     if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
     FRL_PHASE(S);
-    mlp_fwd(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH);
     // park the actor's hidden activations in HBM: the critic pass below reuses h1 / h2, the actor's backward needs them
     // again, and a second actor forward cost 16 % of this kernel (tools/phase_timing.py actor)
     const int spill_n4 = 2 * rc * S.hp / 4;                 // h1 and h2 are adjacent in LDS
     FRL_GLB f32x4* spill = (FRL_GLB f32x4*)(D.act_spill + (((size_t)p * n + ag) * D.S + sl) * 2 * rc * S.hp);
-    for (int i = threadIdx.x; i < spill_n4; i += kWG) spill[i] = ld4((lds_cf)(S.h1 + 4 * i));
     float lp = 0.f;
-    if (sac) {
-        const int r = threadIdx.x;
-        if (r < rc) {
-            for (int c = 0; c < Aa; ++c) {
-                const float mean = S.outb[r * S.op + c];
+    // the action of row r in the finalize phase of the actor; single agent: straight into the critic's input row (xin[:, 0:O)
+    // still holds the normalised obs, the columns past the action are zero), which saves the [s|a] gather of the first head
+    mlp_fwd_rows(NA, 0, NA.n_layers, thA, S, sac ? ACT_NONE : ACT_TANH, [&](int r) {
+        for (int c = 0; c < Aa; ++c) {
+            float av = S.outb[r * S.op + c];
+            if (sac) {
                 const float ls = fminf(fmaxf(thA[NA.extra_off + c], -20.f), 2.f);
                 const float sd = expf(ls);
                 const float eps = (r < nv) ? noise1[(size_t)r * am + c] : 0.f;
-                const float u = mean + sd * eps;
-                const float du = u - mean;
+                const float u = av + sd * eps;
+                const float du = u - av;
                 lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
                 lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
-                S.abuf[r * S.ap + c] = tanhf(u);
+                av = tanhf(u);
             }
+            S.abuf[r * S.ap + c] = av;
+            S.dabuf[r * S.ap + c] = 0.f;
+            if (direct) S.xin[r * S.xp + OT + c] = av;
         }
-    } else {
-        for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-            const int r = e / Aa, c = e - r * Aa;
-            S.abuf[r * S.ap + c] = S.outb[r * S.op + c];
-        }
-    }
-    for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-        const int r = e / Aa, c = e - r * Aa;
-        S.dabuf[r * S.ap + c] = 0.f;
-    }
-    FRL_PHASE(S);
+    }, [&]() {
+        for (int i = threadIdx.x; i < spill_n4; i += kWG) spill[i] = ld4((lds_cf)(S.h1 + 4 * i));
+    });
     // -- dQ/da through the critic head(s)
     float qsum = 0.f;
     for (int h = 0; h < nq; ++h) {
-        gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
-        zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
-        if (bn) { lds_barrier(); normalize_joint(nv); }
-        FRL_PHASE(S);
-        for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
-            const int r = e / Aa, c = e - r * Aa;
-            S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
+        if (!(direct && h == 0)) {
+            gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[0], OT + AT, 0);
+            zero_cols(S.xin, S.xp, rc, OT + AT, kc0);
+            if (bn) { lds_barrier(); normalize_joint(nv); }
+            FRL_PHASE(S);
+            for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
+                const int r = e / Aa, c = e - r * Aa;
+                S.xin[r * S.xp + OT + acol + c] = S.abuf[r * S.ap + c];
+            }
+            FRL_PHASE(S);
         }
-        FRL_PHASE(S);
-        mlp_fwd(NC, h * ql, ql, thC, S, ACT_NONE);
-        if (threadIdx.x < nv) qsum += S.outb[threadIdx.x * S.op];
-        FRL_PHASE(S);
         const int npad = NC.L[h * ql + ql - 1].n_pad;
-        for (int e = threadIdx.x; e < rc * npad; e += kWG) {
-            const int r = e / npad, c = e - r * npad;
-            S.outb[r * S.op + c] = (c == 0 && r < nv) ? dq : 0.f;
-        }
-        FRL_PHASE(S);
+        mlp_fwd_rows(NC, h * ql, ql, thC, S, ACT_NONE, [&](int r) {      // Q of row r -> loss sum; its delta for the dX-only backward
+            lds_f o = S.outb + r * S.op;
+            if (r < nv) qsum += o[0];
+            o[0] = (r < nv) ? dq : 0.f;
+            for (int c = 1; c < npad; ++c) o[c] = 0.f;
+        });
         mlp_bwd(NC, h * ql, ql, thC, nullptr, S, GS_ADD, true, ct0, ct1);
         for (int e = threadIdx.x; e < rc * Aa; e += kWG) {
             const int r = e / Aa, c = e - r * Aa;
@@ -521,7 +516,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_actor_kernel(const Engin
     gather_cols(S.xin, S.xp, rc, nv, idx, ring, R.stride, R.obs_off[ag], Oa, 0);    // (the critic's dX1 landed on xin)
     zero_cols(S.xin, S.xp, rc, Oa, NA.L[0].k_pad);
     if (bn) { lds_barrier(); normalize_cols(S.xin, S.xp, nv, 0, Oa, bn_own, Oa); }
-    FRL_PHASE(S);
+    // the head delta in the same phase: it reads dabuf / abuf and writes outb, none of which the reload above touches
     const int napad = NA.L[NA.n_layers - 1].n_pad;
     for (int e = threadIdx.x; e < rc * napad; e += kWG) {
         const int r = e / napad, c = e - r * napad;
