@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, RC_ROWS > 64 ? 1 : 2) void k(const float* thet
         if (mode == 2) linear_bwd_dw(L, slab, S.h1, S.hp, S.h2, S.hp, RC, true);
         if (mode == 3) linear_fwd(L, theta, S.xin, S.xp, (r & 1) ? S.h1 : S.h2, S.hp, ACT_RELU, RC);      // K = 16 input layer
         if (mode == 4) linear_fwd(L, theta, (r & 1) ? S.h2 : S.h1, S.hp, S.outb, S.op, ACT_NONE, RC);     // N = 16 head
+        if (mode == 9) head_bwd(L, theta, slab, S.outb, S.op, (r & 1) ? S.h2 : S.h1, S.hp, ACT_RELU, RC, GS_STREAM);   // 128 -> 1 head, one VALU pass
         if (mode == 5 || mode == 6) {       // the forward's MFMA loop alone: per call (5) / one long contraction (6), no epilogue, no barrier
             f32x4 acc[2][4];
             acc_zero(acc);
@@ -120,9 +121,9 @@ int main() {
     hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const char* names[9] = {"fwd 128x128", "dX 128x128", "dW 128x128", "fwd 16->128", "fwd 128->16", "mma 8x(K=128)", "mma K=1024", "fwd stamped", "fwd wave rows"};
+    const char* names[10] = {"fwd 128x128", "dX 128x128", "dW 128x128", "fwd 16->128", "fwd 128->16", "mma 8x(K=128)", "mma K=1024", "fwd stamped", "fwd wave rows", "head bwd 128->1"};
     LayerDesc L1{H, 10, H, 16, 0, 16 * H}, L3{1, H, 16, H, 0, 16 * H};
-    for (int mode = 0; mode < 9; ++mode)
+    for (int mode = 0; mode < 10; ++mode)
         for (int wg : {256, 512}) {
             for (int it = 0; it < 2; ++it) {
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(wg), dim3(256), lds, 0, theta, slab, cyc, reps, L);
@@ -134,6 +135,7 @@ int main() {
                 if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(wg), dim3(256), lds, 0, theta, slab, cyc, reps, L);
                 if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(wg), dim3(256), lds, 0, theta, slab, cyc, reps, L);
                 if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(wg), dim3(256), lds, 0, theta, slab, cyc, reps, L);
+                if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(wg), dim3(256), lds, 0, theta, slab, cyc, reps, L3);
                 hipDeviceSynchronize();
             }
             std::vector<long long> c(wg);
