@@ -18,15 +18,16 @@ os.environ.setdefault("FRL_HIP_VARIANT", "phase")
 os.environ.setdefault("FRL_HIPCC_FLAGS", "-DFRL_PHASE_TIMING")
 from freerl_amd import _native as N  # noqa: E402
 
-FWD = lambda n: [n + " l1", n + " l2 + head dots", n + " head finalize"]
-BWD = ["delta", "head bwd (dW3,dX3)", "dW2", "dX2", "dW1"]
-LABELS_TD3 = (["gather s'"] + FWD("pi'") + ["a' = clip(pi'+noise)", "gather [s'|a']"] + FWD("Q1'") + ["q1 read"] + FWD("Q2'") +
-              ["y = r + g min q", "gather [s|a]"] + FWD("Q1") + BWD + ["gather [s|a]"] + FWD("Q2") + BWD)
+FWD = lambda n: [n + " l1", n + " l2 + head dots"]
+BWD = ["head bwd (dW3,dX3)", "dW2", "dX2", "dW1"]
+# barrier-delimited phases of one row chunk (TD3, single agent: the in-place paths of the kernels)
+LABELS_TD3 = (["gather s'"] + FWD("pi'") + ["pi' finalize + a' into the Q input", "Q1' and Q2' l1", "Q1' and Q2' l2 + head dots",
+              "y = r + g min q", "gather [s|a]"] + FWD("Q1") + ["Q1 finalize + delta"] + BWD +
+              ["(second head: input still in place)"] + FWD("Q2") + ["Q2 finalize + delta"] + BWD)
 
-
-LABELS_TD3_ACTOR = (["gather s"] + FWD("pi") + ["a -> abuf", "gather [s|a]", "a -> xin"] + FWD("Q1") + ["q read", "dq"] +
-                    ["head bwd (dX3)", "dX2", "dX1 (action columns)", "da += dx"] + ["reload h1,h2 + gather s", "head delta"] +
-                    ["head bwd (dW3,dX3)", "dW2", "dX2", "dW1"])
+LABELS_TD3_ACTOR = (["gather s"] + FWD("pi") + ["pi finalize + action into the Q input + spill h1,h2"] + FWD("Q1") +
+                    ["Q1 finalize + q + dq", "head bwd (dX3)", "dX2", "dX1 (action columns)", "da += dx",
+                     "reload h1,h2 + gather s + head delta", "head bwd (dW3,dX3)", "dW2", "dX2", "dW1"])
 
 
 def c51(P):
