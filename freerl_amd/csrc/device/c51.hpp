@@ -37,6 +37,20 @@ __device__ __forceinline__ float c51_q(lds_cf lg, int atoms, float vmin, float d
     return q;
 }
 
+// Expected value only, one exp per atom: q = (sum_i z_i e_i) / (sum_i e_i) — the same number as c51_q's sum_i z_i (e_i / sum)
+// up to the last bits; used where only the argmax over actions is wanted.
+__device__ __forceinline__ float c51_q_only(lds_cf lg, int atoms, float vmin, float dz) {
+    float mx = lg[0];
+    for (int i = 1; i < atoms; ++i) mx = fmaxf(mx, lg[i]);
+    float sum = 0.f, zsum = 0.f;
+    for (int i = 0; i < atoms; ++i) {
+        const float e = expf(lg[i] - mx);
+        sum += e;
+        zsum += e * (vmin + dz * (float)i);
+    }
+    return zsum / sum;
+}
+
 // The same softmax by one WAVE (lane i = atom i, atoms <= 64): every lane gets q, `p_lane` is this lane's probability
 // (0 beyond the support).  Sums run as shuffle trees instead of ascending chains: last-bit differences to c51_q.
 __device__ __forceinline__ float c51_softmax_wave(lds_cf lg, int atoms, float vmin, float dz, float& p_lane) {

@@ -46,11 +46,9 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     // q[r][a] of the logits in outb -> qb, then argmax into S.y (one thread per (row, action), then per row)
     auto pick_action = [&]() {
         const int lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
-        for (int e = wave_id(); e < nv * nA; e += kWaves) {          // one wave per (row, action): lane = atom
-            const int r = e / nA, act = e - r * nA;
-            float pl;
-            const float q = c51_softmax_wave(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz, pl);
-            if (lane_id() == 0) qb[r * ap + act] = q;
+        for (int e = threadIdx.x; e < nv * nA; e += kWG) {           // one thread per (row, action); a wave per pair was 2x slower
+            const int r = e / nA, act = e - r * nA;                   // (its shuffle reductions are ds_bpermute round trips)
+            qb[r * ap + act] = c51_q_only(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz);
         }
         FRL_PHASE(S);
         for (int r = threadIdx.x; r < nv; r += kWG) {
