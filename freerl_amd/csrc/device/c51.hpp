@@ -51,18 +51,33 @@ __device__ __forceinline__ float c51_q_only(lds_cf lg, int atoms, float vmin, fl
     return zsum / sum;
 }
 
-// The same softmax by one WAVE (lane i = atom i, atoms <= 64): every lane gets q, `p_lane` is this lane's probability
-// (0 beyond the support).  Sums run as shuffle trees instead of ascending chains: last-bit differences to c51_q.
-__device__ __forceinline__ float c51_softmax_wave(lds_cf lg, int atoms, float vmin, float dz, float& p_lane) {
-    const int l = lane_id();
-    const float x = l < atoms ? lg[l] : -3.0e38f;
-    float mx = x;
+// Softmax of R rows' logits by one WAVE (lane i = atom i, atoms <= 64), the R rows' shuffle reductions interleaved: a
+// __shfl_xor is a ds_bpermute round trip (~130 cycles), and one row at a time the 18 of them were the whole phase.
+// p[k] = this lane's probability in row k (0 beyond the support), q[k] = expected value (all lanes).  Sums run as shuffle
+// trees instead of ascending chains: last-bit differences to c51_q.
+template <int R>
+__device__ __forceinline__ void wave_sum_n(float (&v)[R]) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    const float e = l < atoms ? expf(x - mx) : 0.f;
-    const float sum = wave_sum(e);
-    p_lane = e / sum;
-    return wave_sum(p_lane * (vmin + dz * (float)l));
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] += __shfl_xor(v[k], off, 64);
+}
+template <int R>
+__device__ __forceinline__ void c51_softmax_wave_n(lds_cf (&lg)[R], int atoms, float vmin, float dz, float (&p)[R], float (&q)[R]) {
+    const int l = lane_id();
+    float x[R], mx[R], e[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { x[k] = l < atoms ? lg[k][l] : -3.0e38f; mx[k] = x[k]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < R; ++k) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+#pragma unroll
+    for (int k = 0; k < R; ++k) { e[k] = l < atoms ? expf(x[k] - mx[k]) : 0.f; p[k] = e[k]; }
+    wave_sum_n<R>(p);                                 // p = sum of e
+#pragma unroll
+    for (int k = 0; k < R; ++k) { p[k] = e[k] / p[k]; q[k] = p[k] * (vmin + dz * (float)l); }
+    wave_sum_n<R>(q);
 }
 
 }  // namespace frl

@@ -72,10 +72,21 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     // ---- projection of the target distribution (projection_dist :147-158).  qb row = next_dist (one wave per row), then
     // one thread per row walks the support: every lower-bin index_add_ in atom order, then every upper-bin one (:155-156).
     // (One thread per (row, target bin) scanning all sources was measured: 51x the arithmetic, slower than this chain.)
-    for (int r = wave_id(); r < nv; r += kWaves) {
-        float pl;
-        c51_softmax_wave(S.outb + r * S.op + lb + (int)S.y[r] * atoms, atoms, vmin, dz, pl);
-        if (lane_id() < atoms) qb[r * ap + lane_id()] = pl;
+    constexpr int kRows = 8;                           // rows per wave and pass (rc <= 32 rows: one pass)
+    for (int rb = 0; rb < rc; rb += kRows * kWaves) {
+        lds_cf lg[kRows];
+        float pl[kRows], ql[kRows];
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int r = min(rb + wave_id() + kWaves * k, nv - 1);         // rows past nv recompute a valid one, unused
+            lg[k] = S.outb + r * S.op + lb + (int)S.y[r] * atoms;
+        }
+        c51_softmax_wave_n<kRows>(lg, atoms, vmin, dz, pl, ql);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int r = rb + wave_id() + kWaves * k;
+            if (r < nv && lane_id() < atoms) qb[r * ap + lane_id()] = pl[k];
+        }
     }
     FRL_PHASE(S);
     for (int r = threadIdx.x; r < nv; r += kWG) {
@@ -104,22 +115,41 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
     g_cf isw = as_global(D.isw + (size_t)p * D.batch_max + r0);
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max + r0);
-    for (int r = wave_id(); r < nv; r += kWaves) {             // one wave per row: lane = atom
+    for (int rb = 0; rb < rc; rb += kRows * kWaves) {          // one wave per row (lane = atom), kRows rows interleaved
         const int l = lane_id();
-        const int at = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
-        float pi;
-        c51_softmax_wave(S.outb + r * S.op + lb + at * atoms, atoms, vmin, dz, pi);
-        const float w = a.use_isw ? isw[r] : 1.f;              // `is_weight.reshape(-1,1)`: per-row weights here (:256)
-        const float mi = l < atoms ? m[r * ap + l] : 0.f;
-        const bool inside = pi > 1e-5f && pi < 1.f - 1e-5f;
-        const float ce = wave_sum(l < atoms ? mi * logf(fminf(fmaxf(pi, 1e-5f), 1.f - 1e-5f)) : 0.f);
-        const float gi = (l < atoms && inside) ? -(mi * w / (float)B) / pi : 0.f;       // d loss / d p_i
-        const float gp = wave_sum(gi * pi);
-        if (l < atoms) qb[r * ap + l] = pi * (gi - gp);        // softmax backward: d loss / d logit_i
-        if (l == 0) {
-            lossp += -w * ce;
-            tde[r] = ce;                                        // `error` of :255 (PER priorities use |error|)
-            S.y[r] = (float)at;
+        lds_cf lg[kRows];
+        int at[kRows];
+        float pi[kRows], ql[kRows], ce[kRows], gi[kRows], gp[kRows], w[kRows];
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int r = min(rb + wave_id() + kWaves * k, nv - 1);
+            at[k] = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];
+            lg[k] = S.outb + r * S.op + lb + at[k] * atoms;
+            w[k] = a.use_isw ? isw[r] : 1.f;                    // `is_weight.reshape(-1,1)`: per-row weights here (:256)
+        }
+        c51_softmax_wave_n<kRows>(lg, atoms, vmin, dz, pi, ql);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int r = min(rb + wave_id() + kWaves * k, nv - 1);
+            const float mi = l < atoms ? m[r * ap + l] : 0.f;
+            const bool inside = pi[k] > 1e-5f && pi[k] < 1.f - 1e-5f;
+            ce[k] = l < atoms ? mi * logf(fminf(fmaxf(pi[k], 1e-5f), 1.f - 1e-5f)) : 0.f;
+            gi[k] = (l < atoms && inside) ? -(mi * w[k] / (float)B) / pi[k] : 0.f;      // d loss / d p_i
+            gp[k] = gi[k] * pi[k];
+        }
+        wave_sum_n<kRows>(ce);
+        wave_sum_n<kRows>(gp);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int r = rb + wave_id() + kWaves * k;
+            if (r < nv) {
+                if (l < atoms) qb[r * ap + l] = pi[k] * (gi[k] - gp[k]);     // softmax backward: d loss / d logit_i
+                if (l == 0) {
+                    lossp += -w[k] * ce[k];
+                    tde[r] = ce[k];                                          // `error` of :255 (PER priorities use |error|)
+                    S.y[r] = (float)at[k];
+                }
+            }
         }
     }
     FRL_PHASE(S);
