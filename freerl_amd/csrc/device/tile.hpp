@@ -124,7 +124,8 @@ __device__ __forceinline__ void fetch_w(f32x4 (&b)[BN], g_cf mp, int ld, int k) 
 // KB > 0: K == 16*KB at compile time -> straight-line code with a pinned schedule.  Two things the compiler does
 // to a plain loop here: its waitcnt pass drops to vmcnt(0) at the loop header (it waits for the prefetch it has
 // just issued), and, unrolled but unpinned, its scheduler sinks every load next to its first use.  So: unroll,
-// keep kDepth k-blocks of fragments in flight and fence "fetch block j+kDepth-1 | MFMAs of block j" with
+// keep kDepth k-blocks of fragments in flight (2: with the fetch sliced between the MFMA quarters a third block in
+// flight bought nothing and cost the kernels their last spilled VGPRs) and fence "fetch block j+kDepth-1 | MFMAs of block j" with
 // sched_barrier.  tools/layer_bench.hip: a 128x128 layer on one workgroup 9.1k -> 6.0k cycles (MFMA floor 4.1k).
 // KB == 0: runtime K, two k-blocks per loop trip.
 template <int BM, int BN, int MODE, int KB = 0>
@@ -138,7 +139,7 @@ __device__ __forceinline__ void mma_w(f32x4 (&acc)[BM][BN], lds_cf A, int lda, i
         for (int x = 0; x < BM; ++x) a[x] = ld4(ap + x * 16 * lda + k);
     };
     if constexpr (KB > 0) {
-        constexpr int kDepth = (KB >= 3) ? 3 : 2;
+        constexpr int kDepth = 2;
         f32x4 a[kDepth][BM], b[kDepth][BN];
 #pragma unroll
         for (int j = 0; j < kDepth - 1 && j < KB; ++j) fetch(a[j], b[j], 16 * j);
