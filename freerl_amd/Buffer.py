@@ -132,13 +132,16 @@ class Buffer_for_PPO(_RingView):
 
     def __init__(self, capacity, obs_dim, act_dim, device, trick=None, *, batch_max=256, _engine=None, _learner=0):
         self.capacity = capacity = int(capacity)
-        if trick is not None and trick.get("decaystd"):
-            raise NotImplementedError("trick['decaystd'] (scalar log-prob storage, Buffer.py:277-278) is not ported")
+        # trick['decaystd'] (Buffer.py:277-278): ONE scalar log-prob per step, `all()` returns it as a 1-D tensor
+        self._scalar_logp = bool(trick is not None and trick.get("decaystd"))
+        if self._scalar_logp and _engine is not None:
+            raise NotImplementedError("decaystd storage is a stand-alone buffer: PPO_std_decay.py's learn() is not ported")
         self._act_dim = int(act_dim)
+        self._logp_dim = 1 if self._scalar_logp else int(act_dim)
         if _engine is None:
             hip_id, dev = resolve_device(device)
             eng = Engine(N.ALGO_REPLAY_ONLY, int(obs_dim), int(act_dim), max(capacity, 1), device_id=hip_id,
-                         batch_max=batch_max, extra_cols=int(act_dim) + self._tail_cols)
+                         batch_max=batch_max, extra_cols=self._logp_dim + self._tail_cols)
             self._attach(eng, 0, 0, dev)
             self._own = True
         else:
@@ -153,8 +156,8 @@ class Buffer_for_PPO(_RingView):
         r[self._nobs[0]:self._nobs[0] + self._nobs[1]] = np.asarray(next_obs, dtype=F32).reshape(-1)
         r[self._done[0]] = float(done)
         x0 = self._extra[0]
-        r[x0:x0 + self._act_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
-        r[x0 + self._act_dim] = float(adv_done)
+        r[x0:x0 + self._logp_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
+        r[x0 + self._logp_dim] = float(adv_done)
         self._e.add(self._learner, r)
 
     def clear(self):
@@ -162,20 +165,23 @@ class Buffer_for_PPO(_RingView):
 
     @property
     def action_log_probs(self):
-        return self._column((self._extra[0], self._act_dim))
+        return self._column((self._extra[0], self._logp_dim), squeeze=self._scalar_logp)
 
     @property
     def adv_dones(self):
-        return self._column((self._extra[0] + self._act_dim, 1), squeeze=True, dtype=bool)
+        return self._column((self._extra[0] + self._logp_dim, 1), squeeze=True, dtype=bool)
 
     def all(self):
         idx = np.arange(self.capacity, dtype=np.int64)
-        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (self._extra[0], self._act_dim),
-                  (self._extra[0] + self._act_dim, 1)]
+        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (self._extra[0], self._logp_dim),
+                  (self._extra[0] + self._logp_dim, 1)]
         # one gather per <= 16*batch_max rows (C ABI limit)
         step = 16 * self._e.batch_max
         chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
-        return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))
+        out = [torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields))]
+        if self._scalar_logp:
+            out[5] = out[5].reshape(-1)                     # np.zeros((capacity)) in the reference: shape [N]
+        return tuple(out)
 
 
 class Buffer_for_PPO_2(Buffer_for_PPO):
@@ -198,27 +204,30 @@ class Buffer_for_PPO_2(Buffer_for_PPO):
         r[self._nobs[0]:self._nobs[0] + self._nobs[1]] = np.asarray(next_obs, dtype=F32).reshape(-1)
         r[self._done[0]] = float(done)
         x0 = self._extra[0]
-        r[x0:x0 + self._act_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
-        r[x0 + self._act_dim] = float(np.asarray(value).reshape(-1)[0])
-        r[x0 + self._act_dim + 1] = float(adv_done)
+        r[x0:x0 + self._logp_dim] = np.asarray(action_log_probs, dtype=F32).reshape(-1)
+        r[x0 + self._logp_dim] = float(np.asarray(value).reshape(-1)[0])
+        r[x0 + self._logp_dim + 1] = float(adv_done)
         self._e.add(self._learner, r)
 
     @property
     def values(self):
-        return self._column((self._extra[0] + self._act_dim, 1), squeeze=True)
+        return self._column((self._extra[0] + self._logp_dim, 1), squeeze=True)
 
     @property
     def adv_dones(self):
-        return self._column((self._extra[0] + self._act_dim + 1, 1), squeeze=True, dtype=bool)
+        return self._column((self._extra[0] + self._logp_dim + 1, 1), squeeze=True, dtype=bool)
 
     def all(self):
         idx = np.arange(self.capacity, dtype=np.int64)
         x0 = self._extra[0]
-        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (x0, self._act_dim),
-                  (x0 + self._act_dim + 1, 1), (x0 + self._act_dim, 1)]
+        fields = [self._obs, self._act, self._rew, self._nobs, self._done, (x0, self._logp_dim),
+                  (x0 + self._logp_dim + 1, 1), (x0 + self._logp_dim, 1)]
         step = 16 * self._e.batch_max
         chunks = [self._gather(idx[s:s + step], fields) for s in range(0, self.capacity, step)]
-        return tuple(torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields)))
+        out = [torch.cat([c[f] for c in chunks], dim=0) for f in range(len(fields))]
+        if self._scalar_logp:
+            out[5] = out[5].reshape(-1)
+        return tuple(out)
 
 
 # ------------------------------------------------------------------------------------ PER / N-step (DQN_file/Buffer.py:66-399)

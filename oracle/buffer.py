@@ -45,9 +45,10 @@ class BufferForPPO(Buffer):
     """PPO_file/Buffer.py:266-323: + per-dimension old log-probs and adv_dones; `all()` returns
     the WHOLE arrays (capacity rows) as float32; `clear()` resets the counters only."""
 
-    def __init__(self, capacity, obs_dim, act_dim):
+    def __init__(self, capacity, obs_dim, act_dim, decaystd=False):
         super().__init__(capacity, obs_dim, act_dim)
-        self.action_log_probs = np.zeros((self.capacity, act_dim))
+        # trick['decaystd'] (:277-278): one scalar log-prob per step instead of one per action dimension
+        self.action_log_probs = np.zeros(self.capacity) if decaystd else np.zeros((self.capacity, act_dim))
         self.adv_dones = np.zeros(self.capacity, dtype=bool)
 
     def add(self, obs, action, reward, next_obs, done, action_log_probs, adv_done):

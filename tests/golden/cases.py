@@ -100,6 +100,8 @@ CASES = {
                               orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
                               Batch_ObsNorm=False),
                    table_seed=129, param_seed=1530, perm_seed=2530),
+    # Buffer_for_PPO with and without trick['decaystd'] (PPO_file/Buffer.py:266-323); 44 adds into 32 rows: wraps
+    "ppo_buffer": dict(kind="buffer", obs_dim=5, act_dim=3, capacity=32, n_add=44, table_seed=141),
     # PPO_advance/PPO_2.py:152-292: values stored at rollout time, stable-baselines3-style float64 GAE, two torch Adams
     "ppo_2": dict(kind="ppo", obs_dim=8, act_dim=2, horizon=256, minibatch=64, k_epochs=2,
                   gamma=0.99, lmbda=0.95, clip=0.2, ent=0.005, actor_lr=1e-3, critic_lr=2e-3, last_value=0.37,
@@ -290,6 +292,15 @@ def ppo_inputs(c):
     if "last_value" in c:                      # PPO_2: the critic's value of each step as select_action returned it
         tab["value"] = (0.8 * g.standard_normal(T)).astype(np.float32)
     return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)
+
+
+def ppo_buffer_inputs(c):
+    O, A, n = c["obs_dim"], c["act_dim"], c["n_add"]
+    tab = synth.transitions(c["table_seed"], n, O, A)
+    g = np.random.default_rng(c["table_seed"] + 1)
+    tab["logp"] = (-np.abs(g.standard_normal((n, A))) - 0.5).astype(np.float32)
+    tab["adv_done"] = np.logical_or(tab["done"], g.random(n) < 0.1)
+    return dict(table=tab)
 
 
 def ppo_beta_inputs(c):

@@ -108,6 +108,28 @@ def gen_buffer(out):
                 "act": a.numpy(), "rew": r.numpy(), "next_obs": no.numpy(), "done": d.numpy()})
 
 
+def gen_ppo_buffer(out):
+    """Buffer_for_PPO (PPO_file/Buffer.py:266-323) in both storage modes: per-dimension log-probs, and trick['decaystd'] =
+    one scalar log-prob per step (:277-278); wrap-around adds, all(), clear()."""
+    c = cases.CASES["ppo_buffer"]
+    inp = cases.ppo_buffer_inputs(c)
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    Buf = mod._helpers["Buffer"].Buffer_for_PPO
+    tab = inp["table"]
+    for tag, trick in (("vec", None), ("scalar", {"decaystd": True})):
+        buf = Buf(c["capacity"], c["obs_dim"], c["act_dim"], CPU, trick)
+        for i in range(c["n_add"]):
+            lp = tab["logp"][i] if trick is None else float(tab["logp"][i].sum())
+            buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp,
+                    bool(tab["adv_done"][i]))
+        names = ["obs", "act", "rew", "next_obs", "done", "logp", "adv_done"]
+        for nm, t in zip(names, buf.all()):
+            out["%s/%s" % (tag, nm)] = t.numpy()
+        out["%s/index" % tag], out["%s/size" % tag] = np.int64(buf._index), np.int64(buf._size)
+        buf.clear()
+        out["%s/len_after_clear" % tag] = np.int64(len(buf))
+
+
 # ----------------------------------------------------------------------------- DQN
 def gen_dqn(out):
     c = cases.CASES["dqn"]
@@ -944,7 +966,7 @@ def survey_known_answers():
 
 def main():
     gens = {
-        "buffer": gen_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn_noisy": gen_dqn_noisy, "dqn_c51": gen_dqn_c51, "dqn_rainbow": gen_dqn_rainbow, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
+        "buffer": gen_buffer, "ppo_buffer": gen_ppo_buffer, "per_buffer": gen_per_buffer, "dqn_tricks": gen_dqn_tricks, "dqn_dueling": gen_dqn_dueling, "dqn_noisy": gen_dqn_noisy, "dqn_c51": gen_dqn_c51, "dqn_rainbow": gen_dqn_rainbow, "dqn": gen_dqn, "ddpg": gen_ddpg, "ddpg_full": gen_ddpg_full, "sac_bn": gen_sac_bn,
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "maddpg_full": gen_maddpg_full, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),

@@ -45,6 +45,25 @@ def test_buffer_ring_and_sample_bit_exact():
         np.testing.assert_array_equal(got, fx[key])      # pure data movement: bit-exact
 
 
+@pytest.mark.parametrize("tag,decaystd", [("vec", False), ("scalar", True)])
+def test_ppo_buffer_both_log_prob_layouts(tag, decaystd):
+    """Buffer_for_PPO (PPO_file/Buffer.py:266-323): per-dimension log-probs, and trick['decaystd']'s one scalar per step."""
+    from oracle.buffer import BufferForPPO
+    c = cases.CASES["ppo_buffer"]
+    tab = cases.ppo_buffer_inputs(c)["table"]
+    fx = gold("ppo_buffer")
+    buf = BufferForPPO(c["capacity"], c["obs_dim"], c["act_dim"], decaystd=decaystd)
+    for i in range(c["n_add"]):
+        lp = float(tab["logp"][i].sum()) if decaystd else tab["logp"][i]
+        buf.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), lp,
+                bool(tab["adv_done"][i]))
+    assert buf._index == int(fx[tag + "/index"]) and buf._size == int(fx[tag + "/size"])
+    for got, nm in zip(buf.all(), ["obs", "act", "rew", "next_obs", "done", "logp", "adv_done"]):
+        np.testing.assert_array_equal(got, fx["%s/%s" % (tag, nm)])
+    buf.clear()
+    assert len(buf) == int(fx[tag + "/len_after_clear"]) == 0
+
+
 def test_dqn_learn():
     c = cases.CASES["dqn"]
     inp = cases.dqn_inputs(c)
