@@ -211,6 +211,39 @@ __global__ __launch_bounds__(256) void ppo_gae_sb3_kernel(const EngineDesc* __re
     for (int i = t; i < T; i += kWG) adv[i] = (adv_raw[i] - mean) / (sd + 1e-8f);
 }
 
+// ---- np.random.permutation(horizon) per (learner, epoch) (PPO_with_tricks.py:320) on the device when the caller does not
+// supply the draws: sort (32 random bits, index) pairs — a bitonic sort of one 64-bit word per row in LDS.  (On the host
+// this was 13 of the 65 ms of a 256-learner learn(): a Fisher-Yates of P*K*T swaps plus a 21 MB upload.)
+__global__ __launch_bounds__(256) void ppo_perm_kernel(int* __restrict__ perm, int T, int Tpad, unsigned long long counter,
+                                                        unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int k = blockIdx.x, p = blockIdx.y, K = gridDim.x;
+    const unsigned long long key = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1);
+    for (int i = threadIdx.x; i < Tpad; i += kWG) {
+        unsigned long long v = ~0ull;                                   // padding sorts to the end
+        if (i < T) {
+            const Philox4 r = philox4x32_10(counter, 0x7000u + (unsigned)k, (unsigned)(i >> 2), key);
+            const unsigned w = (i & 3) == 0 ? r.x : ((i & 3) == 1 ? r.y : ((i & 3) == 2 ? r.z : r.w));
+            v = ((unsigned long long)w << 32) | (unsigned)i;
+        }
+        keys[i] = v;
+    }
+    __syncthreads();
+    for (int size = 2; size <= Tpad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < Tpad / 2; t += kWG) {
+                const int lo = 2 * t - (t & (stride - 1));              // element whose partner is lo + stride
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    int* out = perm + ((size_t)p * K + k) * T;
+    for (int i = threadIdx.x; i < T; i += kWG) out[i] = (int)(keys[i] & 0xFFFFFFFFu);
+}
+
 // stand-alone K3 entry (frl_gae): adv_done given as a dense array
 __global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict__ delta, const float* __restrict__ adv_done,
                                                          int T, float c, float* __restrict__ adv) {

@@ -231,7 +231,7 @@ typedef struct frl_ppo_args {
                                   1: PPO.py's combined cautious AdamW over actor + critic parameters (PPO.py:121,145-152,
                                      c_adamw.py:80-127): lr = actor_lr for both nets, eps = adam_eps (1e-6 there), mask =
                                      (exp_avg*grad > 0) / max(mean, 1e-3) PER PARAMETER TENSOR, no bias correction in denom */
-    const int64_t* perms;      /* host [P][k_epochs][horizon] np.random.permutation draws (:320), or NULL */
+    const int64_t* perms;      /* host [P][k_epochs][horizon] np.random.permutation draws (:320), or NULL: drawn on the device */
     float* loss_trace_out;     /* host [P][k_epochs*n_mb][2] (actor, critic) losses or NULL */
     float* adv_out;            /* host [P][horizon] raw GAE advantages or NULL */
     float* vtarget_out;        /* host [P][horizon] or NULL */

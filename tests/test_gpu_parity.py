@@ -702,6 +702,66 @@ def test_ppo_rollout_collector_lays_out_env_segments(N):
     pool.close(); e.close()
 
 
+def test_ppo_device_permutations_visit_every_row_once_per_epoch(N):
+    """frl_ppo_learn without caller-supplied permutations (np.random.permutation per epoch, PPO_with_tricks.py:320) draws
+    them on the device, horizon 200 (not a power of two): (1) one full-batch minibatch is order-independent, so device-drawn
+    and host-supplied orders give the same parameters; (2) with 8-row minibatches the loss traces depend on the order: the
+    same seed reproduces them, another learner / call / seed draws another order; (3) every row is visited exactly once
+    per epoch: at lr = 0 the mean of the 25 minibatch losses equals the full-batch loss."""
+    from freerl_amd.engine import Engine
+    O, A, T = 5, 2, 200
+    def make(seed):
+        e = Engine(N.ALGO_PPO, O, A, T, batch_max=T, n_learners=2, extra_cols=A + 1, seed=seed)
+        g = np.random.default_rng(11)
+        a0 = (g.standard_normal(e.num_params(0)) * 0.1).astype(np.float32)
+        c0 = (g.standard_normal(e.num_params(1)) * 0.1).astype(np.float32)
+        for p in range(2):
+            e.set_params(0, a0, learner=p); e.set_params(1, c0, learner=p)
+        rec = g.standard_normal((T, e.width)).astype(np.float32) * 0.5
+        lay = e.layout
+        rec[:, lay.done_off] = 0; rec[:, lay.extra_off + A] = (g.random(T) < 0.05)
+        rec[:, lay.extra_off:lay.extra_off + A] = -1.0
+        return e, rec
+
+    def fill(e, rec):
+        for p in range(2):
+            e.set_cursor(p, 0, 0)
+        e.add_batch(np.concatenate([rec, rec]), learners=np.repeat(np.arange(2), T))
+    kw = dict(gamma=0.99, lmbda=0.95, clip=0.2, ent_coef=0.01, actor_lr=1e-3, critic_lr=1e-3)
+    # full-batch minibatch: order-independent up to float summation order inside the chunk loop (rows are summed per chunk)
+    e, rec = make(3)
+    fill(e, rec)
+    e.ppo_learn(T, T, 1, **kw)
+    dev = e.get_params(1, learner=0).copy()
+    e.close()
+    e, rec = make(3)
+    fill(e, rec)
+    e.ppo_learn(T, T, 1, perms=np.tile(np.arange(T), (2, 1, 1)).reshape(2, 1, T), **kw)
+    np.testing.assert_allclose(dev, e.get_params(1, learner=0), rtol=2e-4, atol=2e-6)
+    e.close()
+    # minibatches of 8 rows: the traces depend on the order; same seed -> same, other learner / call / seed -> different
+    def traces(seed):
+        e, rec = make(seed)
+        out = []
+        for _ in range(2):
+            fill(e, rec)
+            out.append(e.ppo_learn(T, 8, 2, want_trace=True, **kw)["trace"].copy())
+        e.close()
+        return np.stack(out)                       # [call][learner][step][2]
+    t1, t2, t3 = traces(3), traces(3), traces(4)
+    assert np.all(np.isfinite(t1))
+    np.testing.assert_array_equal(t1, t2)
+    assert not np.array_equal(t1[0, 0], t1[0, 1]) and not np.array_equal(t1[0, 0, :25], t3[0, 0, :25])
+    # every row exactly once per epoch: the critic's epoch-mean loss of an lr = 0 run equals the full-batch loss
+    e, rec = make(5)
+    fill(e, rec)
+    full = e.ppo_learn(T, T, 1, want_trace=True, **dict(kw, actor_lr=0.0, critic_lr=0.0))["trace"][0, 0, 1]
+    fill(e, rec)
+    tr = e.ppo_learn(T, 8, 1, want_trace=True, **dict(kw, actor_lr=0.0, critic_lr=0.0))["trace"][0, :, 1]
+    np.testing.assert_allclose(tr.mean(), full, rtol=1e-4)         # 25 minibatches of 8 = all 200 rows once
+    e.close()
+
+
 def test_ppo_rollout_collector_discrete_policy(N):
     """frl_ppo_rollout with a Categorical policy on CartPole: stored actions are valid action indices, stored log-probs are
     log-softmax values of the collecting policy (lr = 0 keeps it), episodes terminate inside the segments and carry
