@@ -150,9 +150,20 @@ SIGNATURES = {
 _lib = None
 
 
+def _headers():
+    dev = os.path.join(CSRC, "device")
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hpp", ".inc"))] + \
+           [os.path.join(dev, f) for f in sorted(os.listdir(dev))] + [HEADER]
+
+
+def units():
+    """The translation units of the library: the host API and one unit per kernels_*.hip (a kernel's device code is
+    complete in the unit that defines it, so no relocatable device code is needed)."""
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+
+
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".hpp", ".inc"))] + \
-           [os.path.join(CSRC, "device", f) for f in sorted(os.listdir(os.path.join(CSRC, "device")))] + [HEADER]
+    return units() + _headers()
 
 
 def needs_build():
@@ -162,20 +173,52 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force=False, verbose=False):
-    """Compile libfreerl_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+_HIPCC = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile libfreerl_hip.so for gfx950 with hipcc (cross-compiles without a GPU): every unit to an object under
+    _lib/obj/ in parallel (only the stale ones), then one link.  Developer variants (FRL_HIP_VARIANT) are one unity
+    unit built with the extra flags in FRL_HIPCC_FLAGS."""
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-Wno-pass-failed", "-o", LIB_PATH, os.path.join(CSRC, "frl_api.hip")]
     if _VARIANT:
-        cmd += os.environ.get("FRL_HIPCC_FLAGS", "").split()
+        cmd = _HIPCC + ["-shared", "-DFRL_UNITY", "-o", LIB_PATH, os.path.join(CSRC, "frl_api.hip")] + \
+            os.environ.get("FRL_HIPCC_FLAGS", "").split()
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise FrlError("hipcc failed:\n" + r.stdout + r.stderr)
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    todo, objs = [], []
+    for src in units():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            todo.append((src, obj))
+
+    def compile_one(so):
+        cmd = _HIPCC + ["-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return so[0], subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as ex:
+        for src, r in ex.map(compile_one, todo):
+            if r.returncode != 0:
+                raise FrlError("hipcc failed on %s:\n%s%s" % (src, r.stdout, r.stderr))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise FrlError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise FrlError("link failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
 
 

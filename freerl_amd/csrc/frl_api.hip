@@ -14,13 +14,19 @@
 #include "../../include/freerl_hip.h"
 #include "frl_desc.h"
 
+#include "kernels.h"
+#ifdef FRL_UNITY      // developer variants (tools/phase_timing.py): one translation unit, so that the phase-timing symbols exist once
 #include "kernels_replay.hip"
 #include "kernels_update.hip"
+#include "kernels_dqn.hip"
+#include "kernels_critic.hip"
+#include "kernels_actor.hip"
 #include "kernels_act.hip"
 #include "kernels_ppo.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
+#endif
 
 using namespace frl;
 

@@ -1,0 +1,141 @@
+// Argument structs and prototypes of every kernel of the library.  Each kernels_*.hip is its own translation unit
+// (compiled in parallel by freerl_amd/_native.py:build; no relocatable device code needed: a kernel's device code is
+// complete in the unit that defines it); the host API (frl_api.hip) launches them through these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "frl_desc.h"
+
+#ifndef FRL_GRAD_WGS
+#define FRL_GRAD_WGS 2      // gradient-kernel workgroups per CU the register budget is sized for (frl_create picks rc to match)
+#endif
+
+namespace frl {
+
+// ---- kernels_act.hip
+enum ActMode : int {
+    ACTM_RAW = 0,        // head output as is (Q values, V(s), Gaussian mean before squashing)
+    ACTM_ARGMAX = 1,     // DQN greedy action (index as float)
+    ACTM_TANH = 2,       // tanh(head): deterministic actors, SAC/PPO evaluate_action
+    ACTM_SAC_SAMPLE = 3, // tanh(mean + std*eps)
+    ACTM_PPO_SAMPLE = 4, // a = tanh(head) + std*eps ; logp per dimension
+    ACTM_CAT_SAMPLE = 5  // Categorical(softmax(head)).sample() = argmax(p / q), q ~ Exp(1); logp of the draw
+};
+
+struct ActArgs {
+    int net;             // net index
+    int use_target;
+    int mode;
+    int n_rows;          // rows per learner
+    int head;            // critic head (0/1) for ACTM_RAW on twin critics
+    int in_dim;          // logical input width (obs dim, or obs+act for critics)
+    int normalize;       // apply Batch_ObsNorm to the first obs_dim input columns (policy / value nets on raw obs)
+    const float* in;     // [P][n_rows][in_dim] dense
+    const float* eps;    // [P][n_rows][out_dim] standard normal draws, or nullptr
+    float* out;          // [P][n_rows][out_dim]   (ARGMAX: out_dim = 1)
+    float* out_logp;     // [P][n_rows][out_dim] (PPO sample) or nullptr
+};
+
+// ---- kernels_per.hip
+struct PerArgs {
+    double* sum_tree;      // [P][2*cap-1]
+    double* max_tree;      // [P][2*cap-1]
+    int cap;               // leaves per learner
+    int n;                 // entries in this launch
+    const int* leaf;       // [P][n_pitch] buffer indices to write (per_set) / out: sampled indices (per_sample writes D.idx)
+    int n_pitch;
+    const float* prio;     // per_set: [P][n_pitch] priorities, or nullptr: use `fill` for every entry
+    double fill;
+    const int* size;       // [P] rows valid per learner
+    // sampling
+    const double* uniforms;   // [P][n] draws in [0,1) or nullptr (Philox)
+    float* isw;               // [P][batch_max] importance weights out
+    float* prio_out;          // [P][batch_max] float32 priorities of the sampled leaves
+    double beta;
+    unsigned long long rng_counter;
+    const float* td;          // per_update: [P][batch_max] TD errors -> priority (|td| + eps)^alpha in float32
+    float alpha, eps;
+};
+
+// ---- kernels_ppo.hip
+struct PpoArgs {
+    int horizon, minibatch, k_epochs, adv_norm;
+    float gamma, lmbda, clip, ent_coef;
+    float actor_lr, critic_lr, adam_eps, beta1, beta2, clip_norm;
+    int optimizer;    // 0 torch Adam per net, 1 PPO.py's cautious AdamW (lr = actor_lr for both nets)
+    // device scratch, per learner blocks of `horizon` floats
+    float* td;        // [P][T] td_delta, then (after GAE) unused
+    float* vs;        // [P][T] V(s)
+    float* adv_raw;   // [P][T] GAE advantages before normalisation
+    float* adv;       // [P][T] advantages used by the surrogate
+    float* vtarget;   // [P][T]
+    float* trace;     // [P][k_epochs * n_mb][2] per-minibatch (actor, critic) losses
+    const int* perm;  // [P][k_epochs][T]
+    const float* last_value;   // [P] (gae_mode 1)
+    double gamma_d, lmbda_d;   // the float64 scan's discount and lambda (gae_mode 1)
+};
+
+// ---- kernels_replay.hip
+struct GatherFields {
+    int n_fields;
+    int col0[8];
+    int ncols[8];
+    float* out[8];        // out[f][b][ncols[f]] dense
+};
+
+// ---- kernels_update.hip: reduce + clip + Adam.  which = 0: critic / Q-net, 1: actor.
+struct AdamArgs {
+    int which, ns, batch, soft, sac_alpha, G, p0;
+    float lr, eps, beta1, beta2, wd, clip, tau, alpha_lr, target_entropy;
+};
+constexpr int kAdamVec = 8;                              // float4 per thread per workgroup (reduce_kernel / adam_kernel)
+constexpr int kFusedThreads = 1024, kFusedVec = 12;      // adam_fused_kernel: one workgroup per net, gradient in registers
+
+// kernels_act.hip
+__global__ void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a);
+
+// kernels_actor.hip
+__global__ void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns);
+
+// kernels_c51.hip
+__global__ void c51_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns);
+
+// kernels_critic.hip
+__global__ void ac_critic_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns);
+
+// kernels_dqn.hip
+__global__ void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns);
+
+// kernels_noisy.hip
+__global__ void noisy_materialise_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, int target_mask);
+__global__ void noisy_sigma_grad_kernel(const EngineDesc* __restrict__ Dp);
+__global__ void noisy_draw_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, unsigned long long counter);
+
+// kernels_per.hip
+__global__ void per_add_kernel(PerArgs a, const long long* __restrict__ slots, const int* __restrict__ size_before);
+__global__ void per_set_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
+__global__ void per_sample_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
+
+// kernels_ppo.hip
+__global__ void ppo_values_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_gae_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_gae_sb3_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_perm_kernel(int* __restrict__ perm, int T, int Tpad, unsigned long long counter, unsigned long long seed);
+__global__ void gae_dense_kernel(const float* __restrict__ delta, const float* __restrict__ adv_done, int T, float c, float* __restrict__ adv);
+__global__ void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a);
+
+// kernels_replay.hip
+__global__ void replay_scatter_kernel(float* __restrict__ ring, const float* __restrict__ staged, const long long* __restrict__ slots, int n, int width, int stride);
+__global__ void replay_gather_kernel(const float* __restrict__ ring, const long long* __restrict__ idx, int B, int stride, GatherFields F);
+__global__ void replay_read_kernel(const float* __restrict__ ring, long long row0, int n, int width, int stride, float* __restrict__ out);
+__global__ void replay_fill_kernel(float* __restrict__ ring, long long rows, RecordDesc rec, int n_discrete, unsigned long long seed);
+
+// kernels_update.hip
+__global__ void draw_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int want_noise);
+__global__ void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows, int p0);
+__global__ void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
+__global__ void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
+__global__ void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
+__global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau, int p0);
+
+}  // namespace frl

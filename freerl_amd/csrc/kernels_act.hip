@@ -5,33 +5,12 @@
 // or a whole vectorised-env batch staged by the env pool.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/c51.hpp"
 #include "device/net.hpp"
 
 namespace frl {
 
-enum ActMode : int {
-    ACTM_RAW = 0,        // head output as is (Q values, V(s), Gaussian mean before squashing)
-    ACTM_ARGMAX = 1,     // DQN greedy action (index as float)
-    ACTM_TANH = 2,       // tanh(head): deterministic actors, SAC/PPO evaluate_action
-    ACTM_SAC_SAMPLE = 3, // tanh(mean + std*eps)
-    ACTM_PPO_SAMPLE = 4, // a = tanh(head) + std*eps ; logp per dimension
-    ACTM_CAT_SAMPLE = 5  // Categorical(softmax(head)).sample() = argmax(p / q), q ~ Exp(1); logp of the draw
-};
-
-struct ActArgs {
-    int net;             // net index
-    int use_target;
-    int mode;
-    int n_rows;          // rows per learner
-    int head;            // critic head (0/1) for ACTM_RAW on twin critics
-    int in_dim;          // logical input width (obs dim, or obs+act for critics)
-    int normalize;       // apply Batch_ObsNorm to the first obs_dim input columns (policy / value nets on raw obs)
-    const float* in;     // [P][n_rows][in_dim] dense
-    const float* eps;    // [P][n_rows][out_dim] standard normal draws, or nullptr
-    float* out;          // [P][n_rows][out_dim]   (ARGMAX: out_dim = 1)
-    float* out_logp;     // [P][n_rows][out_dim] (PPO sample) or nullptr
-};
 
 __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -4,6 +4,7 @@
 // them is vector work, one thread per (row, action) pair or per row.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/c51.hpp"
 #include "device/net.hpp"
 

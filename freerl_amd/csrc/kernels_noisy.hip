@@ -5,6 +5,7 @@
 // the head's (= mu's) gradient slots, and `noisy_sigma_grad_kernel` derives d/d sigma = d/d W_eff * eps before Adam.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/net.hpp"
 
 namespace frl {

@@ -6,29 +6,11 @@
 // one launch.  HBM-bound pointer chasing: nothing here is matrix work.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/net.hpp"
 
 namespace frl {
 
-struct PerArgs {
-    double* sum_tree;      // [P][2*cap-1]
-    double* max_tree;      // [P][2*cap-1]
-    int cap;               // leaves per learner
-    int n;                 // entries in this launch
-    const int* leaf;       // [P][n_pitch] buffer indices to write (per_set) / out: sampled indices (per_sample writes D.idx)
-    int n_pitch;
-    const float* prio;     // per_set: [P][n_pitch] priorities, or nullptr: use `fill` for every entry
-    double fill;
-    const int* size;       // [P] rows valid per learner
-    // sampling
-    const double* uniforms;   // [P][n] draws in [0,1) or nullptr (Philox)
-    float* isw;               // [P][batch_max] importance weights out
-    float* prio_out;          // [P][batch_max] float32 priorities of the sampled leaves
-    double beta;
-    unsigned long long rng_counter;
-    const float* td;          // per_update: [P][batch_max] TD errors -> priority (|td| + eps)^alpha in float32
-    float alpha, eps;
-};
 
 __device__ __forceinline__ int node_depth(int i) { return 31 - __clz(i + 1); }
 

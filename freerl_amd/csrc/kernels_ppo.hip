@@ -5,27 +5,12 @@
 // hundred tiny kernels per minibatch; here the rollout never leaves HBM.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/net.hpp"
 #include "device/special.hpp"
 
 namespace frl {
 
-struct PpoArgs {
-    int horizon, minibatch, k_epochs, adv_norm;
-    float gamma, lmbda, clip, ent_coef;
-    float actor_lr, critic_lr, adam_eps, beta1, beta2, clip_norm;
-    int optimizer;    // 0 torch Adam per net, 1 PPO.py's cautious AdamW (lr = actor_lr for both nets)
-    // device scratch, per learner blocks of `horizon` floats
-    float* td;        // [P][T] td_delta, then (after GAE) unused
-    float* vs;        // [P][T] V(s)
-    float* adv_raw;   // [P][T] GAE advantages before normalisation
-    float* adv;       // [P][T] advantages used by the surrogate
-    float* vtarget;   // [P][T]
-    float* trace;     // [P][k_epochs * n_mb][2] per-minibatch (actor, critic) losses
-    const int* perm;  // [P][k_epochs][T]
-    const float* last_value;   // [P] (gae_mode 1)
-    double gamma_d, lmbda_d;   // the float64 scan's discount and lambda (gae_mode 1)
-};
 
 // ---- td_delta = r + gamma*(1-done)*V(s') - V(s) for every stored row (PPO_with_tricks.py:304-306)
 __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {

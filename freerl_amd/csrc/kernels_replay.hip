@@ -6,6 +6,7 @@
 // the reference's five arrays (TD3_file/Buffer.py:17-21, :42-46).  HBM-bound byte work.
 #include <hip/hip_runtime.h>
 
+#include "kernels.h"
 #include "device/rng.hpp"
 #include "frl_desc.h"
 
@@ -28,12 +29,6 @@ __global__ void replay_scatter_kernel(float* __restrict__ ring, const float* __r
     }
 }
 
-struct GatherFields {
-    int n_fields;
-    int col0[8];
-    int ncols[8];
-    float* out[8];        // out[f][b][ncols[f]] dense
-};
 
 // One launch produces every field of Buffer.sample(indices): a 16-lane group owns one sampled
 // row and streams its record (coalesced 64-byte segments), writing each field's dense tensor.
