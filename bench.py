@@ -93,6 +93,20 @@ def cpu_baseline(budget_s=12.0):
                       "index draw included) in %.1f s" % (n, dt)}
 
 
+def traffic_figure():
+    """HBM bytes per ac_critic_kernel launch from the PMC passes (profiles/traffic.json, written by tools/pmc_summary.py
+    --traffic together with a digest of the kernel sources it was measured on).  Returns (bytes | None, stale)."""
+    pf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(pf):
+        return None, None
+    try:
+        t = json.load(open(pf))
+    except Exception:
+        return None, None
+    from tools.pmc_summary import kernel_source_digest
+    return t.get("hbm_bytes_per_launch"), (t.get("kernel_source_digest") != kernel_source_digest())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,33 +115,44 @@ def main():
     ap.add_argument("--learners", type=int, default=int(os.environ.get("FRL_BENCH_LEARNERS", "512")),
                     help="independent learners (seeds) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the launcher even for --gpus 1 (RCCL init + the metric all-reduce with one rank)")
     ap.add_argument("--headline-only", action="store_true",
                     help="profiling runs: only the P-learner engine (no P = 1 engine, no CPU baseline), so that rocprofv3's "
                          "per-kernel averages are averages over the headline launches")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    from freerl_amd import _native as N
+    from freerl_amd import dist as fdist
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and (args.gpus > 1 or args.spawn):
+        # started without a launcher: become the launcher — N ranks of this script, one per GPU, under torch.distributed.run
+        have = N.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d needs %d HIP devices on this node, found %d (the engine has no CPU "
+                             "fallback and ranks do not share a GPU)" % (args.gpus, args.gpus, have))
+        sys.exit(fdist.respawn(args.gpus, os.path.abspath(__file__), [a for a in sys.argv[1:] if a != "--spawn"]))
 
     import torch
-    from freerl_amd import _native as N
     from freerl_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available() or N.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    rank, world, local_rank = fdist.init("nccl")            # nccl == RCCL on ROCm; no group when started without a launcher
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if local_rank >= N.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP devices visible" % (rank, local_rank, N.device_count()))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
 
     P = args.learners
     e = make_engine(N, Engine, P, local_rank, seed=1000 + rank)           # seeds sharded by rank
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        fdist.barrier()
         torch.cuda.synchronize()
         e.sync()
 
@@ -139,8 +164,9 @@ def main():
     for k in range(args.steps):
         e.learn(BATCH, **td3_kwargs(k))
     kernel_ms = e.timer_stop()            # HIP events on the engine's stream around the K launches (synchronises)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0         # this rank's K steps, device drained; the job's time is the MAX over ranks (below)
     barrier()
-    dt = time.perf_counter() - t0
     stats = e.stats()
     assert np.all(np.isfinite(stats)), "non-finite losses"
 
@@ -151,35 +177,30 @@ def main():
     prof = e.profile_read()
     e.profile(False)
 
-    # env-steps/s: the full rollout-and-update loop (act -> exploration -> env.step on the host pool ->
+    # env-steps/s: the full rollout-and-update loop (act + exploration on the device -> env.step on the host pool ->
     # add -> learn, one env per learner = the reference's UTD 1) on the synthetic obs-8/act-2 task
     from freerl_amd.envpool import EnvPool, rollout
     pool = EnvPool("SynLinear-v0", P, n_threads=4, seed=1000 + rank)
     rollout(e, pool, args.warmup, start_steps=0, batch=BATCH)
+    barrier()
     ro = rollout(e, pool, args.steps, start_steps=0, batch=BATCH)
-    env_sps_local = ro["env_steps"] / ro["seconds"]
-    ro_updates = ro["updates"] / ro["seconds"]
     pool.close()
 
-    metrics = torch.tensor([dt, float(P * args.steps), kernel_ms], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        tmax = metrics.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(metrics, op=dist.ReduceOp.SUM)                    # the metric all-reduce (RCCL over xGMI)
-        dt_max, total_updates, kernel_ms = float(tmax[0]), float(metrics[1]), float(tmax[2])
-        es = torch.tensor([env_sps_local, ro_updates], dtype=torch.float64, device="cuda")
-        dist.all_reduce(es, op=dist.ReduceOp.SUM)
-        env_sps, ro_ups = float(es[0]), float(es[1])
-    else:
-        dt_max, total_updates = dt, float(P * args.steps)
-        env_sps, ro_ups = env_sps_local, ro_updates
+    # the path's only collective: the metric vector, summed over ranks / wall-clock maxed (RCCL over xGMI)
+    learn_m = fdist.allreduce_metrics(env_steps=0.0, updates=float(P * args.steps), return_sum=0.0, episodes=0.0,
+                                      loss_sum=float(np.mean(stats[:, 0, N.STAT_CRITIC_LOSS])), wall_s=dt, extra_max=[kernel_ms])
+    roll_m = fdist.allreduce_metrics(env_steps=float(ro["env_steps"]), updates=float(ro["updates"]), return_sum=ro["return_sum"],
+                                     episodes=float(ro["episodes"]), loss_sum=0.0, wall_s=ro["seconds"])
+    dt_max, total_updates, kernel_ms = learn_m["wall_s_max"], learn_m["updates"], learn_m["extra_max"][0]
+    env_sps = fdist.throughput(roll_m)["env_steps_per_sec"]
+    ro_ups = fdist.throughput(roll_m)["updates_per_sec"]
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    fdist.finalize()          # every rank leaves the collective window here; what follows is rank 0's own work
 
     if rank == 0:
         fl_a, by_a = e.learn_work(BATCH, True)
         fl_c, by_c = e.learn_work(BATCH, False)
         n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
-        flops = (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps      # per launch, all P learners
-        abytes = (by_a * n_act + by_c * (args.steps - n_act)) / args.steps
         step_s = kernel_ms * 1e-3 / args.steps
         kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
         # dominant kernel: ac_critic_kernel (targets + twin-critic forward/backward of every row chunk)
@@ -187,8 +208,9 @@ def main():
         achieved = fl_c / launch_s / 1e12
         flops, abytes = fl_c, by_c
         lds, rc = e.lds_bytes()
+    e.close()
+    if rank == 0:
         # single-learner latency (P = 1): the reference-compatible drop-in case
-        e.close()
         single = None
         if not args.headline_only:
             e1 = make_engine(N, Engine, 1, local_rank, seed=7)
@@ -202,13 +224,7 @@ def main():
             e1.sync()
             single = n1 / (time.perf_counter() - t1)
             e1.close()
-        traffic = None
-        pf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(pf):
-            try:
-                traffic = json.load(open(pf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_stale = traffic_figure()
         line = {
             "metric": "learner_updates_per_sec", "value": total_updates / dt_max, "unit": "updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / args.steps,
@@ -217,14 +233,16 @@ def main():
                                    "act_dim 2, batch 256, replay 1e6 rows filled, hidden 128, policy_freq 2, "
                                    "device-drawn indices/noise",
                        "learners_per_gpu": P, "updates_per_step": P * world, "row_chunk": rc, "lds_bytes": lds,
-                       "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world},
+                       "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world,
+                       "collective": "metric all-reduce via freerl_amd.dist (backend %s)" % backend},
             "env_steps_per_sec": env_sps,
             "rollout": {"env": "SynLinear-v0 (obs 8, act 2)", "envs_per_learner": 1, "env_workers": 4,
                         "updates_per_sec_in_loop": ro_ups,
-                        "loop": "act kernel -> D2H -> Gaussian exploration -> host env pool step -> staged add -> learn"},
+                        "loop": "act kernel with device-side exploration -> D2H actions -> host env pool step -> staged add "
+                                "(one H2D) -> learn"},
             "single_learner_updates_per_sec": single,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
                          "kernel": "ac_critic_kernel", "avg_launch_ms": launch_s * 1e3,
                          "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
                          "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS,
@@ -234,10 +252,7 @@ def main():
                          "kernels": kern},
             "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
         }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -5,9 +5,11 @@
     policy.update_target(tau) / save(model_dir) / DQN.load(dim_info, is_continue, model_dir)
     policy.agent.Qnet / .Qnet_target / .Qnet_optimizer, policy.buffer
 
-`rng="host"` (default) draws the sample indices exactly like the reference
-(`np.random.choice(size, B, replace=False)`, DQN.py:97) so a seeded run consumes the same RNG
-stream; `rng="device"` draws them with the engine's Philox generator (no host work per learn).
+`rng="host"` draws the sample indices exactly like the reference (`np.random.choice(size, B,
+replace=False)`, DQN.py:97 — a permutation of the whole buffer per learn()) so a seeded run consumes
+the same RNG stream; `rng="device"` draws them with the engine's Philox generator (no host work per
+learn); `rng="auto"` (default) is "host" while the buffer is small enough for that permutation to be
+cheap (< _core.AUTO_DEVICE_MIN_ROWS rows) and "device" beyond.
 """
 import os
 
@@ -15,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
+from ._core import DeviceNet, Engine, OptimizerView, draw_indices, host_draw, init_layers, resolve_device
 from .Buffer import Buffer
 
 
@@ -36,7 +38,7 @@ class Agent:
 
 
 class DQN:
-    def __init__(self, dim_info, is_continue, Qnet_lr, buffer_size, device, trick=None, *, rng="host", hidden=128,
+    def __init__(self, dim_info, is_continue, Qnet_lr, buffer_size, device, trick=None, *, rng="auto", hidden=128,
                  batch_max=1024, seed=0):
         obs_dim, action_dim = dim_info
         if is_continue:
@@ -71,7 +73,7 @@ class DQN:
         in `last_loss` only when `track_loss` was requested (it costs a device sync)."""
         total = len(self.buffer)
         batch = min(total, batch_size)
-        idx = draw_indices(total, batch_size) if self._rng == "host" else None
+        idx = draw_indices(total, batch_size) if host_draw(self._rng, total, batch_size) else None
         st = self._e.learn(batch, gamma=gamma, tau=tau, critic_lr=self.agent.Qnet_optimizer.lr, clip_norm=0.0,
                            idx=idx, want_stats=getattr(self, "track_loss", False))
         if st is not None:

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, F32, init_layers, init_layers_ddpg, resolve_device
+from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, F32, host_draw, init_layers, init_layers_ddpg, resolve_device
 from .Buffer import Buffer
 from .TD3 import actor_layers, critic_layers
 
@@ -35,7 +35,7 @@ class MADDPG:
     _twin = False
 
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, supplement=None, *,
-                 rng="host", hidden=128, batch_max=1024, seed=0):
+                 rng="auto", hidden=128, batch_max=1024, seed=0):
         if not is_continue:
             raise ValueError("only continuous actions are implemented in the reference (MADDPG_simple.py:126)")
         sup = dict(supplement or {})
@@ -102,7 +102,7 @@ class MADDPG:
     def learn(self, batch_size, gamma, tau):
         total = len(self.buffers[self.agent_x])
         idx = None
-        if self._rng == "host":        # one np.random.choice PER AGENT, in agent order (:169, :149)
+        if host_draw(self._rng, total, batch_size):        # one np.random.choice PER AGENT, in agent order (:169, :149)
             idx = np.stack([np.random.choice(total, batch_size, replace=False) for _ in self.agent_ids])[None]
         a0 = self.agents[self.agent_x]
         st = self._e.learn(batch_size, gamma=gamma, tau=tau, actor_lr=a0.actor_optimizer.lr,
@@ -136,7 +136,7 @@ class MATD3(MADDPG):
     _twin = True
 
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, realize=None, *,
-                 rng="host", hidden=128, batch_max=1024, seed=0):
+                 rng="auto", hidden=128, batch_max=1024, seed=0):
         super().__init__(dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick, rng=rng, hidden=hidden,
                          batch_max=batch_max, seed=seed)
         self.realize = realize
@@ -163,7 +163,7 @@ class MATD3(MADDPG):
             policy_freq = 1
         n, total = len(self.agent_ids), len(self.buffers[self.agent_x])
         idx = noise = None
-        if self._rng == "host":
+        if host_draw(self._rng, total, batch_size):
             # the reference's draw order: per updating agent i one np.random.choice, then one randn_like per agent j
             am = max(self._ad)
             idx = np.zeros((1, n, batch_size), np.int64)

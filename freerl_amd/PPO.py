@@ -169,7 +169,7 @@ class PPO:
 
     def learn(self, minibatch_size, gamma, lmbda, clip_param, K_epochs, entropy_coefficient):
         perms = None
-        if self._rng == "host":                                           # np.random.permutation per epoch (:320)
+        if self._rng != "device":                                           # np.random.permutation per epoch (:320)
             perms = np.stack([np.random.permutation(self.horizon) for _ in range(K_epochs)])[None]
         out = self._e.ppo_learn(self.horizon, minibatch_size, K_epochs, gamma=gamma, lmbda=lmbda, clip=clip_param,
                                 ent_coef=entropy_coefficient, actor_lr=self.agent.actor_optimizer.lr,

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, init_layers, resolve_device
+from ._core import BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, host_draw, init_layers, resolve_device
 from .Buffer import Buffer
 from .TD3 import critic_layers
 
@@ -55,7 +55,7 @@ class Alpha:
 
 
 class SAC:
-    def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, *, rng="host",
+    def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, *, rng="auto",
                  hidden=128, batch_max=1024, seed=0):
         obs_dim, action_dim = dim_info
         if not is_continue:
@@ -80,7 +80,7 @@ class SAC:
 
     def select_action(self, obs):
         """tanh(mean + std*eps), eps from torch's generator like Normal.rsample (SAC.py:192-198)."""
-        eps = torch.randn(1, self._act_dim).numpy() if self._rng == "host" else \
+        eps = torch.randn(1, self._act_dim).numpy() if self._rng != "device" else \
             np.random.default_rng().standard_normal((1, self._act_dim)).astype(np.float32)
         return self._e.act(0, N.ACT_SAC_SAMPLE, np.asarray(obs, dtype=np.float32).reshape(1, 1, -1), eps=eps,
                            out_dim=self._act_dim)[0, 0]
@@ -99,7 +99,7 @@ class SAC:
         total = len(self.buffer)
         batch = min(total, batch_size)
         idx = noise = None
-        if self._rng == "host":
+        if host_draw(self._rng, total, batch_size):
             idx = draw_indices(total, batch_size)
             noise = np.zeros((1, 1, 2, batch, self._act_dim), np.float32)
             noise[0, 0, 0] = torch.randn(batch, self._act_dim).numpy()   # actor_target rsample (SAC.py:227)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from ._core import (BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, init_layers, init_layers_ddpg,
+from ._core import (BatchObsNormView, DeviceNet, Engine, OptimizerView, draw_indices, host_draw, init_layers, init_layers_ddpg,
                     resolve_device)
 from .Buffer import Buffer
 
@@ -55,7 +55,7 @@ class TD3:
     _ALGO, _FILE = N.ALGO_TD3, "TD3.pt"
 
     def __init__(self, dim_info, is_continue, actor_lr, critic_lr, buffer_size, device, trick=None, realize=None, *,
-                 rng="host", hidden=128, batch_max=1024, seed=0, critic_weight_decay=0.0, net_init=False,
+                 rng="auto", hidden=128, batch_max=1024, seed=0, critic_weight_decay=0.0, net_init=False,
                  batch_obs_norm=False):
         obs_dim, action_dim = dim_info
         if not is_continue:
@@ -99,7 +99,7 @@ class TD3:
         batch = min(total, batch_size)
         use_noise = bool(self.realize["policy_noise"])
         idx = noise = None
-        if self._rng == "host":
+        if host_draw(self._rng, total, batch_size):
             idx = draw_indices(total, batch_size)                       # np.random.choice (TD3.py:183)
             if use_noise:                                               # torch.randn_like(actions) (TD3.py:197)
                 noise = np.zeros((1, 1, 2, batch, self._act_dim), np.float32)

@@ -590,10 +590,14 @@ extern "C" int frl_buffer_cursor_get(const frl_engine* e, int learner, int* inde
 }
 
 extern "C" int frl_buffer_cursor_set(frl_engine* e, int learner, int index, int size) {
-    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    ENG(e);
     if (learner < 0 || learner >= e->h.P) return fail(FRL_ERR_INVALID, "learner out of range");
     if (index < 0 || index >= e->h.capacity || size < 0 || size > e->h.capacity)
         return fail(FRL_ERR_INVALID, "cursor (%d,%d) outside capacity %d", index, size, e->h.capacity);
+    // rows staged before the cursor moves are committed first: afterwards the same ring slot may be staged again, and one
+    // scatter launch must never hold a slot twice (it writes its rows in no particular order)
+    int rc = flush_stage(e);
+    if (rc) return rc;
     e->index[learner] = index;
     e->size[learner] = size;
     return FRL_OK;
@@ -653,6 +657,8 @@ extern "C" int frl_buffer_read(frl_engine* e, int learner, int row0, int n, floa
 extern "C" int frl_buffer_fill_synthetic(frl_engine* e, int rows, uint64_t seed) {
     ENG(e);
     if (rows < 0 || rows > e->h.capacity) return fail(FRL_ERR_INVALID, "rows out of range");
+    if (e->per_on)       // priorities are assigned by add (PER_Buffer.add, Buffer.py:92-98): a bulk fill would leave the trees empty
+        return fail(FRL_ERR_STATE, "frl_buffer_fill_synthetic bypasses the priority trees: fill a PER engine through frl_buffer_add_batch");
     int rc = flush_stage(e);
     if (rc) return rc;
     const RecordDesc& R = e->h.rec;

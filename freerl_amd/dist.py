@@ -16,17 +16,54 @@ METRIC_FIELDS = ("env_steps", "updates", "return_sum", "episodes", "loss_sum", "
 
 
 def init(backend=None):
-    """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE,
-    MASTER_ADDR/PORT).  Returns (rank, world_size, local_rank).  No-op for a single process."""
+    """Initialise the default process group from the launcher's environment (RANK, WORLD_SIZE,
+    MASTER_ADDR/PORT).  Returns (rank, world_size, local_rank).  A process started without a
+    launcher (WORLD_SIZE unset) is the degenerate single-rank case and creates no group; under a
+    launcher the group is created even for one rank, so a 1-GPU run exercises RCCL's init and
+    all-reduce too."""
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn(n_ranks, script, argv, extra_env=None, timeout=None):
+    """Run `script argv...` as n_ranks processes of ONE node under torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1) and return its exit code: what `bench.py --gpus N` does when
+    it is started without a launcher.  The child ranks see RANK / LOCAL_RANK / WORLD_SIZE and call
+    init()."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL / cross-process device memory on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if extra_env:
+        env.update(extra_env)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
+def finalize():
+    """Barrier + destroy the process group (no-op without one)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def shard_seeds(seeds, rank, world):
@@ -40,18 +77,26 @@ def shard_count(n_units, rank, world):
     return n_units // world + (1 if rank < n_units % world else 0)
 
 
-def allreduce_metrics(env_steps, updates, return_sum, episodes, loss_sum, wall_s, device=None):
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_metrics(env_steps, updates, return_sum, episodes, loss_sum, wall_s, device=None, extra_max=()):
     """Sum the counters over ranks and take the MAX of the wall-clock (the job's time is the
-    slowest rank's).  Returns a dict keyed by METRIC_FIELDS; works without a process group."""
+    slowest rank's) and of any `extra_max` values (returned as a list under "extra_max").  Returns a
+    dict keyed by METRIC_FIELDS; works without a process group."""
     dev = device if device is not None else ("cuda" if torch.cuda.is_available() and dist.is_initialized()
                                              and dist.get_backend() == "nccl" else "cpu")
     sums = torch.tensor([env_steps, updates, return_sum, episodes, loss_sum], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([wall_s], dtype=torch.float64, device=dev)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    tmax = torch.tensor([wall_s] + [float(x) for x in extra_max], dtype=torch.float64, device=dev)
+    if dist.is_available() and dist.is_initialized():        # also with one rank: the collective still runs (RCCL smoke)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    vals = sums.tolist() + tmax.tolist()
-    return dict(zip(METRIC_FIELDS, vals))
+    tm = tmax.tolist()
+    out = dict(zip(METRIC_FIELDS, sums.tolist() + tm[:1]))
+    out["extra_max"] = tm[1:]
+    return out
 
 
 def throughput(metrics):

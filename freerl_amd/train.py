@@ -80,7 +80,7 @@ def build_parser(algo):
     p.add_argument("--device", type=str, default=spec["device"])
     # additions of this build (not in the reference)
     p.add_argument("--results_root", type=str, default=os.path.join(os.getcwd(), "results"))
-    p.add_argument("--rng", type=str, default="host", choices=["host", "device"])
+    p.add_argument("--rng", type=str, default="auto", choices=["auto", "host", "device"])
     return p
 
 

@@ -56,3 +56,56 @@ def test_single_process_is_the_degenerate_case():
     assert fd.shard_seeds([3, 4, 5], 0, 1) == [3, 4, 5] and fd.shard_count(7, 0, 1) == 7
     m = fd.allreduce_metrics(10, 5, 1.0, 2, 0.5, 2.0, device="cpu")
     assert m["env_steps"] == 10 and m["wall_s_max"] == 2.0
+
+
+SPAWN_WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    from freerl_amd import dist as fd
+    rank, world, local = fd.init("gloo")            # the launcher's env: group exists even for one rank
+    import torch.distributed as dist
+    assert dist.is_initialized() and dist.get_world_size() == world == int(sys.argv[1])
+    m = fd.allreduce_metrics(env_steps=7.0, updates=float(rank + 1), return_sum=0.0, episodes=1.0, loss_sum=0.0,
+                             wall_s=1.0 + rank, extra_max=[10.0 * (rank + 1)])
+    fd.finalize()
+    assert not dist.is_initialized()
+    if rank == 0:
+        open(sys.argv[2], "w").write(json.dumps(m))
+''') % ROOT
+
+
+def _spawn(tmp_path, n):
+    import json
+    sys.path.insert(0, ROOT)
+    from freerl_amd import dist as fd
+    script, out = tmp_path / "sw.py", tmp_path / "out.json"
+    script.write_text(SPAWN_WORKER)
+    rc = fd.respawn(n, str(script), [str(n), str(out)], timeout=300)
+    assert rc == 0
+    return json.loads(out.read_text())
+
+
+def test_respawn_path_two_ranks(tmp_path):
+    """What `bench.py --gpus N` does without a launcher: re-exec under torch.distributed.run, one rank per unit,
+    init from the env, the metric all-reduce, finalize."""
+    m = _spawn(tmp_path, 2)
+    assert m["env_steps"] == 14.0 and m["updates"] == 3.0 and m["wall_s_max"] == 2.0 and m["extra_max"] == [20.0]
+
+
+def test_respawn_path_single_rank_still_runs_the_collective(tmp_path):
+    m = _spawn(tmp_path, 1)
+    assert m["env_steps"] == 7.0 and m["wall_s_max"] == 1.0 and m["extra_max"] == [10.0]
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """`python bench.py --gpus 2` on a node with fewer HIP devices must fail loudly, never print n_gpus: 1."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 HIP devices" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout
