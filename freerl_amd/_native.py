@@ -70,9 +70,24 @@ class PpoArgs(C.Structure):
                 ("gae_mode", C.c_int), ("last_value", C.POINTER(C.c_float)), ("gae_gamma", C.c_double), ("gae_lmbda", C.c_double)]
 
 
+class ExploreArgs(C.Structure):
+    _fields_ = [("kind", C.c_int), ("epsilon", C.c_float), ("sigma", C.c_float), ("scale", C.c_float), ("max_action", C.c_float),
+                ("ou_theta", C.c_float), ("ou_sigma", C.c_float), ("ou_dt", C.c_float)]
+
+
 class RolloutArgs(C.Structure):
     _fields_ = [("n_steps", C.c_int), ("envs_per_learner", C.c_int), ("start_steps", C.c_int), ("learn_every", C.c_int),
-                ("policy_freq", C.c_int), ("epsilon", C.c_float), ("explore_sigma", C.c_float), ("learn", LearnArgs)]
+                ("policy_freq", C.c_int), ("epsilon", C.c_float), ("explore_sigma", C.c_float), ("learn", LearnArgs),
+                ("host_explore", C.c_int), ("explore_kind", C.c_int), ("gauss_init_scale", C.c_float),
+                ("gauss_final_scale", C.c_float), ("max_episodes", C.c_int), ("ou_theta", C.c_float), ("ou_sigma", C.c_float),
+                ("ou_dt", C.c_float)]
+
+
+EXPLORE_NONE, EXPLORE_EPS_GREEDY, EXPLORE_GAUSS, EXPLORE_OU = range(4)
+# the vectorised callbacks of a pool over caller-supplied envs (frl_envpool_create_callback)
+ENV_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                          C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_float))
+ENV_RESET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float))
 
 
 class PpoRolloutArgs(C.Structure):
@@ -121,6 +136,7 @@ SIGNATURES = {
     "frl_obsnorm_set": (_i, [_vp, _i, _fp]),
     "frl_act": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
     "frl_act_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "frl_act_explore": (_i, [_vp, _i, _i, _fp, _P(ExploreArgs), _P(C.c_uint8), _fp, _fp]),
     "frl_learn": (_i, [_vp, _P(LearnArgs)]),
     "frl_stats_get": (_i, [_vp, _fp]),
     "frl_last_indices": (_i, [_vp, _i, _i64p]),
@@ -134,6 +150,7 @@ SIGNATURES = {
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "frl_envpool_create": (_i, [_i, _i, _i, C.c_uint64, _P(C.c_double), _i, _P(_vp)]),
+    "frl_envpool_create_callback": (_i, [_i, _i, _i, _i, _f, ENV_STEP_FN, ENV_RESET_FN, _vp, _P(_vp)]),
     "frl_envpool_destroy": (_i, [_vp]),
     "frl_envpool_dims": (_i, [_vp, _ip, _ip, _ip, _ip, _fp, _ip]),
     "frl_envpool_reset": (_i, [_vp, _fp]),

@@ -18,7 +18,12 @@
 
 namespace frl {
 
-enum EnvKind : int { ENV_PENDULUM = 0, ENV_CARTPOLE = 1, ENV_SYNLINEAR = 2, ENV_SYNLINEAR_DISCRETE = 3, ENV_PENDULUM_SHORT = 4 };
+enum EnvKind : int { ENV_PENDULUM = 0, ENV_CARTPOLE = 1, ENV_SYNLINEAR = 2, ENV_SYNLINEAR_DISCRETE = 3, ENV_PENDULUM_SHORT = 4,
+                     ENV_CALLBACK = 100 };     // caller-supplied environments behind one vectorised step / reset callback
+
+typedef int (*EnvStepFn)(void* user, const float* actions, float* next_obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+                         float* obs_next);
+typedef int (*EnvResetFn)(void* user, float* obs_out);
 
 struct XorShift {                       // xoshiro256** seeded by splitmix64
     uint64_t s[4];
@@ -66,7 +71,12 @@ public:
     std::vector<double> state;          // [n][state_dim]
     std::vector<int> t;                 // steps in the current episode
     std::vector<double> ep_return;
+    std::vector<long long> ep_count;    // finished episodes per env (a learner's exploration decay counts ITS episodes, TD3.py:425-427)
     std::vector<XorShift> rng;
+    EnvStepFn cb_step = nullptr;        // ENV_CALLBACK
+    EnvResetFn cb_reset = nullptr;
+    void* cb_user = nullptr;
+    int cb_error = 0;                   // last non-zero return of a callback
     std::vector<double> A, B;           // SynLinear: A[O][O], B[O][2]
     // episode statistics since the last read
     std::atomic<long long> episodes{0};
@@ -78,6 +88,7 @@ public:
         state.assign((size_t)n * spec.state_dim, 0.0);
         t.assign(n, 0);
         ep_return.assign(n, 0.0);
+        ep_count.assign(n, 0);
         rng.resize(n);
         for (int i = 0; i < n; ++i) rng[i].seed(seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull * (uint64_t)(i + 1));
         if (kind == ENV_SYNLINEAR || kind == ENV_SYNLINEAR_DISCRETE) {
@@ -95,6 +106,15 @@ public:
         n_workers = n_threads < 1 ? 1 : n_threads;
         if (n_workers > 1)
             for (int w = 1; w < n_workers; ++w) workers.emplace_back([this, w] { worker_loop(w); });
+    }
+
+    // caller-supplied environments: the callbacks step / reset all n of them (gymnasium protocol on the other side)
+    EnvPool(int n_envs, int obs_dim, int act_dim, int n_actions, float max_action, EnvStepFn step_fn, EnvResetFn reset_fn, void* user)
+        : spec{ENV_CALLBACK, obs_dim, act_dim, n_actions > 0 ? 1 : 0, n_actions, 0, 0, max_action}, n(n_envs), cb_step(step_fn),
+          cb_reset(reset_fn), cb_user(user) {
+        t.assign(n, 0);
+        ep_return.assign(n, 0.0);
+        ep_count.assign(n, 0);
     }
 
     ~EnvPool() {
@@ -199,11 +219,30 @@ public:
     // reward, terminated, truncated, and `obs_next` = what the policy sees next (the reset
     // observation when the episode ended: the reference resets inline, DQN.py:323-335).
     void step(const float* actions, float* next_obs, float* reward, uint8_t* term, uint8_t* trunc, float* obs_next) {
+        if (spec.kind == ENV_CALLBACK) {
+            const int rc = cb_step(cb_user, actions, next_obs, reward, term, trunc, obs_next);
+            if (rc) { cb_error = rc; return; }
+            long long eps = 0;
+            double ret = 0.0;
+            for (int i = 0; i < n; ++i) {
+                t[i] += 1;
+                ep_return[i] += reward[i];
+                if (term[i] || trunc[i]) { ++eps; ret += ep_return[i]; ++ep_count[i]; t[i] = 0; ep_return[i] = 0.0; }
+            }
+            if (eps) { std::lock_guard<std::mutex> lk(stat_mu); episodes += eps; return_sum += ret; }
+            return;
+        }
         job = Job{actions, next_obs, reward, term, trunc, obs_next};
         run_parallel();
     }
 
     void reset_all(float* obs_out) {
+        if (spec.kind == ENV_CALLBACK) {
+            const int rc = cb_reset(cb_user, obs_out);
+            if (rc) cb_error = rc;
+            for (int i = 0; i < n; ++i) { t[i] = 0; ep_return[i] = 0.0; }
+            return;
+        }
         for (int i = 0; i < n; ++i) { reset_one(i); observe(i, obs_out + (size_t)i * spec.obs_dim); }
     }
 
@@ -228,6 +267,7 @@ private:
             if (job.term[i] || job.trunc[i]) {
                 ++eps;
                 ret += ep_return[i];
+                ++ep_count[i];
                 reset_one(i);
                 observe(i, job.obs_next + (size_t)i * O);
             } else {

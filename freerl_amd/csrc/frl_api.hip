@@ -81,6 +81,9 @@ struct frl_engine {
     float* d_act_out = nullptr;
     float* d_act_logp = nullptr;
     size_t act_in_cap = 0, act_out_cap = 0;
+    float* d_ou = nullptr;                // frl_act_explore's Ornstein-Uhlenbeck state [P][n_rows][A]
+    unsigned char* d_ou_flags = nullptr;
+    size_t ou_n = 0;
     // ppo scratch
     float* d_ppo = nullptr;
     size_t ppo_cap = 0;
@@ -232,6 +235,8 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->h.idx) hipFree(e->h.idx);
     if (e->h.steps) hipFree(e->h.steps);
     if (e->d_stage_slots) hipFree(e->d_stage_slots);
+    if (e->d_ou) hipFree(e->d_ou);
+    if (e->d_ou_flags) hipFree(e->d_ou_flags);
     if (e->d_idx64) hipFree(e->d_idx64);
     if (e->d_perm) hipFree(e->d_perm);
     if (e->d) hipFree(e->d);
@@ -775,8 +780,18 @@ extern "C" int frl_alpha_set(frl_engine* e, int learner, const float* vals4, int
 }
 
 // -------------------------------------------------------------------------------------- act
+// Exploration folded into an act launch (ActArgs' second half): the device pointers a collector owns.
+struct ActExplore {
+    frl_explore_args x;
+    const float* scale_dev = nullptr;          // [P] or nullptr (x.scale for everybody)
+    float* ou_state_dev = nullptr;             // [P][n_rows][A]
+    const unsigned char* flags_dev = nullptr;  // [P][n_rows]
+    float* env_out_dev = nullptr;              // [P][n_rows][A] (discrete: [P][n_rows])
+    bool device_eps = false;
+};
+
 static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_target, int n_rows, int in_dim,
-                      const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev) {
+                      const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev, const ActExplore* ex = nullptr) {
     int mode = mode_flags & ~FRL_ACT_NO_OBSNORM;
     if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
     if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
@@ -785,10 +800,25 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     const int nl = N.n_layers / N.heads;
     if (in_dim != N.L[head * nl].k) return fail(FRL_ERR_INVALID, "in_dim %d != layer input %d", in_dim, N.L[head * nl].k);
     if ((mode == FRL_ACT_SAC_SAMPLE || mode == FRL_ACT_PPO_SAMPLE) && N.extra_n == 0) return fail(FRL_ERR_INVALID, "net has no log_std");
-    if (mode == FRL_ACT_CAT_SAMPLE && !eps_dev) return fail(FRL_ERR_INVALID, "FRL_ACT_CAT_SAMPLE needs the Exp(1) draws in eps");
+    if (mode == FRL_ACT_CAT_SAMPLE && !eps_dev && !(ex && ex->device_eps)) return fail(FRL_ERR_INVALID, "FRL_ACT_CAT_SAMPLE needs the Exp(1) draws in eps");
     if (n_rows < 1) return fail(FRL_ERR_INVALID, "n_rows must be >= 1");
     const bool no_norm = (mode_flags & FRL_ACT_NO_OBSNORM) != 0;
     ActArgs a;
+    memset(&a, 0, sizeof a);
+    if (ex) {
+        const frl_explore_args& x = ex->x;
+        if (x.kind < FRL_EXPLORE_NONE || x.kind > FRL_EXPLORE_OU) return fail(FRL_ERR_INVALID, "unknown exploration kind %d", x.kind);
+        if (!ex->env_out_dev) return fail(FRL_ERR_INVALID, "exploration needs an env-action output");
+        if (x.kind == FRL_EXPLORE_EPS_GREEDY && mode != FRL_ACT_ARGMAX) return fail(FRL_ERR_INVALID, "epsilon-greedy goes with FRL_ACT_ARGMAX");
+        if ((x.kind == FRL_EXPLORE_GAUSS || x.kind == FRL_EXPLORE_OU) && !(mode == FRL_ACT_TANHHEAD || mode == FRL_ACT_SAC_SAMPLE))
+            return fail(FRL_ERR_INVALID, "Gaussian / OU action noise goes with FRL_ACT_TANHHEAD or FRL_ACT_SAC_SAMPLE");
+        if (x.kind == FRL_EXPLORE_OU && !ex->ou_state_dev) return fail(FRL_ERR_INVALID, "OU exploration needs a state buffer");
+        a.explore = x.kind; a.device_eps = ex->device_eps ? 1 : 0;
+        a.epsilon = x.epsilon; a.sigma = x.sigma; a.scale0 = x.scale; a.max_action = x.max_action != 0.f ? x.max_action : 1.f;
+        a.ou_theta = x.ou_theta; a.ou_sigma = x.ou_sigma; a.ou_dt = x.ou_dt;
+        a.scale = ex->scale_dev; a.ou_state = ex->ou_state_dev; a.flags = ex->flags_dev; a.env_out = ex->env_out_dev;
+        a.rng_counter = e->rng_counter++;
+    }
     a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
     const int agent = e->h.n_agents > 1 ? net / 2 : 0;            // MADDPG: only the actors (even nets) take a single agent's obs
     a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
@@ -841,6 +871,61 @@ extern "C" int frl_act(frl_engine* e, int net, int mode, int head, int use_targe
     const size_t got = one_per_row ? rows : out_n;
     HIP_TRY(hipMemcpyAsync(out_host, e->d_act_out, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (logp_host) HIP_TRY(hipMemcpyAsync(logp_host, e->d_act_logp, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return FRL_OK;
+}
+
+// select_action + the reference loop's exploration rule in ONE launch, host in / host out (tests, single-env callers): the
+// rollout collectors use the same launch with device-resident buffers.  mode: FRL_ACT_ARGMAX (+ epsilon-greedy),
+// FRL_ACT_TANHHEAD / FRL_ACT_SAC_SAMPLE (+ Gaussian or OU action noise, or none).  Sampling modes draw their own eps.
+extern "C" int frl_act_explore(frl_engine* e, int mode, int n_rows, const float* obs_host, const frl_explore_args* x,
+                               const uint8_t* ended_host, float* store_act_out, float* env_act_out) {
+    ENG(e);
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (!obs_host || !x || !store_act_out || !env_act_out || n_rows < 1) return fail(FRL_ERR_INVALID, "bad argument");
+    const EngineDesc& h = e->h;
+    if (h.n_agents != 1) return fail(FRL_ERR_STATE, "frl_act_explore: single-agent engines");
+    const int O = h.rec.obs_dim[0], nout = h.net[0].L[h.net[0].n_layers / h.net[0].heads - 1].n;
+    const bool disc = (mode == FRL_ACT_ARGMAX);
+    const size_t rows = (size_t)h.P * n_rows, in_n = rows * O, out_n = rows * nout;
+    if (in_n > e->act_in_cap) {
+        if (e->d_act_in) hipFree(e->d_act_in);
+        e->d_act_in = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->d_act_in, in_n * sizeof(float)));
+        e->act_in_cap = in_n;
+    }
+    if (out_n > e->act_out_cap) {
+        for (float** p : {&e->d_act_eps, &e->d_act_out, &e->d_act_logp}) { if (*p) hipFree(*p); *p = nullptr; }
+        HIP_TRY(hipMalloc((void**)&e->d_act_eps, out_n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->d_act_out, out_n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->d_act_logp, out_n * sizeof(float)));
+        e->act_out_cap = out_n;
+    }
+    if (out_n != e->ou_n) {                 // OU state of the host-facing entry point: one process per (learner, row, dimension)
+        if (e->d_ou) hipFree(e->d_ou);
+        e->d_ou = nullptr; e->ou_n = 0;
+        if (e->d_ou_flags) hipFree(e->d_ou_flags);
+        e->d_ou_flags = nullptr;
+        HIP_TRY(hipMalloc((void**)&e->d_ou, out_n * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&e->d_ou_flags, rows));
+        HIP_TRY(hipMemsetAsync(e->d_ou, 0, out_n * sizeof(float), e->stream));
+        e->ou_n = out_n;
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_act_in, obs_host, in_n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (ended_host) {
+        std::vector<unsigned char> fl(rows);
+        for (size_t i = 0; i < rows; ++i) fl[i] = ended_host[i] ? 2 : 0;
+        HIP_TRY(hipMemcpy(e->d_ou_flags, fl.data(), rows, hipMemcpyHostToDevice));
+    }
+    ActExplore ex;
+    ex.x = *x; ex.ou_state_dev = e->d_ou; ex.flags_dev = ended_host ? e->d_ou_flags : nullptr;
+    ex.env_out_dev = e->d_act_eps;           // scratch of the same size, unused by a device_eps launch
+    ex.device_eps = true;
+    int rc = launch_act(e, 0, mode, 0, 0, n_rows, O, e->d_act_in, nullptr, e->d_act_out, nullptr, &ex);
+    if (rc) return rc;
+    const size_t got = disc ? rows : out_n;
+    HIP_TRY(hipMemcpyAsync(store_act_out, e->d_act_out, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(env_act_out, e->d_act_eps, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return FRL_OK;
 }

@@ -34,7 +34,21 @@ struct ActArgs {
     const float* eps;    // [P][n_rows][out_dim] standard normal draws, or nullptr
     float* out;          // [P][n_rows][out_dim]   (ARGMAX: out_dim = 1)
     float* out_logp;     // [P][n_rows][out_dim] (PPO sample) or nullptr
+    // ---- exploration folded into the launch (frl_act_explore, the rollout collectors).  env_out == nullptr: none of it runs.
+    int explore;         // ExploreKind
+    int device_eps;      // 1: the sampling modes draw their own N(0,1) / Exp(1) variates (Philox) instead of reading `eps`
+    float epsilon;       // EXPL_EPS_GREEDY: P(random action)                                   (DQN.py:307-310)
+    float sigma;         // EXPL_GAUSS: std of the action noise in units of max_action           (TD3.py:412 gauss_sigma)
+    float scale0;        // multiplier of the Gaussian noise / of the OU state when `scale` is nullptr (gauss_scale, OUNoise.scale)
+    float max_action;
+    float ou_theta, ou_sigma, ou_dt;   // EXPL_OU: x += theta*(0 - x) + sqrt(dt)*sigma*N(0,1)     (SAC.py:334-356)
+    const float* scale;  // [P] per-learner multiplier (the reference decays it per episode, TD3.py:425-427, SAC.py:548-551) or nullptr
+    float* ou_state;     // [P][n_rows][out_dim]
+    const unsigned char* flags;   // [P][n_rows] bit 1: the row's episode ended on the previous step -> OU state reset first (SAC.py:546-547)
+    float* env_out;      // [P][n_rows][out_dim] env-unit action = clip(a*max_action + noise, +-max_action); discrete: [P][n_rows] index
+    unsigned long long rng_counter;
 };
+enum ExploreKind : int { EXPL_NONE = 0, EXPL_EPS_GREEDY = 1, EXPL_GAUSS = 2, EXPL_OU = 3 };
 
 // ---- kernels_per.hip
 struct PerArgs {
@@ -83,6 +97,21 @@ struct GatherFields {
     float* out[8];        // out[f][b][ncols[f]] dense
 };
 
+// Rollout commit: one launch writes the transitions of a vector step into the ring(s) from what is already on the device
+// (the observations the policy saw, the actions it chose, their log-probs) plus the one block the host uploaded after
+// env.step (next_obs, obs_next, reward, flags, ring rows), and advances the device copy of the current observations.
+struct CommitArgs {
+    float* obs_cur;               // [n][O] in: obs of the transition; out: obs_next (what the policy sees next)
+    const float* store_act;       // [n][aout] action as stored by add() (policy output in (-1,1) / action index)
+    const float* logp;            // [n][n_logp] or nullptr
+    const int* row;               // [n] ring row of env i inside its learner's ring
+    const float* next_obs;        // [n][O]
+    const float* obs_next;        // [n][O]
+    const float* reward;          // [n]
+    const unsigned char* flags;   // [n] bit 0 terminated (the stored `done`), bit 1 episode ended, bit 2 adv_done (PPO)
+    int n, E, O, aout, n_logp;
+};
+
 // ---- kernels_update.hip: reduce + clip + Adam.  which = 0: critic / Q-net, 1: actor.
 struct AdamArgs {
     int which, ns, batch, soft, sac_alpha, G, p0;
@@ -128,6 +157,7 @@ __global__ void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a);
 __global__ void replay_scatter_kernel(float* __restrict__ ring, const float* __restrict__ staged, const long long* __restrict__ slots, int n, int width, int stride);
 __global__ void replay_gather_kernel(const float* __restrict__ ring, const long long* __restrict__ idx, int B, int stride, GatherFields F);
 __global__ void replay_read_kernel(const float* __restrict__ ring, long long row0, int n, int width, int stride, float* __restrict__ out);
+__global__ void replay_commit_kernel(float* __restrict__ ring, RecordDesc rec, int capacity, CommitArgs c);
 __global__ void replay_fill_kernel(float* __restrict__ ring, long long rows, RecordDesc rec, int n_discrete, unsigned long long seed);
 
 // kernels_update.hip

@@ -36,6 +36,21 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
                        as_global(D.obsnorm + (((size_t)p * nag + (nag - 1)) * nag + j) * D.obsnorm_w), D.rec.obs_dim[j]);
     }
     __syncthreads();
+    // device-side draws of this launch: Philox keyed like draw_kernel's (seed, learner), one counter value per launch
+    const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
+    auto normal_at = [&](unsigned stream, unsigned e) {
+        float n0, n1;
+        normal2(philox4x32_10(a.rng_counter, stream, e, key), n0, n1);
+        return n0;
+    };
+    // epsilon-greedy on the greedy index of row r (DQN.py:307-310: np.random.rand() < epsilon -> np.random.randint(action_dim))
+    auto eps_greedy = [&](int row, int best, int n_act) {
+        if (a.env_out && a.explore == EXPL_EPS_GREEDY) {
+            const Philox4 u = philox4x32_10(a.rng_counter, 0x9000u, (unsigned)row, key);
+            if (u01(u.z) <= a.epsilon) best = (int)uniform_index(u, (unsigned)n_act);      // u01 is (0,1]
+        }
+        return best;
+    };
     const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;
     mlp_fwd(N, l0, nl, theta, S, out_act);
     const int nout = N.L[l0 + nl - 1].n;
@@ -49,7 +64,9 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
                 const float q = c51_q(S.outb + r * S.op + lb + j * D.c51_atoms, D.c51_atoms, D.c51_vmin, dz, nullptr);
                 if (j == 0 || q > mx) { mx = q; best = j; }
             }
+            best = eps_greedy(r0 + r, best, D.n_discrete);
             a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;
+            if (a.env_out) a.env_out[(size_t)p * a.n_rows + r0 + r] = (float)best;
         }
         return;
     }
@@ -66,7 +83,9 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
                 const float v = duel ? (o[0] + o[1 + j]) - mean : o[j];
                 if (v > mx) { mx = v; best = j; }
             }
+            best = eps_greedy(r0 + r, best, nq);
             a.out[(size_t)p * a.n_rows + r0 + r] = (float)best;
+            if (a.env_out) a.env_out[(size_t)p * a.n_rows + r0 + r] = (float)best;
         }
         return;
     }
@@ -82,10 +101,14 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
             for (int j = 0; j < nout; ++j) {
                 const float pj = expf(S.outb[r * S.op + j] - mx) / sum;
                 psum += pj;
-                const float v = pj / a.eps[row * nout + j];
+                // q ~ Exp(1): injected, or -log(u) from the launch's Philox stream
+                const float qj = a.device_eps ? -logf(u01(philox4x32_10(a.rng_counter, 0x9100u, (unsigned)((r0 + r) * nout + j), key).x))
+                                              : a.eps[row * nout + j];
+                const float v = pj / qj;
                 if (v > bestv) { bestv = v; best = j; pbest = pj; }
             }
             a.out[row] = (float)best;
+            if (a.env_out) a.env_out[row] = (float)best;
             if (a.out_logp) a.out_logp[row] = logf(fminf(fmaxf(pbest / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
         }
         return;
@@ -97,7 +120,7 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
         if (a.mode == ACTM_SAC_SAMPLE || a.mode == ACTM_PPO_SAMPLE) {
             const float ls = fminf(fmaxf(theta[N.extra_off + c], -20.f), 2.f);
             const float sd = expf(ls);
-            const float eps = a.eps ? a.eps[o] : 0.f;
+            const float eps = a.eps ? a.eps[o] : (a.device_eps ? normal_at(0x9200u, (unsigned)((r0 + r) * nout + c)) : 0.f);
             const float u = v + sd * eps;
             if (a.mode == ACTM_SAC_SAMPLE) {
                 v = tanhf(u);
@@ -108,6 +131,22 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
             }
         }
         a.out[o] = v;
+        if (a.env_out) {
+            // action_ = clip(action * max_action [+ exploration noise], -max_action, max_action): TD3.py:412 (Gaussian),
+            // SAC.py:528-533 (OU / Gaussian / none), PPO_with_tricks.py:529-530 (none)
+            const float ma = a.max_action, sc = a.scale ? a.scale[p] : a.scale0;
+            float x = v * ma;
+            if (a.explore == EXPL_GAUSS) {
+                x += sc * (normal_at(0x9300u, (unsigned)((r0 + r) * nout + c)) * (a.sigma * ma));
+            } else if (a.explore == EXPL_OU) {
+                float st = a.ou_state[o];
+                if (a.flags && (a.flags[(size_t)p * a.n_rows + r0 + r] & 2)) st = 0.f;             // OUNoise.reset() at the episode's end
+                st = st + (a.ou_theta * (0.f - st) + sqrtf(a.ou_dt) * a.ou_sigma * normal_at(0x9300u, (unsigned)((r0 + r) * nout + c)));
+                a.ou_state[o] = st;
+                x += (st * sc) * ma;
+            }
+            a.env_out[o] = fminf(fmaxf(x, -ma), ma);
+        }
     }
 }
 

@@ -44,6 +44,28 @@ __global__ void replay_gather_kernel(const float* __restrict__ ring, const long 
     }
 }
 
+// add(obs, action, reward, next_obs, done[, log_probs, adv_done]) of one vector step for every env (Buffer.add,
+// TD3_file/Buffer.py:28-38; Buffer_for_PPO.add, PPO_file/Buffer.py:292-305): a 16-lane group owns env i = learner * E + j.
+__global__ void replay_commit_kernel(float* __restrict__ ring, RecordDesc rec, int capacity, CommitArgs c) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, lane = threadIdx.x & 15;
+    if (i >= c.n) return;
+    float* r = ring + ((size_t)(i / c.E) * capacity + c.row[i]) * rec.stride;
+    float* oc = c.obs_cur + (size_t)i * c.O;
+    const unsigned char fl = c.flags[i];
+    for (int k = lane; k < c.O; k += 16) {
+        r[rec.obs_off[0] + k] = oc[k];
+        r[rec.nobs_off[0] + k] = c.next_obs[(size_t)i * c.O + k];
+        oc[k] = c.obs_next[(size_t)i * c.O + k];           // same lane read it above
+    }
+    for (int k = lane; k < c.aout; k += 16) r[rec.act_off[0] + k] = c.store_act[(size_t)i * c.aout + k];
+    for (int k = lane; k < c.n_logp; k += 16) r[rec.extra_off + k] = c.logp[(size_t)i * c.n_logp + k];
+    if (lane == 0) {
+        r[rec.rew_off] = c.reward[i];
+        r[rec.done_off] = (fl & 1) ? 1.f : 0.f;
+        if (c.logp) r[rec.extra_off + c.n_logp] = (fl & 4) ? 1.f : 0.f;
+    }
+}
+
 // out[row][width] = ring[slot0 + row][0..width)   (dense read-back of whole records)
 __global__ void replay_read_kernel(const float* __restrict__ ring, long long row0, int n, int width, int stride,
                                    float* __restrict__ out) {

@@ -174,6 +174,27 @@ class Engine:
         return (out, logp) if want_logp else out
 
     # ------------------------------------------------------------------ learn
+    def act_explore(self, mode, obs, *, kind, epsilon=0.0, sigma=0.0, scale=1.0, max_action=1.0, ou_theta=0.15, ou_sigma=0.2,
+                    ou_dt=1e-2, ended=None, out_dim=None):
+        """select_action + the reference loop's exploration rule in one launch (frl_act_explore): obs [P, rows, obs_dim] ->
+        (stored action, env-unit action), each [P, rows, out_dim] ([P, rows] for ACT_ARGMAX).  Draws come from the engine's
+        Philox stream; `ended` [P, rows] resets those rows' OU state first."""
+        obs = np.ascontiguousarray(obs, dtype=F32)
+        assert obs.ndim == 3 and obs.shape[0] == self.P
+        rows = obs.shape[1]
+        x = N.ExploreArgs()
+        x.kind, x.epsilon, x.sigma, x.scale, x.max_action = int(kind), epsilon, sigma, scale, max_action
+        x.ou_theta, x.ou_sigma, x.ou_dt = ou_theta, ou_sigma, ou_dt
+        disc = mode == N.ACT_ARGMAX
+        shape = (self.P, rows) if disc else (self.P, rows, int(out_dim if out_dim is not None else self.act_max))
+        store, env = np.empty(shape, F32), np.empty(shape, F32)
+        ep = None
+        if ended is not None:
+            en = np.ascontiguousarray(ended, dtype=np.uint8).reshape(self.P, rows)
+            ep = en.ctypes.data_as(C.POINTER(C.c_uint8))
+        N.check(self._L.frl_act_explore(self._h, int(mode), rows, _fp(obs), C.byref(x), ep, _fp(store), _fp(env)))
+        return store, env
+
     def learn(self, batch, *, gamma, tau, actor_lr=0.0, critic_lr=0.0, alpha_lr=1e-4, adam_eps=1e-8,
               critic_weight_decay=0.0, clip_norm=0.5, do_actor=True, use_policy_noise=False, policy_noise=0.0,
               noise_clip=0.0, max_action=1.0, policy_noise_scale=1.0, target_entropy=0.0, double_dqn=False, per=False,

@@ -283,6 +283,15 @@ typedef struct frl_envpool frl_envpool;
 /* params: optional SynLinear matrices A[8][8] then B[8][2] (doubles), else NULL */
 int frl_envpool_create(int kind, int n_envs, int n_threads, uint64_t seed, const double* params, int n_params,
                        frl_envpool** out);
+/* A pool over caller-supplied environments (the gymnasium protocol the reference's loops drive, DQN.py:292,316: reset() ->
+ * obs, step(a) -> obs, reward, terminated, truncated): ONE vectorised callback steps all n envs into the pool's pinned
+ * staging and resets the finished ones (obs_next = the reset observation, like the built-in kinds).  Return 0 on success.
+ * n_actions > 0: discrete (actions = [n] indices as float, act_dim 1). */
+typedef int (*frl_env_step_fn)(void* user, const float* actions, float* next_obs, float* reward, uint8_t* terminated,
+                               uint8_t* truncated, float* obs_next);
+typedef int (*frl_env_reset_fn)(void* user, float* obs_out);
+int frl_envpool_create_callback(int n_envs, int obs_dim, int act_dim, int n_actions, float max_action, frl_env_step_fn step,
+                                frl_env_reset_fn reset, void* user, frl_envpool** out);
 int frl_envpool_destroy(frl_envpool* p);
 int frl_envpool_dims(const frl_envpool* p, int* n_envs, int* obs_dim, int* act_dim, int* n_actions, float* max_action,
                      int* max_steps);
@@ -292,6 +301,27 @@ int frl_envpool_set_state(frl_envpool* p, int env, const double* state);     /* 
  * next_obs = observation of the transition, obs_next = what the policy sees next (reset obs after a done) */
 int frl_envpool_step(frl_envpool* p, const float* actions, float* next_obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* obs_next);
+/* The reference loops' per-step exploration rules, applied INSIDE the act launch from the engine's Philox stream (the
+ * reference draws them from NumPy's global generator on the host, one env at a time):
+ *   EPS_GREEDY  DQN.py:307-310    np.random.rand() < epsilon -> np.random.randint(action_dim), else the greedy action
+ *   GAUSS       TD3.py:412        action_ = clip(a*max_action + scale * N(0, sigma*max_action), +-max_action)
+ *   OU          SAC.py:334-356,529  x += theta*(0 - x) + sqrt(dt)*sigma*N(0,1); action_ = clip(a*max_action + x*scale*max_action)
+ *   NONE        SAC.py:533, PPO_with_tricks.py:529-530  action_ = clip(a*max_action)
+ * The action handed to add() is the policy's own output (continuous) or the explored index (discrete), as in the reference. */
+enum frl_explore_kind { FRL_EXPLORE_NONE = 0, FRL_EXPLORE_EPS_GREEDY = 1, FRL_EXPLORE_GAUSS = 2, FRL_EXPLORE_OU = 3 };
+typedef struct frl_explore_args {
+    int kind;
+    float epsilon;
+    float sigma;              /* gauss_sigma */
+    float scale;              /* gauss_scale / OUNoise.scale (1 = none) */
+    float max_action;
+    float ou_theta, ou_sigma, ou_dt;
+} frl_explore_args;
+/* obs host [P][n_rows][obs_dim]; ended host [P][n_rows] or NULL (1: reset that row's OU state first, SAC.py:546-547);
+ * outputs host [P][n_rows][act_dim] (FRL_ACT_ARGMAX: [P][n_rows]): the action add() stores, and the env-unit action. */
+int frl_act_explore(frl_engine* e, int mode, int n_rows, const float* obs_host, const frl_explore_args* x,
+                    const uint8_t* ended_host, float* store_act_out, float* env_act_out);
+
 typedef struct frl_rollout_args {
     int n_steps;             /* vector steps (each steps every env once) */
     int envs_per_learner;    /* E; the pool must hold P*E envs, env i feeds learner i/E */
@@ -300,7 +330,14 @@ typedef struct frl_rollout_args {
     int policy_freq;         /* TD3 delayed actor update (TD3.py:224) */
     float epsilon;           /* DQN epsilon-greedy (DQN.py:307) */
     float explore_sigma;     /* Gaussian action-noise std as a fraction of max_action (gauss_scale*gauss_sigma, TD3.py:412) */
-    frl_learn_args learn;    /* idx / noise / stats_out must be NULL */
+    frl_learn_args learn;    /* idx / noise / stats_out must be NULL; per = 1|2 (PER engines): frl_per_sample / frl_per_update around every learn */
+    int host_explore;        /* 0: exploration inside the act launch — per vector step ONE D2H (env actions) and ONE H2D (the
+                              * env outputs), records assembled on the device; 1: round 1's loop (host generator, obs H2D +
+                              * action D2H + staged records H2D) kept for comparison */
+    int explore_kind;        /* -1: the algorithm's loop default (DQN epsilon-greedy, DDPG/TD3 Gaussian, SAC none), else frl_explore_kind */
+    float gauss_init_scale, gauss_final_scale;   /* with max_episodes > 0: a learner's noise multiplier decays with ITS finished episodes, */
+    int max_episodes;                            /* scale = final + (init - final) * max(0, max_episodes - episodes) / max_episodes (TD3.py:425-427, SAC.py:548-556) */
+    float ou_theta, ou_sigma, ou_dt;             /* OUNoise(theta 0.15, sigma, dt) (SAC.py:334-356) */
 } frl_rollout_args;
 typedef struct frl_rollout_stats {
     long long env_steps, updates, episodes;

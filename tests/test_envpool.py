@@ -77,3 +77,48 @@ def test_pool_argument_validation(native):
     assert L.frl_envpool_create(99, 4, 1, 0, None, 0, C.byref(h)) == 1
     assert L.frl_envpool_create(0, 0, 1, 0, None, 0, C.byref(h)) == 1
     assert L.frl_envpool_destroy(None) == 0
+
+
+def test_callback_pool_steps_python_envs(native):
+    """frl_envpool_create_callback: caller-supplied gymnasium-protocol envs behind the pool's C ABI (no GPU needed for the
+    pool itself): same transitions as stepping twin copies by hand, finished episodes are reset (obs_next = reset obs),
+    an exception inside an env surfaces as a Python exception, not a crash."""
+    from freerl_amd import envs as E
+    from freerl_amd.envpool import CallbackEnvPool
+    n = 3
+    mk = lambda: E.make("PendulumShort-v1", prefer_gymnasium=False)
+    pool = CallbackEnvPool([mk() for _ in range(n)], seed=5)
+    twins = [mk() for _ in range(n)]
+    assert (pool.n, pool.obs_dim, pool.act_dim, pool.n_actions, pool.max_action) == (n, 3, 1, 0, 2.0)
+    obs = pool.reset()
+    for i, t in enumerate(twins):
+        o, _ = t.reset(seed=5)
+        np.testing.assert_allclose(obs[i], o, atol=1e-7)
+    g = np.random.default_rng(0)
+    for step in range(45):
+        act = g.uniform(-2, 2, (n, 1)).astype(np.float32)
+        nobs, rew, term, trunc, onext = pool.step(act)
+        for i, t in enumerate(twins):
+            o, r, te, tr, _ = t.step(act[i].copy())
+            np.testing.assert_allclose(nobs[i], o, atol=1e-6)
+            assert abs(rew[i] - r) < 1e-5 and bool(term[i]) == te and bool(trunc[i]) == tr
+            if te or tr:
+                o2, _ = t.reset(seed=5)
+                np.testing.assert_allclose(onext[i], o2, atol=1e-7)
+            else:
+                np.testing.assert_array_equal(onext[i], nobs[i])
+        assert trunc.all() == (step == 39)
+    pool.close()
+
+    class Broken:
+        observation_space, action_space = twins[0].observation_space, twins[0].action_space
+        def reset(self, seed=None):
+            return np.zeros(3, np.float32), {}
+        def step(self, a):
+            raise RuntimeError("env exploded")
+    bad = CallbackEnvPool([Broken()])
+    bad.reset()
+    with pytest.raises(native.FrlError):
+        bad.step(np.zeros((1, 1), np.float32))
+    assert isinstance(bad.error, RuntimeError)
+    bad.close()

@@ -1,0 +1,241 @@
+"""Device-side exploration and the callback env pool.
+
+The reference's loops draw exploration on the host per env step: epsilon-greedy (DQN.py:307-310), Gaussian action noise with
+a per-episode decayed scale (TD3.py:412,425-427), an Ornstein-Uhlenbeck process (SAC.py:334-356,529,546-547).  Here the
+act launch applies the same rules from the engine's Philox stream, so they are validated statistically: the rule's
+parameters are recovered from many rows, and the stored action is exactly the policy's own output.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    from freerl_amd import _native
+    _native.build()
+    assert _native.device_count() > 0, "no HIP device: the engine has no CPU fallback"
+    return _native
+
+
+def _rand_params(e, N, scale=0.1, seed=0):
+    g = np.random.default_rng(seed)
+    for p in range(e.P):
+        for net in range(e.n_nets):
+            flat = (g.standard_normal(e.num_params(net)) * scale).astype(np.float32)
+            e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
+            e.set_params(net, flat, N.PARAM_TARGET, learner=p)
+
+
+def test_epsilon_greedy_rule(N):
+    """P(random) = epsilon, the random action uniform over the n_actions (so it differs from the greedy one with
+    probability epsilon * (1 - 1/nA)), env action == stored action, epsilon 0 == argmax, another call draws again."""
+    from freerl_amd.engine import Engine
+    P, R, O, nA, eps = 2, 8192, 8, 4, 0.3
+    e = Engine(N.ALGO_DQN, O, nA, 64, discrete=True, batch_max=32, n_learners=P, seed=11)
+    _rand_params(e, N, 0.3)
+    obs = np.random.default_rng(1).standard_normal((P, R, O)).astype(np.float32)
+    greedy = e.act(0, N.ACT_ARGMAX, obs)
+    s0, v0 = e.act_explore(N.ACT_ARGMAX, obs, kind=N.EXPLORE_EPS_GREEDY, epsilon=0.0)
+    np.testing.assert_array_equal(s0, greedy.reshape(P, R))
+    np.testing.assert_array_equal(v0, s0)
+    s1, v1 = e.act_explore(N.ACT_ARGMAX, obs, kind=N.EXPLORE_EPS_GREEDY, epsilon=eps)
+    np.testing.assert_array_equal(v1, s1)
+    assert set(np.unique(s1)) <= set(float(k) for k in range(nA))
+    changed = (s1 != s0)
+    want = eps * (1 - 1 / nA)
+    sd = np.sqrt(want * (1 - want) / (P * R))
+    assert abs(changed.mean() - want) < 5 * sd, (changed.mean(), want)
+    # where the action changed it is uniform over the other nA - 1 actions: every action is hit
+    for p in range(P):
+        cnt = np.bincount(s1[p][changed[p]].astype(int), minlength=nA)
+        assert cnt.min() > 0.5 * cnt.mean()
+    s2, _ = e.act_explore(N.ACT_ARGMAX, obs, kind=N.EXPLORE_EPS_GREEDY, epsilon=eps)
+    assert not np.array_equal(s1, s2)                                  # a new counter value per launch
+    assert not np.array_equal(changed[0], changed[1])                  # and a key per learner
+    e.close()
+
+
+def test_gaussian_action_noise_rule(N):
+    """action_ = clip(a*max_action + scale * N(0, sigma*max_action), +-max_action) (TD3.py:412); the stored action is the
+    actor's own tanh output."""
+    from freerl_amd.engine import Engine
+    P, R, O, A, ma, sigma, scale = 2, 8192, 5, 3, 2.0, 0.1, 0.7
+    e = Engine(N.ALGO_TD3, O, A, 64, twin_critic=True, batch_max=32, n_learners=P, seed=3)
+    _rand_params(e, N, 0.1)
+    obs = np.random.default_rng(2).standard_normal((P, R, O)).astype(np.float32)
+    a = e.act(0, N.ACT_TANHHEAD, obs, out_dim=A)
+    store, env = e.act_explore(N.ACT_TANHHEAD, obs, kind=N.EXPLORE_GAUSS, sigma=sigma, scale=scale, max_action=ma, out_dim=A)
+    np.testing.assert_array_equal(store, a)
+    assert np.all(np.abs(env) <= ma)
+    inside = np.abs(env) < ma
+    noise = (env - store * ma)[inside]
+    want_sd = scale * sigma * ma
+    assert abs(noise.mean()) < 5 * want_sd / np.sqrt(noise.size)
+    assert abs(noise.std() / want_sd - 1) < 0.03
+    k = np.mean(((noise - noise.mean()) / noise.std()) ** 4)
+    assert abs(k - 3.0) < 0.2                                          # Gaussian kurtosis
+    # none: action_ = clip(a * max_action)
+    s2, env2 = e.act_explore(N.ACT_TANHHEAD, obs, kind=N.EXPLORE_NONE, max_action=ma, out_dim=A)
+    np.testing.assert_allclose(env2, np.clip(a * ma, -ma, ma), rtol=0, atol=1e-7)
+    e.close()
+
+
+def test_ou_noise_rule(N):
+    """x += theta*(0 - x) + sqrt(dt)*sigma*N(0,1); action_ = clip(a*max_action + x*scale*max_action) (SAC.py:334-356,529):
+    the state's variance follows the recursion, consecutive states are correlated by (1 - theta), `ended` rows restart
+    from zero (SAC.py:546-547)."""
+    from freerl_amd.engine import Engine
+    P, R, O, A, ma, th, sg, dt, scale = 1, 16384, 4, 2, 1.0, 0.15, 0.2, 1e-2, 0.5
+    e = Engine(N.ALGO_DDPG, O, A, 64, batch_max=32, n_learners=P, seed=5)
+    _rand_params(e, N, 0.02)                                           # |a| small: nothing clips
+    obs = np.random.default_rng(4).standard_normal((P, R, O)).astype(np.float32)
+    kw = dict(kind=N.EXPLORE_OU, scale=scale, max_action=ma, ou_theta=th, ou_sigma=sg, ou_dt=dt, out_dim=A)
+    s1, e1 = e.act_explore(N.ACT_TANHHEAD, obs, **kw)
+    x1 = (e1 - s1 * ma) / (scale * ma)
+    v = dt * sg * sg
+    assert abs(x1.std() ** 2 / v - 1) < 0.04 and abs(x1.mean()) < 5 * np.sqrt(v / x1.size)
+    s2, e2 = e.act_explore(N.ACT_TANHHEAD, obs, **kw)
+    x2 = (e2 - s2 * ma) / (scale * ma)
+    assert abs(x2.std() ** 2 / (((1 - th) ** 2 + 1) * v) - 1) < 0.04
+    innov = x2 - (1 - th) * x1                                         # = sqrt(dt)*sigma*N, independent of x1
+    assert abs(innov.std() ** 2 / v - 1) < 0.04
+    assert abs(np.corrcoef(innov.reshape(-1), x1.reshape(-1))[0, 1]) < 0.03
+    ended = np.zeros((P, R), np.uint8)
+    ended[:, ::2] = 1
+    s3, e3 = e.act_explore(N.ACT_TANHHEAD, obs, ended=ended, **kw)
+    x3 = (e3 - s3 * ma) / (scale * ma)
+    assert abs(x3[:, ::2].std() ** 2 / v - 1) < 0.06                    # restarted from 0
+    assert x3[:, 1::2].std() ** 2 > 2.0 * v                            # third step of the running process
+    e.close()
+
+
+def test_sac_sample_draws_its_own_eps(N):
+    """FRL_ACT_SAC_SAMPLE on the device path: a = tanh(mean + std*eps), eps ~ N(0,1) from the launch's stream."""
+    from freerl_amd.engine import Engine
+    P, R, O, A = 1, 8192, 6, 2
+    e = Engine(N.ALGO_SAC, O, A, 64, twin_critic=True, batch_max=32, n_learners=P, seed=8)
+    _rand_params(e, N, 0.05)
+    fa = e.get_params(0)
+    fa[-A:] = -0.5                                                     # log_std
+    e.set_params(0, fa)
+    obs = np.random.default_rng(6).standard_normal((P, R, O)).astype(np.float32)
+    mean = e.act(0, N.ACT_RAW, obs, out_dim=A)
+    store, env = e.act_explore(N.ACT_SAC_SAMPLE, obs, kind=N.EXPLORE_NONE, max_action=1.5, out_dim=A)
+    eps = (np.arctanh(np.clip(store, -0.999999, 0.999999)) - mean) / np.exp(-0.5)
+    assert abs(eps.mean()) < 0.04 and abs(eps.std() - 1) < 0.03
+    np.testing.assert_allclose(env, np.clip(store * 1.5, -1.5, 1.5), atol=1e-7)
+    e.close()
+
+
+class _Recorder:
+    """Wraps an in-repo env (gymnasium protocol) and records what the pool asked of it."""
+
+    def __init__(self, env):
+        self.env, self.log = env, []
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self.last = None
+
+    def reset(self, seed=None):
+        o, info = self.env.reset(seed=seed)
+        self.last = np.asarray(o, np.float32).copy()
+        return o, info
+
+    def step(self, a):
+        o, r, t, u, info = self.env.step(a)
+        self.log.append((self.last.copy(), np.array(a, np.float32).reshape(-1).copy(), float(r), np.asarray(o, np.float32).copy(), bool(t), bool(u)))
+        self.last = np.asarray(o, np.float32).copy()
+        return o, r, t, u, info
+
+
+@pytest.mark.parametrize("host_explore", [False, True])
+def test_rollout_over_callback_pool_matches_what_the_envs_saw(N, host_explore):
+    """frl_rollout over caller-supplied Python envs: every ring row is the transition its env recorded (obs, reward,
+    next_obs, done), the env-unit action is clip(stored*max_action + noise), and the Gaussian noise decays to exactly zero
+    once a learner has finished max_episodes episodes (TD3.py:425-427)."""
+    from freerl_amd import envs as E
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import CallbackEnvPool, rollout
+    P, Ev, steps = 2, 2, 100
+    envs = [_Recorder(E.make("PendulumShort-v1", prefer_gymnasium=False)) for _ in range(P * Ev)]
+    pool = CallbackEnvPool(envs)
+    assert (pool.obs_dim, pool.act_dim, pool.n_actions, pool.max_action) == (3, 1, 0, 2.0)
+    e = Engine(N.ALGO_TD3, 3, 1, 400, twin_critic=True, batch_max=32, n_learners=P, seed=2)
+    _rand_params(e, N, 0.03, seed=3)                                   # small |a|: the env-action clip stays out of the statistics
+    out = rollout(e, pool, steps, envs_per_learner=Ev, learn_every=0, explore_sigma=0.2, batch=32, host_explore=host_explore,
+                  gauss_init_scale=1.0, gauss_final_scale=0.0, max_episodes=4)
+    assert out["env_steps"] == steps * P * Ev and out["episodes"] == 2 * P * Ev          # 40-step episodes
+    lay, ma = e.layout, 2.0
+    for p in range(P):
+        rows = e.read_rows(p, 0, steps * Ev)
+        assert e.cursor(p) == (steps * Ev, steps * Ev)
+        noises = []
+        for j in range(Ev):
+            log = envs[p * Ev + j].log
+            tr = rows[j::Ev]
+            assert len(log) == steps
+            for t in range(steps):
+                o, a_env, r, o2, term, trunc = log[t]
+                np.testing.assert_allclose(tr[t, lay.obs_off[0]:lay.obs_off[0] + 3], o, atol=1e-7)
+                np.testing.assert_allclose(tr[t, lay.next_obs_off[0]:lay.next_obs_off[0] + 3], o2, atol=1e-7)
+                assert abs(tr[t, lay.rew_off] - r) < 1e-6 * max(1, abs(r)) and tr[t, lay.done_off] == float(term)
+                assert abs(a_env[0]) <= ma + 1e-6 and abs(tr[t, lay.act_off[0]]) <= 1.0
+            stored = tr[:, lay.act_off[0]]
+            a_env = np.array([l[1][0] for l in log])
+            noises.append(a_env - np.clip(stored * ma, -ma, ma))
+        # the learner's two envs finish episodes together at steps 40 and 80: scale 1 -> 0.5 -> 0 (sigma 0.2 * max_action 2)
+        nz = np.stack(noises)
+        s_a, s_b = nz[:, :40].std(), nz[:, 40:80].std()
+        assert 0.3 < s_a < 0.5 and 0.14 < s_b < 0.26 and s_a > 1.4 * s_b, (s_a, s_b)
+        np.testing.assert_allclose(nz[:, 80:], 0, atol=1e-6)
+    pool.close(); e.close()
+
+
+def test_rollout_over_callback_pool_discrete_and_learning(N):
+    """DQN over Python CartPole instances: explored indices are stored and stepped, learning runs on the device draws."""
+    from freerl_amd import envs as E
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import CallbackEnvPool, rollout
+    P, Ev = 2, 3
+    envs = [_Recorder(E.make("CartPole-v1", prefer_gymnasium=False)) for _ in range(P * Ev)]
+    pool = CallbackEnvPool(envs)
+    assert (pool.obs_dim, pool.act_dim, pool.n_actions) == (4, 1, 2)
+    e = Engine(N.ALGO_DQN, 4, 2, 1000, discrete=True, batch_max=32, n_learners=P, seed=4)
+    _rand_params(e, N, 0.2, seed=5)
+    before = e.get_params(0, learner=1).copy()
+    out = rollout(e, pool, 60, envs_per_learner=Ev, start_steps=64, learn_every=1, epsilon=0.5, batch=32, critic_lr=1e-3)
+    assert out["env_steps"] == 60 * P * Ev and out["updates"] > 0 and out["episodes"] > 0
+    lay = e.layout
+    for p in range(P):
+        rows = e.read_rows(p, 0, 60 * Ev)
+        for j in range(Ev):
+            log, tr = envs[p * Ev + j].log, rows[j::Ev]
+            np.testing.assert_array_equal(tr[:, lay.act_off[0]], np.array([l[1][0] for l in log]))
+            np.testing.assert_array_equal(tr[:, lay.done_off], np.array([float(l[4]) for l in log]))
+            np.testing.assert_allclose(tr[:, lay.obs_off[0]:lay.obs_off[0] + 4], np.stack([l[0] for l in log]), atol=1e-7)
+        assert 0.1 < rows[:, lay.act_off[0]].mean() < 0.9
+    assert not np.allclose(before, e.get_params(0, learner=1)) and np.all(np.isfinite(e.stats()))
+    pool.close(); e.close()
+
+
+def test_rollout_on_a_per_engine_samples_and_updates_priorities(N):
+    """A PER-enabled DQN engine in frl_rollout: the loop of DQN_with_tricks.py (sample by priority -> learn with the
+    importance weights -> update the priorities); without learn.per the call is refused instead of training on stale trees."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    P, Ev = 2, 2
+    e = Engine(N.ALGO_DQN, 8, 4, 512, discrete=True, batch_max=32, n_learners=P, seed=6)
+    _rand_params(e, N, 0.2, seed=7)
+    e.per_enable(0.6, 0.4, 0.001, 0.01)
+    pool = EnvPool("SynLinearDiscrete-v0", P * Ev, n_threads=1, seed=3)
+    with pytest.raises(N.FrlError):
+        rollout(e, pool, 40, envs_per_learner=Ev, start_steps=0, batch=32)
+    out = rollout(e, pool, 40, envs_per_learner=Ev, learn_every=0, batch=32)          # collect only: every row at priority 1
+    st0 = e.per_state(0)
+    assert abs(st0["sum"] - 80.0) < 1e-9 and st0["max"] == 1.0
+    out = rollout(e, pool, 30, envs_per_learner=Ev, start_steps=0, batch=32, per=1, double_dqn=True, critic_lr=1e-3)
+    assert out["updates"] == 30 * P
+    st1 = e.per_state(0)
+    assert st1["sum"] != st0["sum"] + 60.0 and st1["beta"] > 0.4 and np.all(np.isfinite(e.stats()))   # priorities rewritten from TD errors
+    pool.close(); e.close()
