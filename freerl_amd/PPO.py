@@ -121,7 +121,8 @@ class PPO:
         stored = action_dim if is_continue else 1            # Buffer act_dim (Buffer.py:3-9)
         self._e = Engine(N.ALGO_PPO, obs_dim, action_dim, max(self.horizon, 2), hidden=hidden, batch_max=minibatch_max,
                          extra_cols=stored + self._buffer_cls._tail_cols, hidden_act=N.ACT_TANH if self.trick["tanh"] else N.ACT_RELU,
-                         discrete=not is_continue, device_id=hip_id, seed=seed, actor_dist=1 if beta else 0)
+                         discrete=not is_continue, device_id=hip_id, seed=seed,
+                         actor_dist=1 if beta else (2 if (self._cautious and not is_continue) else 0))   # PPO.py: Categorical(logits=)
         self.agent = Agent(self._e, obs_dim, action_dim, actor_lr, critic_lr, self.trick, hidden, is_continue, beta=bool(beta))
         self.buffer = self._buffer_cls(self.horizon, obs_dim, stored, self.device, _engine=self._e)
         if self.trick["Batch_ObsNorm"]:                                   # PPO_with_tricks.py:225-226

@@ -58,7 +58,8 @@ class LearnArgs(C.Structure):
                 ("clip_norm", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
                 ("max_action", C.c_float), ("policy_noise_scale", C.c_float), ("target_entropy", C.c_float),
                 ("double_dqn", C.c_int), ("per", C.c_int), ("noisy_eps", C.POINTER(C.c_float)),
-                ("idx", C.POINTER(C.c_int64)), ("noise", C.POINTER(C.c_float)), ("stats_out", C.POINTER(C.c_float))]
+                ("idx", C.POINTER(C.c_int64)), ("noise", C.POINTER(C.c_float)), ("stats_out", C.POINTER(C.c_float)),
+                ("loss_kind", C.c_int), ("huber_delta", C.c_float)]
 
 
 class PpoArgs(C.Structure):

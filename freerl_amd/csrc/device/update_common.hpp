@@ -12,6 +12,17 @@ __device__ __forceinline__ float softplus_t(float x) {     // F.softplus (beta 1
     return x > 20.f ? x : log1pf(expf(x));
 }
 
+// TD loss of one row's error e: value and d/de (before the 1/B of the mean).  MSE: e^2, 2e.  Huber (MAPPO.py:273-276).
+__device__ __forceinline__ void td_loss_row(const LearnArgs& a, float e, float& loss, float& grad) {
+    if (a.huber) {
+        const float d = a.huber_delta, ae = fabsf(e);
+        if (ae <= d) { loss = e * e * 0.5f; grad = e; }
+        else { loss = d * (ae - d * 0.5f); grad = e > 0.f ? d : -d; }
+    } else {
+        loss = e * e; grad = 2.f * e;
+    }
+}
+
 __device__ __forceinline__ Lds carve(const EngineDesc& D, float* smem) {
     return carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
 }

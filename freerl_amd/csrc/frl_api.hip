@@ -313,6 +313,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         h.noisy_split = c.dueling ? per_out : h.net[0].L[1].n_pad;
     } else if (c.algo == FRL_ALGO_PPO) {
         h.n_nets = 2;
+        if (c.discrete && c.actor_dist == 2) h.cat_logits = 1;     // PPO_file/PPO.py:78-90,176,257: raw logits into Categorical(logits=)
         if (c.discrete)     // Actor_discrete (PPO_with_tricks.py:110-121): ReLU body, softmax over n_actions logits
             build_net(h.net[0], {{H, c.obs_dim[0]}, {H, H}, {c.act_dim[0], H}}, 1, ACT_RELU, ACT_NONE, 0);
         else if (c.actor_dist == 1) {   // Actor_Beta (:120-151): alpha_layer and beta_layer share the trunk = one 2A-wide head
@@ -1142,6 +1143,12 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
     a.target_entropy = args->target_entropy;
     a.double_dqn = (h.algo == ALGO_DQN && args->double_dqn) ? 1 : 0;
     a.use_isw = (h.algo == ALGO_DQN && args->per) ? (args->per == 2 ? 2 : 1) : 0;
+    if (args->loss_kind != FRL_LOSS_MSE && args->loss_kind != FRL_LOSS_HUBER) return fail(FRL_ERR_INVALID, "unknown loss_kind %d", args->loss_kind);
+    if (args->loss_kind == FRL_LOSS_HUBER) {
+        if (!(args->huber_delta > 0.f)) return fail(FRL_ERR_INVALID, "Huber loss needs huber_delta > 0");
+        if (h.c51_atoms) return fail(FRL_ERR_STATE, "the Categorical head's loss is a cross-entropy: no Huber variant");
+        a.huber = 1; a.huber_delta = args->huber_delta;
+    }
     a.rng_counter = e->rng_counter++;
     // One chain for the whole population.  Measured and rejected (profiles/README.md): two halves of the population on two
     // streams so that one half's HBM-bound reduce/Adam runs under the other half's MFMA-bound gradient kernel — unchained

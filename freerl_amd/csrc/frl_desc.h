@@ -103,6 +103,8 @@ struct EngineDesc {
     int c51_atoms;        // > 0: Categorical DQN head (DQN_with_tricks.py:82-158): action_dim x atoms logits (+ atoms for Dueling's V)
     float c51_vmin, c51_vmax;
     int dueling;          // DQN: head = [V ; A] (1 + n_discrete outputs), Q = V + A - mean(A) (DQN_with_tricks.py:60-79)
+    int cat_logits;       // PPO discrete: Categorical(logits=l3) (PPO_file/PPO.py:176,257: log-softmax, unclamped) instead of
+                          // PPO_with_tricks.py's Categorical(probs=softmax(l3)) (probabilities clamped to [eps, 1-eps])
     int beta_actor;       // PPO: the actor is Actor_Beta (head = [alpha_layer ; beta_layer], 2*act_dim outputs)
     // Batch_ObsNorm (Normalization_batch_size, PPO_file/normalization.py:53-84): per learner
     // [1 + 3*O] floats = {n, mean[O], S[O], std[O]}; obs_norm_on switches every gather / act to
@@ -134,6 +136,8 @@ struct LearnArgs {
     int p0, p_count;      // this launch covers learners [p0, p0 + p_count): frl_learn pipelines two halves of a population
     int double_dqn;       // DQN trick['Double']: a* = argmax_a Q(s',a), y uses Q_target(s', a*) (DQN_with_tricks.py:263-265)
     int use_isw;          // DQN trick['PER']: loss = mean(w * td^2) with the weights in desc.isw (:276-278)
+    int huber;            // TD loss: 0 F.mse_loss (every hot-path loss of the reference), 1 Huber with `huber_delta`
+    float huber_delta;    // (the reference's huber_loss, MAPPO_file/MAPPO.py:273-276: e^2/2 if |e| <= d else d(|e| - d/2), mean)
 };
 
 }  // namespace frl

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
             }
             a.out[row] = (float)best;
             if (a.env_out) a.env_out[row] = (float)best;
-            if (a.out_logp) a.out_logp[row] = logf(fminf(fmaxf(pbest / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+            if (a.out_logp) a.out_logp[row] = D.cat_logits ? (S.outb[r * S.op + best] - mx) - logf(sum)          // Categorical(logits=)
+                                                           : logf(fminf(fmaxf(pbest / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
         }
         return;
     }

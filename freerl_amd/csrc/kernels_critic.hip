@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void ac_critic_kernel(const Engi
             lds_f o = S.outb + r * S.op;
             float d = 0.f;
             if (r < nv) {
-                const float diff = o[0] - S.y[r];
-                d = 2.f * diff * invB;
-                lossp += diff * diff;
+                float lrow, grow;
+                td_loss_row(a, o[0] - S.y[r], lrow, grow);
+                d = grow * invB;
+                lossp += lrow;
             }
             o[0] = d;
             for (int c = 1; c < npad; ++c) o[c] = 0.f;

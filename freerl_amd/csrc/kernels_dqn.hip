@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void dqn_grad_kernel(const Engin
             ar = (int)ring[(size_t)idx[r] * R.stride + R.act_off[0]];             // actions.long() (DQN.py:114)
             const float diff = q_of(r, ar, a_mean(r)) - S.y[r];
             const float w = a.use_isw == 2 ? isw[r] : wbar;
-            d = 2.f * w * diff / (float)B;
-            lossp += w * diff * diff;
+            float lrow, grow;
+            td_loss_row(a, diff, lrow, grow);
+            d = w * grow / (float)B;
+            lossp += w * lrow;
             tde[r] = diff;
         }
         lds_f o = S.outb + r * S.op;

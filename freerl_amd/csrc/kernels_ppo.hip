@@ -351,10 +351,16 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                             float psum = 0.f;
                             for (int c = 0; c < A; ++c) psum += expf(S.outb[r * S.op + c] - mx) / sum;
                             const int ar = (int)rec[R.act_off[0]];
+                            const float lse = logf(sum);
+                            // log-prob of class c: clamped renormalised probability (probs=) or the log-softmax itself (logits=)
+                            auto logp_of = [&](int c, float pc) {
+                                return D.cat_logits ? (S.outb[r * S.op + c] - mx) - lse
+                                                    : logf(fminf(fmaxf(pc / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+                            };
                             float entr = 0.f, lp_now = 0.f;
                             for (int c = 0; c < A; ++c) {
                                 const float pc = expf(S.outb[r * S.op + c] - mx) / sum;
-                                const float lg = logf(fminf(fmaxf(pc / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+                                const float lg = logp_of(c, pc);
                                 entr -= lg * pc;
                                 if (c == ar) lp_now = lg;
                             }
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                                 float d = 0.f;
                                 if (c < A) {
                                     const float pc = expf(S.outb[r * S.op + c] - mx) / sum;
-                                    const float lg = logf(fminf(fmaxf(pc / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
+                                    const float lg = logp_of(c, pc);
                                     d = coef * ((c == ar ? 1.f : 0.f) - pc) + (a.ent_coef * invm) * pc * (lg + entr);
                                 }
                                 S.abuf[r * S.ap + c] = d;      // staged: outb is still being read by this row

@@ -199,7 +199,7 @@ class Engine:
               critic_weight_decay=0.0, clip_norm=0.5, do_actor=True, use_policy_noise=False, policy_noise=0.0,
               noise_clip=0.0, max_action=1.0, policy_noise_scale=1.0, target_entropy=0.0, double_dqn=False, per=False,
               noisy_eps=None, idx=None, noise=None,
-              want_stats=False):
+              want_stats=False, huber_delta=None):
         a = N.LearnArgs()
         a.batch, a.do_actor, a.use_policy_noise = int(batch), int(bool(do_actor)), int(bool(use_policy_noise))
         a.double_dqn, a.per = int(bool(double_dqn)), int(per)
@@ -208,6 +208,8 @@ class Engine:
         a.critic_weight_decay, a.clip_norm = critic_weight_decay, clip_norm
         a.policy_noise, a.noise_clip, a.max_action, a.policy_noise_scale = policy_noise, noise_clip, max_action, policy_noise_scale
         a.target_entropy = target_entropy
+        if huber_delta is not None:             # TD loss = huber_loss(e, delta).mean() instead of F.mse_loss
+            a.loss_kind, a.huber_delta = 1, float(huber_delta)
         keep = []
         if noisy_eps is not None:
             ne = np.ascontiguousarray(noisy_eps, dtype=F32).reshape(self.P, -1)

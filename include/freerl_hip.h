@@ -86,7 +86,9 @@ typedef struct frl_config {
     int capacity;                 /* replay rows per learner (PPO: horizon) */
     int batch_max;                /* largest batch / minibatch a learn call will use */
     int extra_cols;               /* extra record columns (PPO: act_dim log-probs + 1 adv_done) */
-    int actor_dist;               /* PPO, continuous: 0 Gaussian `Actor` (PPO_with_tricks.py:79-108), 1 `Actor_Beta` (:120-151):
+    int actor_dist;               /* PPO, discrete: 0 Categorical(probs=softmax(l3)) (PPO_with_tricks.py:107-118,333-336), 2
+                                     Categorical(logits=l3) (PPO_file/PPO.py:78-90,176,257: no clamp at float eps).
+                                     PPO, continuous: 0 Gaussian `Actor` (PPO_with_tricks.py:79-108), 1 `Actor_Beta` (:120-151):
                                      the actor's head is [alpha_layer ; beta_layer] = 2*act_dim outputs, no log_std */
     int dueling;                  /* DQN trick['Dueling'] (DQN_with_tricks.py:60-79): the head is [V ; A] = 1 + n_actions outputs and
                                      Q = V + A - mean(A) */
@@ -139,7 +141,12 @@ typedef struct frl_learn_args {
                                   MATD3_simple.py:200: slot j = randn_like(action[agent j]) inside agent i's sample());
                                   NULL: drawn on the device */
     float* stats_out;          /* host [P][n_agents][FRL_STAT_COUNT] or NULL (NULL: call is asynchronous) */
+    int loss_kind;             /* TD loss of the Q / critic update: FRL_LOSS_MSE = F.mse_loss, what every hot-path learn() of the
+                                  reference uses (DQN.py:116, TD3.py:212, SAC.py:237); FRL_LOSS_HUBER = the reference's
+                                  huber_loss(e, d).mean() (MAPPO_file/MAPPO.py:273-276): e^2/2 if |e| <= d else d(|e| - d/2) */
+    float huber_delta;         /* d (MAPPO_attention.py:518 defaults to 10) */
 } frl_learn_args;
+enum frl_loss_kind { FRL_LOSS_MSE = 0, FRL_LOSS_HUBER = 1 };
 
 /* ---------------------------------------------------------------- library / engine lifetime */
 const char* frl_last_error(void);          /* message of the last failing call on this thread */

@@ -253,7 +253,7 @@ class DQN:
         a = act.astype(np.int64).reshape(-1)
         cur = q[np.arange(B), a].reshape(-1, 1)
         if is_weight is None:
-            loss, dcur = nn.mse(cur, y)
+            loss, dcur = getattr(self, "td_loss", nn.mse)(cur, y)      # `td_loss = nn.huber(delta)`: the Huber option
         else:
             # DQN_with_tricks.py:277-278: `is_weight` is a 1-D [B] tensor and `td_error ** 2` is [B,1], so their product
             # broadcasts to [B,B] and `.mean()` = mean(w) * mean(td^2): every sample is weighted by the MEAN weight
@@ -286,16 +286,16 @@ class QNet:
         return out1, out2
 
 
-def _critic_step(qnet, p, opt, oa, y, clip=True):
+def _critic_step(qnet, p, opt, oa, y, clip=True, td_loss=nn.mse):
     """critic_loss = mse(Q1,y) [+ mse(Q2,y)]; zero_grad/backward/clip 0.5/Adam
     (TD3.py:210-213,142-147; DDPG_simple.py:146-149)."""
     (q1, a1), two = qnet.forward(p, oa)
-    l1, d1 = nn.mse(q1, y)
+    l1, d1 = td_loss(q1, y)
     _, g = qnet.q1.backward(p, a1, d1, need_dx=False)
     loss = l1
     if two is not None:
         q2, a2 = two
-        l2, d2 = nn.mse(q2, y)
+        l2, d2 = td_loss(q2, y)
         _, g2 = qnet.q2.backward(p, a2, d2, need_dx=False)
         g.update(g2)
         loss = F32(l1 + l2)
@@ -358,7 +358,7 @@ class TD3:
         next_q = np.minimum(q1t, two[0]) if self.twin else q1t     # TD3.py:203-206
         y = rew + F32(gamma) * next_q * (F32(1) - done)            # TD3.py:209
         oa = np.concatenate([obs, act], axis=1)
-        closs, _ = _critic_step(self.qnet, self.critic, self.critic_opt, oa, y)
+        closs, _ = _critic_step(self.qnet, self.critic, self.critic_opt, oa, y, td_loss=getattr(self, "td_loss", nn.mse))
         self.critic_losses.append(closs)
         if not self.twin_delay:
             policy_freq = 1                             # TD3.py:219-222
@@ -471,7 +471,8 @@ class SAC:
         (q1t, _), (q2t, _) = self.qnet.forward(self.critic_t, np.concatenate([nobs, a_next], axis=1))
         next_q = np.minimum(q1t, q2t)
         y = rew + F32(gamma) * (F32(1) - done) * (next_q + self.alpha * (-logpi_next))
-        closs, _ = _critic_step(self.qnet, self.critic, self.critic_opt, np.concatenate([obs, act], axis=1), y)
+        closs, _ = _critic_step(self.qnet, self.critic, self.critic_opt, np.concatenate([obs, act], axis=1), y,
+                                td_loss=getattr(self, "td_loss", nn.mse))
         a_new, logpi, cache = self.pi.forward(self.actor, obs, nn.f32(eps_new))
         oa_new = np.concatenate([obs, a_new], axis=1)
         (q1, acts1), (q2, acts2) = self.qnet.forward(self.critic, oa_new)

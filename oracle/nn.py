@@ -160,5 +160,21 @@ def mse(a, b):
     return F32(np.mean(diff * diff, dtype=F32)), diff * F32(2.0 / n)
 
 
+def huber(delta):
+    """The TD-loss option north_star names; the reference's only Huber is `huber_loss(e, d) = e**2/2 if |e| <= d else
+    d*(|e| - d/2)`, mean-reduced (MAPPO_file/MAPPO.py:273-276, MAPPO_attention.py:389-397, d = 10).  Returns a function with
+    mse()'s interface: (a, b) -> (loss, d loss / d a)."""
+    d = F32(delta)
+
+    def f(a, b):
+        e = (a - b).astype(F32)
+        n = e.size
+        small = np.abs(e) <= d
+        per = np.where(small, e * e * F32(0.5), d * (np.abs(e) - d * F32(0.5))).astype(F32)
+        grad = np.where(small, e, d * np.sign(e)).astype(F32) * F32(1.0 / n)
+        return F32(np.mean(per, dtype=F32)), grad
+    return f
+
+
 def copy_params(p):
     return {k: np.array(v, dtype=F32, copy=True) for k, v in p.items()}

@@ -37,13 +37,16 @@ F32_EPS = float(np.finfo(np.float32).eps)
 
 class PPO:
     def __init__(self, actor_p, critic_p, obs_dim, act_dim, actor_lr, critic_lr, horizon, trick, discrete=False,
-                 optimizer="adam", beta=False, rollout_values=False):
+                 optimizer="adam", beta=False, rollout_values=False, cat_logits=False):
         """rollout_values=True: PPO_advance/PPO_2.py:152-292 — values stored at rollout time, advantages and returns from the
         buffer's stable-baselines3-style float64 scan, `learn_with(..., last_value=...)`; otherwise that file's learn is
         PPO_file/PPO.py's with two torch Adams.
         optimizer="c_adamw": PPO_file/PPO.py:109-152,213-286 — the same clipped-surrogate learn with no tricks and ONE
         cautious AdamW (lr = actor_lr) over actor + critic parameters, each net's gradients clipped to 0.5 on its own."""
         self.trick = trick
+        # cat_logits: PPO_file/PPO.py's discrete actor returns raw logits (:78-90) into Categorical(logits=...) (:176,257):
+        # log-probs are the log-softmax itself, where PPO_with_tricks.py's Categorical(probs=softmax) clamps at float eps
+        self.cat_logits = bool(cat_logits)
         self.discrete = discrete
         self.beta = beta
         act = "tanh" if trick.get("tanh") else "relu"
@@ -145,6 +148,10 @@ class PPO:
         single-draw multinomial); log_prob = log(clamp(p_a)) (:249-251)."""
         p = self.probs(nn.f32(obs).reshape(1, -1))[0]
         a = int(np.argmax(p / nn.f32(q).reshape(-1)))
+        if self.cat_logits:
+            z = self.pi.forward(self.actor, nn.f32(obs).reshape(1, -1))[0][0]
+            zs = z - z.max()
+            return a, F32(zs[a] - np.log(np.exp(zs).sum(dtype=F32)))
         return a, F32(np.log(np.clip(p[a] / p.sum(dtype=F32), F32_EPS, 1 - F32_EPS)))
 
     def select_action(self, obs, eps):                   # :234-255: a ~ N(mean,std); per-dim log-prob
@@ -237,6 +244,8 @@ class PPO:
         e = np.exp(zs)
         p = (e / e.sum(axis=1, keepdims=True)).astype(F32)
         logit = np.log(np.clip(p / p.sum(axis=1, keepdims=True, dtype=F32), F32_EPS, 1 - F32_EPS)).astype(F32)
+        if self.cat_logits:                       # Categorical(logits=z): logits - logsumexp, unclamped (PPO.py:257-259)
+            logit = (zs - np.log(e.sum(axis=1, keepdims=True, dtype=F32))).astype(F32)
         a = action.astype(np.int64).reshape(-1)
         lp = logit[np.arange(mb), a].reshape(-1, 1)
         ent = -(logit * p).sum(axis=1, keepdims=True)

@@ -138,6 +138,12 @@ CASES = {
                                     orthogonal_init=False, adam_eps=False, lr_decay=False, tanh=False,
                                     Batch_ObsNorm=False),
                          table_seed=128, param_seed=1520, perm_seed=2520),
+    # PPO_file/PPO.py discrete: raw logits into Categorical(logits=...) (PPO.py:78-90,176,257) + the one cautious AdamW.  The head is
+    # scaled (logit_gain) so that some class probabilities fall below float eps: there the clamp of PPO_with_tricks.py's
+    # Categorical(probs=softmax) and the unclamped log-softmax of this variant give different log-probs / entropies
+    "ppo_py_discrete": dict(kind="ppo_discrete", obs_dim=4, n_actions=3, horizon=192, minibatch=64, k_epochs=2,
+                            gamma=0.99, lmbda=0.95, clip=0.2, ent=0.01, actor_lr=1e-3, critic_lr=1e-3, logit_gain=60.0,
+                            trick={}, table_seed=129, param_seed=1530, perm_seed=2530),
 }
 
 
@@ -324,6 +330,9 @@ def ppo_discrete_inputs(c):
     tab["logp"] = (-np.abs(g.standard_normal((T, 1))) - 0.7).astype(np.float32)    # one stored log-prob per step
     tab["adv_done"] = np.logical_or(tab["done"], g.random(T) < 0.03)
     actor = synth.mlp_params(c["param_seed"], actor_layers(O, nA, head="l3"))
+    if c.get("logit_gain"):
+        actor["l3.weight"] = (actor["l3.weight"] * np.float32(c["logit_gain"])).astype(np.float32)
+        actor["l3.bias"] = (actor["l3.bias"] * np.float32(c["logit_gain"])).astype(np.float32)
     critic = synth.mlp_params(c["param_seed"] + 1, critic_layers(O))
     perms = [synth.permutation(c["perm_seed"] + k, T) for k in range(c["k_epochs"])]
     return dict(table=tab, params=dict(actor=actor, critic=critic), perms=perms)

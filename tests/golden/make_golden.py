@@ -691,6 +691,43 @@ def gen_ppo_py(out):
     out["buffer_size_after"] = np.int64(len(pol.buffer))
 
 
+def gen_ppo_py_discrete(out):
+    """PPO_file/PPO.py with is_continue=False: Actor_discrete returns raw logits (:78-90), Categorical(logits=...) in
+    select_action / learn (:176,257), update_ac_ (one cautious AdamW)."""
+    c = cases.CASES["ppo_py_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    import warnings
+    warnings.simplefilter("ignore", FutureWarning)
+    mod = import_reference("PPO_file", "PPO")
+    pol = mod.PPO([c["obs_dim"], c["n_actions"]], False, c["actor_lr"], c["critic_lr"], c["horizon"], CPU)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    losses = {"actor": [], "critic": []}
+    orig = pol.agent.update_ac_
+
+    def rec(la, lc):
+        losses["actor"].append(float(la.detach())); losses["critic"].append(float(lc.detach()))
+        return orig(la, lc)
+    pol.agent.update_ac_ = rec
+    out["evaluate_action"] = np.array([pol.evaluate_action(tab["obs"][i]) for i in range(16)], dtype=np.int64)
+    sel = []
+    for i in range(12):
+        torch.manual_seed(900 + i)               # Categorical.sample() = argmax(probs / q), q = empty(1, nA).exponential_(1)
+        sel.append(pol.select_action(tab["obs"][i]))
+    out["select_action"] = np.array([int(a) for a, _ in sel], dtype=np.int64)
+    out["select_logp"] = np.array([float(lp) for _, lp in sel], dtype=np.float32)
+    with inject(np.random, "permutation", feeder(inp["perms"])):
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    out["loss_actor"] = np.array(losses["actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(losses["critic"], dtype=np.float32)
+    for net in ("actor", "critic"):
+        synth.pack_digest(net, t2n(getattr(pol.agent, net).state_dict()), out)
+
+
 def gen_ppo_2(out):
     """PPO_advance/PPO_2.py: add(..., value), learn(..., last_value) with Buffer_for_PPO_2.compute_returns_and_advantage."""
     c = cases.CASES["ppo_2"]
@@ -755,6 +792,22 @@ def gen_ppo_discrete(out):
 
 
 # ----------------------------------------------------------------------------- normalisers
+def gen_huber(out):
+    """The reference's only Huber: huber_loss(e, d) (MAPPO_file/MAPPO.py:273-276), used mean-reduced as a value loss
+    (MAPPO_attention.py:389-397).  Inputs: a = synth.normal(7001, (256, 1)) * 6, b = synth.normal(7002, (256, 1)); outputs
+    per delta: the element-wise values, the mean, and d mean / d a by autograd."""
+    ref = import_reference("MAPPO_file", "MAPPO")
+    a = torch.tensor(synth.normal(7001, (256, 1)) * np.float32(6.0), requires_grad=True)
+    b = torch.tensor(synth.normal(7002, (256, 1)))
+    for tag, d in (("1", 1.0), ("10", 10.0)):
+        per = ref.huber_loss(a - b, d)
+        loss = per.mean()
+        (g,) = torch.autograd.grad(loss, a)
+        out["per_" + tag] = per.detach().numpy().copy()
+        out["loss_" + tag] = np.float32(loss.item())
+        out["grad_" + tag] = g.numpy().copy()
+
+
 def gen_norm(out):
     mod = import_reference("PPO_file", "PPO_with_tricks")
     nz = mod._helpers["normalization"]
@@ -970,8 +1023,8 @@ def main():
         "td3": lambda o: gen_td3("td3", o), "td3_pendulum": lambda o: gen_td3("td3_pendulum", o),
         "sac": gen_sac, "maddpg": gen_maddpg, "maddpg_full": gen_maddpg_full, "matd3": gen_matd3,
         "ppo": lambda o: gen_ppo("ppo", o), "ppo_tricks": lambda o: gen_ppo("ppo_tricks", o),
-        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_2": gen_ppo_2, "ppo_beta": gen_ppo_beta,
-        "norm": gen_norm,
+        "ppo_discrete": gen_ppo_discrete, "ppo_py": gen_ppo_py, "ppo_py_discrete": gen_ppo_py_discrete, "ppo_2": gen_ppo_2, "ppo_beta": gen_ppo_beta,
+        "norm": gen_norm, "huber": gen_huber,
         "traj_dqn": gen_traj_dqn, "traj_ddpg": lambda o: gen_traj_ac("ddpg", o),
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),
         "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_matd3": gen_traj_matd3,

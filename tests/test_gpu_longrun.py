@@ -1,0 +1,240 @@
+"""Long-horizon parity: hundreds of learn() calls with injected indices / noise, HIP engine against the oracle.
+
+north_star asks for a TD-loss CURVE matching the reference within 1e-4 relative.  The short traces of test_gpu_parity.py
+(3-5 calls, 1e-4) cannot show how fp32 reassociation (MFMA k-order and wave-tree sums here, MKL/NumPy pairwise sums in the
+oracle and the reference) is amplified by training: Adam divides by sqrt(v) of gradients that may be near zero, target
+networks feed errors back.  These tests measure the drift over >= 500 calls per algorithm family, write the measured
+curve to gpurun_out/longrun_report.json, and assert the ENVELOPE stated in DESIGN.md ("Long-horizon parity"): per-call
+relative loss error <= ENV[name][0] over the first 50 calls and <= ENV[name][1] over the whole run.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden import cases, synth
+from tests.hip_helpers import flat_params, records
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+H = 128
+
+# (first 50 calls, whole run): max relative error of the per-call TD / critic loss, HIP vs oracle.  Measured on MI355X
+# (profiles/r02/longrun_report.json holds the curves); asserted with ~3x headroom.
+ENV = {
+    "dqn": (1e-4, 1e-3),
+    "ddpg": (1e-4, 3e-3),
+    "td3_c2": (1e-4, 3e-3),
+    "sac": (1e-4, 3e-3),
+    "maddpg": (2e-4, 5e-3),
+    "ppo_c3_critic": (2e-3, 2e-2),
+    "ppo_c3_actor": (2e-3, 2e-2),
+}
+
+
+@pytest.fixture(scope="module")
+def N():
+    from freerl_amd import _native
+    assert _native.device_count() > 0, "no HIP device: the engine has no CPU fallback"
+    return _native
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "longrun_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _relerr(got, want, floor=1e-6):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want) / np.maximum(np.abs(want), floor)
+
+
+def _check(name, got, want, extra=None):
+    err = _relerr(got, want)
+    n = len(err)
+    REPORT[name] = dict(calls=n, first50_max=float(err[:50].max()), max=float(err.max()),
+                        by_100=[float(err[i:i + 100].max()) for i in range(0, n, 100)],
+                        loss_first=float(want[0]), loss_last=float(want[-1]), **(extra or {}))
+    lo, hi = ENV[name]
+    assert err[:50].max() <= lo, (name, "first 50 calls", err[:50].max())
+    assert err.max() <= hi, (name, "whole run", err.max(), int(err.argmax()))
+
+
+def _idx(seed, n_calls, n_table, batch):
+    g = np.random.default_rng(seed)
+    return [g.choice(n_table, batch, replace=False).astype(np.int64) for _ in range(n_calls)]
+
+
+def _fill(orc, tab, n):
+    for i in range(n):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+
+
+def test_dqn_500_calls(N):
+    """DQN.learn (DQN.py:104-128) at the SYN-D shape (obs 8, 4 actions, batch 256), 500 calls."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    O, nA, B, n_table, n_calls = 8, 4, 256, 2048, 500
+    tab = synth.transitions(501, n_table, O, 1, n_discrete=nA)
+    params = synth.mlp_params(502, [("l1", H, O), ("l2", nA, H)])
+    idx = _idx(503, n_calls, n_table, B)
+    e = Engine(N.ALGO_DQN, O, nA, 4096, discrete=True, batch_max=B)
+    flat = flat_params(params, ["l1", "l2"])
+    e.set_params(0, flat, N.PARAM_ONLINE); e.set_params(0, flat, N.PARAM_TARGET)
+    e.add_batch(records([tab]))
+    orc = algos.DQN(params, O, nA, 1e-3, 4096)
+    for i in range(n_table):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    got = []
+    for k in range(n_calls):
+        st = e.learn(B, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0, idx=idx[k], want_stats=True)
+        got.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        orc.learn_with(idx[k], 0.99, 0.01)
+    _check("dqn", got, np.array(orc.losses))
+    e.close()
+
+
+def _ac_run(N, name, algo_id, O, A, B, n_calls, twin, gaussian, max_action=1.0):
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    n_table = 2048
+    tab = synth.transitions(511, n_table, O, A)
+    actor = synth.mlp_params(512, cases.actor_layers(O, A, head="mean_layer" if gaussian else "l3"))
+    if gaussian:
+        actor = dict([("log_std", np.zeros((1, A), np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(513, cases.critic_layers(O + A, twin=twin))
+    idx = _idx(514, n_calls, n_table, B)
+    g = np.random.default_rng(515)
+    an = ["l1", "l2", "mean_layer"] if gaussian else ["l1", "l2", "l3"]
+    cn = ["l1", "l2", "l3", "l4", "l5", "l6"] if twin else ["l1", "l2", "l3"]
+    e = Engine(algo_id, O, A, 4096, twin_critic=twin, batch_max=B)
+    for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+        e.set_params(0, flat_params(actor, an, "log_std" if gaussian else None), kind)
+        e.set_params(1, flat_params(critic, cn), kind)
+    e.add_batch(records([tab]))
+    if gaussian:
+        e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
+        orc = algos.SAC(actor, critic, O, A, 1e-3, 1e-3, 4096)
+    elif algo_id == N.ALGO_TD3:
+        orc = algos.TD3(actor, critic, O, A, 1e-3, 1e-3, 4096)
+    else:
+        orc = algos.DDPG(actor, critic, O, A, 1e-3, 1e-3, 4096)
+    _fill(orc, tab, n_table)
+    got, want, got_a, want_a = [], [], [], []
+    for k in range(n_calls):
+        n0 = g.standard_normal((B, A)).astype(np.float32)
+        n1 = g.standard_normal((B, A)).astype(np.float32)
+        nz = np.zeros((1, 1, 2, B, A), np.float32)
+        nz[0, 0, 0], nz[0, 0, 1] = n0, n1
+        if gaussian:
+            st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4, target_entropy=-float(A),
+                         idx=idx[k], noise=nz, want_stats=True)
+            out = orc.learn_with(idx[k], n0, n1, 0.99, 0.005)
+            do_actor = True
+        elif algo_id == N.ALGO_TD3:
+            do_actor = (k + 1) % 2 == 0
+            st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=do_actor, use_policy_noise=True,
+                         policy_noise=0.2, noise_clip=0.5, max_action=max_action, policy_noise_scale=1.0, idx=idx[k], noise=nz,
+                         want_stats=True)
+            out = orc.learn_with(idx[k], n0, 0.99, 0.005, 0.2, 0.5, max_action, 2, 1.0)
+        else:
+            do_actor = True
+            st = e.learn(B, gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx[k], want_stats=True)
+            out = orc.learn_with(idx[k], None, 0.99, 0.01)
+        got.append(st[0, 0, N.STAT_CRITIC_LOSS]); want.append(out[0])
+        if do_actor:
+            got_a.append(st[0, 0, N.STAT_ACTOR_LOSS]); want_a.append(out[1])
+    # the actor loss (-Q mean) crosses zero: report it against the critic-loss scale instead of its own
+    a_err = np.abs(np.array(got_a, np.float64) - np.array(want_a, np.float64)) / max(1e-6, float(np.mean(np.abs(want))))
+    _check(name, got, want, dict(actor_abs_err_over_critic_scale_max=float(a_err.max())))
+    assert a_err.max() <= 3 * ENV[name][1]
+    e.close()
+
+
+def test_ddpg_500_calls(N):
+    _ac_run(N, "ddpg", N.ALGO_DDPG, 8, 2, 256, 500, twin=False, gaussian=False)
+
+
+def test_td3_config2_dims_batch256_500_calls(N):
+    """BASELINE config 2's own dims (Pendulum: obs 3, act 1, max_action 2) at its batch 256 (TD3.py:189-233, policy_freq 2)."""
+    _ac_run(N, "td3_c2", N.ALGO_TD3, 3, 1, 256, 500, twin=True, gaussian=False, max_action=2.0)
+
+
+def test_sac_500_calls(N):
+    _ac_run(N, "sac", N.ALGO_SAC, 8, 2, 256, 500, twin=True, gaussian=True)
+
+
+def test_maddpg_200_calls(N):
+    """MADDPG_simple.learn (MADDPG_simple.py:165-186): 3 heterogeneous agents, 200 calls (the oracle is ~50 ms per call)."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    c = dict(cases.CASES["maddpg"])
+    n_calls, B = 200, 64
+    c["n_learn"] = 0
+    inp = cases.maddpg_inputs(c)
+    dims = c["dims"]
+    ids = list(dims)
+    e = Engine(N.ALGO_MADDPG, [dims[a][0] for a in ids], [dims[a][1] for a in ids], c["capacity"], batch_max=B)
+    for j, a in enumerate(ids):
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(2 * j, flat_params(inp["params"][a]["actor"], ["l1", "l2", "l3"]), kind)
+            e.set_params(2 * j + 1, flat_params(inp["params"][a]["critic"], ["l1", "l2", "l3"]), kind)
+    e.add_batch(records([inp["tables"][a] for a in ids]))
+    orc = algos.MADDPG(inp["params"], dims, c["actor_lr"], c["critic_lr"], c["capacity"])
+    n_table = c["n_table"]
+    for i in range(n_table):
+        orc.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    g = np.random.default_rng(521)
+    got, want = [], []
+    for k in range(n_calls):
+        idx = np.stack([g.choice(n_table, B, replace=False) for _ in ids]).astype(np.int64)
+        st = e.learn(B, gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], idx=idx[None],
+                     want_stats=True)
+        orc.learn_with([idx[j] for j in range(len(ids))], c["gamma"], c["tau"])
+        got.append([st[0, j, N.STAT_CRITIC_LOSS] for j in range(len(ids))])
+        want.append([orc.critic_losses[a][-1] for a in ids])
+    _check("maddpg", np.array(got).reshape(-1), np.array(want).reshape(-1))
+    e.close()
+
+
+def test_ppo_config3_full_K10(N):
+    """BASELINE config 3 at its full shape (PPO_with_tricks.py:290-354): obs 17, act 6, horizon 2048, minibatch 64,
+    K_epochs 10 = 320 actor + 320 critic steps in one learn(); actor AND critic traces checked through the last epoch."""
+    from freerl_amd.engine import Engine
+    from oracle import ppo as oppo
+    c = dict(cases.CASES["ppo"], obs_dim=17, act_dim=6, horizon=2048, minibatch=64, k_epochs=10, table_seed=531,
+             param_seed=532, perm_seed=533, actor_lr=3e-4, critic_lr=3e-4)
+    inp = cases.ppo_inputs(c)
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    e = Engine(N.ALGO_PPO, O, A, T, batch_max=c["minibatch"], extra_cols=A + 1)
+    an = ["l1", "l2", "mean_layer"]
+    e.set_params(0, flat_params(inp["params"]["actor"], an, "log_std"))
+    e.set_params(1, flat_params(inp["params"]["critic"], ["l1", "l2", "l3"]))
+    tab = inp["table"]
+    extra = np.concatenate([tab["logp"], tab["adv_done"].astype(np.float32).reshape(-1, 1)], axis=1)
+    e.add_batch(records([tab], extra=extra))
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, c["actor_lr"], c["critic_lr"], T, c["trick"])
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), tab["logp"][i],
+                bool(tab["adv_done"][i]))
+    out = e.ppo_learn(T, c["minibatch"], c["k_epochs"], gamma=c["gamma"], lmbda=c["lmbda"], clip=c["clip"], ent_coef=c["ent"],
+                      actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], perms=np.stack(inp["perms"])[None], want_trace=True)
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    tr = out["trace"][0]
+    assert tr.shape[0] == 320
+    _check("ppo_c3_critic", tr[:, 1], np.array(orc.critic_losses))
+    # the surrogate loss is O(advantage mean) and crosses zero: relative to the mean |loss|
+    al = np.array(orc.actor_losses, np.float64)
+    scale = float(np.mean(np.abs(al)))
+    err = np.abs(tr[:, 0].astype(np.float64) - al) / scale
+    REPORT["ppo_c3_actor"] = dict(calls=320, first50_max=float(err[:50].max()), max=float(err.max()),
+                                  by_100=[float(err[i:i + 100].max()) for i in range(0, 320, 100)], scale=scale)
+    assert err[:50].max() <= ENV["ppo_c3_actor"][0] and err.max() <= ENV["ppo_c3_actor"][1], (err[:50].max(), err.max())
+    e.close()

@@ -287,6 +287,81 @@ def test_sac_learn(N):
     e.close()
 
 
+@pytest.mark.parametrize("delta", [0.5, 10.0])
+def test_huber_td_loss_option(N, delta):
+    """frl_learn_args.loss_kind = FRL_LOSS_HUBER (north_star's "Huber/MSE TD-loss"; the reference's huber_loss, MAPPO.py:
+    273-276, pinned on the oracle side by tests/golden/huber.npz): DQN, TD3 and SAC against the oracle with the same
+    injected indices / noise.  delta 0.5 puts most TD errors on the linear branch, 10 (the reference's default) on the
+    quadratic one — where the loss is exactly half the MSE."""
+    from oracle import algos, nn
+    # DQN
+    c = cases.CASES["dqn"]
+    inp = cases.dqn_inputs(c)
+    from freerl_amd.engine import Engine
+    e = Engine(N.ALGO_DQN, c["obs_dim"], c["n_actions"], c["capacity"], discrete=True, batch_max=c["batch"])
+    flat = flat_params(inp["params"]["Qnet"], ["l1", "l2"])
+    e.set_params(0, flat, N.PARAM_ONLINE); e.set_params(0, flat, N.PARAM_TARGET)
+    e.add_batch(records([inp["table"]]))
+    orc = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+    orc.td_loss = nn.huber(delta)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    losses = []
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], critic_lr=c["lr"], clip_norm=0.0, idx=inp["idx"][k],
+                     want_stats=True, huber_delta=delta)
+        losses.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        orc.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    np.testing.assert_allclose(losses, np.array(orc.losses), rtol=LOSS_RTOL)
+    mse = gold("dqn")["loss"]
+    if delta >= 10:
+        np.testing.assert_allclose(losses[0], 0.5 * mse[0], rtol=1e-5)      # all errors quadratic: half the MSE on the first call
+    else:
+        assert losses[0] < 0.5 * mse[0]
+    assert_params_close(unflat_params(e.get_params(0), orc.q, ["l1", "l2"]), orc.q, "huber/dqn")
+    e.close()
+    # TD3 (twin critic: both heads) and SAC
+    for algo_id, name, gaussian in ((N.ALGO_TD3, "td3", False), (N.ALGO_SAC, "sac", True)):
+        c = cases.CASES[name]
+        inp = cases.ac_inputs(c, twin=True, gaussian=gaussian)
+        an = ["l1", "l2", "mean_layer"] if gaussian else AC_NAMES
+        e = _setup_ac(N, algo_id, c, inp, True, an, "log_std" if gaussian else None)
+        if gaussian:
+            e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
+            orc = algos.SAC(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"], c["critic_lr"], c["capacity"])
+        else:
+            orc = algos.TD3(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"], c["critic_lr"], c["capacity"])
+        orc.td_loss = nn.huber(delta)
+        _fill_oracle(orc, inp["table"])
+        got, want = [], []
+        for k in range(c["n_learn"]):
+            if gaussian:
+                nz = np.stack([inp["noise"][k][0], inp["noise"][k][1]])[None, None]
+                st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], alpha_lr=1e-4,
+                             target_entropy=-float(c["act_dim"]), idx=inp["idx"][k], noise=nz, want_stats=True, huber_delta=delta)
+                want.append(orc.learn_with(inp["idx"][k], inp["noise"][k][0], inp["noise"][k][1], c["gamma"], c["tau"])[0])
+            else:
+                nz = np.zeros((1, 1, 2, c["batch"], c["act_dim"]), np.float32)
+                nz[0, 0, 0] = inp["noise"][k][0]
+                st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                             do_actor=(k + 1) % c["policy_freq"] == 0, use_policy_noise=True, policy_noise=c["policy_noise"],
+                             noise_clip=c["noise_clip"], max_action=c["max_action"], policy_noise_scale=c["policy_noise_scale"],
+                             idx=inp["idx"][k], noise=nz, want_stats=True, huber_delta=delta)
+                want.append(orc.learn_with(inp["idx"][k], inp["noise"][k][0], c["gamma"], c["tau"], c["policy_noise"], c["noise_clip"],
+                                           c["max_action"], c["policy_freq"], c["policy_noise_scale"])[0])
+            got.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        np.testing.assert_allclose(got, want, rtol=LOSS_RTOL)
+        _check_ac_params(N, e, orc, True, an, "huber/" + name, "log_std" if gaussian else None)
+        e.close()
+    # refused where it has no meaning
+    e = Engine(N.ALGO_DQN, 4, 3, 64, discrete=True, batch_max=8, c51=(51, -10.0, 10.0))
+    e.fill_synthetic(32, seed=1)
+    with pytest.raises(N.FrlError):
+        e.learn(8, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0, huber_delta=1.0)
+    e.close()
+
+
 def test_maddpg_learn(N):
     from freerl_amd.engine import Engine
     from oracle import algos
@@ -835,6 +910,52 @@ def test_ppo_discrete_learn(N):
         np.testing.assert_allclose(ga[k], orc.actor[k], rtol=2e-3, atol=2e-5, err_msg=k)
     synth.check_digest("actor", ga, fx, 2e-3, 2e-5, "hip-vs-reference")
     e.close()
+
+
+def test_ppo_py_discrete_categorical_logits(N):
+    """PPO_file/PPO.py's discrete policy: Categorical(logits=l3(...)) (PPO.py:78-90,176,257), frl_config.actor_dist = 2, with the
+    cautious AdamW.  The case's logits spread past float eps, so the clamped probs= form gives other numbers (checked on the
+    oracle side); here: engine vs reference golden and vs oracle, through the class (`PPO(..., trick=None)`)."""
+    import torch
+    from freerl_amd.PPO import PPO
+    from oracle import ppo as oppo
+    c = cases.CASES["ppo_py_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    fx = gold("ppo_py_discrete")
+    O, nA, T = c["obs_dim"], c["n_actions"], c["horizon"]
+    pol = PPO([O, nA], False, c["actor_lr"], c["critic_lr"], T, "cuda", trick=None, minibatch_max=c["minibatch"])
+    assert pol._e.cfg.actor_dist == 2
+    pol.agent.actor.load_state_dict({k: torch.as_tensor(v) for k, v in inp["params"]["actor"].items()})
+    pol.agent.critic.load_state_dict({k: torch.as_tensor(v) for k, v in inp["params"]["critic"].items()})
+    tab = inp["table"]
+    np.testing.assert_array_equal(np.array([pol.evaluate_action(tab["obs"][i]) for i in range(16)]), fx["evaluate_action"])
+    sel = []
+    for i in range(12):
+        torch.manual_seed(900 + i)              # the class draws q = empty(1, nA).exponential_(1) like Categorical.sample()
+        sel.append(pol.select_action(tab["obs"][i]))
+    np.testing.assert_array_equal(np.array([int(a) for a, _ in sel]), fx["select_action"])
+    np.testing.assert_allclose(np.array([float(lp) for _, lp in sel]), fx["select_logp"], rtol=1e-5, atol=1e-6)
+    orc = oppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, nA, c["actor_lr"], c["critic_lr"], T, c["trick"],
+                   discrete=True, optimizer="c_adamw", cat_logits=True)
+    for i in range(T):
+        args = (tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), tab["logp"][i],
+                bool(tab["adv_done"][i]))
+        pol.add(*args); orc.add(*args)
+    pol.track_loss = True
+    perms = iter(inp["perms"])
+    orig = np.random.permutation
+    np.random.permutation = lambda n: next(perms)
+    try:
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    finally:
+        np.random.permutation = orig
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    tr = pol.last_trace
+    np.testing.assert_allclose(tr[0, :, 0], fx["loss_actor"], rtol=5e-4, atol=5e-6)
+    np.testing.assert_allclose(tr[0, :, 1], fx["loss_critic"], rtol=5e-4)
+    np.testing.assert_allclose(tr[0, :, 0], np.array(orc.actor_losses), rtol=5e-4, atol=5e-6)
+    ga = {k: v.numpy() for k, v in pol.agent.actor.state_dict().items()}
+    synth.check_digest("actor", ga, fx, 5e-3, 5e-4, "hip-vs-reference")
 
 
 def test_ddpg_full_batch_obs_norm_and_weight_decay(N):

@@ -541,3 +541,53 @@ def test_sac_batch_obs_norm():
     np.testing.assert_allclose(pol.bn.running_ms.std, fx["bn_std"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(pol.alpha, fx["alpha"], rtol=1e-6)
     _check_ac(pol, fx, 5e-3, 5e-5, moments=False)
+
+
+def test_huber_matches_reference_function():
+    """oracle.nn.huber against the reference's huber_loss (MAPPO_file/MAPPO.py:273-276) run under autograd: element values,
+    mean, and the gradient of the mean (tests/golden/huber.npz, generated by make_golden.gen_huber)."""
+    from oracle import nn
+    fx = np.load(os.path.join(GOLD, "huber.npz"))
+    a = synth.normal(7001, (256, 1)) * np.float32(6.0)
+    b = synth.normal(7002, (256, 1))
+    for tag, d in (("1", 1.0), ("10", 10.0)):
+        loss, grad = nn.huber(d)(a, b)
+        np.testing.assert_allclose(loss, fx["loss_" + tag], rtol=1e-6)
+        np.testing.assert_allclose(grad, fx["grad_" + tag], rtol=1e-6, atol=1e-9)
+        assert (np.abs(a - b) > d).any() and (np.abs(a - b) <= d).any()          # both branches are exercised
+
+
+def test_ppo_py_discrete_categorical_logits():
+    """PPO_file/PPO.py, is_continue=False: Categorical(logits=l3(...)) (PPO.py:78-90,176,257) + the cautious AdamW.  The
+    case's head is scaled so that some probabilities fall below float eps — the PPO_with_tricks.py form (clamped
+    Categorical(probs=softmax)) must NOT reproduce these numbers."""
+    import torch
+    c = cases.CASES["ppo_py_discrete"]
+    inp = cases.ppo_discrete_inputs(c)
+    fx = gold("ppo_py_discrete")
+    tab = inp["table"]
+
+    def run(cat_logits):
+        pol = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["n_actions"], c["actor_lr"],
+                      c["critic_lr"], c["horizon"], c["trick"], discrete=True, optimizer="c_adamw", cat_logits=cat_logits)
+        for i in range(c["horizon"]):
+            pol.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                    tab["logp"][i], bool(tab["adv_done"][i]))
+        sel = []
+        for i in range(12):
+            torch.manual_seed(900 + i)
+            q = torch.empty(1, c["n_actions"]).exponential_(1).numpy()
+            sel.append(pol.select_action_discrete(tab["obs"][i], q))
+        ev = np.array([pol.evaluate_action(tab["obs"][i]) for i in range(16)])
+        pol.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+        return pol, sel, ev
+    pol, sel, ev = run(True)
+    np.testing.assert_array_equal(ev, fx["evaluate_action"])
+    np.testing.assert_array_equal(np.array([a for a, _ in sel]), fx["select_action"])
+    np.testing.assert_allclose(np.array([lp for _, lp in sel]), fx["select_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.array(pol.actor_losses), fx["loss_actor"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(np.array(pol.critic_losses), fx["loss_critic"], rtol=2e-4)
+    synth.check_digest("actor", pol.actor, fx, 5e-3, 5e-4)
+    synth.check_digest("critic", pol.critic, fx, 5e-3, 5e-4)
+    other, sel2, _ = run(False)
+    assert np.max(np.abs(np.array(other.actor_losses) - fx["loss_actor"]) / np.abs(fx["loss_actor"])) > 1e-3
