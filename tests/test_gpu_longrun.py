@@ -20,17 +20,22 @@ pytestmark = pytest.mark.gpu
 REPORT = {}
 H = 128
 
-# (first 50 calls, whole run): max relative error of the per-call TD / critic loss, HIP vs oracle.  Measured on MI355X
-# (profiles/r02/longrun_report.json holds the curves); asserted with ~3x headroom.
+# name -> (calls in the tight window, tolerance there, tolerance over the whole run): max relative error of the per-call TD /
+# critic loss, HIP vs oracle.  Measured on MI355X (profiles/r02/longrun_report.json holds the curves).  DQN and PPO have no
+# actor-through-critic feedback and stay at rounding level for the whole run; the actor-critic families stay at rounding
+# level for ~100 calls and then drift apart exponentially — and so does the oracle against ITSELF when every parameter
+# is nudged by one float32 ulp (the `self_drift` each test measures next to the HIP drift): the trajectory is chaotic in
+# fp32, no implementation can hold 1e-4 at 500 calls, the reference on another BLAS would not either.
 ENV = {
-    "dqn": (1e-4, 1e-3),
-    "ddpg": (1e-4, 3e-3),
-    "td3_c2": (1e-4, 3e-3),
-    "sac": (1e-4, 3e-3),
-    "maddpg": (2e-4, 5e-3),
-    "ppo_c3_critic": (2e-3, 2e-2),
-    "ppo_c3_actor": (2e-3, 2e-2),
+    "dqn": (500, 1e-5, 1e-5),
+    "ddpg": (100, 1e-4, 5e-2),
+    "td3_c2": (100, 1e-4, 5e-2),
+    "sac": (100, 1e-4, 5e-2),
+    "maddpg": (30, 1e-4, 1e-1),
+    "ppo_c3_critic": (320, 1e-5, 1e-5),
+    "ppo_c3_actor": (320, 1e-4, 1e-4),
 }
+SELF_DRIFT_FACTOR = 30.0      # HIP drift <= this x the oracle's own 1-ulp drift (+ 1e-4): same order of magnitude, not a bug
 
 
 @pytest.fixture(scope="module")
@@ -54,15 +59,29 @@ def _relerr(got, want, floor=1e-6):
     return np.abs(got - want) / np.maximum(np.abs(want), floor)
 
 
-def _check(name, got, want, extra=None):
+def _check(name, got, want, extra=None, self_want=None):
     err = _relerr(got, want)
     n = len(err)
-    REPORT[name] = dict(calls=n, first50_max=float(err[:50].max()), max=float(err.max()),
-                        by_100=[float(err[i:i + 100].max()) for i in range(0, n, 100)],
+    REPORT[name] = dict(calls=n, max=float(err.max()), by_100=[float(err[i:i + 100].max()) for i in range(0, n, 100)],
                         loss_first=float(want[0]), loss_last=float(want[-1]), **(extra or {}))
-    lo, hi = ENV[name]
-    assert err[:50].max() <= lo, (name, "first 50 calls", err[:50].max())
-    assert err.max() <= hi, (name, "whole run", err.max(), int(err.argmax()))
+    n_tight, tight, whole = ENV[name]
+    REPORT[name]["tight_window"] = [n_tight, float(err[:n_tight].max())]
+    assert err[:n_tight].max() <= tight, (name, "first %d calls" % n_tight, err[:n_tight].max())
+    assert err.max() <= whole, (name, "whole run", err.max(), int(err.argmax()))
+    if self_want is not None:        # the oracle against itself, every parameter nudged by one ulp
+        sd = _relerr(self_want, want)
+        REPORT[name]["self_drift_by_100"] = [float(sd[i:i + 100].max()) for i in range(0, n, 100)]
+        assert err.max() <= SELF_DRIFT_FACTOR * sd.max() + 1e-4, (name, err.max(), sd.max())
+
+
+def _nudge(params, seed):
+    """Every parameter moved by one float32 ulp in a random direction: a rounding-sized perturbation everywhere."""
+    g = np.random.default_rng(seed)
+    out = {}
+    for k, v in params.items():
+        v = np.asarray(v, np.float32)
+        out[k] = np.nextafter(v, np.where(g.random(v.shape) < 0.5, -np.inf, np.inf).astype(np.float32)).astype(np.float32)
+    return out
 
 
 def _idx(seed, n_calls, n_table, batch):
@@ -119,13 +138,15 @@ def _ac_run(N, name, algo_id, O, A, B, n_calls, twin, gaussian, max_action=1.0):
     e.add_batch(records([tab]))
     if gaussian:
         e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
-        orc = algos.SAC(actor, critic, O, A, 1e-3, 1e-3, 4096)
+        mk = lambda a_p, c_p: algos.SAC(a_p, c_p, O, A, 1e-3, 1e-3, 4096)
     elif algo_id == N.ALGO_TD3:
-        orc = algos.TD3(actor, critic, O, A, 1e-3, 1e-3, 4096)
+        mk = lambda a_p, c_p: algos.TD3(a_p, c_p, O, A, 1e-3, 1e-3, 4096)
     else:
-        orc = algos.DDPG(actor, critic, O, A, 1e-3, 1e-3, 4096)
+        mk = lambda a_p, c_p: algos.DDPG(a_p, c_p, O, A, 1e-3, 1e-3, 4096)
+    orc, orc2 = mk(actor, critic), mk(_nudge(actor, 91), _nudge(critic, 92))
     _fill(orc, tab, n_table)
-    got, want, got_a, want_a = [], [], [], []
+    _fill(orc2, tab, n_table)
+    got, want, got_a, want_a, want2 = [], [], [], [], []
     for k in range(n_calls):
         n0 = g.standard_normal((B, A)).astype(np.float32)
         n1 = g.standard_normal((B, A)).astype(np.float32)
@@ -135,6 +156,7 @@ def _ac_run(N, name, algo_id, O, A, B, n_calls, twin, gaussian, max_action=1.0):
             st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4, target_entropy=-float(A),
                          idx=idx[k], noise=nz, want_stats=True)
             out = orc.learn_with(idx[k], n0, n1, 0.99, 0.005)
+            want2.append(orc2.learn_with(idx[k], n0, n1, 0.99, 0.005)[0])
             do_actor = True
         elif algo_id == N.ALGO_TD3:
             do_actor = (k + 1) % 2 == 0
@@ -142,17 +164,19 @@ def _ac_run(N, name, algo_id, O, A, B, n_calls, twin, gaussian, max_action=1.0):
                          policy_noise=0.2, noise_clip=0.5, max_action=max_action, policy_noise_scale=1.0, idx=idx[k], noise=nz,
                          want_stats=True)
             out = orc.learn_with(idx[k], n0, 0.99, 0.005, 0.2, 0.5, max_action, 2, 1.0)
+            want2.append(orc2.learn_with(idx[k], n0, 0.99, 0.005, 0.2, 0.5, max_action, 2, 1.0)[0])
         else:
             do_actor = True
             st = e.learn(B, gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx[k], want_stats=True)
             out = orc.learn_with(idx[k], None, 0.99, 0.01)
+            want2.append(orc2.learn_with(idx[k], None, 0.99, 0.01)[0])
         got.append(st[0, 0, N.STAT_CRITIC_LOSS]); want.append(out[0])
         if do_actor:
             got_a.append(st[0, 0, N.STAT_ACTOR_LOSS]); want_a.append(out[1])
     # the actor loss (-Q mean) crosses zero: report it against the critic-loss scale instead of its own
     a_err = np.abs(np.array(got_a, np.float64) - np.array(want_a, np.float64)) / max(1e-6, float(np.mean(np.abs(want))))
-    _check(name, got, want, dict(actor_abs_err_over_critic_scale_max=float(a_err.max())))
-    assert a_err.max() <= 3 * ENV[name][1]
+    _check(name, got, want, dict(actor_abs_err_over_critic_scale_max=float(a_err.max())), self_want=want2)
+    assert a_err.max() <= 3 * ENV[name][2]
     e.close()
 
 
@@ -169,13 +193,13 @@ def test_sac_500_calls(N):
     _ac_run(N, "sac", N.ALGO_SAC, 8, 2, 256, 500, twin=True, gaussian=True)
 
 
-def test_maddpg_200_calls(N):
-    """MADDPG_simple.learn (MADDPG_simple.py:165-186): 3 heterogeneous agents, 200 calls (the oracle is ~50 ms per call)."""
+def test_maddpg_150_calls(N):
+    """MADDPG_simple.learn (MADDPG_simple.py:165-186): 3 heterogeneous agents, 1024-row table, batch 128, 150 calls x 3 agents
+    (the oracle is ~0.1 s per call)."""
     from freerl_amd.engine import Engine
     from oracle import algos
-    c = dict(cases.CASES["maddpg"])
-    n_calls, B = 200, 64
-    c["n_learn"] = 0
+    c = dict(cases.CASES["maddpg"], n_table=1024, capacity=2048, n_learn=0)
+    n_calls, B = 150, 128
     inp = cases.maddpg_inputs(c)
     dims = c["dims"]
     ids = list(dims)
@@ -186,13 +210,19 @@ def test_maddpg_200_calls(N):
             e.set_params(2 * j + 1, flat_params(inp["params"][a]["critic"], ["l1", "l2", "l3"]), kind)
     e.add_batch(records([inp["tables"][a] for a in ids]))
     orc = algos.MADDPG(inp["params"], dims, c["actor_lr"], c["critic_lr"], c["capacity"])
+    nudged = {a: dict(actor=_nudge(inp["params"][a]["actor"], 93 + j), critic=_nudge(inp["params"][a]["critic"], 96 + j))
+              for j, a in enumerate(ids)}
+    orc2 = algos.MADDPG(nudged, dims, c["actor_lr"], c["critic_lr"], c["capacity"])
     n_table = c["n_table"]
     for i in range(n_table):
+        orc2.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                 {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                 {a: bool(inp["tables"][a]["done"][i]) for a in ids})
         orc.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
                 {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
                 {a: bool(inp["tables"][a]["done"][i]) for a in ids})
     g = np.random.default_rng(521)
-    got, want = [], []
+    got, want, want2 = [], [], []
     for k in range(n_calls):
         idx = np.stack([g.choice(n_table, B, replace=False) for _ in ids]).astype(np.int64)
         st = e.learn(B, gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], idx=idx[None],
@@ -200,7 +230,9 @@ def test_maddpg_200_calls(N):
         orc.learn_with([idx[j] for j in range(len(ids))], c["gamma"], c["tau"])
         got.append([st[0, j, N.STAT_CRITIC_LOSS] for j in range(len(ids))])
         want.append([orc.critic_losses[a][-1] for a in ids])
-    _check("maddpg", np.array(got).reshape(-1), np.array(want).reshape(-1))
+        orc2.learn_with([idx[j] for j in range(len(ids))], c["gamma"], c["tau"])
+        want2.append([orc2.critic_losses[a][-1] for a in ids])
+    _check("maddpg", np.array(got).reshape(-1), np.array(want).reshape(-1), self_want=np.array(want2).reshape(-1))
     e.close()
 
 
@@ -234,7 +266,7 @@ def test_ppo_config3_full_K10(N):
     al = np.array(orc.actor_losses, np.float64)
     scale = float(np.mean(np.abs(al)))
     err = np.abs(tr[:, 0].astype(np.float64) - al) / scale
-    REPORT["ppo_c3_actor"] = dict(calls=320, first50_max=float(err[:50].max()), max=float(err.max()),
-                                  by_100=[float(err[i:i + 100].max()) for i in range(0, 320, 100)], scale=scale)
-    assert err[:50].max() <= ENV["ppo_c3_actor"][0] and err.max() <= ENV["ppo_c3_actor"][1], (err[:50].max(), err.max())
+    REPORT["ppo_c3_actor"] = dict(calls=320, max=float(err.max()), by_100=[float(err[i:i + 100].max()) for i in range(0, 320, 100)],
+                                  scale=scale)
+    assert err.max() <= ENV["ppo_c3_actor"][2], err.max()
     e.close()
