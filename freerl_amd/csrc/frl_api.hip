@@ -23,6 +23,7 @@
 #include "kernels_actor.hip"
 #include "kernels_act.hip"
 #include "kernels_ppo.hip"
+#include "kernels_ppo2.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
@@ -475,6 +476,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+        if (h.algo == ALGO_PPO) {
+            const int lb = ppo2_lds_floats(2) * (int)sizeof(float);
+            CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_v2_k1_relu, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_v2_k2_relu, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_v2_k1_tanh, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_v2_k2_tanh, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        }
     }
     CREATE_TRY(hipStreamSynchronize(e->stream));
     *out = e;

@@ -168,4 +168,11 @@ __global__ void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau, int p0);
 
+// kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>
+__global__ void ppo_update_v2_k1_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_update_v2_k2_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_update_v2_k1_tanh(const EngineDesc* __restrict__ Dp, PpoArgs a);
+__global__ void ppo_update_v2_k2_tanh(const EngineDesc* __restrict__ Dp, PpoArgs a);
+constexpr int ppo2_lds_floats(int k0b) { return 8 * k0b * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 96; }
+
 }  // namespace frl

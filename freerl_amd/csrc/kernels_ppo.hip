@@ -237,6 +237,19 @@ __global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict_
     gae_scan(as_global(delta + o), as_global(adv_done + o), 1, 0, T, c, as_global(adv + o), (lds_f)lds_s);
 }
 
+// Developer instrument (tools/ppo_timing.py; -DFRL_PPO_TIMING, unity build): thread 0 of learner 0's two workgroups adds up
+// the shader clock per section of a minibatch step.
+#ifdef FRL_PPO_TIMING
+__device__ long long g_ppo_clk[2][8];
+#define PPO_T0() long long t_prev_ = clock64(); long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PPO_T(slot) do { const long long t_now_ = clock64(); t_acc_[slot] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
+#define PPO_TDUMP() do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_ppo_clk[blockIdx.y][i_] = t_acc_[i_]; } while (0)
+#else
+#define PPO_T0() do {} while (0)
+#define PPO_T(slot) do {} while (0)
+#define PPO_TDUMP() do {} while (0)
+#endif
+
 // ---- all minibatch updates of one learner in one launch
 __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -268,6 +281,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     float* trace = a.trace + (size_t)p * a.k_epochs * n_mb * 2;
     constexpr float kHalfLog2PiPlusHalf = 1.41893853320467274178f;   // 0.5 + 0.5*log(2*pi)
     constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+    PPO_T0();
 
     for (int k = 0; k < a.k_epochs; ++k) {
         g_ci perm = as_global_i(a.perm + ((size_t)p * a.k_epochs + k) * T);
@@ -290,7 +304,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 zero_cols(S.xin, S.xp, rc, O, NA.L[0].k_pad);
                 if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, O, bn, O); }
                 __syncthreads();
+                PPO_T(0);
                 mlp_fwd(NA, 0, NA.n_layers, thA, S, (discrete || beta) ? ACT_NONE : ACT_TANH);    // mean = tanh(mean_layer(.)) (:99)
+                PPO_T(1);
                 if (beta) {
                     // Beta(alpha, beta) per action dimension (:325-332): alpha = softplus(z_a) + 1, beta = softplus(z_b) + 1;
                     // log_prob(a) = (alpha-1) ln a + (beta-1) ln(1-a) - ln B; entropy = ln B - (alpha-1) psi(alpha) -
@@ -432,7 +448,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 }
                 // one call site for the three policy distributions (every inlined copy of the backward pass is ~20 k
                 // instructions of a kernel that walks its whole code once per minibatch step)
+                PPO_T(2);
                 mlp_bwd(NA, 0, NA.n_layers, thA, gA, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
+                PPO_T(3);
             }
             if (!discrete && !beta && threadIdx.x < A) {
                 const float raw = thA[NA.extra_off + threadIdx.x];
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 adam_net(NA.size, thA, as_global(D.m + offA), as_global(D.v + offA), gA, nullptr, a.actor_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                          a.clip_norm, tA, 0.f, S.red);
             __syncthreads();
+            PPO_T(4);
             if (threadIdx.x == 0) trace[2 * j_tr] = aloss;
             }
             if (!do_critic) continue;
@@ -458,7 +477,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 zero_cols(S.xin, S.xp, rc, O, NC.L[0].k_pad);
                 if (bn) { __syncthreads(); normalize_cols(S.xin, S.xp, nv, 0, O, bn, O); }
                 __syncthreads();
+                PPO_T(0);
                 mlp_fwd(NC, 0, NC.n_layers, thC, S, ACT_NONE);
+                PPO_T(1);
                 for (int e = threadIdx.x; e < rc * ncpad; e += kWG) {
                     const int r = e / ncpad, c = e - r * ncpad;
                     float d = 0.f;
@@ -470,7 +491,9 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                     S.outb[r * S.op + c] = d;
                 }
                 __syncthreads();
+                PPO_T(2);
                 mlp_bwd(NC, 0, NC.n_layers, thC, gC, S, r0 == 0 ? GS_STORE : GS_ADD, false, 0, 0);
+                PPO_T(3);
             }
             const float closs = block_sum(closs_p, S.red) * invm;
             __syncthreads();
@@ -481,6 +504,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
                 adam_net(NC.size, thC, as_global(D.m + offC), as_global(D.v + offC), gC, nullptr, a.critic_lr, a.adam_eps, a.beta1, a.beta2, 0.f,
                          a.clip_norm, tC, 0.f, S.red);
             __syncthreads();
+            PPO_T(4);
             if (threadIdx.x == 0) trace[2 * j_tr + 1] = closs;
         }
     }
@@ -490,6 +514,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
         if (do_actor) { steps[0] = tA; st[ST_ACTOR_LOSS] = trace[2 * j]; }
         if (do_critic) { steps[1] = tC; st[ST_CRITIC_LOSS] = trace[2 * j + 1]; }
     }
+    PPO_TDUMP();
 }
 
 }  // namespace frl
