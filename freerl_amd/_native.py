@@ -149,6 +149,7 @@ SIGNATURES = {
     "frl_per_state": (_i, [_vp, _i, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
+    "frl_ppo_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "frl_envpool_create": (_i, [_i, _i, _i, C.c_uint64, _P(C.c_double), _i, _P(_vp)]),
     "frl_envpool_create_callback": (_i, [_i, _i, _i, _i, _f, ENV_STEP_FN, ENV_RESET_FN, _vp, _P(_vp)]),

@@ -1,0 +1,17 @@
+#pragma once
+#include <hip/hip_runtime.h>
+namespace frl {
+// Developer instrument (tools/ppo_timing.py; -DFRL_PPO_TIMING, unity build): thread 0 of learner 0's two workgroups adds up
+// the shader clock per section of a minibatch step.
+#ifdef FRL_PPO_TIMING
+__device__ long long g_ppo_clk[2][8];
+#define PPO_T0() long long t_prev_ = clock64(); long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PPO_T(slot) do { const long long t_now_ = clock64(); t_acc_[slot] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
+#define PPO_TDUMP() do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_ppo_clk[blockIdx.y][i_] = t_acc_[i_]; } while (0)
+#else
+#define PPO_T0() do {} while (0)
+#define PPO_T(slot) do {} while (0)
+#define PPO_TDUMP() do {} while (0)
+#endif
+
+}  // namespace frl

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "device/net.hpp"
 #include "device/special.hpp"
+#include "device/ppo_timing.hpp"
 
 namespace frl {
 
@@ -236,19 +237,6 @@ __global__ __launch_bounds__(256) void gae_dense_kernel(const float* __restrict_
     const size_t o = (size_t)blockIdx.x * T;
     gae_scan(as_global(delta + o), as_global(adv_done + o), 1, 0, T, c, as_global(adv + o), (lds_f)lds_s);
 }
-
-// Developer instrument (tools/ppo_timing.py; -DFRL_PPO_TIMING, unity build): thread 0 of learner 0's two workgroups adds up
-// the shader clock per section of a minibatch step.
-#ifdef FRL_PPO_TIMING
-__device__ long long g_ppo_clk[2][8];
-#define PPO_T0() long long t_prev_ = clock64(); long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define PPO_T(slot) do { const long long t_now_ = clock64(); t_acc_[slot] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
-#define PPO_TDUMP() do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_ppo_clk[blockIdx.y][i_] = t_acc_[i_]; } while (0)
-#else
-#define PPO_T0() do {} while (0)
-#define PPO_T(slot) do {} while (0)
-#define PPO_TDUMP() do {} while (0)
-#endif
 
 // ---- all minibatch updates of one learner in one launch
 __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __restrict__ Dp, PpoArgs a) {

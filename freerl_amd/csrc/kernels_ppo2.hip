@@ -24,6 +24,7 @@
 
 #include "kernels.h"
 #include "device/net.hpp"
+#include "device/ppo_timing.hpp"
 
 namespace frl {
 
@@ -70,13 +71,17 @@ __device__ __forceinline__ f32x4 mfma4(f32x4 acc, const f32x4& a, const f32x4& b
     return acc;
 }
 
-// torch's single-tensor Adam on one element (clip coefficient already folded into g)
-__device__ __forceinline__ float adam_elem(float th, float g, float& m, float& v, float w1, float w2, float b2, float bc2s,
+// torch's single-tensor Adam on one element (clip coefficient already folded into g).  The moments are exact fp32
+// fma chains like everywhere else; the step itself, step * m / (sqrt(v) / sqrt(bc2) + eps), uses the hardware's 1-ulp
+// sqrt and reciprocal instead of the correctly rounded sequences (3 x ~10 VALU instructions per element, 88 elements per
+// lane and step: the difference between a 28 k and an 8 k cycle Adam phase).  Its relative error (<= ~3 ulp of the UPDATE,
+// which is itself ~lr times smaller than the parameter) is below the rounding of the subtraction that applies it.
+__device__ __forceinline__ float adam_elem(float th, float g, float& m, float& v, float w1, float w2, float b2, float inv_bc2s,
                                            float eps, float step) {
     m = m + (g - m) * w1;
     v = v * b2 + (w2 * g) * g;
-    const float denom = sqrtf(v) / bc2s + eps;
-    return th - step * (m / denom);
+    const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2s + eps;
+    return th - step * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 }  // namespace
@@ -166,9 +171,49 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
     }
     __syncthreads();
 
+    // the rows of one 64-row chunk as this lane needs them: its column's observation (B operand of layer 1) and, for the
+    // head's four outputs it will hold, the stored action / old log-probs; loaded one step AHEAD (before the reductions and
+    // Adam of the current step) so that the dependent perm -> record round trips are off the critical path
+    struct Rows { f32x4 xb[K0B]; f32x4 act, lpo; float tgt; int valid; };
+    auto load_rows = [&](int k, int s, int r0, int m) {
+        Rows X;
+        const int row = r0 + 16 * w + i16;
+        X.valid = row < m ? 1 : 0;
+        const int ridx = X.valid ? as_global_i(a.perm + ((size_t)p * a.k_epochs + k) * T)[s + row] : 0;
+        g_cf rec = ring + (size_t)ridx * R.stride;
+#pragma unroll
+        for (int kb = 0; kb < K0B; ++kb) {
+            const int c0 = kb * 16 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = 0.f;
+                if (X.valid && c0 + e < O) {
+                    x = rec[R.obs_off[0] + c0 + e];
+                    if (bn) x = (x - bn[1 + c0 + e]) / (bn[1 + 2 * O + c0 + e] + 1e-8f);     // Batch_ObsNorm (normalization.py:78-84)
+                }
+                X.xb[kb][e] = x;
+            }
+        }
+        X.act = f32x4{0.f, 0.f, 0.f, 0.f}; X.lpo = f32x4{0.f, 0.f, 0.f, 0.f}; X.tgt = 0.f;
+        if (X.valid) {
+            if (critic) X.tgt = vt[ridx];
+            else {
+                X.tgt = adv[ridx];
+                if (discrete) { X.act[0] = rec[R.act_off[0]]; X.lpo[0] = rec[logp_col]; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * q + r < A) { X.act[r] = rec[R.act_off[0] + 4 * q + r]; X.lpo[r] = rec[logp_col + 4 * q + r]; }
+                }
+            }
+        }
+        return X;
+    };
+    double pw1 = powi_d((double)a.beta1, t_step), pw2 = powi_d((double)a.beta2, t_step);      // beta^t, advanced per step
     float last_loss = 0.f;
+    Rows nxt = load_rows(0, 0, 0, min(mb, T));
+    PPO_T0();
     for (int k = 0; k < a.k_epochs; ++k) {
-        g_ci perm = as_global_i(a.perm + ((size_t)p * a.k_epochs + k) * T);
         for (int s = 0; s < T; s += mb) {
             const int m = min(mb, T - s);
             const float invm = 1.f / (float)m;
@@ -185,24 +230,11 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             }
             for (int r0 = 0; r0 < m; r0 += 64) {
                 // ---------------------------------------------------------------- this wave's 16 rows, in registers
-                const int row = r0 + 16 * w + i16;                 // minibatch row of this lane's column
-                const bool valid = row < m;
-                const int ridx = valid ? perm[s + row] : 0;
-                g_cf rec = ring + (size_t)ridx * R.stride;
+                const Rows cur = (r0 == 0) ? nxt : load_rows(k, s, r0, m);
+                const bool valid = cur.valid != 0;
                 f32x4 xb[K0B];                                     // B operand of layer 1: X[in = 16 kb + 4q + e][row]
 #pragma unroll
-                for (int kb = 0; kb < K0B; ++kb) {
-                    const int c0 = kb * 16 + 4 * q;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = 0.f;
-                        if (valid && c0 + e < O) {
-                            x = rec[R.obs_off[0] + c0 + e];
-                            if (bn) x = (x - bn[1 + c0 + e]) / (bn[1 + 2 * O + c0 + e] + 1e-8f);     // Batch_ObsNorm (normalization.py:78-84)
-                        }
-                        xb[kb][e] = x;
-                    }
-                }
+                for (int kb = 0; kb < K0B; ++kb) xb[kb] = cur.xb[kb];
                 // layer 1
                 f32x4 h1[kHT], h2[kHT];
 #pragma unroll
@@ -230,11 +262,12 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                 for (int kb = 0; kb < kHT; ++kb)
                     z = mfma4(z, ld4((lds_cf)(S.w3 + kb * 256 + ((q * 16 + (i16 ^ q)) << 2))), h2[kb]);
 
+                PPO_T(0);
                 // ---------------------------------------------------------------- per-row loss and head delta dz[out][row]
                 f32x4 dz = {0.f, 0.f, 0.f, 0.f};
                 if (critic) {                                      // mse(v_target[idx], V(obs[idx])) (:349-351)
                     if (valid && q == 0) {
-                        const float diff = z[0] - vt[ridx];
+                        const float diff = z[0] - cur.tgt;
                         dz[0] = 2.f * diff * invm;
                         lossp += diff * diff;
                     }
@@ -249,7 +282,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                         const float lsr = fminf(fmaxf(S.ls[c & 15], -20.f), 2.f);
                         mean[r] = tanhf(z[r]);
                         var[r] = expf(2.f * lsr);
-                        dm[r] = (valid && c < A) ? rec[R.act_off[0] + c] - mean[r] : 0.f;
+                        dm[r] = (valid && c < A) ? cur.act[r] - mean[r] : 0.f;
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {                   // sequential over lane groups: dims 0..3, 4..7, ...
@@ -262,7 +295,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                                 if (c < A) {
                                     const float lsr = fminf(fmaxf(S.ls[c], -20.f), 2.f), sd = expf(lsr);
                                     lp_now += -(dm[r] * dm[r]) / (2.f * sd * sd) - lsr - kLogSqrt2Pi_;
-                                    lp_old += valid ? rec[logp_col + c] : 0.f;
+                                    lp_old += cur.lpo[r];
                                 }
                             }
                         }
@@ -270,7 +303,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     lp_now = __shfl(lp_now, i16 + 48, 64); lp_old = __shfl(lp_old, i16 + 48, 64);
                     float coef = 0.f;
                     if (valid) {
-                        const float ratio = expf(lp_now - lp_old), Ar = adv[ridx];
+                        const float ratio = expf(lp_now - lp_old), Ar = cur.tgt;
                         const float s1 = ratio * Ar, s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
                         if (q == 0) lossp += -fminf(s1, s2);
                         coef = (s1 <= s2 ? Ar : 0.f) * (-invm) * ratio;      // d loss / d sum_c logp_now
@@ -318,13 +351,13 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) et[r] = (4 * q + r < A) ? lg[r] * pc[r] : 0.f;
                     const float entr = -seq_sum(et);
-                    const int ar = valid ? (int)rec[R.act_off[0]] : 0;
+                    const int ar = (int)cur.act[0];                 // every lane group loaded the row's action index
                     float lp_now = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (4 * q + r == ar) lp_now = lg[r];
                     lp_now += __shfl_xor(lp_now, 16, 64); lp_now += __shfl_xor(lp_now, 32, 64);      // one group holds it, the others 0
                     if (valid) {
-                        const float ratio = expf(lp_now - rec[logp_col]), Ar = adv[ridx];
+                        const float ratio = expf(lp_now - cur.lpo[0]), Ar = cur.tgt;
                         const float s1 = ratio * Ar, s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
                         if (q == 0) lossp += -fminf(s1, s2) - a.ent_coef * entr;
                         const float coef = (s1 <= s2 ? Ar : 0.f) * (-invm) * ratio;
@@ -335,6 +368,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     }
                 }
 
+                PPO_T(1);
                 // ---------------------------------------------------------------- exchange 1: H2 and dz -> head gradient
                 lds_barrier();                                     // the previous chunk's / step's readers of ea / eb are done
                 const int wslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);          // + ((f16 ^ (i16 >> 2)) << 2)
@@ -366,6 +400,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d2[it][r] = acc[r] * hact_grad<HACT>(h2[it][r]);
                 }
+                PPO_T(2);
                 lds_barrier();
                 // ---------------------------------------------------------------- exchange 2: H1 and dz2 -> layer-2 gradient
 #pragma unroll
@@ -402,6 +437,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d1[it][r] = acc[r] * hact_grad<HACT>(h1[it][r]);
                 }
+                PPO_T(3);
                 lds_barrier();
                 // ---------------------------------------------------------------- exchange 3: X and dz1 -> layer-1 gradient
 #pragma unroll
@@ -426,6 +462,12 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                 }
             }
 
+            PPO_T(4);
+            {       // the next step's rows: in flight during the reductions and Adam
+                int k2 = k, s2 = s + mb;
+                if (s2 >= T) { s2 = 0; ++k2; }
+                if (k2 < a.k_epochs) nxt = load_rows(k2, s2, 0, min(mb, T - s2));
+            }
             // -------------------------------------------------------------------- bias / log_std gradients, norm, loss
             // bias partials: lane (i16, q) summed rows 4q..4q+3 of every 16-row block: add the four lane groups
 #pragma unroll
@@ -478,14 +520,16 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             float coef = 1.f;
             if (a.clip_norm > 0.f) coef = fminf(a.clip_norm / (total + 1e-6f), 1.f);
             ++t_step;
-            const double bc1 = 1.0 - powi_d((double)a.beta1, t_step), bc2 = 1.0 - powi_d((double)a.beta2, t_step);
-            const float step = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
+            pw1 *= (double)a.beta1; pw2 *= (double)a.beta2;
+            const double bc1 = 1.0 - pw1, bc2 = 1.0 - pw2;
+            const float step = (float)((double)lr / bc1), inv_bc2s = 1.f / (float)sqrt(bc2);
             const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
 
+            PPO_T(5);
             // -------------------------------------------------------------------- clip + Adam from the accumulators
             // (every wave finished its backward chain before the barriers above: the weights may change now)
             auto upd = [&](lds_f W, int dw, float g, float& mm, float& vv) {
-                W[dw] = adam_elem(W[dw], g * coef, mm, vv, w1, w2, a.beta2, bc2s, a.adam_eps, step);
+                W[dw] = adam_elem(W[dw], g * coef, mm, vv, w1, w2, a.beta2, inv_bc2s, a.adam_eps, step);
             };
             const int oslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);              // transposed-owner address, as in the dX reads
 #pragma unroll
@@ -516,8 +560,10 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             last_loss = loss;
             if (tid == 0) trace[2 * (k * n_mb + s / mb) + (critic ? 1 : 0)] = loss;
             lds_barrier();                                         // the next step's forward reads the new weights
+            PPO_T(6);
         }
     }
+    PPO_TDUMP();
 
     // ---- parameters and Adam state back to global memory
     for (int e = tid; e < L1.k_pad * kHid; e += kWG) {

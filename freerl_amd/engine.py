@@ -325,6 +325,11 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ timing
+    def ppo_work(self, horizon, k_epochs):
+        fl, by = C.c_double(0), C.c_double(0)
+        N.check(self._L.frl_ppo_work(self._h, int(horizon), int(k_epochs), C.byref(fl), C.byref(by)))
+        return fl.value, by.value
+
     def timer_start(self):
         N.check(self._L.frl_timer_start(self._h))
 

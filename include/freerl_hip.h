@@ -366,6 +366,9 @@ typedef struct frl_ppo_rollout_args {
 } frl_ppo_rollout_args;
 int frl_ppo_rollout(frl_engine* e, frl_envpool* p, const frl_ppo_rollout_args* args, frl_rollout_stats* out);
 
+/* Algorithmic flops / bytes of one frl_ppo_learn over all learners (the figure a PPO roofline fraction is computed from). */
+int frl_ppo_work(const frl_engine* e, int horizon, int k_epochs, double* flops_out, double* bytes_out);
+
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);
 int frl_timer_stop(frl_engine* e, float* ms_out);           /* synchronises */

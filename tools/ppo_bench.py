@@ -48,8 +48,11 @@ def run(P):
         e.sync()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    print("P=%4d  PPO.learn (horizon %d, mb %d, K %d): %.1f ms  -> %.0f samples/s consumed, %.0f minibatch steps/s"
-          % (P, T, MB, K, best * 1e3, P * T / best, P * K * (T // MB) / best), flush=True)
+    fl, by = e.ppo_work(T, K)
+    print("P=%4d  PPO.learn (horizon %d, mb %d, K %d): %.1f ms  -> %.0f samples/s consumed, %.0f minibatch steps/s; "
+          "%.2f GFLOP per learner = %.1f TFLOP/s (%.3f of the fp32 MFMA peak 157.3)"
+          % (P, T, MB, K, best * 1e3, P * T / best, P * K * (T // MB) / best, fl / P / 1e9, fl / best / 1e12, fl / best / 1e12 / 157.3),
+          flush=True)
     e.close()
 
 

@@ -42,8 +42,11 @@ assert fn(buf) == 0
 clk = np.array(buf[:], dtype=np.float64).reshape(2, 8)
 steps = K * (T // MB)
 names = ["gather", "forward", "row math", "backward", "clip + Adam"]
+if not os.environ.get("FRL_PPO_STREAMING"):        # the on-chip kernel (kernels_ppo2.hip) has its own sections
+    names = ["gather + forward", "row math", "exchange 1 + dW3 + dH2", "exchange 2 + dW2 + dH1", "exchange 3 + dW1",
+             "bias / norm / loss reductions", "clip + Adam"]
 for w, who in enumerate(("actor", "critic")):
-    tot = clk[w, :5].sum()
+    tot = clk[w, :len(names)].sum()
     print("P=%d %s: %.0f cycles per minibatch step" % (P, who, tot / steps))
     for i, n in enumerate(names):
         print("   %-12s %8.0f  %5.1f%%" % (n, clk[w, i] / steps, 100 * clk[w, i] / tot))
