@@ -168,6 +168,11 @@ __global__ void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau, int p0);
 
+// kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)
+__global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
+
 // kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>
 __global__ void ppo_update_v2_k1_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);
 __global__ void ppo_update_v2_k2_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);

@@ -23,21 +23,12 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
-#include "device/net.hpp"
+#include "device/chain.hpp"
 #include "device/ppo_timing.hpp"
 
 namespace frl {
 
 namespace {
-
-constexpr int kHid = 128, kHT = kHid / 16;
-
-// dword offset of element (f16, k16) of 16x16 fragment tile `tile` in a fragment-ordered LDS image: the 16-byte slot of
-// (q = k16 >> 2, f16) sits at q*16 + (f16 ^ q)
-__device__ __forceinline__ int frag_dw(int tile, int f16, int k16) {
-    const int q = k16 >> 2;
-    return tile * 256 + ((q * 16 + (f16 ^ q)) << 2) + (k16 & 3);
-}
 
 struct Ppo2Lds {
     lds_f w1, w2, w3, b1, b2, b3, ls, ea, eb, red;
@@ -58,30 +49,6 @@ __device__ __forceinline__ Ppo2Lds ppo2_carve(float* smem) {
     S.ls = p; p += 16;
     S.red = p; p += 96;
     return S;
-}
-
-template <int HACT>
-__device__ __forceinline__ float hact_fwd(float x) { return HACT == ACT_TANH ? tanhf(x) : fmaxf(x, 0.f); }
-template <int HACT>
-__device__ __forceinline__ float hact_grad(float h) { return HACT == ACT_TANH ? 1.f - h * h : (h > 0.f ? 1.f : 0.f); }
-
-__device__ __forceinline__ f32x4 mfma4(f32x4 acc, const f32x4& a, const f32x4& b) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
-    return acc;
-}
-
-// torch's single-tensor Adam on one element (clip coefficient already folded into g).  The moments are exact fp32
-// fma chains like everywhere else; the step itself, step * m / (sqrt(v) / sqrt(bc2) + eps), uses the hardware's 1-ulp
-// sqrt and reciprocal instead of the correctly rounded sequences (3 x ~10 VALU instructions per element, 88 elements per
-// lane and step: the difference between a 28 k and an 8 k cycle Adam phase).  Its relative error (<= ~3 ulp of the UPDATE,
-// which is itself ~lr times smaller than the parameter) is below the rounding of the subtraction that applies it.
-__device__ __forceinline__ float adam_elem(float th, float g, float& m, float& v, float w1, float w2, float b2, float inv_bc2s,
-                                           float eps, float step) {
-    m = m + (g - m) * w1;
-    v = v * b2 + (w2 * g) * g;
-    const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2s + eps;
-    return th - step * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 }  // namespace

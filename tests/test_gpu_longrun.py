@@ -35,6 +35,9 @@ ENV = {
     "ppo_c3_critic": (320, 1e-5, 1e-5),
     "ppo_c3_actor": (320, 1e-4, 1e-4),
 }
+# the register-chained critic stage (kernels_critic2.hip, forced with FRL_CRITIC_V2=1; the bench's path at >= 128 learners)
+# against the same oracle: same whole-run envelope; SAC's divergence set in before call 100 in one of its builds (4.4e-4)
+ENV_CHAINED = dict(ENV, sac=(100, 1e-3, 5e-2))
 SELF_DRIFT_FACTOR = 30.0      # HIP drift <= this x the oracle's own 1-ulp drift (+ 1e-4): same order of magnitude, not a bug
 
 
@@ -64,7 +67,7 @@ def _check(name, got, want, extra=None, self_want=None):
     n = len(err)
     REPORT[name] = dict(calls=n, max=float(err.max()), by_100=[float(err[i:i + 100].max()) for i in range(0, n, 100)],
                         loss_first=float(want[0]), loss_last=float(want[-1]), **(extra or {}))
-    n_tight, tight, whole = ENV[name]
+    n_tight, tight, whole = (ENV_CHAINED if name.endswith("/chained") else ENV)[name.split("/")[0]]
     REPORT[name]["tight_window"] = [n_tight, float(err[:n_tight].max())]
     assert err[:n_tight].max() <= tight, (name, "first %d calls" % n_tight, err[:n_tight].max())
     assert err.max() <= whole, (name, "whole run", err.max(), int(err.argmax()))
@@ -176,21 +179,27 @@ def _ac_run(N, name, algo_id, O, A, B, n_calls, twin, gaussian, max_action=1.0):
     # the actor loss (-Q mean) crosses zero: report it against the critic-loss scale instead of its own
     a_err = np.abs(np.array(got_a, np.float64) - np.array(want_a, np.float64)) / max(1e-6, float(np.mean(np.abs(want))))
     _check(name, got, want, dict(actor_abs_err_over_critic_scale_max=float(a_err.max())), self_want=want2)
-    assert a_err.max() <= 3 * ENV[name][2]
+    assert a_err.max() <= 3 * ENV[name.split("/")[0]][2]
     e.close()
 
 
-def test_ddpg_500_calls(N):
-    _ac_run(N, "ddpg", N.ALGO_DDPG, 8, 2, 256, 500, twin=False, gaussian=False)
+@pytest.fixture(params=["rowchunk", "chained"])
+def ac_path(request, monkeypatch):
+    monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
+    return "" if request.param == "rowchunk" else "/chained"
 
 
-def test_td3_config2_dims_batch256_500_calls(N):
+def test_ddpg_500_calls(N, ac_path):
+    _ac_run(N, "ddpg" + ac_path, N.ALGO_DDPG, 8, 2, 256, 500, twin=False, gaussian=False)
+
+
+def test_td3_config2_dims_batch256_500_calls(N, ac_path):
     """BASELINE config 2's own dims (Pendulum: obs 3, act 1, max_action 2) at its batch 256 (TD3.py:189-233, policy_freq 2)."""
-    _ac_run(N, "td3_c2", N.ALGO_TD3, 3, 1, 256, 500, twin=True, gaussian=False, max_action=2.0)
+    _ac_run(N, "td3_c2" + ac_path, N.ALGO_TD3, 3, 1, 256, 500, twin=True, gaussian=False, max_action=2.0)
 
 
-def test_sac_500_calls(N):
-    _ac_run(N, "sac", N.ALGO_SAC, 8, 2, 256, 500, twin=True, gaussian=True)
+def test_sac_500_calls(N, ac_path):
+    _ac_run(N, "sac" + ac_path, N.ALGO_SAC, 8, 2, 256, 500, twin=True, gaussian=True)
 
 
 def test_maddpg_150_calls(N):

@@ -185,7 +185,16 @@ def _check_ac_params(N, e, orc, twin, actor_names, label, actor_extra=None, lear
     return online
 
 
-def test_ddpg_learn(N):
+@pytest.fixture(params=["rowchunk", "chained"])
+def ac_path(request, monkeypatch):
+    """The critic stage of DDPG / TD3 / SAC has two implementations behind frl_learn: the row-chunk kernels + reduce / Adam
+    launches (any shape; what populations below 128 learners get) and the one-workgroup-per-learner register-chained kernel
+    with Adam fused (kernels_critic2.hip; the bench's path).  FRL_CRITIC_V2 forces either, so both meet the same oracle."""
+    monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
+    return request.param
+
+
+def test_ddpg_learn(N, ac_path):
     from oracle import algos
     c = cases.CASES["ddpg"]
     inp = cases.ac_inputs(c, twin=False)
@@ -212,7 +221,7 @@ def test_ddpg_learn(N):
 
 
 @pytest.mark.parametrize("name", ["td3", "td3_pendulum"])
-def test_td3_learn(N, name):
+def test_td3_learn(N, name, ac_path):
     from oracle import algos
     c = cases.CASES[name]
     inp = cases.ac_inputs(c, twin=True)
@@ -247,7 +256,7 @@ def test_td3_learn(N, name):
     e.close()
 
 
-def test_sac_learn(N):
+def test_sac_learn(N, ac_path):
     from oracle import algos
     c = cases.CASES["sac"]
     inp = cases.ac_inputs(c, twin=True, gaussian=True)
@@ -288,7 +297,7 @@ def test_sac_learn(N):
 
 
 @pytest.mark.parametrize("delta", [0.5, 10.0])
-def test_huber_td_loss_option(N, delta):
+def test_huber_td_loss_option(N, delta, ac_path):
     """frl_learn_args.loss_kind = FRL_LOSS_HUBER (north_star's "Huber/MSE TD-loss"; the reference's huber_loss, MAPPO.py:
     273-276, pinned on the oracle side by tests/golden/huber.npz): DQN, TD3 and SAC against the oracle with the same
     injected indices / noise.  delta 0.5 puts most TD errors on the linear branch, 10 (the reference's default) on the
@@ -1030,10 +1039,11 @@ def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
     e = Engine(N.ALGO_TD3, 8, 2, 512, twin_critic=True, batch_max=256)
     assert e.lds_bytes()[1] == int(rows)
     e.close()
+    monkeypatch.setenv("FRL_CRITIC_V2", "0")                 # these are the row-chunk kernels' knobs
     test_dqn_learn_matches_oracle_and_reference(N)
-    test_td3_learn(N, "td3")
-    test_td3_learn(N, "td3_pendulum")
-    test_sac_learn(N)
+    test_td3_learn(N, "td3", "rowchunk")
+    test_td3_learn(N, "td3_pendulum", "rowchunk")
+    test_sac_learn(N, "rowchunk")
     test_maddpg_learn(N)
     test_matd3_learn(N)
 
@@ -1044,9 +1054,10 @@ def test_workgroups_walking_several_row_chunks_give_the_same_answers(N, rows, cp
     others add to it; frl_create's schedule).  FRL_CPS forces that for the single-learner golden cases, Rainbow included."""
     monkeypatch.setenv("FRL_RC", rows)
     monkeypatch.setenv("FRL_CPS", cps)
+    monkeypatch.setenv("FRL_CRITIC_V2", "0")
     test_dqn_learn_matches_oracle_and_reference(N)
-    test_td3_learn(N, "td3")
-    test_sac_learn(N)
+    test_td3_learn(N, "td3", "rowchunk")
+    test_sac_learn(N, "rowchunk")
     test_maddpg_learn(N)
     test_matd3_learn(N)
     test_dqn_rainbow_all_six_tricks(N)
