@@ -93,6 +93,63 @@ def cpu_baseline(budget_s=12.0):
                       "index draw included) in %.1f s" % (n, dt)}
 
 
+def dropin_classes():
+    """learn() through the reference-shaped CLASSES (freerl_amd.TD3 / .DQN: what an unchanged *_file training script calls),
+    one learner, replay 1e6 rows full, batch 256: `rng="host"` consumes the reference's legacy NumPy stream — its
+    np.random.choice(1e6, 256, replace=False) permutes the whole buffer per call (TD3.py:183), which is also what bounds the
+    reference itself (22-30 ms) — `rng="device"` draws on the GPU; the default "auto" is "device" from 32768
+    rows on.  updates/s of the blocking Python call sequence, losses not read back."""
+    import torch
+    from freerl_amd import _native as N
+    from freerl_amd.DQN import DQN
+    from freerl_amd.TD3 import TD3
+    out = {}
+    for name, mk, call in (
+            ("TD3", lambda rng: TD3([OBS, ACT], True, 1e-3, 1e-3, CAP, "cuda", rng=rng, batch_max=BATCH),
+             lambda p: p.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0)),
+            ("DQN", lambda rng: DQN([OBS, 4], False, 1e-3, CAP, "cuda", rng=rng, batch_max=BATCH),
+             lambda p: p.learn(BATCH, 0.99, 0.01))):
+        for rng in ("host", "device", "auto"):
+            pol = mk(rng)
+            pol._e.fill_synthetic(CAP, seed=3)
+            n = 12 if rng == "host" else 300
+            for _ in range(3):
+                call(pol)
+            pol._e.sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                call(pol)
+            pol._e.sync()
+            out["%s.learn rng=%s" % (name, rng)] = n / (time.perf_counter() - t0)
+            pol._e.close()
+    return {"unit": "updates/s (one learner, replay 1e6 full, batch 256, through the Python class)", **out}
+
+
+def dqn_single_learner_loop():
+    """north_star's env-steps/s target is quoted on the DQN loop (DQN.py:294-339: select_action -> epsilon-greedy -> env.step ->
+    add -> learn per env step) of ONE learner.  LunarLander-v2 cannot be built here (no Box2D), so the env is the synthetic
+    discrete task at its dims (obs 8, 4 actions); the reference's own loop measured ~560 env-steps/s on CPU with a small
+    buffer and ~45 with the 1e6-row buffer full (np.random.choice permutes the buffer per learn)."""
+    from freerl_amd import _native as N
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    out = {}
+    for E in (1, 8, 64):
+        e = Engine(N.ALGO_DQN, 8, 4, 100_000, discrete=True, batch_max=BATCH, n_learners=1, seed=1)
+        g = np.random.default_rng(0)
+        flat = (g.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
+        e.set_params(0, flat, N.PARAM_ONLINE); e.set_params(0, flat, N.PARAM_TARGET)
+        e.fill_synthetic(4 * BATCH, seed=5)
+        pool = EnvPool("SynLinearDiscrete-v0", E, n_threads=1, seed=2)
+        kw = dict(envs_per_learner=E, start_steps=0, learn_every=1, epsilon=0.1, batch=BATCH, gamma=0.99, tau=0.01, critic_lr=1e-3)
+        rollout(e, pool, 20, **kw)
+        r = rollout(e, pool, 400, **kw)
+        out["%d env(s)" % E] = r["env_steps"] / r["seconds"]
+        pool.close(); e.close()
+    return {"unit": "env-steps/s, one DQN learner, one learn() per vector step", **out,
+            "reference_cpu_env_steps_per_sec": {"small buffer": 560, "replay 1e6 full": 45}}
+
+
 def traffic_figure():
     """HBM bytes per ac_critic_kernel launch from the PMC passes (profiles/traffic.json, written by tools/pmc_summary.py
     --traffic together with a digest of the kernel sources it was measured on).  Returns (bytes | None, stale)."""
@@ -203,8 +260,14 @@ def main():
         n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
         step_s = kernel_ms * 1e-3 / args.steps
         kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
-        # dominant kernel: ac_critic_kernel (targets + twin-critic forward/backward of every row chunk)
+        # dominant kernel: the critic stage.  At this population it is ac_critic_v2_twin_kernel (kernels_critic2.hip): targets,
+        # twin-critic forward / backward, clip + Adam + soft update of one learner per workgroup in ONE launch ("adam_critic"
+        # absent from the per-kernel times); below 128 learners ac_critic_kernel + adam_fused_kernel.  Its flops are the same
+        # algorithmic figure either way (frl_learn_work): the Adam / soft-update phase adds HBM bytes, not flops.
+        fused = "adam_critic" not in kern
+        dominant = "ac_critic_v2_twin_kernel" if fused else "ac_critic_kernel"
         launch_s = kern["grad_critic"]["avg_ms"] * 1e-3
+        stage_s = launch_s + (0.0 if fused else kern["adam_critic"]["avg_ms"] * 1e-3)
         achieved = fl_c / launch_s / 1e12
         flops, abytes = fl_c, by_c
         lds, rc = e.lds_bytes()
@@ -243,13 +306,18 @@ def main():
             "single_learner_updates_per_sec": single,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
-                         "kernel": "ac_critic_kernel", "avg_launch_ms": launch_s * 1e3,
+                         "kernel": dominant, "avg_launch_ms": launch_s * 1e3,
+                         "critic_stage_ms": stage_s * 1e3, "critic_stage_tflops": fl_c / stage_s / 1e12,
+                         "note": "round 1's 0.51 was ac_critic_kernel alone (0.523 ms) with clip + Adam in a second launch (0.120 ms): "
+                                 "0.41 for the stage this kernel now covers on its own",
                          "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
                          "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS,
                          "step_flops_avg": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps,
                          "step_ms_avg": step_s * 1e3,
                          "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "kernels": kern},
+            "dropin_classes": None if args.headline_only else dropin_classes(),
+            "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(),
             "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
         }
         print(json.dumps(line), flush=True)

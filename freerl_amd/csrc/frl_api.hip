@@ -1095,7 +1095,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
                               NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
         const bool v2 = v2_shape && (force_v2 ? atoi(force_v2) != 0 : pc >= 128);
         if (v2) {
-            { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 5; }
+            { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
             const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
             if (NC0.heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);

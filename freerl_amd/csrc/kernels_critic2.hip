@@ -181,11 +181,10 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         return X;
     };
 
-    // Every workgroup runs the same ~750 k cycles and ends in the one phase that touches HBM (theta / m / v / target, ~1.2 MB
-    // per learner): launched together they would all hit that phase together — the memory system idle for 80 % of the launch,
-    // then 256 CUs queueing on it (measured: the Adam phase took 187 k cycles per learner for ~20 k cycles of work).  Four
-    // start phases, 40 k cycles apart, spread the bursts over the launch; the cost is the last group's 120 k-cycle head start
-    // of idling at the tail of the launch.
+    // Developer knob (FRL_STAGGER): every workgroup runs the same ~700 k cycles and ends in the one phase that streams HBM
+    // (theta / m / v / target, ~1 MB per learner), so the 256 CUs reach it together and share the chip's bandwidth (111 k
+    // cycles per learner against 61 k for a CU on its own).  Four start phases spread the bursts (72 k) but the delayed
+    // groups finish later by as much: no net gain at two learners per CU (profiles/README.md), so the default is 0.
     if (a.stagger > 0) {
         const int group = (blockIdx.x >> 3) & 3;
         for (int i = 0; i < group * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
