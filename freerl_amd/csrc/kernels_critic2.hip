@@ -140,14 +140,24 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
             for (int r = 0; r < 4; ++r) h1[ot][r] = fmaxf(acc[r], 0.f);
         }
+        // the 32 MFMAs of one output tile are ONE dependent accumulator chain: walk the eight tiles' chains side by side (k-block
+        // outer, k-step middle, tile inner) so that consecutive MFMAs never wait for each other's result
 #pragma unroll
-        for (int ot = 0; ot < kHT; ++ot) {
-            f32x4 acc = ld4((lds_cf)(S.b2 + ot * 16 + 4 * q));
+        for (int ot = 0; ot < kHT; ++ot) h2[ot] = ld4((lds_cf)(S.b2 + ot * 16 + 4 * q));
 #pragma unroll
-            for (int kb = 0; kb < kHT; ++kb) acc = mfma4(acc, ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot)), h1[kb]);
+        for (int kb = 0; kb < kHT; ++kb) {
+            f32x4 wf[kHT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h2[ot][r] = fmaxf(acc[r], 0.f);
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ot = 0; ot < kHT; ++ot) h2[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[kb][e], h2[ot], 0, 0, 0);
         }
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[ot][r] = fmaxf(h2[ot][r], 0.f);
         f32x4 z = ld4((lds_cf)(S.b3 + 4 * q));
 #pragma unroll
         for (int kb = 0; kb < kHT; ++kb) z = mfma4(z, ld4((lds_cf)(S.w3 + kb * 256 + fslot)), h2[kb]);
@@ -189,80 +199,158 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         const int group = (blockIdx.x >> 3) & 3;
         for (int i = 0; i < group * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
     }
+    // ---- The target passes carry TWO 16-row tiles per wave (128 rows per chunk): nothing is differentiated through them, so the
+    // registers the gradient accumulators need later hold a second tile now, and every weight fragment read from LDS feeds
+    // eight MFMAs on two independent accumulator chains.  Row of (chunk c2, tile t) on this lane: 128 c2 + 32 w + 16 t + i16.
+    int ridxT[4];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        const int row = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16;
+        ridxT[j4] = row < B ? idx[row] : -1;
+    }
+    struct RowIn2 { f32x4 x[2]; float rew[2], done[2]; };
+    auto load_row2 = [&](bool want_rd, int c2) {                       // s' (obs columns) [+ reward / done] of both tiles
+        RowIn2 X;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            X.x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; X.rew[t] = 0.f; X.done[t] = 0.f;
+            const int ri = c2 == 0 ? ridxT[t] : ridxT[2 + t];
+            if (ri >= 0) {
+                g_cf rec = ring + (size_t)ri * R.stride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < O) X.x[t][e] = rec[R.nobs_off[0] + 4 * q + e];
+                if (want_rd) { X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off]; }
+            }
+        }
+        return X;
+    };
+    auto forward2 = [&](const f32x4 (&xb)[2], f32x4 (&z)[2]) {
+        f32x4 h1[2][kHT], h2[2][kHT];
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot) {
+            const f32x4 wf = ld4((lds_cf)(S.w1 + ot * 256 + fslot)), bb = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 acc = mfma4(bb, wf, xb[t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[t][ot][r] = fmaxf(acc[r], 0.f);
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot) h2[0][ot] = h2[1][ot] = ld4((lds_cf)(S.b2 + ot * 16 + 4 * q));
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) {                             // sixteen accumulator chains side by side (see forward)
+            f32x4 wf[kHT];
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[t][ot][r] = fmaxf(h2[t][ot][r], 0.f);
+        z[0] = z[1] = ld4((lds_cf)(S.b3 + 4 * q));
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) {
+            const f32x4 wf = ld4((lds_cf)(S.w3 + kb * 256 + fslot));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) z[t] = mfma4(z[t], wf, h2[t][kb]);
+        }
+    };
+    const int nch2 = (B + 127) / 128;
+
     // =========================================================== a' = actor_target(s') for the whole batch -> S.ab (SAC: + log pi)
     PPO_T0();
-    RowIn nxt = load_row(0, 0);
+    RowIn2 nxt2 = load_row2(false, 0);
     stage(tgA, NA, 0);
     PPO_T(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int row = c * 64 + 16 * w + i16;
-        const bool valid = row < B;
-        const RowIn cur = nxt;
-        nxt = load_row(c + 1 < nchunks ? 0 : 1, c + 1 < nchunks ? c + 1 : 0);      // the last one: first chunk of the target-critic pass
-        f32x4 xb = cur.x, h1[kHT], h2[kHT];
-        const f32x4 z = forward(xb, h1, h2);
-        if (q == 0 && row < kCr2Batch) {                               // act_dim <= 4: the head's outputs sit on lane group 0
-            f32x4 an = {0.f, 0.f, 0.f, 0.f};
-            float lp = 0.f;
-            if (valid) {
-                if (sac) {                                             // SAC.py:70-97 on actor_target (SAC.py:227)
+    for (int c2 = 0; c2 < nch2; ++c2) {
+        const RowIn2 cur = nxt2;
+        nxt2 = load_row2(true, c2 + 1 < nch2 ? c2 + 1 : 0);            // (after the last chunk: chunk 0 of the target-critic pass)
+        f32x4 z[2];
+        forward2(cur.x, z);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r < A) {
-                            const float ls = fminf(fmaxf(S.ls[r], -20.f), 2.f), sd = expf(ls);
-                            const float u = z[r] + sd * noise0[(size_t)row * am + r], du = u - z[r];
-                            lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
-                            lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
-                            an[r] = tanhf(u);
-                        }
-                    }
-                } else {
+        for (int t = 0; t < 2; ++t) {
+            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            const bool valid = row < B;
+            if (q == 0 && row < kCr2Batch) {                           // act_dim <= 4: the head's outputs sit on lane group 0
+                f32x4 an = {0.f, 0.f, 0.f, 0.f};
+                float lp = 0.f;
+                if (valid) {
+                    if (sac) {                                         // SAC.py:70-97 on actor_target (SAC.py:227)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r < A) {
-                            float v = tanhf(z[r]);
-                            if (a.use_policy_noise) {                  // TD3.py:196-198
-                                float nz = a.policy_noise_scale * (noise0[(size_t)row * am + r] * a.policy_noise);
-                                nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
-                                v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
+                        for (int r = 0; r < 4; ++r) {
+                            if (r < A) {
+                                const float ls = fminf(fmaxf(S.ls[r], -20.f), 2.f), sd = expf(ls);
+                                const float u = z[t][r] + sd * noise0[(size_t)row * am + r], du = u - z[t][r];
+                                lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                                lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                                an[r] = tanhf(u);
                             }
-                            an[r] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (r < A) {
+                                float v = tanhf(z[t][r]);
+                                if (a.use_policy_noise) {              // TD3.py:196-198
+                                    float nz = a.policy_noise_scale * (noise0[(size_t)row * am + r] * a.policy_noise);
+                                    nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
+                                    v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
+                                }
+                                an[r] = v;
+                            }
                         }
                     }
                 }
+                st4(S.ab + row * 4, an);
+                S.lpn[row] = lp;
             }
-            st4(S.ab + row * 4, an);
-            S.lpn[row] = lp;
         }
     }
     PPO_T(1);
     // =========================================================== y = r + gamma (1 - d) min_h Q_target_h(s', a')  (SAC: - alpha log pi)
+    RowIn nxt;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         stage(tgC, NC, 3 * hd);
-        for (int c = 0; c < nchunks; ++c) {
-            const int row = c * 64 + 16 * w + i16;
-            const bool valid = row < B;
-            const RowIn cur = nxt;
-            {       // next: the following chunk of this pass, else the first chunk of the next pass ([s | a] after the last target head)
-                const bool last = c + 1 >= nchunks;
-                nxt = load_row(last ? (hd == NH - 1 ? 2 : 1) : 1, last ? 0 : c + 1);
-            }
-            f32x4 xb = cur.x, h1[kHT], h2[kHT];
+        for (int c2 = 0; c2 < nch2; ++c2) {
+            const RowIn2 cur = nxt2;
+            if (c2 + 1 < nch2) nxt2 = load_row2(true, c2 + 1);
+            else if (hd + 1 < NH) nxt2 = load_row2(true, 0);
+            else nxt = load_row(2, 0);                                 // first chunk of the critic pass: [s | a], 64-row mapping
+            f32x4 xb[2], z[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 4 * q + e;
-                if (valid && f >= O && f < O + A) xb[e] = S.ab[row * 4 + f - O];          // a' from the target-actor pass
+            for (int t = 0; t < 2; ++t) {
+                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+                xb[t] = cur.x[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * q + e;
+                    if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];      // a' from the target-actor pass
+                }
             }
-            const f32x4 z = forward(xb, h1, h2);
-            if (q == 0 && valid) {
-                float qv = z[0];
-                if (hd == 1) qv = fminf(S.q1[row], qv);
-                if (hd == NH - 1) {
-                    const float rew = cur.rew, done = cur.done;
-                    S.yb[row] = sac ? rew + a.gamma * (1.f - done) * (qv + alpha * (-S.lpn[row])) : rew + a.gamma * qv * (1.f - done);
-                } else {
-                    S.q1[row] = qv;
+            forward2(xb, z);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+                if (q == 0 && row < B) {
+                    float qv = z[t][0];
+                    if (hd == 1) qv = fminf(S.q1[row], qv);
+                    if (hd == NH - 1) {
+                        const float rew = cur.rew[t], done = cur.done[t];
+                        S.yb[row] = sac ? rew + a.gamma * (1.f - done) * (qv + alpha * (-S.lpn[row])) : rew + a.gamma * qv * (1.f - done);
+                    } else {
+                        S.q1[row] = qv;
+                    }
                 }
             }
         }
@@ -350,20 +438,24 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
                     for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], af[x], bf[kt]);
             }
-            f32x4 d1[kHT];                                             // dH1 = W2^T dz2 through the ReLU
+            f32x4 d1[kHT];                                             // dH1 = W2^T dz2 through the ReLU; eight chains side by side
 #pragma unroll
-            for (int it = 0; it < kHT; ++it) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < kHT; ++it) d1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ob = 0; ob < kHT; ++ob) {
-                    f32x4 wa;
+            for (int ob = 0; ob < kHT; ++ob) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) wa[e] = S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-                    acc = mfma4(acc, wa, d2[ob]);
+                for (int e = 0; e < 4; ++e) {
+                    float wa[kHT];
+#pragma unroll
+                    for (int it = 0; it < kHT; ++it) wa[it] = S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+#pragma unroll
+                    for (int it = 0; it < kHT; ++it) d1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[it], d2[ob][e], d1[it], 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? acc[r] : 0.f;
             }
+#pragma unroll
+            for (int it = 0; it < kHT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? d1[it][r] : 0.f;
             lds_barrier();
             // ---- exchange 3: X and dz1 -> layer-1 gradient
             put_tile(S.ea, 0, xb);
