@@ -25,6 +25,7 @@
 #include "kernels_ppo.hip"
 #include "kernels_ppo2.hip"
 #include "kernels_critic2.hip"
+#include "kernels_actor2.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
@@ -481,6 +482,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             const int lb = critic2_lds_floats() * (int)sizeof(float);
             CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
             CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         }
         if (h.algo == ALGO_PPO) {
             const int lb = ppo2_lds_floats(2) * (int)sizeof(float);
@@ -1075,6 +1077,15 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     memset(&ad, 0, sizeof ad);
     ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
     ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy; ad.p0 = p0; ad.G = h.Gmax;
+    // one learner per workgroup, register-chained, Adam fused (kernels_critic2.hip): the reference's standard narrow shape
+    // at populations that give every CU a learner; everything else takes the row-chunk kernels + reduce / Adam launches
+    const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
+    const char* force_v2 = getenv("FRL_CRITIC_V2");
+    const bool v2_shape = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
+                  NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
+                  a.batch <= 256 && !h.obs_norm_on && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
+                  NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
+    const bool v2 = v2_shape && (force_v2 ? atoi(force_v2) != 0 : pc >= 128);
     if (stage == 0) {
         if (dev_rng) {
             prof_begin(e, PK_DRAW);
@@ -1085,15 +1096,6 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             hipLaunchKernelGGL(obsnorm_kernel, dim3(pc), blk, 0, st, e->d, a.batch, 0, p0);
         if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
             hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
-        // one learner per workgroup, register-chained, Adam fused (kernels_critic2.hip): the reference's standard narrow shape
-        // at populations that give every CU a learner; everything else takes the row-chunk kernels + reduce / Adam launches
-        const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
-        const char* force_v2 = getenv("FRL_CRITIC_V2");
-        const bool v2_shape = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
-                              NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
-                              a.batch <= 256 && !h.obs_norm_on && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
-                              NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
-        const bool v2 = v2_shape && (force_v2 ? atoi(force_v2) != 0 : pc >= 128);
         if (v2) {
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
@@ -1120,6 +1122,12 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         prof_end(e);
     } else if (stage == 1) {
+        if (v2 && h.algo != ALGO_SAC) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 in one launch
+            prof_begin(e, PK_GRAD_ACTOR);
+            hipLaunchKernelGGL(ac_actor_v2_kernel, dim3(pc), blk, (size_t)critic2_lds_floats() * sizeof(float), st, e->d, a);
+            prof_end(e);
+            return;
+        }
         prof_begin(e, PK_GRAD_ACTOR);
         hipLaunchKernelGGL(ac_actor_kernel, grid_chunks, blk, e->lds_bytes, st, e->d, a, ns);
         prof_end(e);

@@ -173,6 +173,9 @@ __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, Lear
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
 
+// kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
+__global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+
 // kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>
 __global__ void ppo_update_v2_k1_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);
 __global__ void ppo_update_v2_k2_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);

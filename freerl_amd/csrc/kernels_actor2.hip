@@ -1,0 +1,189 @@
+// Actor stage of DDPG / TD3 for one learner per workgroup, register-chained (device/chain_net.hpp; the counterpart of
+// kernels_critic2.hip): a = actor(s); Q1(s, a) through the (already updated, frozen) critic; dQ/da; actor backward; clip,
+// Adam and the soft update of the actor's target — DDPG_simple.py:151-154, TD3.py:224-233 — in ONE launch, no gradient slabs.
+//
+// Three passes over the learner's batch, the net a pass needs staged once into the LDS images:
+//   A  actor forward (two row tiles per wave)                       -> a[row] in LDS
+//   B  critic forward on [s | a] + the dX-only backward chain       -> dQ/da[row] in LDS, sum of Q for the loss
+//   C  actor forward AGAIN (its activations are registers of pass A, long gone) + backward with the weight-gradient exchanges
+// Recomputing the forward costs 320 of the pass's 928 MFMAs per wave and chunk; keeping both nets' images resident instead
+// would leave no LDS for the exchange buffers.  Shape: as kernels_critic2.hip; SAC's actor (log-prob terms, alpha) stays on
+// ac_actor_kernel.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "device/chain_net.hpp"
+#include "device/update_common.hpp"
+
+namespace frl {
+
+__global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = a.p0 + blockIdx.x;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    ChainNet C;
+    C.init(smem);
+    const ChainLds& S = C.S;
+    const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], A = R.act_dim[0];
+    const size_t lbase = (size_t)p * D.learner_stride;
+    g_f thA = as_global(D.theta + lbase + D.net_off[0]);
+    g_f tgA = as_global(D.target + lbase + D.net_off[0]);
+    g_f mA = as_global(D.m + lbase + D.net_off[0]);
+    g_f vA = as_global(D.v + lbase + D.net_off[0]);
+    g_cf thC = as_global(D.theta + lbase + D.net_off[1]);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
+    const float invB = 1.f / (float)B;
+    const int nchunks = (B + 63) / 64, nch2 = (B + 127) / 128;
+    lds_f dab = S.eb;                                                  // dQ/da[row][4] at the start of eb: pass B has no exchanges
+
+    // observation columns of this lane's rows: pass A / B in the two-tile mapping (128 c2 + 32 w + 16 t + i16), pass C in the
+    // 64-row mapping (64 c + 16 w + i16); ring addresses once, fields one chunk ahead of their use
+    int ridxT[4], ridx[4];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        const int rowT = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16, row = j4 * 64 + 16 * w + i16;
+        ridxT[j4] = rowT < B ? idx[rowT] : -1;
+        ridx[j4] = row < B ? idx[row] : -1;
+    }
+    struct RowIn2 { f32x4 x[2]; };
+    auto load_obs2 = [&](int c2) {
+        RowIn2 X;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            X.x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ri = c2 == 0 ? ridxT[t] : ridxT[2 + t];
+            if (ri >= 0) {
+                g_cf rec = ring + (size_t)ri * R.stride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < O) X.x[t][e] = rec[R.obs_off[0] + 4 * q + e];
+            }
+        }
+        return X;
+    };
+    auto load_obs = [&](int c) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        const int ri = c == 0 ? ridx[0] : (c == 1 ? ridx[1] : (c == 2 ? ridx[2] : ridx[3]));
+        if (ri >= 0) {
+            g_cf rec = ring + (size_t)ri * R.stride;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < O) x[e] = rec[R.obs_off[0] + 4 * q + e];
+        }
+        return x;
+    };
+
+    // =========================================================== A: a = tanh(actor(s)) -> S.ab
+    RowIn2 nxt2 = load_obs2(0);
+    C.stage(thA, NA, 0);
+    for (int c2 = 0; c2 < nch2; ++c2) {
+        const RowIn2 cur = nxt2;
+        nxt2 = load_obs2(c2 + 1 < nch2 ? c2 + 1 : 0);                  // (after the last chunk: chunk 0 again, for pass B)
+        f32x4 z[2], h1[2][kHT], h2[2][kHT];
+        C.forward<2>(cur.x, h1, h2, z);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            if (q == 0 && row < kChainBatch) {
+                f32x4 an = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < A && row < B) an[r] = tanhf(z[t][r]);
+                st4(S.ab + row * 4, an);
+            }
+        }
+    }
+    // =========================================================== B: Q1(s, a) and dQ/da through the frozen critic (TD3.py:227: Q1 only)
+    C.stage(thC, NC, 0);
+    float qsum = 0.f;
+    f32x4 nxt;
+    for (int c2 = 0; c2 < nch2; ++c2) {
+        const RowIn2 cur = nxt2;
+        if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
+        else nxt = load_obs(0);                                        // first chunk of pass C
+        f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            xb[t] = cur.x[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * q + e;
+                if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];
+            }
+        }
+        C.forward<2>(xb, h1, h2, z);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            const bool valid = row < B;
+            f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+            if (q == 0 && valid) { qsum += z[t][0]; dz[0] = -invB; }   // actor_loss = -Q1(s, actor(s)).mean()
+            f32x4 d2[kHT], d1[kHT];
+            C.delta2(dz, h2[t], d2);
+            C.delta1(d2, h1[t], d1);
+            const f32x4 dx = C.delta0(d1);                             // d loss / d [s | a] column 4q + r of this row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * q + r;
+                if (valid && f >= O && f < O + A) dab[row * 4 + f - O] = dx[r];
+            }
+        }
+    }
+    // =========================================================== C: actor forward again, delta through tanh, backward into the accumulators
+    HeadGrad g;
+    C.grad_zero(g);
+    C.stage(thA, NA, 0);                                               // (its leading barrier also publishes dab)
+    // dab lives in eb, which the backward's exchanges overwrite: this lane's four values per chunk into registers first
+    f32x4 dqa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int row = c * 64 + 16 * w + i16;
+        dqa[c] = (q == 0 && row < B) ? ld4((lds_cf)(dab + row * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int row = c * 64 + 16 * w + i16;
+        f32x4 xb[1] = {nxt}, z[1], h1[1][kHT], h2[1][kHT];
+        nxt = load_obs(c + 1 < nchunks ? c + 1 : 0);
+        C.forward<1>(xb, h1, h2, z);
+        const f32x4 dq = c == 0 ? dqa[0] : (c == 1 ? dqa[1] : (c == 2 ? dqa[2] : dqa[3]));
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0 && row < B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < A) { const float av = tanhf(z[0][r]); dz[r] = dq[r] * (1.f - av * av); }
+        }
+        C.backward(g, xb[0], h1[0], h2[0], dz);
+    }
+    C.grad_finish(g);
+    // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target
+    float ss = wave_sum(C.grad_sumsq(g));
+    const float qs = wave_sum(qsum);
+    lds_barrier();
+    if (l == 0) { S.red[w] = ss; S.red[8 + w] = qs; }
+    lds_barrier();
+    const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
+    const float qtot = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t = steps[0] + 1;
+    const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
+    AdamCoef co;
+    co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
+    co.step = (float)((double)a.actor_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
+    co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
+    co.tk = 1.f - a.tau; co.tau = a.tau; co.soft = true;
+    C.adam_head(g, NA.L[0], NA.L[1], NA.L[2], thA, mA, vA, tgA, co, 0.f, 0, 0);
+    if (tid == 0) {
+        steps[0] = t;
+        float* st = D.stats + (size_t)p * ST_COUNT;
+        st[ST_ACTOR_LOSS] = -qtot * invB;
+        st[ST_ACTOR_GNORM] = total;
+    }
+}
+
+}  // namespace frl
