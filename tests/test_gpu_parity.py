@@ -638,6 +638,51 @@ def test_population_learners_are_independent(N):
     e.close()
 
 
+def test_bench_sized_population_takes_the_chained_kernels_and_matches(N, monkeypatch):
+    """At >= 128 learners frl_learn selects the one-workgroup-per-learner chained kernels on its own (what bench.py runs):
+    144 learners, no override; four of them (first, last, two in between — different workgroups / CUs) against their own
+    oracles with their own indices and noise, actor step included."""
+    from oracle import algos
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    c = dict(cases.CASES["td3"])
+    inp = cases.ac_inputs(c, twin=True)
+    P, watch = 144, (0, 1, 77, 143)
+    e = _setup_ac(N, N.ALGO_TD3, c, inp, True, AC_NAMES, n_learners=P)
+    fa, fc = flat_params(inp["params"]["actor"], AC_NAMES), flat_params(inp["params"]["critic"], TWIN_NAMES)
+    recs = records([inp["table"]])
+    for p in range(1, P):                      # _setup_ac fills learner 0: same parameters and table for the others
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(0, fa, kind, learner=p); e.set_params(1, fc, kind, learner=p)
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+    orcs = {}
+    for p in watch:
+        o = algos.TD3(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"], c["critic_lr"], c["capacity"])
+        _fill_oracle(o, inp["table"])
+        orcs[p] = o
+    B, A = c["batch"], c["act_dim"]
+    for k in range(2):
+        idx = np.stack([synth.indices(7100 + 10 * k + (p % 7), c["n_table"], B) for p in range(P)])[:, None]
+        nz = np.zeros((P, 1, 2, B, A), np.float32)
+        for p in range(P):
+            nz[p, 0, 0] = synth.normal(8100 + 10 * k + (p % 5), (B, A))
+        st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True,
+                     policy_noise=0.2, noise_clip=0.5, max_action=2.0, idx=idx, noise=nz, want_stats=True)
+        for p in watch:
+            cl, al = orcs[p].learn_with(idx[p, 0], nz[p, 0, 0], 0.99, 0.005, 0.2, 0.5, 2.0, 2, 1.0)
+            np.testing.assert_allclose(st[p, 0, N.STAT_CRITIC_LOSS], cl, rtol=LOSS_RTOL)
+            if k % 2 == 1:
+                np.testing.assert_allclose(st[p, 0, N.STAT_ACTOR_LOSS], al, rtol=LOSS_RTOL, atol=1e-6)
+    e.profile(True)
+    for p in watch:
+        _check_ac_params(N, e, orcs[p], True, AC_NAMES, "pop144_%d" % p, learner=p)
+    # the chained path leaves no separate Adam launch for the critic: that is how the selection is observable
+    e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=True, use_policy_noise=True, policy_noise=0.2,
+            noise_clip=0.5, max_action=2.0)
+    kern = e.profile_read()
+    assert "grad_critic" in kern and "adam_critic" not in kern and "adam_actor" not in kern, kern
+    e.close()
+
+
 def test_full_size_device_rng_properties(N):
     """BASELINE config-2 scale (replay 1e6 rows, batch 256), device-drawn indices and noise.
     Size-independent properties: (1) bitwise determinism from the seed; (2) tau = 1 makes the
