@@ -220,6 +220,27 @@ def test_ddpg_learn(N, ac_path):
     e.close()
 
 
+def test_ddpg_critic_weight_decay(N, ac_path):
+    """DDPG.py's supplement['weight_decay'] on its own (critic Adam weight_decay 1e-3, L2-in-gradient form, DDPG.py:131-134) on
+    both critic-stage implementations (with Batch_ObsNorm, as in the ddpg_full golden, only the row-chunk kernels run)."""
+    from oracle import algos
+    c = cases.CASES["ddpg"]
+    inp = cases.ac_inputs(c, twin=False)
+    e = _setup_ac(N, N.ALGO_DDPG, c, inp, False, AC_NAMES)
+    orc = algos.DDPG(inp["params"]["actor"], inp["params"]["critic"], c["obs_dim"], c["act_dim"], c["actor_lr"], c["critic_lr"],
+                     c["capacity"], critic_weight_decay=1e-3)
+    _fill_oracle(orc, inp["table"])
+    cl = []
+    for k in range(c["n_learn"]):
+        st = e.learn(c["batch"], gamma=c["gamma"], tau=c["tau"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                     critic_weight_decay=1e-3, idx=inp["idx"][k], want_stats=True)
+        cl.append(st[0, 0, N.STAT_CRITIC_LOSS])
+        orc.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+    np.testing.assert_allclose(cl, np.array(orc.critic_losses), rtol=LOSS_RTOL)
+    _check_ac_params(N, e, orc, False, AC_NAMES, "ddpg_wd/" + ac_path)
+    e.close()
+
+
 @pytest.mark.parametrize("name", ["td3", "td3_pendulum"])
 def test_td3_learn(N, name, ac_path):
     from oracle import algos
