@@ -270,7 +270,7 @@ def main():
         stage_s = launch_s + (0.0 if fused else kern["adam_critic"]["avg_ms"] * 1e-3)
         achieved = fl_c / launch_s / 1e12
         flops, abytes = fl_c, by_c
-        lds, rc = e.lds_bytes()
+        chained, lds, rc = e.learn_path(BATCH)
     e.close()
     if rank == 0:
         # single-learner latency (P = 1): the reference-compatible drop-in case
@@ -295,7 +295,8 @@ def main():
             "config": {"workload": "TD3.learn() (BASELINE configs[1] algorithm; north_star synthetic shape): obs_dim 8, "
                                    "act_dim 2, batch 256, replay 1e6 rows filled, hidden 128, policy_freq 2, "
                                    "device-drawn indices/noise",
-                       "learners_per_gpu": P, "updates_per_step": P * world, "row_chunk": rc, "lds_bytes": lds,
+                       "learners_per_gpu": P, "updates_per_step": P * world, "kernel_family": "chained (one workgroup per learner)" if chained else "row-chunk",
+                       "rows_per_workgroup": rc, "lds_bytes": lds,
                        "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world,
                        "collective": "metric all-reduce via freerl_amd.dist (backend %s)" % backend},
             "env_steps_per_sec": env_sps,

@@ -115,6 +115,7 @@ SIGNATURES = {
     "frl_destroy": (_i, [_vp]),
     "frl_sync": (_i, [_vp]),
     "frl_lds_bytes": (_i, [_vp, _ip, _ip]),
+    "frl_learn_path": (_i, [_vp, _i, _ip, _ip, _ip]),
     "frl_record_layout_get": (_i, [_vp, _P(RecordLayout)]),
     "frl_buffer_add": (_i, [_vp, _i, _fp]),
     "frl_buffer_add_batch": (_i, [_vp, _i, _ip, _fp]),

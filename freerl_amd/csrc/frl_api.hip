@@ -514,6 +514,19 @@ extern "C" int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* rc_out) {
     return FRL_OK;
 }
 
+static bool chained_path(const EngineDesc& h, int batch, int pc);
+
+extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, int* bytes_out, int* rows_out) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    if (e->h.algo == ALGO_PPO) return fail(FRL_ERR_INVALID, "frl_learn_path describes frl_learn(); PPO updates go through frl_ppo_learn");
+    if (batch <= 0 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch out of range");
+    const bool v2 = chained_path(e->h, batch, e->h.P);
+    if (chained_out) *chained_out = v2 ? 1 : 0;
+    if (bytes_out) *bytes_out = v2 ? critic2_lds_floats() * (int)sizeof(float) : e->lds_bytes;
+    if (rows_out) *rows_out = v2 ? batch : e->h.rc;
+    return FRL_OK;
+}
+
 // ----------------------------------------------------------------------------------- replay
 extern "C" int frl_record_layout_get(const frl_engine* e, frl_record_layout* out) {
     if (!e || !out) return fail(FRL_ERR_INVALID, "NULL argument");
@@ -1066,6 +1079,19 @@ static void launch_adam(frl_engine* e, hipStream_t st, const AdamArgs& ad, int u
     }
 }
 
+// One learner per workgroup, register-chained, Adam fused (kernels_critic2.hip / kernels_actor2.hip): the reference's standard
+// narrow shape at populations that give every CU a learner; everything else takes the row-chunk kernels + reduce / Adam
+// launches.  FRL_CRITIC_V2=0/1 overrides the population threshold (tests run both families on the same inputs).
+static bool chained_path(const EngineDesc& h, int batch, int pc) {
+    const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
+    const bool shape = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
+                       NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
+                       batch <= 256 && !h.obs_norm_on && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
+                       NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
+    const char* force = getenv("FRL_CRITIC_V2");
+    return shape && (force ? atoi(force) != 0 : pc >= 128);
+}
+
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
@@ -1077,15 +1103,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     memset(&ad, 0, sizeof ad);
     ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
     ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy; ad.p0 = p0; ad.G = h.Gmax;
-    // one learner per workgroup, register-chained, Adam fused (kernels_critic2.hip): the reference's standard narrow shape
-    // at populations that give every CU a learner; everything else takes the row-chunk kernels + reduce / Adam launches
-    const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
-    const char* force_v2 = getenv("FRL_CRITIC_V2");
-    const bool v2_shape = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
-                  NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
-                  a.batch <= 256 && !h.obs_norm_on && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
-                  NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
-    const bool v2 = v2_shape && (force_v2 ? atoi(force_v2) != 0 : pc >= 128);
+    const bool v2 = chained_path(h, a.batch, pc);
     if (stage == 0) {
         if (dev_rng) {
             prof_begin(e, PK_DRAW);
@@ -1100,7 +1118,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
             const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
-            if (NC0.heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
+            if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
             else hipLaunchKernelGGL(ac_critic_v2_single_kernel, dim3(pc), blk, lb, st, e->d, a);
             prof_end(e);
             return;
@@ -1122,7 +1140,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         prof_end(e);
     } else if (stage == 1) {
-        if (v2 && h.algo != ALGO_SAC) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 in one launch
+        if (v2) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 / SAC in one launch
             prof_begin(e, PK_GRAD_ACTOR);
             hipLaunchKernelGGL(ac_actor_v2_kernel, dim3(pc), blk, (size_t)critic2_lds_floats() * sizeof(float), st, e->d, a);
             prof_end(e);

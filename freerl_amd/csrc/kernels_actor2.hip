@@ -1,14 +1,16 @@
-// Actor stage of DDPG / TD3 for one learner per workgroup, register-chained (device/chain_net.hpp; the counterpart of
-// kernels_critic2.hip): a = actor(s); Q1(s, a) through the (already updated, frozen) critic; dQ/da; actor backward; clip,
-// Adam and the soft update of the actor's target — DDPG_simple.py:151-154, TD3.py:224-233 — in ONE launch, no gradient slabs.
+// Actor stage of DDPG / TD3 / SAC for one learner per workgroup, register-chained (device/chain_net.hpp; the counterpart of
+// kernels_critic2.hip): a = actor(s) (SAC: the reparameterised tanh-Gaussian sample and its log-prob); Q(s, a) through the
+// (already updated, frozen) critic — Q1 for DDPG / TD3, the mean of the twins for SAC; dQ/da; actor backward; clip, Adam and
+// the soft update of the actor's target; SAC's alpha step — DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260 — in ONE
+// launch, no gradient slabs.
 //
 // Three passes over the learner's batch, the net a pass needs staged once into the LDS images:
 //   A  actor forward (two row tiles per wave)                       -> a[row] in LDS
 //   B  critic forward on [s | a] + the dX-only backward chain       -> dQ/da[row] in LDS, sum of Q for the loss
+//      (SAC: once per twin head, each staged in turn, the two dQ/da added)
 //   C  actor forward AGAIN (its activations are registers of pass A, long gone) + backward with the weight-gradient exchanges
 // Recomputing the forward costs 320 of the pass's 928 MFMAs per wave and chunk; keeping both nets' images resident instead
-// would leave no LDS for the exchange buffers.  Shape: as kernels_critic2.hip; SAC's actor (log-prob terms, alpha) stays on
-// ac_actor_kernel.
+// would leave no LDS for the exchange buffers.  Shape: as kernels_critic2.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -38,6 +40,12 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
     const float invB = 1.f / (float)B;
+    const bool sac = (D.algo == ALGO_SAC);
+    const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+    const int am = D.act_max;
+    g_cf noise1 = as_global(D.noise + ((size_t)p * D.noise_sets + 1) * D.batch_max * am);     // the actor stage's eps (set 1)
+    const int nq = sac ? NC.heads : 1;                                 // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
+    const float dqv = sac ? -0.5f * invB : -invB;
     const int nchunks = (B + 63) / 64, nch2 = (B + 127) / 128;
     lds_f dab = S.eb;                                                  // dQ/da[row][4] at the start of eb: pass B has no exchanges
 
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         return x;
     };
 
-    // =========================================================== A: a = tanh(actor(s)) -> S.ab
+    // =========================================================== A: a = tanh(actor(s)) -> S.ab  (SAC: a = tanh(mean + std eps), sum of log pi)
+    float lpsum = 0.f;
     RowIn2 nxt2 = load_obs2(0);
     C.stage(thA, NA, 0);
     for (int c2 = 0; c2 < nch2; ++c2) {
@@ -92,46 +101,60 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
             if (q == 0 && row < kChainBatch) {
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < A && row < B) an[r] = tanhf(z[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    if (r < A && row < B) {
+                        if (sac) {                                     // SAC.py:70-97
+                            const float ls = fminf(fmaxf(S.ls[r], -20.f), 2.f), sd = expf(ls);
+                            const float u = z[t][r] + sd * noise1[(size_t)row * am + r], du = u - z[t][r];
+                            lpsum += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                            lpsum -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                            an[r] = tanhf(u);
+                        } else {
+                            an[r] = tanhf(z[t][r]);
+                        }
+                    }
+                }
                 st4(S.ab + row * 4, an);
             }
         }
     }
-    // =========================================================== B: Q1(s, a) and dQ/da through the frozen critic (TD3.py:227: Q1 only)
-    C.stage(thC, NC, 0);
+    // =========================================================== B: Q(s, a) and dQ/da through the frozen critic (TD3.py:227: Q1 only; SAC.py:250: both heads)
     float qsum = 0.f;
     f32x4 nxt;
-    for (int c2 = 0; c2 < nch2; ++c2) {
-        const RowIn2 cur = nxt2;
-        if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
-        else nxt = load_obs(0);                                        // first chunk of pass C
-        f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
+    for (int hd = 0; hd < nq; ++hd) {
+        C.stage(thC, NC, 3 * hd);
+        for (int c2 = 0; c2 < nch2; ++c2) {
+            const RowIn2 cur = nxt2;
+            if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
+            else if (hd + 1 < nq) nxt2 = load_obs2(0);                 // the next head starts over
+            else nxt = load_obs(0);                                    // first chunk of pass C
+            f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = c2 * 128 + 32 * w + 16 * t + i16;
-            xb[t] = cur.x[t];
+            for (int t = 0; t < 2; ++t) {
+                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+                xb[t] = cur.x[t];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 4 * q + e;
-                if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * q + e;
+                    if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];
+                }
             }
-        }
-        C.forward<2>(xb, h1, h2, z);
+            C.forward<2>(xb, h1, h2, z);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = c2 * 128 + 32 * w + 16 * t + i16;
-            const bool valid = row < B;
-            f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-            if (q == 0 && valid) { qsum += z[t][0]; dz[0] = -invB; }   // actor_loss = -Q1(s, actor(s)).mean()
-            f32x4 d2[kHT], d1[kHT];
-            C.delta2(dz, h2[t], d2);
-            C.delta1(d2, h1[t], d1);
-            const f32x4 dx = C.delta0(d1);                             // d loss / d [s | a] column 4q + r of this row
+            for (int t = 0; t < 2; ++t) {
+                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+                const bool valid = row < B;
+                f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+                if (q == 0 && valid) { qsum += z[t][0]; dz[0] = dqv; } // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
+                f32x4 d2[kHT], d1[kHT];
+                C.delta2(dz, h2[t], d2);
+                C.delta1(d2, h1[t], d1);
+                const f32x4 dx = C.delta0(d1);                         // d loss / d [s | a] column 4q + r of this row
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 4 * q + r;
-                if (valid && f >= O && f < O + A) dab[row * 4 + f - O] = dx[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 4 * q + r;
+                    if (valid && f >= O && f < O + A) dab[row * 4 + f - O] = hd == 0 ? dx[r] : dab[row * 4 + f - O] + dx[r];
+                }
             }
         }
     }
@@ -140,12 +163,19 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     C.grad_zero(g);
     C.stage(thA, NA, 0);                                               // (its leading barrier also publishes dab)
     // dab lives in eb, which the backward's exchanges overwrite: this lane's four values per chunk into registers first
-    f32x4 dqa[4];
+    f32x4 dqa[4], epsa[4];                                             // (SAC: the rows' eps as well, ahead of the loop)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int row = c * 64 + 16 * w + i16;
         dqa[c] = (q == 0 && row < B) ? ld4((lds_cf)(dab + row * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        epsa[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sac && q == 0 && row < B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < A) epsa[c][r] = noise1[(size_t)row * am + r];
+        }
     }
+    float gls[4] = {0.f, 0.f, 0.f, 0.f};                               // d loss / d log_std, this lane's rows
     for (int c = 0; c < nchunks; ++c) {
         const int row = c * 64 + 16 * w + i16;
         f32x4 xb[1] = {nxt}, z[1], h1[1][kHT], h2[1][kHT];
@@ -154,21 +184,56 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         const f32x4 dq = c == 0 ? dqa[0] : (c == 1 ? dqa[1] : (c == 2 ? dqa[2] : dqa[3]));
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
         if (q == 0 && row < B) {
+            if (sac) {                                                 // through a = tanh(u), u = mean + exp(log_std) eps, and alpha log pi
+                const f32x4 ep = c == 0 ? epsa[0] : (c == 1 ? epsa[1] : (c == 2 ? epsa[2] : epsa[3]));
+                const f32x4 av4 = ld4((lds_cf)(S.ab + row * 4));
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < A) { const float av = tanhf(z[0][r]); dz[r] = dq[r] * (1.f - av * av); }
+                for (int r = 0; r < 4; ++r) {
+                    if (r < A) {
+                        const float av = av4[r];
+                        const float d = dq[r] * (1.f - av * av) + (alpha * invB) * (2.f * av);
+                        const float ls = fminf(fmaxf(S.ls[r], -20.f), 2.f);
+                        dz[r] = d;
+                        gls[r] += d * expf(ls) * ep[r] - alpha * invB;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < A) { const float av = tanhf(z[0][r]); dz[r] = dq[r] * (1.f - av * av); }
+            }
         }
         C.backward(g, xb[0], h1[0], h2[0], dz);
     }
     C.grad_finish(g);
     // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target
     float ss = wave_sum(C.grad_sumsq(g));
-    const float qs = wave_sum(qsum);
+    const float qs = wave_sum(qsum), lps = wave_sum(lpsum);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gls[r] = wave_sum(gls[r]);
     lds_barrier();
-    if (l == 0) { S.red[w] = ss; S.red[8 + w] = qs; }
+    if (l == 0) {
+        S.red[w] = ss; S.red[8 + w] = qs; S.red[12 + w] = lps;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.red[16 + 4 * r + w] = gls[r];
+    }
     lds_barrier();
-    const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
+    // log_std gradient of component i16 (lanes i16 < A); outside the clamp [-20, 2] the gradient is zero (SAC.py:77)
+    float g_extra = 0.f, ss_extra = 0.f;
+    if (sac) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < A) {
+                const float raw = S.ls[r];
+                const float gr = (raw >= -20.f && raw <= 2.f) ? ((S.red[16 + 4 * r] + S.red[17 + 4 * r]) + S.red[18 + 4 * r]) + S.red[19 + 4 * r] : 0.f;
+                ss_extra += gr * gr;
+                if (i16 == r) g_extra = gr;
+            }
+        }
+    }
+    const float total = sqrtf((((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]) + ss_extra);
     const float qtot = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
+    const float lptot = ((S.red[12] + S.red[13]) + S.red[14]) + S.red[15];
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     const int t = steps[0] + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
@@ -177,12 +242,32 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     co.step = (float)((double)a.actor_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
     co.tk = 1.f - a.tau; co.tau = a.tau; co.soft = true;
-    C.adam_head(g, NA.L[0], NA.L[1], NA.L[2], thA, mA, vA, tgA, co, 0.f, 0, 0);
+    C.adam_head(g, NA.L[0], NA.L[1], NA.L[2], thA, mA, vA, tgA, co, g_extra, NA.extra_off, sac ? NA.extra_n : 0);
     if (tid == 0) {
         steps[0] = t;
         float* st = D.stats + (size_t)p * ST_COUNT;
-        st[ST_ACTOR_LOSS] = -qtot * invB;
+        st[ST_ACTOR_LOSS] = sac ? (-(qtot * 0.5f) + alpha * lptot) * invB : -qtot * invB;   // SAC.py:251: (alpha log pi - Q).mean()
         st[ST_ACTOR_GNORM] = total;
+        if (sac) {                                                     // alpha step on the batch's entropy (SAC.py:154-169,257-260)
+            float* al = D.alpha + p * 4;
+            const float ent_mean = -lptot * invB;
+            const float mean_term = ent_mean - a.target_entropy;
+            const float gl = alpha * mean_term;                        // d alpha_loss / d log_alpha
+            const int ta = steps[kMaxNets] + 1;
+            float mi = al[1], vi = al[2];
+            mi = mi + (gl - mi) * (1.f - a.beta1);
+            vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
+            const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
+            const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
+            al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
+            al[1] = mi;
+            al[2] = vi;
+            al[3] = expf(al[0]);
+            steps[kMaxNets] = ta;
+            st[ST_ALPHA_LOSS] = alpha * mean_term;
+            st[ST_ALPHA] = al[3];
+            st[ST_ENTROPY] = ent_mean;
+        }
     }
 }
 

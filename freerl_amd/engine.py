@@ -72,6 +72,12 @@ class Engine:
         N.check(self._L.frl_lds_bytes(self._h, C.byref(b), C.byref(r)))
         return b.value, r.value
 
+    def learn_path(self, batch):
+        """(chained, lds_bytes, rows_per_workgroup) of the kernel family learn() launches at this batch size."""
+        c, b, r = C.c_int(0), C.c_int(0), C.c_int(0)
+        N.check(self._L.frl_learn_path(self._h, int(batch), C.byref(c), C.byref(b), C.byref(r)))
+        return bool(c.value), b.value, r.value
+
     # ------------------------------------------------------------------ replay
     def add(self, learner, record):
         rec = np.ascontiguousarray(record, dtype=F32)

@@ -238,3 +238,30 @@ def test_per_tree_at_depth(N):
         np.testing.assert_allclose(e.per_state()["sum"], tree.sum(), rtol=1e-7)
     assert e.cursor(0) == (index, size)
     e.close()
+
+
+def test_learn_path_reports_the_kernel_family(N, monkeypatch):
+    """frl_learn_path: the chained kernels take the narrow standard shape at populations >= 128 (or when forced), the
+    row-chunk kernels everything else; the reported LDS bytes fit the CU either way."""
+    from freerl_amd.engine import Engine
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    for algo, twin in ((N.ALGO_TD3, True), (N.ALGO_SAC, True), (N.ALGO_DDPG, False)):
+        small = Engine(algo, 8, 2, 512, twin_critic=twin, batch_max=256)
+        chained, lds, rows = small.learn_path(256)
+        assert not chained and rows == small.lds_bytes()[1] and lds == small.lds_bytes()[0]
+        monkeypatch.setenv("FRL_CRITIC_V2", "1")
+        assert small.learn_path(256)[0]
+        monkeypatch.delenv("FRL_CRITIC_V2")
+        small.close()
+        pop = Engine(algo, 8, 2, 512, n_learners=128, twin_critic=twin, batch_max=256)
+        chained, lds, rows = pop.learn_path(256)
+        assert chained and rows == 256 and lds <= 160 * 1024
+        pop.close()
+    wide = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=128, twin_critic=True, batch_max=256)     # obs + act > 16, act > 4
+    assert not wide.learn_path(256)[0]
+    with pytest.raises(RuntimeError):
+        wide.learn_path(257)
+    wide.close()
+    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=128, twin_critic=True, batch_max=256, hidden=256)
+    assert not h256.learn_path(256)[0]
+    h256.close()

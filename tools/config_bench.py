@@ -51,7 +51,7 @@ def run(case, P, steps=20):
             e.set_alpha_state([np.log(0.01), 0, 0, 0.01], learner=p)
     e.fill_synthetic(CAP, seed=5)
     e.sync()
-    lds, rc = e.lds_bytes()
+    chained, lds, rc = e.learn_path(B)
 
     def step(k):
         e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(algo != N.ALGO_TD3 or k % 2 == 1), **kw)
@@ -65,8 +65,8 @@ def run(case, P, steps=20):
     dt = (time.perf_counter() - t0) / steps
     w1, w0 = e.learn_work(B, True), e.learn_work(B, False)          # (flops, bytes) of the whole population's learn()
     fl = (0.5 * (w1[0] + w0[0]) if algo == N.ALGO_TD3 else w1[0])
-    print("%-13s P=%4d  rows/workgroup %3d  LDS %3d KB  %8.3f ms per learn() -> %9.0f updates/s  %6.1f TFLOP/s" %
-          (name, P, rc, lds // 1024, dt * 1e3, P / dt, fl / dt / 1e12), flush=True)
+    print("%-13s P=%4d  %-9s rows/workgroup %3d  LDS %3d KB  %8.3f ms per learn() -> %9.0f updates/s  %6.1f TFLOP/s" %
+          (name, P, "chained" if chained else "row-chunk", rc, lds // 1024, dt * 1e3, P / dt, fl / dt / 1e12), flush=True)
     e.close()
 
 

@@ -28,7 +28,7 @@ def kernel_source_digest():
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "freerl_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("kernels_critic2.hip", "kernels_critic.hip", "kernels.h", "frl_desc.h", "device/chain.hpp", "device/net.hpp", "device/tile.hpp",
+    for f in ("kernels_critic2.hip", "kernels_critic.hip", "kernels.h", "frl_desc.h", "device/chain.hpp", "device/chain_net.hpp", "device/net.hpp", "device/tile.hpp",
               "device/update_common.hpp"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()[:16]
