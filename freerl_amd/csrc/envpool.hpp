@@ -7,7 +7,9 @@
 // Dynamics restate the same published equations as freerl_amd/envs.py (Pendulum-v1, CartPole-v1)
 // plus the synthetic linear-Gaussian task; plain C++, no HIP in this header.
 #pragma once
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -118,11 +120,9 @@ public:
     }
 
     ~EnvPool() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-            ++generation;
-        }
+        quit.store(true);
+        generation.fetch_add(1);
+        { std::lock_guard<std::mutex> lk(mu); }
         cv.notify_all();
         for (auto& th : workers) th.join();
     }
@@ -248,16 +248,30 @@ public:
 
 private:
     struct Job { const float* actions; float* next_obs; float* reward; uint8_t* term; uint8_t* trunc; float* obs_next; } job{};
-    int n_workers = 1;
+    // Worker hand-off without a futex on the hot path: a rollout loop calls step() every 0.1 - 1 ms, and waking threads
+    // through a condition variable cost 25 - 40 us per call (more than stepping 512 of the built-in envs).  Workers poll
+    // `generation` for kSpinUs after their last job and only then sleep on the condition variable; the caller polls `pending`.
+    // Pools too small to amortise even that (under kEnvsPerWorker envs per worker) use fewer workers, down to the caller alone.
+    static constexpr int kEnvsPerWorker = 64;
+    static constexpr int kSpinUs = 2000;
+    int n_workers = 1, active = 1;
     std::vector<std::thread> workers;
     std::mutex mu;
-    std::condition_variable cv, cv_done;
-    long long generation = 0;
-    int pending = 0;
-    bool quit = false;
+    std::condition_variable cv;
+    std::atomic<long long> generation{0};
+    std::atomic<int> pending{0}, sleepers{0};
+    std::atomic<bool> quit{false};
+
+    static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
 
     void do_range(int w) {
-        const int per = (n + n_workers - 1) / n_workers, lo = w * per, hi = lo + per > n ? n : lo + per;
+        const int per = (n + active - 1) / active, lo = w * per, hi = lo + per > n ? n : lo + per;
         const int O = spec.obs_dim, A_ = spec.act_dim;
         long long eps = 0;
         double ret = 0.0;
@@ -282,32 +296,38 @@ private:
     }
 
     void run_parallel() {
-        if (n_workers == 1) { do_range(0); return; }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            pending = n_workers - 1;
-            ++generation;
+        active = std::min(n_workers, std::max(1, (n + kEnvsPerWorker - 1) / kEnvsPerWorker));
+        if (active == 1) { do_range(0); return; }
+        pending.store(n_workers - 1, std::memory_order_relaxed);       // every worker acknowledges every job (idle ones at once),
+                                                                       // so `active` is never read across two generations
+        generation.fetch_add(1);                         // (seq_cst: publishes job / active / pending; ordered against `sleepers`)
+        if (sleepers.load() > 0) {
+            { std::lock_guard<std::mutex> lk(mu); }      // a worker between its predicate check and its wait holds mu
+            cv.notify_all();
         }
-        cv.notify_all();
         do_range(0);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [this] { return pending == 0; });
+        while (pending.load(std::memory_order_acquire) != 0) cpu_relax();
     }
 
     void worker_loop(int w) {
         long long seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return generation != seen; });
-                seen = generation;
-                if (quit) return;
+            const auto t_idle = std::chrono::steady_clock::now();
+            for (int spins = 0; generation.load(std::memory_order_acquire) == seen; ++spins) {
+                cpu_relax();
+                if ((spins & 255) == 255 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_idle).count() > kSpinUs) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1);
+                    cv.wait(lk, [&] { return generation.load() != seen; });
+                    sleepers.fetch_sub(1);
+                    break;
+                }
             }
-            do_range(w);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0) cv_done.notify_one();
-            }
+            seen = generation.load(std::memory_order_acquire);
+            if (quit.load()) return;
+            if (w < active) do_range(w);
+            pending.fetch_sub(1, std::memory_order_release);
         }
     }
 };

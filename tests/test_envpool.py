@@ -122,3 +122,24 @@ def test_callback_pool_steps_python_envs(native):
         bad.step(np.zeros((1, 1), np.float32))
     assert isinstance(bad.error, RuntimeError)
     bad.close()
+
+
+def test_threaded_pool_matches_the_single_threaded_one(native):
+    """Workers spin for their next job and fall asleep after 2 ms without one: back-to-back steps, steps after a pause and
+    a pool small enough to run on the caller alone all give the single-threaded pool's trajectories (per-env generators)."""
+    import time
+    from freerl_amd.envpool import EnvPool
+    for name, n in (("SynLinear-v0", 300), ("CartPole-v1", 130), ("SynLinearDiscrete-v0", 40)):
+        one, many = EnvPool(name, n, n_threads=1, seed=11), EnvPool(name, n, n_threads=4, seed=11)
+        np.testing.assert_array_equal(one.reset(), many.reset())
+        g = np.random.default_rng(1)
+        for t in range(60):
+            if one.n_actions:
+                act = g.integers(0, one.n_actions, (n, 1)).astype(np.float32)
+            else:
+                act = g.uniform(-1, 1, (n, one.act_dim)).astype(np.float32)
+            if t in (20, 21, 40):
+                time.sleep(0.01)                     # past the spin window: the workers are woken through the condition variable
+            for x, y in zip(one.step(act), many.step(act)):
+                np.testing.assert_array_equal(x, y)
+        one.close(); many.close()
