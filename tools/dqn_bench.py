@@ -64,7 +64,7 @@ def run(P, variant, steps=30):
     e.close()
 
 
-def run_rollout(P, E, steps=60):
+def run_rollout(P, E, steps=300):
     from freerl_amd.envpool import EnvPool, rollout
     e = Engine(N.ALGO_DQN, O, NA, CAP, discrete=True, batch_max=B, n_learners=P, seed=1)
     rng = np.random.default_rng(0)

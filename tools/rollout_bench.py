@@ -16,7 +16,7 @@ from freerl_amd.envpool import EnvPool, rollout
 B, CAP = 256, 100_000
 
 
-def run(algo, P, E, host, steps=60):
+def run(algo, P, E, host, steps=300):
     dqn = algo == "dqn"
     e = Engine(N.ALGO_DQN if dqn else N.ALGO_TD3, 8, 4 if dqn else 2, CAP, discrete=dqn, twin_critic=not dqn, batch_max=B,
                n_learners=P, seed=1)
