@@ -26,6 +26,7 @@
 #include "kernels_ppo2.hip"
 #include "kernels_critic2.hip"
 #include "kernels_actor2.hip"
+#include "kernels_dqn2.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
@@ -237,6 +238,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     for (float* p : dev) if (p) hipFree(p);
     if (e->h.idx) hipFree(e->h.idx);
     if (e->h.steps) hipFree(e->h.steps);
+    if (e->h.ticket) hipFree(e->h.ticket);
     if (e->d_stage_slots) hipFree(e->d_stage_slots);
     if (e->d_ou) hipFree(e->d_ou);
     if (e->d_ou_flags) hipFree(e->d_ou_flags);
@@ -450,6 +452,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.noise, e->noise_count, e->stream));
         CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
+        CREATE_TRY(dalloc_zero(&h.ticket, P, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
         {
             int omax = 1;
@@ -472,6 +475,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->index.assign(P, 0);
     e->size.assign(P, 0);
     e->staged_per_learner.assign(P, 0);
+    if (h.algo == ALGO_DQN)
+        CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
     if (e->lds_bytes > 64 * 1024) {
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
@@ -1092,6 +1097,16 @@ static bool chained_path(const EngineDesc& h, int batch, int pc) {
     return shape && (force ? atoi(force) != 0 : pc >= 128);
 }
 
+// kernels_dqn2.hip: the reference's plain Q-net (obs -> 128 -> n_actions) with the TD update of DQN.py / the Double variant;
+// every other head (Dueling, Noisy, Categorical) and PER-weighted losses take the row-chunk chain.  FRL_DQN_FUSED=0/1 overrides.
+static bool dqn_fused_path(const EngineDesc& h, const LearnArgs& a) {
+    const NetDesc& N = h.net[0];
+    const bool shape = h.algo == ALGO_DQN && !h.dueling && !h.noisy && !h.c51_atoms && !a.use_isw && h.hidden == 128 && N.n_layers == 2 &&
+                       N.L[0].k_pad == 16 && N.L[1].n_pad == 16 && a.batch <= kDqn2Batch && !h.obs_norm_on && N.hidden_act == ACT_RELU;
+    const char* force = getenv("FRL_DQN_FUSED");
+    return shape && (force ? atoi(force) != 0 : true);
+}
+
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
@@ -1104,6 +1119,16 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
     ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy; ad.p0 = p0; ad.G = h.Gmax;
     const bool v2 = chained_path(h, a.batch, pc);
+    if (stage == 0 && dqn_fused_path(h, a)) {
+        // a few learners: one 64-row chunk per workgroup (the last to arrive reduces and steps); populations: one workgroup each
+        const int nchunks = (a.batch + 63) / 64;
+        a.dqn_split = (pc <= 16) ? std::min(std::min(4, nchunks), h.S) : 1;      // measured: P = 64 x 4 workgroups 74 us, x 1 45 us
+        if (const char* sp = getenv("FRL_DQN_SPLIT")) a.dqn_split = std::max(1, std::min(std::min(atoi(sp), nchunks), h.S));
+        prof_begin(e, PK_GRAD_CRITIC);
+        hipLaunchKernelGGL(dqn_fused_kernel, dim3(pc * a.dqn_split), blk, (size_t)dqn2_lds_floats() * sizeof(float), st, e->d, a);
+        prof_end(e);
+        return;
+    }
     if (stage == 0) {
         if (dev_rng) {
             prof_begin(e, PK_DRAW);

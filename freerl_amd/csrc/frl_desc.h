@@ -84,6 +84,7 @@ struct EngineDesc {
     int noise_sets;       // max(2, n_agents)
     float* stats;         // [P][n_agents][ST_COUNT]
     int* steps;           // [P][kMaxNets + 1] Adam step counters (+1: SAC alpha)
+    int* ticket;          // [P] arrival counter of a learner's workgroups in dqn_fused_kernel (zero between launches)
     float* alpha;         // [P][4]: log_alpha, m, v, alpha (SAC)
     unsigned long long seed;
     int act_max;          // max act_dim over agents (row pitch of `noise`)
@@ -136,6 +137,7 @@ struct LearnArgs {
     int p0, p_count;      // this launch covers learners [p0, p0 + p_count): frl_learn pipelines two halves of a population
     int double_dqn;       // DQN trick['Double']: a* = argmax_a Q(s',a), y uses Q_target(s', a*) (DQN_with_tricks.py:263-265)
     int use_isw;          // DQN trick['PER']: loss = mean(w * td^2) with the weights in desc.isw (:276-278)
+    int dqn_split;        // dqn_fused_kernel: workgroups per learner (its 64-row chunks dealt round-robin)
     int stagger;          // kernels_critic2 / _actor2: s_sleep(127) units between the four start phases of the workgroups (0: none)
     int huber;            // TD loss: 0 F.mse_loss (every hot-path loss of the reference), 1 Huber with `huber_delta`
     float huber_delta;    // (the reference's huber_loss, MAPPO_file/MAPPO.py:273-276: e^2/2 if |e| <= d else d(|e| - d/2), mean)

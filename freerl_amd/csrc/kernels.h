@@ -175,6 +175,10 @@ constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+// kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
+constexpr int kDqn2Batch = 256;
+constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 2 * kDqn2Batch; }
+__global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 
 // kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>
 __global__ void ppo_update_v2_k1_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);

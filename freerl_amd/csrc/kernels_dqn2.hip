@@ -1,0 +1,385 @@
+// DQN.learn (DQN_file/DQN.py:97-118; Double: DQN_with_tricks.py:263-265) for one learner in ONE launch, register-chained
+// (device/chain.hpp): the index draw, y = r + gamma max_a Q_t(s', a) (1 - d), the TD loss on the taken action, backward, clip,
+// Adam and the soft target update.  The reference's Q-net is obs -> 128 -> n_actions (DQN.py:32-45): 1.7 k parameters and
+// 1.5 k MACs per row, so the three-launch chain of the row-chunk path (draw_kernel -> dqn_grad_kernel -> adam_fused_kernel,
+// gradient slabs in between) is launch- and latency-bound at every population size.  Here both nets sit in LDS as
+// fragment-ordered images (16 KB), every wave carries 16 rows through them in registers, the weight gradients live in the
+// owner lanes' accumulators across the batch, and Adam runs from those registers.
+//
+// `a.p_count` learners x `a.dqn_split` workgroups: a learner's 64-row chunks are dealt round-robin to its workgroups; with
+// more than one, each writes its partial gradient to the learner's slab and the last one to arrive (atomic ticket) adds the
+// partials in workgroup order and applies the update — the single learner's latency path (one chunk per workgroup).
+//
+// Shape: plain or Double DQN head (no Dueling / Noisy / Categorical / PER weights), hidden 128 (ReLU), obs_dim <= 16,
+// n_actions <= 16, batch <= 256.  Everything else runs dqn_grad_kernel / c51_grad_kernel.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "device/chain.hpp"
+#include "device/update_common.hpp"
+#include "device/ppo_timing.hpp"
+
+namespace frl {
+
+namespace {
+
+struct Dqn2Lds {
+    lds_f w1[2], w2[2], b1[2], b2[2];      // [0] online, [1] target
+    lds_f ea, eb, red;
+    FRL_LDS int* lidx;
+};
+
+struct Dqn2 {
+    Dqn2Lds S;
+    int tid, l, w, i16, q, fslot, tslot;
+
+    __device__ __forceinline__ void init(float* smem) {
+        lds_f p = (lds_f)smem;
+        for (int k = 0; k < 2; ++k) { S.w1[k] = p; p += kHT * 256; S.w2[k] = p; p += kHT * 256; }
+        S.ea = p; p += kHT * 4 * 256;
+        S.eb = p; p += 4 * 256;
+        for (int k = 0; k < 2; ++k) { S.b1[k] = p; p += kHid; S.b2[k] = p; p += 16; }
+        S.red = p; p += 64;
+        S.lidx = (FRL_LDS int*)p; p += 2 * kDqn2Batch;
+        tid = threadIdx.x; l = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6); i16 = l & 15; q = l >> 4;
+        fslot = (q * 16 + (i16 ^ q)) << 2;
+        tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);
+    }
+
+    // engine layout Wk[k][n] (n contiguous), then b[n_pad] -> fragment-ordered images (as ChainNet::stage, two layers)
+    __device__ __forceinline__ void stage(g_cf th, const LayerDesc& L1, const LayerDesc& L2, int k) const {
+        const int n = tid & 127;
+        f32x4 u1, u1b, u3[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u1[e] = th[L1.w_off + (4 * (tid >> 7) + e) * kHid + n];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u1b[e] = th[L1.w_off + (4 * (2 + (tid >> 7)) + e) * kHid + n];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k4 = (tid >> 4) + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u3[j][e] = th[L2.w_off + (4 * k4 + e) * 16 + (tid & 15)];
+        }
+        { const int qq = tid >> 7; st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1); }
+        { const int qq = 2 + (tid >> 7); st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1b); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k4 = (tid >> 4) + 16 * j, kb = k4 >> 2, qq = k4 & 3;
+            st4(S.w2[k] + kb * 256 + ((qq * 16 + ((tid & 15) ^ qq)) << 2), u3[j]);
+        }
+        if (tid < kHid) S.b1[k][tid] = th[L1.b_off + tid];
+        if (tid < 16) S.b2[k][tid] = th[L2.b_off + tid];
+    }
+
+    // h1 = relu(W1 x + b1), z = W2 h1 + b2 for this wave's 16 rows (x: B operand, columns 4q + e of row i16)
+    __device__ __forceinline__ void forward(int k, const f32x4& xb, f32x4 (&h1)[kHT], f32x4& z) const {
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot) {
+            const f32x4 wf = ld4((lds_cf)(S.w1[k] + ot * 256 + fslot)), bb = ld4((lds_cf)(S.b1[k] + ot * 16 + 4 * q));
+            const f32x4 acc = mfma4(bb, wf, xb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[ot][r] = fmaxf(acc[r], 0.f);
+        }
+        // the head's 32 MFMAs as two accumulator chains (even / odd k-blocks), added at the end
+        f32x4 z0 = ld4((lds_cf)(S.b2[k] + 4 * q)), z1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < kHT; kb += 2) {
+            const f32x4 wa = ld4((lds_cf)(S.w2[k] + kb * 256 + fslot)), wb = ld4((lds_cf)(S.w2[k] + (kb + 1) * 256 + fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], h1[kb][e], z0, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[e], h1[kb + 1][e], z1, 0, 0, 0);
+            }
+        }
+        z = z0 + z1;
+    }
+    // forward without keeping h1 (target / action-selection passes)
+    __device__ __forceinline__ f32x4 forward_z(int k, const f32x4& xb) const {
+        f32x4 h1[kHT], z;
+        forward(k, xb, h1, z);
+        return z;
+    }
+
+    __device__ __forceinline__ void put_tile(lds_f E, int ft, const f32x4& t) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[(ft * 4 + w) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
+    }
+    __device__ __forceinline__ f32x4 get_frag(lds_cf E, int ft, int bb) const { return ld4(E + (ft * 4 + bb) * 256 + fslot); }
+};
+
+// the weight-gradient accumulators of one lane (MFMA D layout): layer 1 out = 16 (2w + x) + 4q + r, in = i16;
+// head out = 4q + r, in = 16 (2w + x) + i16; bias partials per lane group until the end
+struct Dqn2Grad { f32x4 g1[2], g2[2]; float gb1[2], gb2; };
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int nsp = a.dqn_split, unit = blockIdx.x / nsp, sp = blockIdx.x - unit * nsp;
+    const int p = a.p0 + unit;
+    const NetDesc& N = D.net[0];
+    const RecordDesc& R = D.rec;
+    const LayerDesc &L1 = N.L[0], &L2 = N.L[1];
+    Dqn2 C;
+    C.init(smem);
+    const Dqn2Lds& S = C.S;
+    const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], nA = D.n_discrete;
+    const size_t base = (size_t)p * D.learner_stride + D.net_off[0];
+    g_f th = as_global(D.theta + base);
+    g_f tg = as_global(D.target + base);
+    g_f mA = as_global(D.m + base);
+    g_f vA = as_global(D.v + base);
+    g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+    g_i idx = (g_i)(D.idx + (size_t)p * D.batch_max);
+    const float invB = 1.f / (float)B;
+    const int nchunks = (B + 63) / 64;
+
+    // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones)
+    PPO_T0();
+    if (a.device_rng) {
+        draw_indices(idx, S.lidx, B, a.size, a.rng_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1));
+    } else {
+        for (int i = tid; i < B; i += kWG) S.lidx[i] = idx[i];
+    }
+    PPO_T(0);
+    C.stage(th, L1, L2, 0);
+    C.stage(tg, L1, L2, 1);
+    lds_barrier();
+    PPO_T(1);
+
+    struct RowIn { f32x4 xs, xn; float act, rew, done; };
+    auto load_row = [&](int c) {
+        RowIn X;
+        X.xs = f32x4{0.f, 0.f, 0.f, 0.f}; X.xn = X.xs; X.act = 0.f; X.rew = 0.f; X.done = 0.f;
+        const int row = c * 64 + 16 * w + i16;
+        if (row < B) {
+            g_cf rec = ring + (size_t)S.lidx[row] * R.stride;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < O) { X.xs[e] = rec[R.obs_off[0] + 4 * q + e]; X.xn[e] = rec[R.nobs_off[0] + 4 * q + e]; }
+            X.act = rec[R.act_off[0]]; X.rew = rec[R.rew_off]; X.done = rec[R.done_off];
+        }
+        return X;
+    };
+    // value / first index of the row's maximum over the nA live outputs of a head tile (outputs 4q + r of row i16)
+    auto row_max = [&](const f32x4& z, float& mx, int& best) {
+        mx = -INFINITY; best = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < nA && z[r] > mx) { mx = z[r]; best = 4 * q + r; }
+#pragma unroll
+        for (int s = 16; s < 64; s <<= 1) {
+            const float om = __shfl_xor(mx, s, 64);
+            const int ob = __shfl_xor(best, s, 64);
+            if (om > mx || (om == mx && ob < best)) { mx = om; best = ob; }
+        }
+    };
+    auto row_pick = [&](const f32x4& z, int j) {      // z[j] of the row (j uniform over the row's four lanes)
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r == j) v = z[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+
+    Dqn2Grad g;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { g.g1[x] = f32x4{0.f, 0.f, 0.f, 0.f}; g.g2[x] = g.g1[x]; g.gb1[x] = 0.f; }
+    g.gb2 = 0.f;
+    float lossp = 0.f;
+    g_f tde = as_global(D.td_err + (size_t)p * D.batch_max);
+    RowIn nxt = load_row(sp);
+    for (int c = sp; c < nchunks; c += nsp) {
+        const RowIn cur = nxt;
+        if (c + nsp < nchunks) nxt = load_row(c + nsp);
+        PPO_T(2);
+        const int row = c * 64 + 16 * w + i16;
+        const bool valid = row < B;
+        // ---- y = r + gamma max_a Q_target(s', a) (1 - d); Double: the online net picks a
+        float mx; int best;
+        const f32x4 zt = C.forward_z(1, cur.xn);
+        if (a.double_dqn) {
+            const f32x4 zo = C.forward_z(0, cur.xn);
+            row_max(zo, mx, best);
+            mx = row_pick(zt, best);
+        } else {
+            row_max(zt, mx, best);
+        }
+        const float y = cur.rew + a.gamma * mx * (1.f - cur.done);
+        // ---- Q(s, a), TD loss, head delta (d loss / d Q on the taken action)
+        f32x4 h1[kHT], z;
+        C.forward(0, cur.xs, h1, z);
+        const int at = (int)cur.act;                                   // actions.long() (DQN.py:114)
+        const float diff = row_pick(z, at) - y;
+        float lrow, grow;
+        td_loss_row(a, diff, lrow, grow);
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * q + r == at) dz[r] = grow * invB;
+            if (q == 0) { lossp += lrow; tde[row] = diff; }
+        }
+        PPO_T(3);
+        // ---- backward: head gradient (H1 x dz over the chunk's 64 rows), dH1, layer-1 gradient (X x dH1)
+        lds_barrier();                                                 // the previous chunk's readers of ea / eb are done
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) C.put_tile(S.ea, ft, h1[ft]);
+        C.put_tile(S.eb, 0, dz);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4 af = C.get_frag(S.eb, 0, bb);
+            if (w == 0) g.gb2 += (af[0] + af[1]) + (af[2] + af[3]);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) g.g2[x] = mfma4(g.g2[x], af, C.get_frag(S.ea, 2 * w + x, bb));
+        }
+        f32x4 d1[kHT];
+#pragma unroll
+        for (int it = 0; it < kHT; ++it) {
+            f32x4 wa;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wa[e] = S.w2[0][it * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+            const f32x4 acc = mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, wa, dz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? acc[r] : 0.f;
+        }
+        lds_barrier();
+        C.put_tile(S.eb, 0, cur.xs);
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) C.put_tile(S.ea, ft, d1[ft]);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4 bf = C.get_frag(S.eb, 0, bb);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const f32x4 af = C.get_frag(S.ea, 2 * w + x, bb);
+                g.gb1[x] += (af[0] + af[1]) + (af[2] + af[3]);
+                g.g1[x] = mfma4(g.g1[x], af, bf);
+            }
+        }
+        PPO_T(4);
+    }
+    // bias partials of the four lane groups (rows 4q .. 4q + 3 of every 16-row block) added up
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { g.gb1[x] += __shfl_xor(g.gb1[x], 16, 64); g.gb1[x] += __shfl_xor(g.gb1[x], 32, 64); }
+    g.gb2 += __shfl_xor(g.gb2, 16, 64); g.gb2 += __shfl_xor(g.gb2, 32, 64);
+    float lsum = wave_sum(lossp);
+
+    // ---- several workgroups per learner: partials to the slab; the last to arrive adds them in workgroup order
+    const int o1[2] = {L1.w_off + i16 * kHid + 16 * (2 * w) + 4 * q, L1.w_off + i16 * kHid + 16 * (2 * w + 1) + 4 * q};
+    const int o2[2] = {L2.w_off + (16 * (2 * w) + i16) * 16 + 4 * q, L2.w_off + (16 * (2 * w + 1) + i16) * 16 + 4 * q};
+    const int ob1[2] = {L1.b_off + 16 * (2 * w) + i16, L1.b_off + 16 * (2 * w + 1) + i16};
+    const int ob2 = L2.b_off + i16;
+    if (nsp > 1) {
+        g_f slab = as_global(D.slab + ((size_t)p * D.S + sp) * D.learner_stride + D.net_off[0]);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            st4(slab + o1[x], g.g1[x]); st4(slab + o2[x], g.g2[x]);
+            if (q == 0) slab[ob1[x]] = g.gb1[x];
+        }
+        if (w == 0 && q == 0) slab[ob2] = g.gb2;
+        lds_barrier();
+        if (l == 0) S.red[w] = lsum;
+        lds_barrier();
+        if (tid == 0) D.part[((size_t)p * D.S + sp) * 4] = ((S.red[0] + S.red[1]) + S.red[2]) + S.red[3];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) S.lidx[0] = atomicAdd(D.ticket + p, 1);
+        __syncthreads();
+        if (S.lidx[0] != nsp - 1) return;
+        __threadfence();
+        if (tid == 0) D.ticket[p] = 0;                                 // ready for the next launch
+        lsum = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { g.g1[x] = f32x4{0.f, 0.f, 0.f, 0.f}; g.g2[x] = g.g1[x]; g.gb1[x] = 0.f; }
+        g.gb2 = 0.f;
+        for (int k = 0; k < nsp; ++k) {
+            g_cf sk = as_global(D.slab + ((size_t)p * D.S + k) * D.learner_stride + D.net_off[0]);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                g.g1[x] += ld4(sk + o1[x]); g.g2[x] += ld4(sk + o2[x]);
+                g.gb1[x] += sk[ob1[x]];
+            }
+            g.gb2 += sk[ob2];
+            if (tid == 0) lsum += D.part[((size_t)p * D.S + k) * 4];
+        }
+        if (l != 0) lsum = 0.f;
+        if (w != 0) lsum = 0.f;
+    }
+
+    // ---- clip_grad_norm_, Adam (torch's single-tensor order), soft update, losses
+    PPO_T(5);
+    float ss = 0.f;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        ss += (g.g1[x][0] * g.g1[x][0] + g.g1[x][1] * g.g1[x][1]) + (g.g1[x][2] * g.g1[x][2] + g.g1[x][3] * g.g1[x][3]);
+        ss += (g.g2[x][0] * g.g2[x][0] + g.g2[x][1] * g.g2[x][1]) + (g.g2[x][2] * g.g2[x][2] + g.g2[x][3] * g.g2[x][3]);
+        if (q == 0) ss += g.gb1[x] * g.gb1[x];
+    }
+    if (w == 0 && q == 0) ss += g.gb2 * g.gb2;
+    ss = wave_sum(ss);
+    lds_barrier();
+    if (l == 0) { S.red[w] = ss; S.red[8 + w] = lsum; }
+    lds_barrier();
+    const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
+    const float loss = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t = steps[0] + 1;
+    const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
+    const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
+    const float step = (float)((double)a.critic_lr / bc1), bc2s = (float)sqrt(bc2);
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
+    auto adam1 = [&](float gi, float& thi, float& mi, float& vi, float& tgi) {
+        gi *= coef;
+        if (a.critic_wd != 0.f) gi += a.critic_wd * thi;
+        mi = mi + (gi - mi) * w1;
+        vi = vi * a.beta2 + (w2 * gi) * gi;
+        thi = thi - step * (mi / (sqrtf(vi) / bc2s + a.adam_eps));
+        tgi = tgi * tk + thi * a.tau;
+    };
+    // every load of the update before its first store (the compiler cannot prove theta / m / v / target distinct and would
+    // otherwise wait for each float4's stores before the next one's loads: six dependent round trips instead of one)
+    struct In4 { f32x4 th, m, v, tg; };
+    auto load4 = [&](int o) { return In4{ld4((g_cf)(th + o)), ld4((g_cf)(mA + o)), ld4((g_cf)(vA + o)), ld4((g_cf)(tg + o))}; };
+    auto adam4 = [&](int o, const f32x4& gr, In4 in) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t1 = in.th[r], m1 = in.m[r], v1 = in.v[r], g1 = in.tg[r];
+            adam1(gr[r], t1, m1, v1, g1);
+            in.th[r] = t1; in.m[r] = m1; in.v[r] = v1; in.tg[r] = g1;
+        }
+        st4(th + o, in.th); st4(mA + o, in.m); st4(vA + o, in.v); st4(tg + o, in.tg);
+    };
+    const In4 i1[2] = {load4(o1[0]), load4(o1[1])}, i2[2] = {load4(o2[0]), load4(o2[1])};
+    const bool own_b2 = (w == 0 && q == 0);
+    float bt[3] = {0.f, 0.f, 0.f}, bm[3] = {0.f, 0.f, 0.f}, bv[3] = {0.f, 0.f, 0.f}, bg[3] = {0.f, 0.f, 0.f};
+    const int ob[3] = {ob1[0], ob1[1], ob2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < 2 ? q == 0 : own_b2) { bt[k] = th[ob[k]]; bm[k] = mA[ob[k]]; bv[k] = vA[ob[k]]; bg[k] = tg[ob[k]]; }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { adam4(o1[x], g.g1[x], i1[x]); adam4(o2[x], g.g2[x], i2[x]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < 2 ? q == 0 : own_b2) {
+            adam1(k < 2 ? g.gb1[k] : g.gb2, bt[k], bm[k], bv[k], bg[k]);
+            th[ob[k]] = bt[k]; mA[ob[k]] = bm[k]; vA[ob[k]] = bv[k]; tg[ob[k]] = bg[k];
+        }
+    }
+    if (tid == 0) {
+        steps[0] = t;
+        float* st = D.stats + (size_t)p * ST_COUNT;
+        st[ST_CRITIC_LOSS] = loss * invB;
+        st[ST_CRITIC_GNORM] = total;
+    }
+    PPO_T(6);
+    PPO_TDUMP();
+}
+
+}  // namespace frl

@@ -264,7 +264,9 @@ class DQN:
         dq = np.zeros_like(q)
         dq[np.arange(B), a] = dcur.reshape(-1)
         _, g = self.net.backward(self.q, acts, dq, need_dx=False)
-        self.opt.step(self.q, g)                        # Agent.update_Qnet: no clipping (DQN.py:56-59)
+        if getattr(self, "clip", 0.0) > 0.0:            # not in DQN.py (Agent.update_Qnet, :56-59, has no clipping): the engine's
+            nn.clip_grad_norm(g, self.clip)             # clip_norm argument, checked with torch's clip_grad_norm_ arithmetic
+        self.opt.step(self.q, g)
         nn.soft_update(self.q_t, self.q, tau)           # DQN.py:120-128
         self.losses.append(loss)
         self.last_td = (cur - y).reshape(-1)

@@ -105,7 +105,17 @@ def test_buffer_empty_ragged_and_errors(N):
 
 
 # --------------------------------------------------------------------------------------- DQN
-def test_dqn_learn_matches_oracle_and_reference(N):
+@pytest.fixture(params=["rowchunk", "fused", "fused_split"])
+def dqn_path(request, monkeypatch):
+    """DQN.learn has two implementations behind frl_learn: draw_kernel -> dqn_grad_kernel (row chunks, slabs) ->
+    adam_fused_kernel (any head), and dqn_fused_kernel (kernels_dqn2.hip: the plain / Double Q-net, everything in one launch) —
+    with one workgroup per learner or the batch's 64-row chunks on several (the last to arrive reduces and steps)."""
+    monkeypatch.setenv("FRL_DQN_FUSED", "0" if request.param == "rowchunk" else "1")
+    monkeypatch.setenv("FRL_DQN_SPLIT", "1" if request.param == "fused" else "4")
+    return request.param
+
+
+def test_dqn_learn_matches_oracle_and_reference(N, dqn_path):
     from freerl_amd.engine import Engine
     from oracle import algos
     c = cases.CASES["dqn"]
@@ -143,6 +153,47 @@ def test_dqn_learn_matches_oracle_and_reference(N):
     for k in got_m:
         np.testing.assert_allclose(got_m[k], orc.opt.m[k], rtol=1e-3, atol=1e-7)
     assert e.opt_step(0) == int(fx["step"])
+    e.close()
+
+
+@pytest.mark.parametrize("double,clip,wd,batch", [(True, 0.0, 0.0, 256), (False, 0.05, 0.0, 256), (True, 0.5, 1e-2, 200), (False, 0.0, 0.0, 37)])
+def test_dqn_double_clip_weight_decay_ragged_batches(N, dqn_path, double, clip, wd, batch):
+    """The Double target (DQN_with_tricks.py:263-265: the online net picks, the target net values), clip_grad_norm_, L2 weight
+    decay and batches that end inside a 64-row chunk / inside a 16-row tile, three learners with different tables: both
+    implementations against the oracle."""
+    from freerl_amd.engine import Engine
+    from oracle import algos, nn
+    c = cases.CASES["dqn"]
+    P = 3
+    e = Engine(N.ALGO_DQN, c["obs_dim"], c["n_actions"], c["capacity"], discrete=True, batch_max=256, n_learners=P)
+    orcs = []
+    for p in range(P):
+        inp = cases.dqn_inputs(dict(c, table_seed=c["table_seed"] + p, param_seed=c["param_seed"] + p))
+        flat = flat_params(inp["params"]["Qnet"], ["l1", "l2"])
+        e.set_params(0, flat, N.PARAM_ONLINE, learner=p); e.set_params(0, flat, N.PARAM_TARGET, learner=p)
+        recs = records([inp["table"]])
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+        orc = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+        orc.opt.wd = wd
+        orc.clip = clip
+        tab = inp["table"]
+        for i in range(c["n_table"]):
+            orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+        orcs.append(orc)
+    g = np.random.default_rng(5)
+    for k in range(4):
+        idx = np.stack([g.choice(c["n_table"], batch, replace=False) for _ in range(P)]).astype(np.int32)
+        st = e.learn(batch, gamma=c["gamma"], tau=c["tau"], critic_lr=c["lr"], clip_norm=clip, critic_weight_decay=wd,
+                     double_dqn=double, idx=idx[:, None, :], want_stats=True)
+        for p in range(P):
+            orcs[p].learn_with(idx[p], c["gamma"], c["tau"], double=double)
+            np.testing.assert_allclose(st[p, 0, N.STAT_CRITIC_LOSS], orcs[p].losses[-1], rtol=LOSS_RTOL)
+    for p in range(P):
+        got = unflat_params(e.get_params(0, N.PARAM_ONLINE, learner=p), orcs[p].q, ["l1", "l2"])
+        assert_params_close(got, orcs[p].q, "dqn2/Qnet/%d" % p)
+        got_t = unflat_params(e.get_params(0, N.PARAM_TARGET, learner=p), orcs[p].q_t, ["l1", "l2"])
+        assert_params_close(got_t, orcs[p].q_t, "dqn2/Qnet_target/%d" % p)
+        assert e.opt_step(0, learner=p) == 4
     e.close()
 
 
@@ -191,6 +242,7 @@ def ac_path(request, monkeypatch):
     launches (any shape; what populations below 128 learners get) and the one-workgroup-per-learner register-chained kernel
     with Adam fused (kernels_critic2.hip; the bench's path).  FRL_CRITIC_V2 forces either, so both meet the same oracle."""
     monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
+    monkeypatch.setenv("FRL_DQN_FUSED", "1" if request.param == "chained" else "0")      # (tests that also touch DQN: both of its paths)
     return request.param
 
 
@@ -1106,7 +1158,8 @@ def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
     assert e.lds_bytes()[1] == int(rows)
     e.close()
     monkeypatch.setenv("FRL_CRITIC_V2", "0")                 # these are the row-chunk kernels' knobs
-    test_dqn_learn_matches_oracle_and_reference(N)
+    monkeypatch.setenv("FRL_DQN_FUSED", "0")
+    test_dqn_learn_matches_oracle_and_reference(N, "rowchunk")
     test_td3_learn(N, "td3", "rowchunk")
     test_td3_learn(N, "td3_pendulum", "rowchunk")
     test_sac_learn(N, "rowchunk")
@@ -1121,7 +1174,8 @@ def test_workgroups_walking_several_row_chunks_give_the_same_answers(N, rows, cp
     monkeypatch.setenv("FRL_RC", rows)
     monkeypatch.setenv("FRL_CPS", cps)
     monkeypatch.setenv("FRL_CRITIC_V2", "0")
-    test_dqn_learn_matches_oracle_and_reference(N)
+    monkeypatch.setenv("FRL_DQN_FUSED", "0")
+    test_dqn_learn_matches_oracle_and_reference(N, "rowchunk")
     test_td3_learn(N, "td3", "rowchunk")
     test_sac_learn(N, "rowchunk")
     test_maddpg_learn(N)
