@@ -1099,15 +1099,16 @@ static bool chained_path(const EngineDesc& h, int batch, int pc) {
 
 // kernels_dqn2.hip: the reference's plain Q-net (obs -> 128 -> n_actions) with the TD update of DQN.py / the Double variant;
 // every other head (Dueling, Noisy, Categorical) and PER-weighted losses take the row-chunk chain.  FRL_DQN_FUSED=0/1 overrides.
-static bool dqn_fused_path(const EngineDesc& h, const LearnArgs& a) {
+static bool dqn_fused_path(const EngineDesc& h, int batch, bool per_weights) {
     const NetDesc& N = h.net[0];
-    const bool shape = h.algo == ALGO_DQN && !h.dueling && !h.noisy && !h.c51_atoms && !a.use_isw && h.hidden == 128 && N.n_layers == 2 &&
-                       N.L[0].k_pad == 16 && N.L[1].n_pad == 16 && a.batch <= kDqn2Batch && !h.obs_norm_on && N.hidden_act == ACT_RELU;
+    const bool shape = h.algo == ALGO_DQN && !h.dueling && !h.noisy && !h.c51_atoms && !per_weights && h.hidden == 128 && N.n_layers == 2 &&
+                       N.L[0].k_pad == 16 && N.L[1].n_pad == 16 && batch <= kDqn2Batch && !h.obs_norm_on && N.hidden_act == ACT_RELU;
     const char* force = getenv("FRL_DQN_FUSED");
     return shape && (force ? atoi(force) != 0 : true);
 }
 
-static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise) {
+static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise,
+                               const DqnStepArgs* step = nullptr) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
     const int ns = ((a.batch + h.rc - 1) / h.rc + h.cps - 1) / h.cps;      // workgroups (= slabs) per unit
@@ -1119,13 +1120,16 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     ad.ns = ns; ad.batch = a.batch; ad.eps = a.adam_eps; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.clip = a.clip_norm;
     ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy; ad.p0 = p0; ad.G = h.Gmax;
     const bool v2 = chained_path(h, a.batch, pc);
-    if (stage == 0 && dqn_fused_path(h, a)) {
+    if (stage == 0 && dqn_fused_path(h, a.batch, a.use_isw != 0)) {
         // a few learners: one 64-row chunk per workgroup (the last to arrive reduces and steps); populations: one workgroup each
         const int nchunks = (a.batch + 63) / 64;
         a.dqn_split = (pc <= 16) ? std::min(std::min(4, nchunks), h.S) : 1;      // measured: P = 64 x 4 workgroups 74 us, x 1 45 us
         if (const char* sp = getenv("FRL_DQN_SPLIT")) a.dqn_split = std::max(1, std::min(std::min(atoi(sp), nchunks), h.S));
         prof_begin(e, PK_GRAD_CRITIC);
-        hipLaunchKernelGGL(dqn_fused_kernel, dim3(pc * a.dqn_split), blk, (size_t)dqn2_lds_floats() * sizeof(float), st, e->d, a);
+        DqnStepArgs sa;
+        memset(&sa, 0, sizeof sa);
+        if (step) sa = *step;
+        hipLaunchKernelGGL(dqn_fused_kernel, dim3(pc * a.dqn_split), blk, (size_t)dqn2_lds_floats() * sizeof(float), st, e->d, a, sa);
         prof_end(e);
         return;
     }
@@ -1185,7 +1189,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     }
 }
 
-extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
+// `step` (frl_rollout only, DQN engines on the fused path): the vector step's add() and the next select_action in the same launch
+static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step) {
     ENG(e);
     if (!args) return fail(FRL_ERR_INVALID, "args is NULL");
     const EngineDesc& h = e->h;
@@ -1244,13 +1249,15 @@ extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) {
         if (args->noisy_eps) { rc = noisy_upload(e, args->noisy_eps, first, 3 - first); if (rc) return rc; }
         else hipLaunchKernelGGL(noisy_draw_kernel, dim3(h.P, 3), dim3(256), 0, e->stream, e->d, 0, 3, e->rng_counter++);
     }
-    launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise);
+    launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise, step);
     if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise);
     if (soft_stage) launch_learn_stage(e, e->stream, a, 2, 0, h.P, dev_rng, needs_noise);
     HIP_TRY(hipGetLastError());
     if (args->stats_out) return frl_stats_get(e, args->stats_out);
     return FRL_OK;
 }
+
+extern "C" int frl_learn(frl_engine* e, const frl_learn_args* args) { return learn_impl(e, args, nullptr); }
 
 // Algorithmic work of one launch (DESIGN.md "Roofline"): flops = 2*B*sum(in*out) per forward
 // pass, x2 more per backward pass that needs both dX and dW, x1 for dX-only passes; bytes =

@@ -178,7 +178,24 @@ __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs 
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 2 * kDqn2Batch; }
-__global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+// The rollout loop's neighbours of learn() folded into the same launch (frl_rollout, DQN.py:294-339): add() of the vector
+// step's transitions before the sample, select_action + epsilon-greedy on the post-update net for the next step after it.
+struct DqnStepArgs {
+    int commit, act;              // which of the two run (0 / 0: plain learn())
+    int E, O;                     // envs per learner, obs_dim
+    const float* obs_cur;         // [P*E][O] obs of the transition
+    const float* store_act;       // [P*E] action index as stored by add()
+    const int* row;               // [P*E] ring row of env i inside its learner's ring
+    const float* next_obs;        // [P*E][O] observation the transition ended in
+    const float* obs_next;        // [P*E][O] observation the policy sees next (the reset observation after an episode end)
+    const float* reward;          // [P*E]
+    const unsigned char* flags;   // [P*E] bit 0 terminated
+    float* act_out;               // [P*E] explored action index (what the next add() stores)
+    float* env_out;               // [P*E] the same, for the env
+    float epsilon;
+    unsigned long long act_counter;   // Philox counter of the act draw (act_kernel's stream 0x9000)
+};
+__global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s);
 
 // kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>
 __global__ void ppo_update_v2_k1_relu(const EngineDesc* __restrict__ Dp, PpoArgs a);

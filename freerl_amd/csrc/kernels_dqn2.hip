@@ -113,7 +113,7 @@ struct Dqn2Grad { f32x4 g1[2], g2[2]; float gb1[2], gb2; };
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+__global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const int nsp = a.dqn_split, unit = blockIdx.x / nsp, sp = blockIdx.x - unit * nsp;
@@ -135,11 +135,33 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     g_i idx = (g_i)(D.idx + (size_t)p * D.batch_max);
     const float invB = 1.f / (float)B;
     const int nchunks = (B + 63) / 64;
+    const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1);
+
+    // ---- add() of this vector step (Buffer.add, DQN_file/Buffer.py:28-38): a 16-lane group per env of the learner.  Every
+    // workgroup of the learner writes the same rows (it samples from them next, and its own stores are the ones it sees).
+    if (s.commit) {
+        g_f wring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+        const int lane = tid & 15;
+        for (int j = tid >> 4; j < s.E; j += kWG / 16) {
+            const size_t i = (size_t)p * s.E + j;
+            g_f r = wring + (size_t)s.row[i] * R.stride;
+            for (int k = lane; k < s.O; k += 16) {
+                r[R.obs_off[0] + k] = s.obs_cur[i * s.O + k];
+                r[R.nobs_off[0] + k] = s.next_obs[i * s.O + k];
+            }
+            if (lane == 0) {
+                r[R.act_off[0]] = s.store_act[i];
+                r[R.rew_off] = s.reward[i];
+                r[R.done_off] = (s.flags[i] & 1) ? 1.f : 0.f;
+            }
+        }
+        __syncthreads();                                               // (waits for the stores: the gathers below may read these rows)
+    }
 
     // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones)
     PPO_T0();
     if (a.device_rng) {
-        draw_indices(idx, S.lidx, B, a.size, a.rng_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1));
+        draw_indices(idx, S.lidx, B, a.size, a.rng_counter, 0u, key);
     } else {
         for (int i = tid; i < B; i += kWG) S.lidx[i] = idx[i];
     }
@@ -347,12 +369,15 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     // otherwise wait for each float4's stores before the next one's loads: six dependent round trips instead of one)
     struct In4 { f32x4 th, m, v, tg; };
     auto load4 = [&](int o) { return In4{ld4((g_cf)(th + o)), ld4((g_cf)(mA + o)), ld4((g_cf)(vA + o)), ld4((g_cf)(tg + o))}; };
-    auto adam4 = [&](int o, const f32x4& gr, In4 in) {
+    // (s.act: the updated weights also go into the online net's LDS image — this lane's four values sit in four 16-byte
+    // slots of its fragment tile, the owner-write pattern of device/chain.hpp)
+    auto adam4 = [&](int o, const f32x4& gr, In4 in, lds_f img) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float t1 = in.th[r], m1 = in.m[r], v1 = in.v[r], g1 = in.tg[r];
             adam1(gr[r], t1, m1, v1, g1);
             in.th[r] = t1; in.m[r] = m1; in.v[r] = v1; in.tg[r] = g1;
+            if (s.act) img[C.tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t1;
         }
         st4(th + o, in.th); st4(mA + o, in.m); st4(vA + o, in.v); st4(tg + o, in.tg);
     };
@@ -364,12 +389,13 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     for (int k = 0; k < 3; ++k)
         if (k < 2 ? q == 0 : own_b2) { bt[k] = th[ob[k]]; bm[k] = mA[ob[k]]; bv[k] = vA[ob[k]]; bg[k] = tg[ob[k]]; }
 #pragma unroll
-    for (int x = 0; x < 2; ++x) { adam4(o1[x], g.g1[x], i1[x]); adam4(o2[x], g.g2[x], i2[x]); }
+    for (int x = 0; x < 2; ++x) { adam4(o1[x], g.g1[x], i1[x], S.w1[0] + (2 * w + x) * 256); adam4(o2[x], g.g2[x], i2[x], S.w2[0] + (2 * w + x) * 256); }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (k < 2 ? q == 0 : own_b2) {
             adam1(k < 2 ? g.gb1[k] : g.gb2, bt[k], bm[k], bv[k], bg[k]);
             th[ob[k]] = bt[k]; mA[ob[k]] = bm[k]; vA[ob[k]] = bv[k]; tg[ob[k]] = bg[k];
+            if (s.act) { if (k < 2) S.b1[0][16 * (2 * w + k) + i16] = bt[k]; else S.b2[0][i16] = bt[k]; }
         }
     }
     if (tid == 0) {
@@ -379,6 +405,32 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         st[ST_CRITIC_GNORM] = total;
     }
     PPO_T(6);
+    // ---- select_action on what the policy sees next (DQN.py:70-84: argmax_a Q(s, a)) + epsilon-greedy (:307-310), act_kernel's draws
+    if (s.act) {
+        lds_barrier();
+        for (int c = 0; c * 64 < s.E; ++c) {
+            const int j = c * 64 + 16 * w + i16;
+            f32x4 xb = {0.f, 0.f, 0.f, 0.f};
+            if (j < s.E) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < s.O) xb[e] = s.obs_next[((size_t)p * s.E + j) * s.O + 4 * q + e];
+            }
+            float mx; int best;
+            row_max(C.forward_z(0, xb), mx, best);
+            if (j < s.E && q == 0) {
+                const Philox4 u = philox4x32_10(s.act_counter, 0x9000u, (unsigned)j, key);
+                if (u01(u.z) <= s.epsilon) best = (int)uniform_index(u, (unsigned)nA);
+                s.act_out[(size_t)p * s.E + j] = (float)best;
+                s.env_out[(size_t)p * s.E + j] = (float)best;
+            }
+        }
+    }
+    // the observation the next vector step starts from (every workgroup of the learner has read obs_cur before its ticket)
+    if (s.commit) {
+        float* oc = const_cast<float*>(s.obs_cur);
+        for (int k = tid; k < s.E * s.O; k += kWG) oc[(size_t)p * s.E * s.O + k] = s.obs_next[(size_t)p * s.E * s.O + k];
+    }
     PPO_TDUMP();
 }
 

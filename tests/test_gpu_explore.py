@@ -239,3 +239,35 @@ def test_rollout_on_a_per_engine_samples_and_updates_priorities(N):
     st1 = e.per_state(0)
     assert st1["sum"] != st0["sum"] + 60.0 and st1["beta"] > 0.4 and np.all(np.isfinite(e.stats()))   # priorities rewritten from TD errors
     pool.close(); e.close()
+
+
+@pytest.mark.parametrize("P,Ev,split", [(3, 2, "1"), (2, 5, "4"), (1, 70, "2")])
+def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkeypatch, P, Ev, split):
+    """frl_rollout on a plain DQN engine folds add(), learn() and the next select_action + epsilon-greedy into one launch per
+    vector step (kernels_dqn2.hip).  Same engine seed, same pool seed: the separate commit / learn / act launches
+    (FRL_DQN_STEP_FUSE=0) consume the same Philox counters, so the rings, the parameters and the returns must agree — the only
+    arithmetic that differs is the Q forward behind the argmax (MFMA chain against act_kernel's row-chunk layers)."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    monkeypatch.setenv("FRL_DQN_SPLIT", split)
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("FRL_DQN_STEP_FUSE", fuse)
+        e = Engine(N.ALGO_DQN, 8, 4, 16384, discrete=True, batch_max=64, n_learners=P, seed=11)
+        _rand_params(e, N, 0.3, seed=12)
+        pool = EnvPool("SynLinearDiscrete-v0", P * Ev, n_threads=1, seed=5)
+        kw = dict(envs_per_learner=Ev, start_steps=128 // Ev, learn_every=1, epsilon=0.2, batch=64, critic_lr=1e-3, tau=0.05)
+        o1 = rollout(e, pool, 90, **kw)
+        o2 = rollout(e, pool, 35, **kw)                     # a second call: starts with a separate act launch again
+        rows = [e.read_rows(p, 0, 125 * Ev) for p in range(P)]
+        res.append((o1, o2, rows, [e.get_params(0, learner=p) for p in range(P)], [e.get_params(0, N.PARAM_TARGET, learner=p) for p in range(P)],
+                    [e.opt_step(0, learner=p) for p in range(P)]))
+        pool.close(); e.close()
+    a, b = res
+    assert a[0]["updates"] == b[0]["updates"] > 0 and a[1]["updates"] == b[1]["updates"] == 35 * P
+    for p in range(P):
+        np.testing.assert_array_equal(a[2][p], b[2][p])
+        np.testing.assert_array_equal(a[3][p], b[3][p])
+        np.testing.assert_array_equal(a[4][p], b[4][p])
+        assert a[5][p] == b[5][p]
+    assert a[0]["return_sum"] == b[0]["return_sum"] and a[1]["episodes"] == b[1]["episodes"]
