@@ -666,21 +666,20 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
         for (int j = full * 4; j < i; ++j) d |= (lidx[j] == mine);
         return d;
     };
+    FRL_LDS int* lmark = lidx + ((batch + 3) & ~3);         // second half of the caller's 2 x batch ints of LDS
     for (unsigned round = 1; round < 64; ++round) {
         int dup = 0;
-        for (int i = threadIdx.x; i < batch; i += kWG)
-            if (dup_before(i)) dup = 1;
-        // redraw AFTER everyone has finished comparing against the old values
+        for (int i = threadIdx.x; i < batch; i += kWG) {
+            const int d = dup_before(i) ? 1 : 0;
+            lmark[i] = d;
+            dup |= d;
+        }
+        // redraw AFTER everyone has finished comparing against the old values (one scan per round: a small buffer — the
+        // first thousand steps of a run — has tens of collisions per batch and takes several rounds)
         const int any = __syncthreads_or(dup);
         if (!any) break;
-        FRL_LDS int* lmark = lidx + ((batch + 3) & ~3);     // second half of the caller's 2 x batch ints of LDS
-        for (int i = threadIdx.x; i < batch; i += kWG) lmark[i] = dup_before(i) ? 1 : 0;
-        __syncthreads();
         for (int i = threadIdx.x; i < batch; i += kWG)
-            if (lmark[i]) lidx[i] = -1 - i;
-        __syncthreads();
-        for (int i = threadIdx.x; i < batch; i += kWG)
-            if (lidx[i] < 0)
+            if (lmark[i])
                 lidx[i] = (int)uniform_index(philox4x32_10(counter, stream + round * 0x10000u, (unsigned)i, key),
                                              (unsigned)size);
         __syncthreads();

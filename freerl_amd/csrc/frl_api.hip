@@ -452,7 +452,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.noise, e->noise_count, e->stream));
         CREATE_TRY(dalloc_zero(&h.stats, P * h.n_agents * ST_COUNT, e->stream));
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
-        CREATE_TRY(dalloc_zero(&h.ticket, P, e->stream));
+        CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
         {
             int omax = 1;

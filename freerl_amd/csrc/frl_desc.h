@@ -84,7 +84,7 @@ struct EngineDesc {
     int noise_sets;       // max(2, n_agents)
     float* stats;         // [P][n_agents][ST_COUNT]
     int* steps;           // [P][kMaxNets + 1] Adam step counters (+1: SAC alpha)
-    int* ticket;          // [P] arrival counter of a learner's workgroups in dqn_fused_kernel (zero between launches)
+    int* ticket;          // [P + 1] arrival counters in dqn_fused_kernel: a learner's workgroups; [P]: the learners (zero between launches)
     float* alpha;         // [P][4]: log_alpha, m, v, alpha (SAC)
     unsigned long long seed;
     int act_max;          // max act_dim over agents (row pitch of `noise`)

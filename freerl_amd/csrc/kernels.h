@@ -177,7 +177,7 @@ constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
-constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 2 * kDqn2Batch; }
+constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }
 // The rollout loop's neighbours of learn() folded into the same launch (frl_rollout, DQN.py:294-339): add() of the vector
 // step's transitions before the sample, select_action + epsilon-greedy on the post-update net for the next step after it.
 struct DqnStepArgs {
@@ -194,6 +194,8 @@ struct DqnStepArgs {
     float* env_out;               // [P*E] the same, for the env
     float epsilon;
     unsigned long long act_counter;   // Philox counter of the act draw (act_kernel's stream 0x9000)
+    int* done_flag;               // host-visible word (or nullptr): set to done_value once env_out is written, so that the
+    int done_value;               // host can pick the actions up without waiting for the launch to retire
 };
 __global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s);
 

@@ -26,6 +26,7 @@ namespace {
 struct Dqn2Lds {
     lds_f w1[2], w2[2], b1[2], b2[2];      // [0] online, [1] target
     lds_f ea, eb, red;
+    lds_f onx;                             // [64][16] obs_next of the learner's first 64 envs (frl_rollout's folded step)
     FRL_LDS int* lidx;
 };
 
@@ -40,35 +41,44 @@ struct Dqn2 {
         S.eb = p; p += 4 * 256;
         for (int k = 0; k < 2; ++k) { S.b1[k] = p; p += kHid; S.b2[k] = p; p += 16; }
         S.red = p; p += 64;
+        S.onx = p; p += 64 * 16;
         S.lidx = (FRL_LDS int*)p; p += 2 * kDqn2Batch;
         tid = threadIdx.x; l = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6); i16 = l & 15; q = l >> 4;
         fslot = (q * 16 + (i16 ^ q)) << 2;
         tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);
     }
 
-    // engine layout Wk[k][n] (n contiguous), then b[n_pad] -> fragment-ordered images (as ChainNet::stage, two layers)
-    __device__ __forceinline__ void stage(g_cf th, const LayerDesc& L1, const LayerDesc& L2, int k) const {
+    // engine layout Wk[k][n] (n contiguous), then b[n_pad] -> fragment-ordered images (as ChainNet::stage, two layers); the
+    // loads and the LDS stores are separate calls so that a kernel can keep other work between them
+    struct StageRegs { f32x4 u1, u1b, u3[2]; float b1, b2; };
+    __device__ __forceinline__ StageRegs stage_load(g_cf th, const LayerDesc& L1, const LayerDesc& L2) const {
+        StageRegs X;
         const int n = tid & 127;
-        f32x4 u1, u1b, u3[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u1[e] = th[L1.w_off + (4 * (tid >> 7) + e) * kHid + n];
+        for (int e = 0; e < 4; ++e) X.u1[e] = th[L1.w_off + (4 * (tid >> 7) + e) * kHid + n];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u1b[e] = th[L1.w_off + (4 * (2 + (tid >> 7)) + e) * kHid + n];
+        for (int e = 0; e < 4; ++e) X.u1b[e] = th[L1.w_off + (4 * (2 + (tid >> 7)) + e) * kHid + n];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k4 = (tid >> 4) + 16 * j;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u3[j][e] = th[L2.w_off + (4 * k4 + e) * 16 + (tid & 15)];
+            for (int e = 0; e < 4; ++e) X.u3[j][e] = th[L2.w_off + (4 * k4 + e) * 16 + (tid & 15)];
         }
-        { const int qq = tid >> 7; st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1); }
-        { const int qq = 2 + (tid >> 7); st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1b); }
+        X.b1 = tid < kHid ? th[L1.b_off + tid] : 0.f;
+        X.b2 = tid < 16 ? th[L2.b_off + tid] : 0.f;
+        return X;
+    }
+    __device__ __forceinline__ void stage_store(int k, const StageRegs& X) const {
+        const int n = tid & 127;
+        { const int qq = tid >> 7; st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), X.u1); }
+        { const int qq = 2 + (tid >> 7); st4(S.w1[k] + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), X.u1b); }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k4 = (tid >> 4) + 16 * j, kb = k4 >> 2, qq = k4 & 3;
-            st4(S.w2[k] + kb * 256 + ((qq * 16 + ((tid & 15) ^ qq)) << 2), u3[j]);
+            st4(S.w2[k] + kb * 256 + ((qq * 16 + ((tid & 15) ^ qq)) << 2), X.u3[j]);
         }
-        if (tid < kHid) S.b1[k][tid] = th[L1.b_off + tid];
-        if (tid < 16) S.b2[k][tid] = th[L2.b_off + tid];
+        if (tid < kHid) S.b1[k][tid] = X.b1;
+        if (tid < 16) S.b2[k][tid] = X.b2;
     }
 
     // h1 = relu(W1 x + b1), z = W2 h1 + b2 for this wave's 16 rows (x: B operand, columns 4q + e of row i16)
@@ -137,39 +147,40 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     const int nchunks = (B + 63) / 64;
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1);
 
-    // ---- add() of this vector step (Buffer.add, DQN_file/Buffer.py:28-38): a 16-lane group per env of the learner.  Every
-    // workgroup of the learner writes the same rows (it samples from them next, and its own stores are the ones it sees).
+    // ---- everything that does not depend on the index draw is issued first: both nets' weights, and add() of this vector
+    // step (Buffer.add, DQN_file/Buffer.py:28-38): a 16-lane group per env of the learner.  Every workgroup of the learner
+    // writes the same rows (it samples from them next, and its own stores are the ones it sees); obs_next is kept in LDS for
+    // the select_action at the end.
+    PPO_T0();
+    const Dqn2::StageRegs so = C.stage_load(th, L1, L2), stg = C.stage_load(tg, L1, L2);
     if (s.commit) {
         g_f wring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         const int lane = tid & 15;
         for (int j = tid >> 4; j < s.E; j += kWG / 16) {
             const size_t i = (size_t)p * s.E + j;
-            g_f r = wring + (size_t)s.row[i] * R.stride;
-            for (int k = lane; k < s.O; k += 16) {
-                r[R.obs_off[0] + k] = s.obs_cur[i * s.O + k];
-                r[R.nobs_off[0] + k] = s.next_obs[i * s.O + k];
-            }
-            if (lane == 0) {
-                r[R.act_off[0]] = s.store_act[i];
-                r[R.rew_off] = s.reward[i];
-                r[R.done_off] = (s.flags[i] & 1) ? 1.f : 0.f;
-            }
+            const int row = s.row[i];
+            float oc = 0.f, no = 0.f, on = 0.f, sa = 0.f, rw = 0.f;
+            unsigned char fl = 0;
+            if (lane < s.O) { oc = s.obs_cur[i * s.O + lane]; no = s.next_obs[i * s.O + lane]; on = s.obs_next[i * s.O + lane]; }
+            if (lane == 0) { sa = s.store_act[i]; rw = s.reward[i]; fl = s.flags[i]; }
+            g_f r = wring + (size_t)row * R.stride;
+            if (lane < s.O) { r[R.obs_off[0] + lane] = oc; r[R.nobs_off[0] + lane] = no; }
+            if (lane == 0) { r[R.act_off[0]] = sa; r[R.rew_off] = rw; r[R.done_off] = (fl & 1) ? 1.f : 0.f; }
+            if (j < 64) S.onx[j * 16 + lane] = on;
         }
-        __syncthreads();                                               // (waits for the stores: the gathers below may read these rows)
     }
-
-    // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones)
-    PPO_T0();
+    C.stage_store(0, so);
+    C.stage_store(1, stg);
+    PPO_T(1);
+    // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones).  The barriers inside wait
+    // for the stores above: the gathers below may read the rows just added.
     if (a.device_rng) {
         draw_indices(idx, S.lidx, B, a.size, a.rng_counter, 0u, key);
     } else {
         for (int i = tid; i < B; i += kWG) S.lidx[i] = idx[i];
+        __syncthreads();
     }
     PPO_T(0);
-    C.stage(th, L1, L2, 0);
-    C.stage(tg, L1, L2, 1);
-    lds_barrier();
-    PPO_T(1);
 
     struct RowIn { f32x4 xs, xn; float act, rew, done; };
     auto load_row = [&](int c) {
@@ -298,6 +309,18 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     const int o2[2] = {L2.w_off + (16 * (2 * w) + i16) * 16 + 4 * q, L2.w_off + (16 * (2 * w + 1) + i16) * 16 + 4 * q};
     const int ob1[2] = {L1.b_off + 16 * (2 * w) + i16, L1.b_off + 16 * (2 * w + 1) + i16};
     const int ob2 = L2.b_off + i16;
+    // the update's loads of theta / m / v / target now: in flight under the partial-gradient exchange and the reductions (and
+    // all of them before the first store — the compiler cannot prove the four arrays distinct and would otherwise wait for
+    // each float4's stores before the next one's loads: six dependent round trips instead of one)
+    struct In4 { f32x4 th, m, v, tg; };
+    auto load4 = [&](int o) { return In4{ld4((g_cf)(th + o)), ld4((g_cf)(mA + o)), ld4((g_cf)(vA + o)), ld4((g_cf)(tg + o))}; };
+    const In4 i1[2] = {load4(o1[0]), load4(o1[1])}, i2[2] = {load4(o2[0]), load4(o2[1])};
+    const bool own_b2 = (w == 0 && q == 0);
+    float bt[3] = {0.f, 0.f, 0.f}, bm[3] = {0.f, 0.f, 0.f}, bv[3] = {0.f, 0.f, 0.f}, bg[3] = {0.f, 0.f, 0.f};
+    const int ob[3] = {ob1[0], ob1[1], ob2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < 2 ? q == 0 : own_b2) { bt[k] = th[ob[k]]; bm[k] = mA[ob[k]]; bv[k] = vA[ob[k]]; bg[k] = tg[ob[k]]; }
     if (nsp > 1) {
         g_f slab = as_global(D.slab + ((size_t)p * D.S + sp) * D.learner_stride + D.net_off[0]);
 #pragma unroll
@@ -365,10 +388,6 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         thi = thi - step * (mi / (sqrtf(vi) / bc2s + a.adam_eps));
         tgi = tgi * tk + thi * a.tau;
     };
-    // every load of the update before its first store (the compiler cannot prove theta / m / v / target distinct and would
-    // otherwise wait for each float4's stores before the next one's loads: six dependent round trips instead of one)
-    struct In4 { f32x4 th, m, v, tg; };
-    auto load4 = [&](int o) { return In4{ld4((g_cf)(th + o)), ld4((g_cf)(mA + o)), ld4((g_cf)(vA + o)), ld4((g_cf)(tg + o))}; };
     // (s.act: the updated weights also go into the online net's LDS image — this lane's four values sit in four 16-byte
     // slots of its fragment tile, the owner-write pattern of device/chain.hpp)
     auto adam4 = [&](int o, const f32x4& gr, In4 in, lds_f img) {
@@ -381,13 +400,6 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         }
         st4(th + o, in.th); st4(mA + o, in.m); st4(vA + o, in.v); st4(tg + o, in.tg);
     };
-    const In4 i1[2] = {load4(o1[0]), load4(o1[1])}, i2[2] = {load4(o2[0]), load4(o2[1])};
-    const bool own_b2 = (w == 0 && q == 0);
-    float bt[3] = {0.f, 0.f, 0.f}, bm[3] = {0.f, 0.f, 0.f}, bv[3] = {0.f, 0.f, 0.f}, bg[3] = {0.f, 0.f, 0.f};
-    const int ob[3] = {ob1[0], ob1[1], ob2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (k < 2 ? q == 0 : own_b2) { bt[k] = th[ob[k]]; bm[k] = mA[ob[k]]; bv[k] = vA[ob[k]]; bg[k] = tg[ob[k]]; }
 #pragma unroll
     for (int x = 0; x < 2; ++x) { adam4(o1[x], g.g1[x], i1[x], S.w1[0] + (2 * w + x) * 256); adam4(o2[x], g.g2[x], i2[x], S.w2[0] + (2 * w + x) * 256); }
 #pragma unroll
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             if (j < s.E) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < s.O) xb[e] = s.obs_next[((size_t)p * s.E + j) * s.O + 4 * q + e];
+                    if (4 * q + e < s.O) xb[e] = c == 0 ? S.onx[j * 16 + 4 * q + e] : s.obs_next[((size_t)p * s.E + j) * s.O + 4 * q + e];
             }
             float mx; int best;
             row_max(C.forward_z(0, xb), mx, best);
@@ -429,7 +441,21 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     // the observation the next vector step starts from (every workgroup of the learner has read obs_cur before its ticket)
     if (s.commit) {
         float* oc = const_cast<float*>(s.obs_cur);
-        for (int k = tid; k < s.E * s.O; k += kWG) oc[(size_t)p * s.E * s.O + k] = s.obs_next[(size_t)p * s.E * s.O + k];
+        for (int k = tid; k < s.E * s.O; k += kWG) {
+            const int j = k / s.O, col = k - j * s.O;
+            oc[(size_t)p * s.E * s.O + k] = j < 64 ? S.onx[j * 16 + col] : s.obs_next[(size_t)p * s.E * s.O + k];
+        }
+    }
+    if (s.act && s.done_flag) {
+        __syncthreads();                                               // every wave's env_out stores have been issued and counted down
+        if (tid == 0) {
+            __threadfence_system();                                    // this learner's actions are out; the last learner to get here flags the host
+            if (atomicAdd(D.ticket + D.P, 1) == a.p_count - 1) {
+                D.ticket[D.P] = 0;
+                __threadfence_system();
+                __hip_atomic_store(s.done_flag, s.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     PPO_TDUMP();
 }

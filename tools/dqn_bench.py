@@ -72,7 +72,7 @@ def run_rollout(P, E, steps=300):
         flat = (rng.standard_normal(e.get_params(0, learner=p).size) * 0.05).astype(np.float32)
         e.set_params(0, flat, N.PARAM_ONLINE, learner=p)
         e.set_params(0, flat, N.PARAM_TARGET, learner=p)
-    e.fill_synthetic(4 * B, seed=5)                        # past `start_steps`: every vector step is followed by a learn()
+    e.fill_synthetic(CAP // 2, seed=5)                     # a run's steady state (ring half full): every vector step is followed by a learn()
     pool = EnvPool("SynLinearDiscrete-v0", P * E, n_threads=min(8, os.cpu_count() or 1), seed=2)
     kw = dict(envs_per_learner=E, start_steps=0, learn_every=1, epsilon=0.1, batch=B, gamma=0.99, tau=0.01, critic_lr=1e-3,
               clip_norm=0.0)

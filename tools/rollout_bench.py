@@ -26,7 +26,7 @@ def run(algo, P, E, host, steps=300):
             flat = (g.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
             e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
             e.set_params(net, flat, N.PARAM_TARGET, learner=p)
-    e.fill_synthetic(4 * B, seed=5)
+    e.fill_synthetic(CAP // 2, seed=5)
     pool = EnvPool("SynLinearDiscrete-v0" if dqn else "SynLinear-v0", P * E, n_threads=min(8, os.cpu_count() or 1), seed=2)
     kw = dict(envs_per_learner=E, start_steps=0, learn_every=1, batch=B, host_explore=host)
     rollout(e, pool, 5, **kw)
