@@ -520,11 +520,18 @@ extern "C" int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* rc_out) {
 }
 
 static bool chained_path(const EngineDesc& h, int batch, int pc);
+static bool dqn_fused_path(const EngineDesc& h, int batch, bool per_weights);
 
 extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, int* bytes_out, int* rows_out) {
     if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
     if (e->h.algo == ALGO_PPO) return fail(FRL_ERR_INVALID, "frl_learn_path describes frl_learn(); PPO updates go through frl_ppo_learn");
     if (batch <= 0 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch out of range");
+    if (dqn_fused_path(e->h, batch, e->per_on)) {           // kernels_dqn2.hip (a PER engine's weighted loss takes the row-chunk chain)
+        if (chained_out) *chained_out = 1;
+        if (bytes_out) *bytes_out = dqn2_lds_floats() * (int)sizeof(float);
+        if (rows_out) *rows_out = e->h.P <= 16 ? std::min(batch, 64) : batch;
+        return FRL_OK;
+    }
     const bool v2 = chained_path(e->h, batch, e->h.P);
     if (chained_out) *chained_out = v2 ? 1 : 0;
     if (bytes_out) *bytes_out = v2 ? critic2_lds_floats() * (int)sizeof(float) : e->lds_bytes;

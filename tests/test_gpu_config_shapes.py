@@ -265,3 +265,10 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=128, twin_critic=True, batch_max=256, hidden=256)
     assert not h256.learn_path(256)[0]
     h256.close()
+    monkeypatch.delenv("FRL_DQN_FUSED", raising=False)
+    dqn = Engine(N.ALGO_DQN, 8, 4, 512, discrete=True, batch_max=256)
+    assert dqn.learn_path(256) == (True, 77184, 64)                   # the one-launch update, a 64-row chunk per workgroup for one learner
+    dqn.close()
+    rainbow = Engine(N.ALGO_DQN, 8, 4, 512, discrete=True, batch_max=256, dueling=True, noisy=True, c51=(51, -10.0, 10.0))
+    assert not rainbow.learn_path(256)[0]
+    rainbow.close()
