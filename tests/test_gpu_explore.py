@@ -241,8 +241,9 @@ def test_rollout_on_a_per_engine_samples_and_updates_priorities(N):
     pool.close(); e.close()
 
 
-@pytest.mark.parametrize("P,Ev,split,cap", [(3, 2, "1", 16384), (2, 5, "4", 16384), (1, 70, "2", 16384), (2, 3, "4", 300)])
-def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkeypatch, P, Ev, split, cap):
+@pytest.mark.parametrize("P,Ev,split,cap,every", [(3, 2, "1", 16384, 1), (2, 5, "4", 16384, 1), (1, 70, "2", 16384, 1), (2, 3, "4", 300, 1),
+                                                  (2, 2, "4", 16384, 3)])
+def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkeypatch, P, Ev, split, cap, every):
     """frl_rollout on a plain DQN engine folds add(), learn() and the next select_action + epsilon-greedy into one launch per
     vector step (kernels_dqn2.hip).  Same engine seed, same pool seed: the separate commit / learn / act launches
     (FRL_DQN_STEP_FUSE=0) consume the same Philox counters, so the rings, the parameters and the returns must agree — the only
@@ -256,7 +257,7 @@ def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkey
         e = Engine(N.ALGO_DQN, 8, 4, cap, discrete=True, batch_max=64, n_learners=P, seed=11)       # cap 300: the ring wraps
         _rand_params(e, N, 0.3, seed=12)
         pool = EnvPool("SynLinearDiscrete-v0", P * Ev, n_threads=1, seed=5)
-        kw = dict(envs_per_learner=Ev, start_steps=128 // Ev, learn_every=1, epsilon=0.2, batch=64, critic_lr=1e-3, tau=0.05)
+        kw = dict(envs_per_learner=Ev, start_steps=128 // Ev, learn_every=every, epsilon=0.2, batch=64, critic_lr=1e-3, tau=0.05)
         o1 = rollout(e, pool, 90, **kw)
         o2 = rollout(e, pool, 35, **kw)                     # a second call: starts with a separate act launch again
         rows = [e.read_rows(p, 0, min(cap, 125 * Ev)) for p in range(P)]
@@ -264,7 +265,7 @@ def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkey
                     [e.opt_step(0, learner=p) for p in range(P)]))
         pool.close(); e.close()
     a, b = res
-    assert a[0]["updates"] == b[0]["updates"] > 0 and a[1]["updates"] == b[1]["updates"] == 35 * P
+    assert a[0]["updates"] == b[0]["updates"] > 0 and a[1]["updates"] == b[1]["updates"] == (35 // every) * P
     for p in range(P):
         np.testing.assert_array_equal(a[2][p], b[2][p])
         np.testing.assert_array_equal(a[3][p], b[3][p])
