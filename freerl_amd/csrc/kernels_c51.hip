@@ -47,9 +47,27 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     // q[r][a] of the logits in outb -> qb, then argmax into S.y (one thread per (row, action), then per row)
     auto pick_action = [&]() {
         const int lb = c51_combine(S.outb, S.op, nv, nA, atoms, duel);
-        for (int e = threadIdx.x; e < nv * nA; e += kWG) {           // one thread per (row, action); a wave per pair was 2x slower
-            const int r = e / nA, act = e - r * nA;                   // (its shuffle reductions are ds_bpermute round trips)
-            qb[r * ap + act] = c51_q_only(S.outb + r * S.op + lb + act * atoms, atoms, vmin, dz);
+        // two adjacent lanes per (row, action), half the support each (one thread per pair left half the workgroup idle for the
+        // longest vector phase of the chunk; a whole wave per pair was measured 2x slower: its reductions are ds_bpermute round
+        // trips).  Only the argmax over actions is taken from these values: hardware exp.
+        const int half = (atoms + 1) / 2, npair = nv * nA;
+        for (int e0 = 0; e0 < 2 * npair; e0 += kWG) {
+            const int e = e0 + threadIdx.x, pr = min(e >> 1, npair - 1), hf = e & 1;
+            const int r = pr / nA, act = pr - r * nA;
+            lds_cf lg = S.outb + r * S.op + lb + act * atoms;
+            const int i0 = hf * half, i1 = hf ? atoms : half;
+            float mx = lg[i0];
+            for (int i = i0 + 1; i < i1; ++i) mx = fmaxf(mx, lg[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            float sum = 0.f, zsum = 0.f;
+            for (int i = i0; i < i1; ++i) {
+                const float ex = __expf(lg[i] - mx);
+                sum += ex;
+                zsum += ex * (vmin + dz * (float)i);
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            zsum += __shfl_xor(zsum, 1, 64);
+            if (e < 2 * npair && hf == 0) qb[r * ap + act] = zsum / sum;
         }
         FRL_PHASE(S);
         for (int r = threadIdx.x; r < nv; r += kWG) {
@@ -71,8 +89,6 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     mlp_fwd(N, 0, nl, target, S, ACT_NONE);
     int lb = a.double_dqn ? c51_combine(S.outb, S.op, nv, nA, atoms, duel) : pick_action();
     // ---- projection of the target distribution (projection_dist :147-158).  qb row = next_dist (one wave per row), then
-    // one thread per row walks the support: every lower-bin index_add_ in atom order, then every upper-bin one (:155-156).
-    // (One thread per (row, target bin) scanning all sources was measured: 51x the arithmetic, slower than this chain.)
     constexpr int kRows = 8;                           // rows per wave and pass (rc <= 32 rows: one pass)
     for (int rb = 0; rb < rc; rb += kRows * kWaves) {
         lds_cf lg[kRows];
@@ -90,6 +106,11 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
         }
     }
     FRL_PHASE(S);
+    // one thread per row walks the support: every lower-bin index_add_ in atom order, then every upper-bin one (:155-156).
+    // Measured and not taken (profiles/README.md): one thread per (row, target bin) scanning all sources (51x the arithmetic);
+    // per-source tables + one thread per (row, bin) finding its sources' run by bisection (28 k -> 35-65 k cycles: dependent LDS
+    // reads); tables + a single register walk per row, 8 rows per wave (35-40 k: a dependent read per run for the previous
+    // run's upper parts, divergent lanes).
     for (int r = threadIdx.x; r < nv; r += kWG) {
         lds_cf ndl = qb + r * ap;
         g_cf rec = ring + (size_t)idx[r] * R.stride;
