@@ -492,12 +492,26 @@ __device__ __forceinline__ void mlp_bwd(const NetDesc& N, int l0, int nl, g_cf t
 // X[r][dst0 + c] = ring[idx[r0 + r]][src0 + c] for r < nvalid, c < ncols; 0 for r >= nvalid
 __device__ __forceinline__ void gather_cols(lds_f X, int ldx, int rc, int nvalid, g_ci idx, g_cf ring, int stride,
                                             int src0, int ncols, int dst0) {
+    // Eight elements per thread and round: their row indices, then their ring loads, then the LDS stores.  One element per
+    // iteration is two DEPENDENT global round trips that the compiler does not overlap with the next iteration's: 94 k cycles
+    // for the 376 observation columns of 32 Humanoid rows (47 iterations), a quarter of SAC's critic kernel at those dims.
     const int total = rc * ncols;
-    for (int e = threadIdx.x; e < total; e += kWG) {
-        const int r = e / ncols, c = e - r * ncols;
-        float v = 0.f;
-        if (r < nvalid) v = ring[(size_t)idx[r] * stride + src0 + c];
-        X[r * ldx + dst0 + c] = v;
+    constexpr int U = 8;
+    for (int e0 = threadIdx.x; e0 < total; e0 += kWG * U) {
+        int ri[U], rr[U], cc[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kWG;
+            rr[u] = e / ncols;
+            cc[u] = e - rr[u] * ncols;
+            ri[u] = (e < total && rr[u] < nvalid) ? idx[rr[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ri[u] >= 0 ? ring[(size_t)ri[u] * stride + src0 + cc[u]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e0 + u * kWG < total) X[rr[u] * ldx + dst0 + cc[u]] = v[u];
     }
 }
 // Batch_ObsNorm: X[r][c0 + c] = (X[r][c0 + c] - mean[c]) / (std[c] + 1e-8) for r < nvalid
