@@ -241,9 +241,10 @@ def test_rollout_on_a_per_engine_samples_and_updates_priorities(N):
     pool.close(); e.close()
 
 
-@pytest.mark.parametrize("P,Ev,split,cap,every", [(3, 2, "1", 16384, 1), (2, 5, "4", 16384, 1), (1, 70, "2", 16384, 1), (2, 3, "4", 300, 1),
-                                                  (2, 2, "4", 16384, 3)])
-def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkeypatch, P, Ev, split, cap, every):
+@pytest.mark.parametrize("P,Ev,split,cap,every,handover", [
+    (3, 2, "1", 16384, 1, "flag"), (2, 5, "4", 16384, 1, "flag"), (1, 70, "2", 16384, 1, "flag"), (2, 3, "4", 300, 1, "flag"),
+    (2, 2, "4", 16384, 3, "flag"), (3, 2, "4", 16384, 1, "sync"), (2, 4, "1", 16384, 2, "memcpy")])
+def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkeypatch, P, Ev, split, cap, every, handover):
     """frl_rollout on a plain DQN engine folds add(), learn() and the next select_action + epsilon-greedy into one launch per
     vector step (kernels_dqn2.hip).  Same engine seed, same pool seed: the separate commit / learn / act launches
     (FRL_DQN_STEP_FUSE=0) consume the same Philox counters, so the rings, the parameters and the returns must agree — the only
@@ -251,6 +252,12 @@ def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkey
     from freerl_amd.engine import Engine
     from freerl_amd.envpool import EnvPool, rollout
     monkeypatch.setenv("FRL_DQN_SPLIT", split)
+    # how the block reaches the launch and the actions the host: pinned memory in place + a flagged word (default for small steps),
+    # in place + stream synchronisation, or a hipMemcpyAsync each way (what large vector steps get)
+    if handover == "sync":
+        monkeypatch.setenv("FRL_ROLLOUT_POLL", "0")
+    if handover == "memcpy":
+        monkeypatch.setenv("FRL_ROLLOUT_ZEROCOPY", "0")
     res = []
     for fuse in ("0", "1"):
         monkeypatch.setenv("FRL_DQN_STEP_FUSE", fuse)
