@@ -526,7 +526,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
     if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
     if (e->h.algo == ALGO_PPO) return fail(FRL_ERR_INVALID, "frl_learn_path describes frl_learn(); PPO updates go through frl_ppo_learn");
     if (batch <= 0 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch out of range");
-    if (dqn_fused_path(e->h, batch, e->per_on)) {           // kernels_dqn2.hip (a PER engine's weighted loss takes the row-chunk chain)
+    if (dqn_fused_path(e->h, batch, e->per_on)) {           // kernels_dqn2.hip
         if (chained_out) *chained_out = 1;
         if (bytes_out) *bytes_out = dqn2_lds_floats() * (int)sizeof(float);
         if (rows_out) *rows_out = e->h.P <= 16 ? std::min(batch, 64) : batch;
@@ -1104,11 +1104,12 @@ static bool chained_path(const EngineDesc& h, int batch, int pc) {
     return shape && (force ? atoi(force) != 0 : pc >= 128);
 }
 
-// kernels_dqn2.hip: the reference's plain Q-net (obs -> 128 -> n_actions) with the TD update of DQN.py / the Double variant;
-// every other head (Dueling, Noisy, Categorical) and PER-weighted losses take the row-chunk chain.  FRL_DQN_FUSED=0/1 overrides.
+// kernels_dqn2.hip: the reference's Q-net (obs -> 128 -> n_actions, or the Dueling [V ; A] head) with the TD update of DQN.py and
+// DQN_with_tricks.py's Double / PER-weighted variants; Noisy and Categorical heads take the row-chunk chain.  FRL_DQN_FUSED=0/1 overrides.
 static bool dqn_fused_path(const EngineDesc& h, int batch, bool per_weights) {
     const NetDesc& N = h.net[0];
-    const bool shape = h.algo == ALGO_DQN && !h.dueling && !h.noisy && !h.c51_atoms && !per_weights && h.hidden == 128 && N.n_layers == 2 &&
+    (void)per_weights;          // PER's importance weights (mean or per-row) are applied in the launch
+    const bool shape = h.algo == ALGO_DQN && !h.noisy && !h.c51_atoms && h.hidden == 128 && N.n_layers == 2 &&
                        N.L[0].k_pad == 16 && N.L[1].n_pad == 16 && batch <= kDqn2Batch && !h.obs_norm_on && N.hidden_act == ACT_RELU;
     const char* force = getenv("FRL_DQN_FUSED");
     return shape && (force ? atoi(force) != 0 : true);

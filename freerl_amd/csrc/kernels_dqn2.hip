@@ -10,8 +10,8 @@
 // more than one, each writes its partial gradient to the learner's slab and the last one to arrive (atomic ticket) adds the
 // partials in workgroup order and applies the update — the single learner's latency path (one chunk per workgroup).
 //
-// Shape: plain or Double DQN head (no Dueling / Noisy / Categorical / PER weights), hidden 128 (ReLU), obs_dim <= 16,
-// n_actions <= 16, batch <= 256.  Everything else runs dqn_grad_kernel / c51_grad_kernel.
+// Shape: plain or Dueling head ([V ; A], DQN_with_tricks.py:60-79), Double target, PER's importance weights (:276-278); hidden
+// 128 (ReLU), obs_dim <= 16, head rows <= 16, batch <= 256.  Noisy and Categorical heads run dqn_grad_kernel / c51_grad_kernel.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -196,12 +196,35 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         }
         return X;
     };
-    // value / first index of the row's maximum over the nA live outputs of a head tile (outputs 4q + r of row i16)
+    // Head tile -> Q values in place: plain head: as is (action j on output j); Dueling (DQN_with_tricks.py:60-79, head rows
+    // [V ; A_0..A_nA-1]): Q_j = (V + A_j) - mean_a A on output 1 + j.  o0 = output of action 0.
+    const bool duel = D.dueling != 0;
+    const int o0 = duel ? 1 : 0;
+    auto to_q = [&](f32x4 z) {
+        if (duel) {
+            float sa = 0.f, v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * q + r;
+                if (o >= 1 && o <= nA) sa += z[r];
+                if (o == 0) v = z[r];
+            }
+            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            const float mean = sa / (float)nA;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = (v + z[r]) - mean;
+        }
+        return z;
+    };
+    // value / first index of the row's maximum over the nA actions of a Q tile (outputs 4q + r of row i16)
     auto row_max = [&](const f32x4& z, float& mx, int& best) {
         mx = -INFINITY; best = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * q + r < nA && z[r] > mx) { mx = z[r]; best = 4 * q + r; }
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * q + r - o0;
+            if (j >= 0 && j < nA && z[r] > mx) { mx = z[r]; best = j; }
+        }
 #pragma unroll
         for (int s = 16; s < 64; s <<= 1) {
             const float om = __shfl_xor(mx, s, 64);
@@ -209,11 +232,11 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             if (om > mx || (om == mx && ob < best)) { mx = om; best = ob; }
         }
     };
-    auto row_pick = [&](const f32x4& z, int j) {      // z[j] of the row (j uniform over the row's four lanes)
+    auto row_pick = [&](const f32x4& z, int j) {      // Q of action j of the row (j uniform over the row's four lanes)
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * q + r == j) v = z[r];
+            if (4 * q + r == o0 + j) v = z[r];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         return v;
@@ -225,6 +248,15 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     g.gb2 = 0.f;
     float lossp = 0.f;
     g_f tde = as_global(D.td_err + (size_t)p * D.batch_max);
+    // PER (DQN_with_tricks.py:276-278): use_isw == 1: `(is_weight * td_error**2).mean()` multiplies a [B] by a [B,1] tensor,
+    // i.e. every row carries the MEAN weight; 2: per-row weights
+    g_cf isw = as_global(D.isw + (size_t)p * D.batch_max);
+    float wbar = 1.f;
+    if (a.use_isw == 1) {
+        float ws = 0.f;
+        for (int i = tid; i < B; i += kWG) ws += isw[i];
+        wbar = block_sum(ws, S.red) / (float)B;
+    }
     RowIn nxt = load_row(sp);
     for (int c = sp; c < nchunks; c += nsp) {
         const RowIn cur = nxt;
@@ -234,9 +266,9 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         const bool valid = row < B;
         // ---- y = r + gamma max_a Q_target(s', a) (1 - d); Double: the online net picks a
         float mx; int best;
-        const f32x4 zt = C.forward_z(1, cur.xn);
+        const f32x4 zt = to_q(C.forward_z(1, cur.xn));
         if (a.double_dqn) {
-            const f32x4 zo = C.forward_z(0, cur.xn);
+            const f32x4 zo = to_q(C.forward_z(0, cur.xn));
             row_max(zo, mx, best);
             mx = row_pick(zt, best);
         } else {
@@ -247,15 +279,21 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         f32x4 h1[kHT], z;
         C.forward(0, cur.xs, h1, z);
         const int at = (int)cur.act;                                   // actions.long() (DQN.py:114)
-        const float diff = row_pick(z, at) - y;
+        const float diff = row_pick(to_q(z), at) - y;
         float lrow, grow;
         td_loss_row(a, diff, lrow, grow);
+        const float wr = a.use_isw == 2 ? (valid ? isw[row] : 0.f) : wbar;
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
+            const float d = wr * grow * invB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * q + r == at) dz[r] = grow * invB;
-            if (q == 0) { lossp += lrow; tde[row] = diff; }
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * q + r;
+                if (!duel) { if (o == at) dz[r] = d; }
+                else if (o == 0) dz[r] = d;                                              // dV
+                else if (o <= nA) dz[r] = d * ((o - 1 == at ? 1.f : 0.f) - 1.f / (float)nA);   // dA_j through V + A_j - mean A
+            }
+            if (q == 0) { lossp += wr * lrow; tde[row] = diff; }
         }
         PPO_T(3);
         // ---- backward: head gradient (H1 x dz over the chunk's 64 rows), dH1, layer-1 gradient (X x dH1)
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
                     if (4 * q + e < s.O) xb[e] = c == 0 ? S.onx[j * 16 + 4 * q + e] : s.obs_next[((size_t)p * s.E + j) * s.O + 4 * q + e];
             }
             float mx; int best;
-            row_max(C.forward_z(0, xb), mx, best);
+            row_max(to_q(C.forward_z(0, xb)), mx, best);
             if (j < s.E && q == 0) {
                 const Philox4 u = philox4x32_10(s.act_counter, 0x9000u, (unsigned)j, key);
                 if (u01(u.z) <= s.epsilon) best = (int)uniform_index(u, (unsigned)nA);

@@ -1216,7 +1216,7 @@ def test_per_buffer_sumtree_on_device(N):
     e.close()
 
 
-def test_dqn_with_tricks_double_per_nstep(N):
+def test_dqn_with_tricks_double_per_nstep(N, dqn_path):
     """DQN_with_tricks.learn (Double + PER + N_Step) through the class: n-step fold on add, PER sample -> fused update with
     the reference's weight broadcasting -> priority update; vs the golden from the imported reference."""
     from freerl_amd.DQN_with_tricks import DQN
@@ -1253,7 +1253,7 @@ def test_dqn_with_tricks_double_per_nstep(N):
     synth.check_digest("Qnet", got, fx, 2e-3, 2e-5, "hip-vs-reference")
 
 
-def test_dqn_dueling_double(N):
+def test_dqn_dueling_double(N, dqn_path):
     """Dueling + Double through the class (DQN_with_tricks.py:60-79,263-265): head [V ; A] in the engine, Q = V + A - mean(A)
     in the act and update kernels, the reference's l1/V/A state_dict layout."""
     from freerl_amd.DQN_with_tricks import DQN
