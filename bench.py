@@ -125,7 +125,7 @@ def dropin_classes():
     return {"unit": "updates/s (one learner, replay 1e6 full, batch 256, through the Python class)", **out}
 
 
-def dqn_single_learner_loop():
+def dqn_single_learner_loop(P=512):
     """north_star's env-steps/s target is quoted on the DQN loop (DQN.py:294-339: select_action -> epsilon-greedy -> env.step ->
     add -> learn per env step) of ONE learner.  LunarLander-v2 cannot be built here (no Box2D), so the env is the synthetic
     discrete task at its dims (obs 8, 4 actions); the reference's own loop measured ~560 env-steps/s on CPU with a small
@@ -146,8 +146,22 @@ def dqn_single_learner_loop():
         r = rollout(e, pool, 400, **kw)
         out["%d env(s)" % E] = r["env_steps"] / r["seconds"]
         pool.close(); e.close()
+    # the same loop for a population (BASELINE configs[0]'s algorithm at the bench's learner count, one env per learner)
+    e = Engine(N.ALGO_DQN, 8, 4, 100_000, discrete=True, batch_max=BATCH, n_learners=P, seed=1)
+    g = np.random.default_rng(0)
+    for p in range(P):
+        flat = (g.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
+        e.set_params(0, flat, N.PARAM_ONLINE, learner=p); e.set_params(0, flat, N.PARAM_TARGET, learner=p)
+    e.fill_synthetic(50_000, seed=5)
+    pool = EnvPool("SynLinearDiscrete-v0", P, n_threads=4, seed=2)
+    kw = dict(envs_per_learner=1, start_steps=0, learn_every=1, epsilon=0.1, batch=BATCH, gamma=0.99, tau=0.01, critic_lr=1e-3)
+    rollout(e, pool, 20, **kw)
+    r = rollout(e, pool, 300, **kw)
+    pool.close(); e.close()
     return {"unit": "env-steps/s, one DQN learner, one learn() per vector step, replay 1e5 rows half full", **out,
-            "reference_cpu_env_steps_per_sec": {"small buffer": 560, "replay 1e6 full": 45}}
+            "reference_cpu_env_steps_per_sec": {"small buffer": 560, "replay 1e6 full": 45},
+            "population": {"learners": P, "envs_per_learner": 1, "env_steps_per_sec": r["env_steps"] / r["seconds"],
+                           "updates_per_sec": r["updates"] / r["seconds"]}}
 
 
 def traffic_figure():
@@ -318,7 +332,7 @@ def main():
                          "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "kernels": kern},
             "dropin_classes": None if args.headline_only else dropin_classes(),
-            "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(),
+            "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(args.learners),
             "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
         }
         print(json.dumps(line), flush=True)
