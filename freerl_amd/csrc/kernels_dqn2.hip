@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             }
         }
     }
+    PPO_T(7);
     PPO_TDUMP();
 }
 

@@ -22,17 +22,23 @@ for p in range(P):
     flat = (rng.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
     e.set_params(0, flat, N.PARAM_ONLINE, learner=p); e.set_params(0, flat, N.PARAM_TARGET, learner=p)
 e.fill_synthetic(100_000, seed=5)
-for k in range(6):
-    e.learn(256, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0)
+if len(sys.argv) > 2 and sys.argv[2] == "rollout":          # the folded step of frl_rollout (add() + learn() + select_action)
+    from freerl_amd.envpool import EnvPool, rollout
+    pool = EnvPool("SynLinearDiscrete-v0", P, n_threads=1, seed=2)
+    rollout(e, pool, 50, envs_per_learner=1, start_steps=0, learn_every=1, epsilon=0.1, batch=256, gamma=0.99, tau=0.01, critic_lr=1e-3)
+    pool.close()
+else:
+    for k in range(6):
+        e.learn(256, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0)
 fn = N.lib().frl_debug_ppo_clocks
 fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_longlong)]
 buf = (C.c_longlong * 16)()
 assert fn(buf) == 0
 clk = np.array(buf[:8], dtype=np.float64)
-names = ["index draw", "both nets -> LDS images", "row prefetch issue", "target + online forward, TD delta (4 chunks)",
-         "exchanges + dW2 + dH1 + dW1 (4 chunks)", "bias / loss reductions", "norm + Adam + soft update", "-"]
-tot = clk[:7].sum()
+names = ["index draw", "weight + block loads issued, add() stores, images stored", "row prefetch issue", "target + online forward, TD delta (4 chunks)",
+         "exchanges + dW2 + dH1 + dW1 (4 chunks)", "bias / loss reductions", "norm + Adam + soft update", "select_action + hand-over"]
+tot = clk[:8].sum()
 print("P=%d: %.0f cycles per learner" % (P, tot))
-for i, n in enumerate(names[:7]):
+for i, n in enumerate(names[:8]):
     print("   %-50s %8.0f  %5.1f%%" % (n, clk[i], 100 * clk[i] / tot))
 e.close()
