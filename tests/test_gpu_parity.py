@@ -197,6 +197,43 @@ def test_dqn_double_clip_weight_decay_ragged_batches(N, dqn_path, double, clip, 
     e.close()
 
 
+@pytest.mark.parametrize("obs_dim,n_act,dueling", [(16, 16, False), (3, 2, False), (5, 15, True), (16, 7, True)])
+def test_dqn_head_shapes_at_the_tile_edges(N, dqn_path, obs_dim, n_act, dueling):
+    """Inputs and heads that fill (or barely use) the 16-wide tiles of both DQN implementations — 16 observation columns, 16
+    actions, a Dueling head of 1 + 15 rows — Double target, batch 96 (a full chunk and a half): against the oracle."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    c = dict(cases.CASES["dqn"], obs_dim=obs_dim, n_actions=n_act, batch=96, n_learn=3)
+    inp = (cases.dqn_dueling_inputs if dueling else cases.dqn_inputs)(c)
+    prm = inp["params"]["Qnet"]
+    if dueling:                      # engine head rows: [V ; A]
+        eng = {"l1.weight": prm["l1.weight"], "l1.bias": prm["l1.bias"],
+               "l2.weight": np.vstack([prm["V.weight"], prm["A.weight"]]), "l2.bias": np.concatenate([prm["V.bias"], prm["A.bias"]])}
+    else:
+        eng = prm
+    e = Engine(N.ALGO_DQN, obs_dim, n_act, c["capacity"], discrete=True, batch_max=96, dueling=dueling)
+    flat = flat_params(eng, ["l1", "l2"])
+    e.set_params(0, flat, N.PARAM_ONLINE); e.set_params(0, flat, N.PARAM_TARGET)
+    e.add_batch(records([inp["table"]]))
+    orc = algos.DQN(prm, obs_dim, n_act, c["lr"], c["capacity"], dueling=dueling)
+    tab = inp["table"]
+    for i in range(c["n_table"]):
+        orc.add(tab["obs"][i], tab["act"][i][0], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    greedy = e.act(0, N.ACT_ARGMAX, tab["obs"][:64])[0, :, 0].astype(np.int64)
+    np.testing.assert_array_equal(greedy, [orc.select_action(tab["obs"][i]) for i in range(64)])
+    for k in range(c["n_learn"]):
+        st = e.learn(96, gamma=c["gamma"], tau=c["tau"], critic_lr=c["lr"], clip_norm=0.0, double_dqn=True, idx=inp["idx"][k], want_stats=True)
+        orc.learn_with(inp["idx"][k], c["gamma"], c["tau"], double=True)
+        np.testing.assert_allclose(st[0, 0, N.STAT_CRITIC_LOSS], orc.losses[-1], rtol=LOSS_RTOL)
+    for kind, want in ((N.PARAM_ONLINE, orc.q), (N.PARAM_TARGET, orc.q_t)):
+        got = unflat_params(e.get_params(0, kind), eng, ["l1", "l2"])
+        if dueling:
+            got = {"l1.weight": got["l1.weight"], "l1.bias": got["l1.bias"], "V.weight": got["l2.weight"][:1], "V.bias": got["l2.bias"][:1],
+                   "A.weight": got["l2.weight"][1:], "A.bias": got["l2.bias"][1:]}
+        assert_params_close(got, want, "dqn_edges/%d/%d/%d" % (obs_dim, n_act, dueling))
+    e.close()
+
+
 # ------------------------------------------------------------------------- DDPG / TD3 / SAC
 AC_NAMES = ["l1", "l2", "l3"]
 TWIN_NAMES = ["l1", "l2", "l3", "l4", "l5", "l6"]
