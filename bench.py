@@ -153,7 +153,7 @@ def dqn_single_learner_loop(P=512):
         flat = (g.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
         e.set_params(0, flat, N.PARAM_ONLINE, learner=p); e.set_params(0, flat, N.PARAM_TARGET, learner=p)
     e.fill_synthetic(50_000, seed=5)
-    pool = EnvPool("SynLinearDiscrete-v0", P, n_threads=4, seed=2)
+    pool = EnvPool("SynLinearDiscrete-v0", P, n_threads=8, seed=2)
     kw = dict(envs_per_learner=1, start_steps=0, learn_every=1, epsilon=0.1, batch=BATCH, gamma=0.99, tau=0.01, critic_lr=1e-3)
     rollout(e, pool, 20, **kw)
     r = rollout(e, pool, 300, **kw)
@@ -251,7 +251,7 @@ def main():
     # env-steps/s: the full rollout-and-update loop (act + exploration on the device -> env.step on the host pool ->
     # add -> learn, one env per learner = the reference's UTD 1) on the synthetic obs-8/act-2 task
     from freerl_amd.envpool import EnvPool, rollout
-    pool = EnvPool("SynLinear-v0", P, n_threads=4, seed=1000 + rank)
+    pool = EnvPool("SynLinear-v0", P, n_threads=8, seed=1000 + rank)
     rollout(e, pool, args.warmup, start_steps=0, batch=BATCH)
     barrier()
     ro = rollout(e, pool, args.steps, start_steps=0, batch=BATCH)
@@ -314,7 +314,7 @@ def main():
                        "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world,
                        "collective": "metric all-reduce via freerl_amd.dist (backend %s)" % backend},
             "env_steps_per_sec": env_sps,
-            "rollout": {"env": "SynLinear-v0 (obs 8, act 2)", "envs_per_learner": 1, "env_workers": 4,
+            "rollout": {"env": "SynLinear-v0 (obs 8, act 2)", "envs_per_learner": 1, "env_workers": 8,
                         "updates_per_sec_in_loop": ro_ups,
                         "loop": "act kernel with device-side exploration -> D2H actions -> host env pool step -> staged add "
                                 "(one H2D) -> learn"},
