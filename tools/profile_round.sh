@@ -19,6 +19,8 @@ done
 python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_kernel
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ppo -- python $R/tools/ppo_bench.py 256 > $O/stats_ppo.log 2>&1
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dqn -- python $R/tools/dqn_bench.py 512 > $O/stats_dqn.log 2>&1
+cp $(ls $O/stats_dqn/*/*kernel_stats.csv | head -1) $O/kernel_stats_dqn.csv
 cd $R && timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-rm -rf $O/stats $O/stats_ppo $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
+rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
 ls -la $O
