@@ -15,7 +15,9 @@ namespace frl {
 __device__ __forceinline__ int node_depth(int i) { return 31 - __clz(i + 1); }
 
 // Recompute the ancestors of `n` written leaves of one learner, deepest level first; leaf_of(i) = buffer index or -1.
-// Every thread repairs the ancestor of its leaf at the current depth (duplicates write the same value).
+// Every thread repairs the ancestor of its leaf at the current depth (duplicates write the same value).  (Measured and not
+// taken: the top 11 levels repaired in LDS — the kernel's time is in the bottom levels' random 8-byte accesses into 1.6 MB of
+// tree per learner, not in the number of barriers.)
 template <class LeafOf>
 __device__ __forceinline__ void per_repair(double* sum, double* mx, int cap, int n, LeafOf leaf_of) {
     const int nn = 2 * cap - 1, dmax = node_depth(nn - 1);
@@ -59,11 +61,23 @@ __global__ __launch_bounds__(256) void per_set_kernel(const EngineDesc* __restri
     double* mx = a.max_tree + (size_t)p * nn;
     const int* leaf = a.leaf + (size_t)p * a.n_pitch;
     const double fill = a.fill;
-    // leaves: a later entry for the same leaf wins, as in the reference's sequential loop (:126-129)
+    // leaves: a later entry for the same leaf wins, as in the reference's sequential loop (:126-129).  The batch's leaf
+    // indices go through LDS for that test (n <= 4096): as a loop over global memory the later-entry scan of thread 0 alone
+    // was 255 dependent-latency loads, most of the kernel.
+    __shared__ int lleaf[4096];
+    for (int i = threadIdx.x; i < a.n; i += kWG) lleaf[i] = leaf[i];
+    for (int i = a.n + threadIdx.x; i < ((a.n + 3) & ~3); i += kWG) lleaf[i] = -1;
+    __syncthreads();
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int i = threadIdx.x; i < a.n; i += kWG) {
-        const int li = leaf[i];
+        const int li = lleaf[i];
         bool last = true;
-        for (int j = i + 1; j < a.n; ++j) last &= (leaf[j] != li);
+        int j = i + 1;
+        for (; j < a.n && (j & 3); ++j) last &= (lleaf[j] != li);
+        for (; j < a.n; j += 4) {
+            const i32x4 v = *(const i32x4*)(lleaf + j);
+            last &= (v.x != li) & (v.y != li) & (v.z != li) & (v.w != li);
+        }
         if (!last) continue;
         double v = fill;
         if (a.td) v = (double)powf(fabsf(a.td[(size_t)p * D.batch_max + i]) + a.eps, a.alpha);
