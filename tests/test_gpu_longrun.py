@@ -97,9 +97,13 @@ def _fill(orc, tab, n):
         orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
 
 
-def test_dqn_500_calls(N):
-    """DQN.learn (DQN.py:104-128) at the SYN-D shape (obs 8, 4 actions, batch 256), 500 calls."""
+@pytest.mark.parametrize("path", ["rowchunk", "fused", "fused_split"])
+def test_dqn_500_calls(N, path, monkeypatch):
+    """DQN.learn (DQN.py:104-128) at the SYN-D shape (obs 8, 4 actions, batch 256), 500 calls, on the row-chunk chain and on the
+    one-launch update (one workgroup, and a 64-row chunk per workgroup with the partial gradients added by the last to arrive)."""
     from freerl_amd.engine import Engine
+    monkeypatch.setenv("FRL_DQN_FUSED", "0" if path == "rowchunk" else "1")
+    monkeypatch.setenv("FRL_DQN_SPLIT", "1" if path == "fused" else "4")
     from oracle import algos
     O, nA, B, n_table, n_calls = 8, 4, 256, 2048, 500
     tab = synth.transitions(501, n_table, O, 1, n_discrete=nA)
@@ -117,7 +121,7 @@ def test_dqn_500_calls(N):
         st = e.learn(B, gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0, idx=idx[k], want_stats=True)
         got.append(st[0, 0, N.STAT_CRITIC_LOSS])
         orc.learn_with(idx[k], 0.99, 0.01)
-    _check("dqn", got, np.array(orc.losses))
+    _check("dqn" if path == "rowchunk" else "dqn/" + path, got, np.array(orc.losses))
     e.close()
 
 
