@@ -212,7 +212,7 @@ def main():
 
     if not torch.cuda.is_available() or N.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    rank, world, local_rank = fdist.init("nccl")            # nccl == RCCL on ROCm; no group when started without a launcher
+    rank, world, local_rank = fdist.init()      # under a launcher: the engine's RCCL communicator (frl_comm_create) + a gloo control plane
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if local_rank >= N.device_count():
@@ -265,7 +265,7 @@ def main():
     dt_max, total_updates, kernel_ms = learn_m["wall_s_max"], learn_m["updates"], learn_m["extra_max"][0]
     env_sps = fdist.throughput(roll_m)["env_steps_per_sec"]
     ro_ups = fdist.throughput(roll_m)["updates_per_sec"]
-    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    backend = fdist.collective_name()
     fdist.finalize()          # every rank leaves the collective window here; what follows is rank 0's own work
 
     if rank == 0:
@@ -312,7 +312,7 @@ def main():
                        "learners_per_gpu": P, "updates_per_step": P * world, "kernel_family": "chained (one workgroup per learner)" if chained else "row-chunk",
                        "rows_per_workgroup": rc, "lds_bytes": lds,
                        "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world,
-                       "collective": "metric all-reduce via freerl_amd.dist (backend %s)" % backend},
+                       "collective": "metric all-reduce: %s" % backend},
             "env_steps_per_sec": env_sps,
             "rollout": {"env": "SynLinear-v0 (obs 8, act 2)", "envs_per_learner": 1, "env_workers": 8,
                         "updates_per_sec_in_loop": ro_ups,

@@ -19,6 +19,8 @@ HEADER = os.path.join(ROOT, "include", "freerl_hip.h")
 
 FRL_MAX_AGENTS = 8
 FRL_STAT_COUNT = 8
+FRL_COMM_ID_BYTES = 128
+FRL_COMM_MAX_VALUES = 64
 
 # enum frl_algo
 ALGO_REPLAY_ONLY, ALGO_DQN, ALGO_DDPG, ALGO_TD3, ALGO_SAC, ALGO_MADDPG, ALGO_PPO = -1, 0, 1, 2, 3, 4, 5
@@ -84,7 +86,7 @@ class RolloutArgs(C.Structure):
                 ("ou_dt", C.c_float)]
 
 
-EXPLORE_NONE, EXPLORE_EPS_GREEDY, EXPLORE_GAUSS, EXPLORE_OU = range(4)
+EXPLORE_NONE, EXPLORE_EPS_GREEDY, EXPLORE_GAUSS, EXPLORE_OU, EXPLORE_OFF = range(5)
 # the vectorised callbacks of a pool over caller-supplied envs (frl_envpool_create_callback)
 ENV_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                           C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_float))
@@ -161,6 +163,11 @@ SIGNATURES = {
     "frl_envpool_step": (_i, [_vp, _fp, _fp, _fp, _P(C.c_uint8), _P(C.c_uint8), _fp]),
     "frl_rollout": (_i, [_vp, _vp, _P(RolloutArgs), _P(RolloutStats)]),
     "frl_ppo_rollout": (_i, [_vp, _vp, _P(PpoRolloutArgs), _P(RolloutStats)]),
+    "frl_comm_unique_id": (_i, [_P(C.c_uint8)]),
+    "frl_comm_create": (_i, [_P(C.c_uint8), _i, _i, _i, _P(_vp)]),
+    "frl_comm_destroy": (_i, [_vp]),
+    "frl_comm_info": (_i, [_vp, _ip, _ip]),
+    "frl_metrics_allreduce": (_i, [_vp, _P(C.c_double), _i, _P(C.c_double), _i]),
     "frl_timer_start": (_i, [_vp]),
     "frl_timer_stop": (_i, [_vp, _fp]),
     "frl_profile_enable": (_i, [_vp, _i]),

@@ -220,6 +220,7 @@ public:
     // observation when the episode ended: the reference resets inline, DQN.py:323-335).
     void step(const float* actions, float* next_obs, float* reward, uint8_t* term, uint8_t* trunc, float* obs_next) {
         if (spec.kind == ENV_CALLBACK) {
+            cb_error = 0;                                   // a failed callback is reported once, by the call that saw it
             const int rc = cb_step(cb_user, actions, next_obs, reward, term, trunc, obs_next);
             if (rc) { cb_error = rc; return; }
             long long eps = 0;
@@ -239,7 +240,7 @@ public:
     void reset_all(float* obs_out) {
         if (spec.kind == ENV_CALLBACK) {
             const int rc = cb_reset(cb_user, obs_out);
-            if (rc) cb_error = rc;
+            cb_error = rc;
             for (int i = 0; i < n; ++i) { t[i] = 0; ep_return[i] = 0.0; }
             return;
         }

@@ -102,8 +102,11 @@ struct frl_engine {
     double* d_per_max = nullptr;
     float per_alpha = 0.5f, per_eps = 0.01f;
     double per_beta = 0.4, per_beta_inc = 0.001;
+    std::vector<int> bucket_cursor;
     std::vector<int> size_flushed;        // rows valid per learner as of the last flush (PER_Buffer.add's `len(self.buffer) == 0`)
     int* d_size = nullptr;                // [2][P]: size before the flush being applied / current size
+    int* stage_bucket = nullptr;          // PER, pinned: [off[P + 1] | size_before[P] | leaf[stage_cap]] of the flush being applied
+    int* d_stage_bucket = nullptr;
     float* d_per_prio = nullptr;          // [P][batch_max] float32 priorities of the last sample
     double* d_uniforms = nullptr;         // [P][batch_max]
     // optional per-kernel timing (frl_profile_*): event pairs recorded around each launch
@@ -230,6 +233,8 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_per_sum) hipFree(e->d_per_sum);
     if (e->d_per_max) hipFree(e->d_per_max);
     if (e->d_size) hipFree(e->d_size);
+    if (e->d_stage_bucket) hipFree(e->d_stage_bucket);
+    if (e->stage_bucket) hipHostFree(e->stage_bucket);
     if (e->d_per_prio) hipFree(e->d_per_prio);
     if (e->d_uniforms) hipFree(e->d_uniforms);
     if (e->h_noisy) hipHostFree(e->h_noisy);
@@ -521,6 +526,14 @@ extern "C" int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* rc_out) {
 
 static bool chained_path(const EngineDesc& h, int batch, int pc);
 static bool dqn_fused_path(const EngineDesc& h, int batch, bool per_weights);
+// workgroups per learner of the one-launch DQN update (kernels_dqn2.hip).  A few learners: one 64-row chunk per workgroup (the
+// last to arrive reduces and steps); populations: one workgroup each (measured: P = 64 x 4 workgroups 74 us, x 1 45 us).
+static int dqn_split_for(const EngineDesc& h, int batch, int pc) {
+    const int nchunks = (batch + 63) / 64;
+    int split = (pc <= 16) ? std::min(std::min(4, nchunks), h.S) : 1;
+    if (const char* sp = getenv("FRL_DQN_SPLIT")) split = std::max(1, std::min(std::min(atoi(sp), nchunks), h.S));
+    return split;
+}
 
 extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, int* bytes_out, int* rows_out) {
     if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
@@ -529,7 +542,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
     if (dqn_fused_path(e->h, batch, e->per_on)) {           // kernels_dqn2.hip
         if (chained_out) *chained_out = 1;
         if (bytes_out) *bytes_out = dqn2_lds_floats() * (int)sizeof(float);
-        if (rows_out) *rows_out = e->h.P <= 16 ? std::min(batch, 64) : batch;
+        if (rows_out) { const int sp = dqn_split_for(e->h, batch, e->h.P); *rows_out = ((batch + 63) / 64 + sp - 1) / sp * 64 < batch ? ((batch + 63) / 64 + sp - 1) / sp * 64 : batch; }
         return FRL_OK;
     }
     const bool v2 = chained_path(e->h, batch, e->h.P);
@@ -572,11 +585,23 @@ static int flush_stage(frl_engine* e) {
                        e->d_stage_slots, n, R.width, R.stride);
     HIP_TRY(hipGetLastError());
     if (e->per_on) {                 // PER_Buffer.add (Buffer.py:92-98): the new rows enter at the current maximum priority
-        HIP_TRY(hipMemcpy(e->d_size, e->size_flushed.data(), (size_t)e->h.P * sizeof(int), hipMemcpyHostToDevice));   // pageable source: synchronous copy
+        // bucket the flush's rows by learner (counting sort; rows keep their staging order inside a bucket)
+        const int P = e->h.P, cap = e->h.capacity;
+        int* off = e->stage_bucket;
+        int* before = off + P + 1;
+        int* leaf = before + P;
+        std::fill(off, off + P + 1, 0);
+        for (int i = 0; i < n; ++i) off[e->stage_slots[i] / cap + 1]++;
+        for (int p = 0; p < P; ++p) off[p + 1] += off[p];
+        std::vector<int>& cur = e->bucket_cursor;
+        cur.assign(off, off + P);
+        for (int i = 0; i < n; ++i) { const long long s = e->stage_slots[i]; const int p = (int)(s / cap); leaf[cur[p]++] = (int)(s - (long long)p * cap); }
+        memcpy(before, e->size_flushed.data(), (size_t)P * sizeof(int));
+        HIP_TRY(hipMemcpyAsync(e->d_stage_bucket, e->stage_bucket, (size_t)(2 * P + 1 + n) * sizeof(int), hipMemcpyHostToDevice, e->stream));
         PerArgs pa;
         memset(&pa, 0, sizeof pa);
-        pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = e->h.capacity; pa.n = n;
-        hipLaunchKernelGGL(per_add_kernel, dim3(e->h.P), dim3(256), 0, e->stream, pa, (const long long*)e->d_stage_slots, (const int*)e->d_size);
+        pa.sum_tree = e->d_per_sum; pa.max_tree = e->d_per_max; pa.cap = cap; pa.n = n;
+        hipLaunchKernelGGL(per_add_kernel, dim3(P), dim3(256), 0, e->stream, pa, (const int*)e->d_stage_bucket, P);
         HIP_TRY(hipGetLastError());
     }
     e->size_flushed = e->size;
@@ -848,7 +873,8 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     ActArgs a;
     memset(&a, 0, sizeof a);
     if (ex) {
-        const frl_explore_args& x = ex->x;
+        frl_explore_args x = ex->x;
+        if (x.kind == FRL_EXPLORE_OFF) x.kind = FRL_EXPLORE_NONE;
         if (x.kind < FRL_EXPLORE_NONE || x.kind > FRL_EXPLORE_OU) return fail(FRL_ERR_INVALID, "unknown exploration kind %d", x.kind);
         if (!ex->env_out_dev) return fail(FRL_ERR_INVALID, "exploration needs an env-action output");
         if (x.kind == FRL_EXPLORE_EPS_GREEDY && mode != FRL_ACT_ARGMAX) return fail(FRL_ERR_INVALID, "epsilon-greedy goes with FRL_ACT_ARGMAX");
@@ -1129,10 +1155,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     ad.tau = a.tau; ad.alpha_lr = a.alpha_lr; ad.target_entropy = a.target_entropy; ad.p0 = p0; ad.G = h.Gmax;
     const bool v2 = chained_path(h, a.batch, pc);
     if (stage == 0 && dqn_fused_path(h, a.batch, a.use_isw != 0)) {
-        // a few learners: one 64-row chunk per workgroup (the last to arrive reduces and steps); populations: one workgroup each
-        const int nchunks = (a.batch + 63) / 64;
-        a.dqn_split = (pc <= 16) ? std::min(std::min(4, nchunks), h.S) : 1;      // measured: P = 64 x 4 workgroups 74 us, x 1 45 us
-        if (const char* sp = getenv("FRL_DQN_SPLIT")) a.dqn_split = std::max(1, std::min(std::min(atoi(sp), nchunks), h.S));
+        a.dqn_split = dqn_split_for(h, a.batch, pc);
         prof_begin(e, PK_GRAD_CRITIC);
         DqnStepArgs sa;
         memset(&sa, 0, sizeof sa);
@@ -1386,6 +1409,8 @@ extern "C" int frl_per_enable(frl_engine* e, double alpha, double beta, double b
     HIP_TRY(hipMemsetAsync(e->d_per_sum, 0, P * nn * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->d_per_max, 0, P * nn * sizeof(double), e->stream));
     HIP_TRY(hipMalloc((void**)&e->d_size, 2 * P * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&e->d_stage_bucket, (2 * P + 1 + (size_t)e->stage_cap) * sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&e->stage_bucket, (2 * P + 1 + (size_t)e->stage_cap) * sizeof(int)));
     const size_t bm = (size_t)std::max(e->h.batch_max, 1);
     HIP_TRY(hipMalloc((void**)&e->d_per_prio, P * bm * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&e->d_uniforms, P * bm * sizeof(double)));
@@ -1443,6 +1468,7 @@ extern "C" int frl_per_update(frl_engine* e, int batch, const int64_t* idx, cons
     ENG(e);
     if (!e->per_on) return fail(FRL_ERR_STATE, "frl_per_enable first");
     if (batch < 1 || batch > e->h.batch_max) return fail(FRL_ERR_INVALID, "batch %d outside [1,%d]", batch, e->h.batch_max);
+    if (batch > kPerSetMax) return fail(FRL_ERR_INVALID, "priority update of %d rows: at most %d per call (split the batch)", batch, kPerSetMax);
     int rc = flush_stage(e);
     if (rc) return rc;
     const size_t P = e->h.P, bm = e->h.batch_max;
@@ -1494,3 +1520,4 @@ extern "C" int frl_debug_phase_clocks(int* out, int stride) {
 #endif
 #include "frl_api_ppo.inc"
 #include "frl_api_rollout.inc"
+#include "frl_api_comm.inc"

@@ -51,6 +51,7 @@ struct ActArgs {
 enum ExploreKind : int { EXPL_NONE = 0, EXPL_EPS_GREEDY = 1, EXPL_GAUSS = 2, EXPL_OU = 3 };
 
 // ---- kernels_per.hip
+constexpr int kPerSetMax = 4096;      // rows of one per_set_kernel launch (its later-entry-wins scan stages them in LDS)
 struct PerArgs {
     double* sum_tree;      // [P][2*cap-1]
     double* max_tree;      // [P][2*cap-1]
@@ -141,7 +142,7 @@ __global__ void noisy_sigma_grad_kernel(const EngineDesc* __restrict__ Dp);
 __global__ void noisy_draw_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, unsigned long long counter);
 
 // kernels_per.hip
-__global__ void per_add_kernel(PerArgs a, const long long* __restrict__ slots, const int* __restrict__ size_before);
+__global__ void per_add_kernel(PerArgs a, const int* __restrict__ bucket, int P);
 __global__ void per_set_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
 __global__ void per_sample_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
 

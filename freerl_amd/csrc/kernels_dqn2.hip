@@ -408,12 +408,15 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     if (w == 0 && q == 0) ss += g.gb2 * g.gb2;
     ss = wave_sum(ss);
     lds_barrier();
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     if (l == 0) { S.red[w] = ss; S.red[8 + w] = lsum; }
+    // the step count reaches every wave through LDS: thread 0 stores the incremented count at the end of the update with no
+    // barrier in between, so a late wave reading it from global memory could see the NEXT step's bias corrections
+    if (tid == 0) S.red[16] = __int_as_float(steps[0]);
     lds_barrier();
     const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
     const float loss = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t = steps[0] + 1;
+    const int t = __float_as_int(S.red[16]) + 1;
     const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     const float step = (float)((double)a.critic_lr / bc1), bc2s = (float)sqrt(bc2);

@@ -37,23 +37,28 @@ __device__ __forceinline__ void per_repair(double* sum, double* mx, int cap, int
 }
 
 // PER_Buffer.add (:92-98) for the rows of one flush: every new row gets the max priority (1.0 on an empty buffer).
-// `slots` = learner*capacity + row for all learners; workgroup p takes its own.
-__global__ __launch_bounds__(256) void per_add_kernel(PerArgs a, const long long* __restrict__ slots, const int* __restrict__ size_before) {
+// The host buckets the flush's rows by learner (they are staged in order, a counting sort): bucket = [off[P + 1] |
+// size_before[P] | leaf[n]], workgroup p repairs the ancestors of ITS leaf[off[p] .. off[p + 1]) only.  (Round 2 handed
+// every workgroup the whole flush as learner*capacity + row words: P x n slot tests with a 64-bit division each, per tree
+// level — 199 us for a 4096-row add at 512 learners.)
+__global__ __launch_bounds__(256) void per_add_kernel(PerArgs a, const int* __restrict__ bucket, int P) {
     const int p = blockIdx.x, cap = a.cap, nn = 2 * cap - 1;
+    const int o0 = bucket[p], n = bucket[p + 1] - o0;
+    if (n <= 0) return;
     double* sum = a.sum_tree + (size_t)p * nn;
     double* mx = a.max_tree + (size_t)p * nn;
-    const double fill = (size_before[p] == 0) ? 1.0 : mx[0];
-    auto leaf_of = [&](int i) { const long long s = slots[i]; return (s / cap == p) ? (int)(s - (long long)p * cap) : -1; };
+    const int* leaf = bucket + 2 * P + 1 + o0;
+    const double fill = (bucket[P + 1 + p] == 0) ? 1.0 : mx[0];
     __syncthreads();                                   // everyone has read mx[0]
-    for (int i = threadIdx.x; i < a.n; i += kWG) {
-        const int li = leaf_of(i);
-        if (li >= 0) { sum[li + cap - 1] = fill; mx[li + cap - 1] = fill; }
+    for (int i = threadIdx.x; i < n; i += kWG) {
+        const int li = leaf[i];
+        sum[li + cap - 1] = fill; mx[li + cap - 1] = fill;
     }
     __syncthreads();
-    per_repair(sum, mx, cap, a.n, leaf_of);
+    per_repair(sum, mx, cap, n, [&](int i) { return leaf[i]; });
 }
 
-// Write n leaves of one learner and repair both trees.  One workgroup per learner; n <= 4096.
+// Write n leaves of one learner and repair both trees.  One workgroup per learner; n <= kPerSetMax (frl_per_update checks).
 __global__ __launch_bounds__(256) void per_set_kernel(const EngineDesc* __restrict__ Dp, PerArgs a) {
     const EngineDesc& D = *Dp;
     const int p = blockIdx.x, cap = a.cap, nn = 2 * cap - 1;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void per_set_kernel(const EngineDesc* __restri
     // leaves: a later entry for the same leaf wins, as in the reference's sequential loop (:126-129).  The batch's leaf
     // indices go through LDS for that test (n <= 4096): as a loop over global memory the later-entry scan of thread 0 alone
     // was 255 dependent-latency loads, most of the kernel.
-    __shared__ int lleaf[4096];
+    __shared__ __attribute__((aligned(16))) int lleaf[kPerSetMax];
     for (int i = threadIdx.x; i < a.n; i += kWG) lleaf[i] = leaf[i];
     for (int i = a.n + threadIdx.x; i < ((a.n + 3) & ~3); i += kWG) lleaf[i] = -1;
     __syncthreads();

@@ -4,8 +4,10 @@ The reference is single-process / single-device and none of its algorithms excha
 or replay data, so the path shards by independent units — (seed, env-instance
 set, learner) — with no data-path collective; the only exchange is the all-reduce of a short
 metrics vector (env steps, updates, sum of returns, episodes, sum of losses) per reporting
-interval.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" runs the same code on CPU tensors
-(tests).  At <= 16 floats the collective is latency-bound; link bandwidth is irrelevant.
+interval: `frl_metrics_allreduce` of the C ABI (include/freerl_hip.h) — ncclAllReduce over RCCL / xGMI on the
+engine's own communicator — with this module as its binding and bootstrap; a gloo process group is the host-side
+control plane and runs the same Python path on CPU tensors in the tests.  At <= 64 doubles the collective is
+latency-bound; link bandwidth is irrelevant.
 """
 import os
 
@@ -15,24 +17,74 @@ import torch.distributed as dist
 METRIC_FIELDS = ("env_steps", "updates", "return_sum", "episodes", "loss_sum", "wall_s_max")
 
 
+_comm = None          # frl_comm* (ctypes void pointer) of this rank, or None
+_comm_note = "none (single process)"
+
+
+def _native_comm_create(rank, world, local_rank):
+    """The C ABI's RCCL communicator (include/freerl_hip.h: frl_comm_*): rank 0 makes the 128-byte id, the launcher's
+    process group carries it to the other ranks, every rank joins.  Returns the handle or raises FrlError."""
+    import ctypes as C
+    from . import _native as N
+    L = N.lib()
+    uid = torch.zeros(N.FRL_COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_uint8 * N.FRL_COMM_ID_BYTES)()
+        N.check(L.frl_comm_unique_id(buf))
+        uid = torch.tensor(list(buf), dtype=torch.uint8)
+    if dist.get_backend() == "nccl":
+        uid = uid.cuda()
+    dist.broadcast(uid, src=0)
+    raw = (C.c_uint8 * N.FRL_COMM_ID_BYTES)(*[int(x) for x in uid.cpu().tolist()])
+    h = C.c_void_p()
+    N.check(L.frl_comm_create(raw, int(rank), int(world), int(local_rank), C.byref(h)))
+    return h
+
+
 def init(backend=None):
-    """Initialise the default process group from the launcher's environment (RANK, WORLD_SIZE,
-    MASTER_ADDR/PORT).  Returns (rank, world_size, local_rank).  A process started without a
-    launcher (WORLD_SIZE unset) is the degenerate single-rank case and creates no group; under a
-    launcher the group is created even for one rank, so a 1-GPU run exercises RCCL's init and
-    all-reduce too."""
+    """Initialise from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR/PORT).  Returns (rank, world_size,
+    local_rank).  A process started without a launcher (WORLD_SIZE unset) is the degenerate single-rank case and creates
+    nothing.  Under a launcher — even with one rank — two things are set up:
+      * a torch.distributed process group (gloo) as the host-side control plane: rendezvous, barrier, and the channel the
+        RCCL bootstrap id travels over;
+      * on a GPU box, the engine's own RCCL communicator (frl_comm_create) — the metric all-reduce is the C ABI's
+        frl_metrics_allreduce over it.  backend="gloo" skips this (CPU tests: the same Python path, gloo tensors).
+    If the communicator cannot be created the reduce falls back to the process group with a warning on stderr: the metric
+    exchange is bookkeeping, not the product path, and a bench line over gloo beats no line."""
+    global _comm, _comm_note
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.exists("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container hostname may not resolve
+        want_native = backend != "gloo" and torch.cuda.is_available()
+        if want_native:
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception:
+            if not want_native:
+                raise
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        _comm_note = "torch.distributed %s" % dist.get_backend()
+        if want_native:
+            try:
+                _comm = _native_comm_create(rank, world, local_rank)
+                _comm_note = "frl_metrics_allreduce over RCCL (%d rank%s; bootstrap via torch.distributed %s)" % (
+                    world, "" if world == 1 else "s", dist.get_backend())
+            except Exception as ex:      # noqa: BLE001 - reported, then the process group carries the metrics
+                import sys
+                print("freerl_amd.dist: RCCL communicator unavailable (%s); metrics go over torch.distributed %s"
+                      % (ex, dist.get_backend()), file=sys.stderr, flush=True)
     return rank, world, local_rank
+
+
+def collective_name():
+    """What carries the metric all-reduce in this process (for the bench line)."""
+    return _comm_note
 
 
 def free_port():
@@ -60,9 +112,14 @@ def respawn(n_ranks, script, argv, extra_env=None, timeout=None):
 
 
 def finalize():
-    """Barrier + destroy the process group (no-op without one)."""
+    """Barrier + destroy the communicator and the process group (no-op without them)."""
+    global _comm
+    barrier()
+    if _comm is not None:
+        from . import _native as N
+        N.lib().frl_comm_destroy(_comm)
+        _comm = None
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -78,23 +135,38 @@ def shard_count(n_units, rank, world):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized():
+    """All ranks have arrived: a one-word all-reduce on the RCCL communicator when there is one (the GPU ranks' own
+    channel), the process group's barrier otherwise."""
+    if _comm is not None:
+        import ctypes as C
+        from . import _native as N
+        one = (C.c_double * 1)(1.0)
+        N.check(N.lib().frl_metrics_allreduce(_comm, one, 1, None, 0))
+    elif dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
 def allreduce_metrics(env_steps, updates, return_sum, episodes, loss_sum, wall_s, device=None, extra_max=()):
-    """Sum the counters over ranks and take the MAX of the wall-clock (the job's time is the
-    slowest rank's) and of any `extra_max` values (returned as a list under "extra_max").  Returns a
-    dict keyed by METRIC_FIELDS; works without a process group."""
-    dev = device if device is not None else ("cuda" if torch.cuda.is_available() and dist.is_initialized()
-                                             and dist.get_backend() == "nccl" else "cpu")
-    sums = torch.tensor([env_steps, updates, return_sum, episodes, loss_sum], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([wall_s] + [float(x) for x in extra_max], dtype=torch.float64, device=dev)
-    if dist.is_available() and dist.is_initialized():        # also with one rank: the collective still runs (RCCL smoke)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tm = tmax.tolist()
-    out = dict(zip(METRIC_FIELDS, sums.tolist() + tm[:1]))
+    """Sum the counters over ranks and take the MAX of the wall-clock (the job's time is the slowest rank's) and of any
+    `extra_max` values (returned as a list under "extra_max").  Returns a dict keyed by METRIC_FIELDS.  With the RCCL
+    communicator of init() this is ONE call of the C ABI's frl_metrics_allreduce (float64, ncclAllReduce sum + max);
+    without it the process group's all_reduce on CPU tensors (gloo tests), and without either the single-process identity."""
+    sums = [float(env_steps), float(updates), float(return_sum), float(episodes), float(loss_sum)]
+    tm = [float(wall_s)] + [float(x) for x in extra_max]
+    if _comm is not None:
+        import ctypes as C
+        from . import _native as N
+        cs, cm = (C.c_double * len(sums))(*sums), (C.c_double * len(tm))(*tm)
+        N.check(N.lib().frl_metrics_allreduce(_comm, cs, len(sums), cm, len(tm)))
+        sums, tm = list(cs), list(cm)
+    elif dist.is_available() and dist.is_initialized():        # also with one rank: the collective still runs
+        dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        ts = torch.tensor(sums, dtype=torch.float64, device=dev)
+        tt = torch.tensor(tm, dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sums, tm = ts.tolist(), tt.tolist()
+    out = dict(zip(METRIC_FIELDS, sums + tm[:1]))
     out["extra_max"] = tm[1:]
     return out
 

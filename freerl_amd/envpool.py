@@ -149,7 +149,7 @@ def rollout(engine, pool, n_steps, *, envs_per_learner=1, start_steps=500, learn
     a.n_steps, a.envs_per_learner, a.start_steps, a.learn_every = int(n_steps), int(envs_per_learner), int(start_steps), int(learn_every)
     a.policy_freq, a.epsilon, a.explore_sigma = int(policy_freq), epsilon, explore_sigma
     a.host_explore = int(bool(host_explore))
-    a.explore_kind = -1 if explore is None else {"none": N.EXPLORE_NONE, "eps": N.EXPLORE_EPS_GREEDY, "gauss": N.EXPLORE_GAUSS,
+    a.explore_kind = 0 if explore is None else {"none": N.EXPLORE_OFF, "eps": N.EXPLORE_EPS_GREEDY, "gauss": N.EXPLORE_GAUSS,
                                                  "ou": N.EXPLORE_OU}[explore]
     a.gauss_init_scale, a.gauss_final_scale, a.max_episodes = gauss_init_scale, gauss_final_scale, int(max_episodes)
     a.ou_theta, a.ou_sigma, a.ou_dt = ou_theta, ou_sigma, ou_dt
@@ -163,6 +163,8 @@ def rollout(engine, pool, n_steps, *, envs_per_learner=1, start_steps=500, learn
     la.policy_noise, la.noise_clip, la.max_action, la.policy_noise_scale = policy_noise, noise_clip, pool.max_action or 1.0, 1.0
     la.target_entropy = float(-pool.act_dim if target_entropy is None else target_entropy)
     st = N.RolloutStats()
+    if hasattr(pool, "error"):
+        pool.error = None                      # a stale exception of an earlier call must not be re-raised
     rc = engine._L.frl_rollout(engine._h, pool._h, C.byref(a), C.byref(st))
     if rc and getattr(pool, "error", None) is not None:
         raise pool.error
@@ -184,6 +186,8 @@ def ppo_rollout(engine, pool, n_iters, *, envs_per_learner, steps_per_env, minib
     la.gamma, la.lmbda, la.clip, la.ent_coef = gamma, lmbda, clip, ent_coef
     la.actor_lr, la.critic_lr, la.adam_eps, la.clip_norm = actor_lr, critic_lr, adam_eps, clip_norm
     st = N.RolloutStats()
+    if hasattr(pool, "error"):
+        pool.error = None
     rc = engine._L.frl_ppo_rollout(engine._h, pool._h, C.byref(a), C.byref(st))
     if rc and getattr(pool, "error", None) is not None:
         raise pool.error

@@ -485,7 +485,14 @@ def run(algo, argv=None, env=None, log=print):
     model_dir = make_dir(args.results_root, args.env_name, policy_name=args.policy_name, trick=args.trick)
     log("model_dir:", model_dir)
     writer = ScalarWriter(model_dir)
-    kw = dict(rng=args.rng)
+    # the engine's Philox key follows --seed too: with rng="auto" the index / noise draws move from the seeded NumPy / torch
+    # streams to the device generator once the buffer holds _core.AUTO_DEVICE_MIN_ROWS rows, and two --seed values must not
+    # share that stream
+    kw = dict(rng=args.rng, seed=args.seed)
+    if args.rng == "auto":
+        from ._core import AUTO_DEVICE_MIN_ROWS
+        log("rng=auto: index / noise draws follow the reference's host streams below %d buffer rows, the device "
+            "generator (keyed by --seed) from there on; --rng host keeps the reference's streams throughout" % AUTO_DEVICE_MIN_ROWS)
     if algo == "dqn":
         from .DQN import DQN
         policy = DQN(dim_info, is_continue, Qnet_lr=args.Qnet_lr, buffer_size=args.buffer_size, device=device, **kw)

@@ -319,7 +319,8 @@ int frl_envpool_step(frl_envpool* p, const float* actions, float* next_obs, floa
  *   OU          SAC.py:334-356,529  x += theta*(0 - x) + sqrt(dt)*sigma*N(0,1); action_ = clip(a*max_action + x*scale*max_action)
  *   NONE        SAC.py:533, PPO_with_tricks.py:529-530  action_ = clip(a*max_action)
  * The action handed to add() is the policy's own output (continuous) or the explored index (discrete), as in the reference. */
-enum frl_explore_kind { FRL_EXPLORE_NONE = 0, FRL_EXPLORE_EPS_GREEDY = 1, FRL_EXPLORE_GAUSS = 2, FRL_EXPLORE_OU = 3 };
+enum frl_explore_kind { FRL_EXPLORE_NONE = 0, FRL_EXPLORE_EPS_GREEDY = 1, FRL_EXPLORE_GAUSS = 2, FRL_EXPLORE_OU = 3,
+                        FRL_EXPLORE_OFF = 4 /* frl_rollout_args.explore_kind only: explicitly no exploration noise */ };
 typedef struct frl_explore_args {
     int kind;
     float epsilon;
@@ -345,7 +346,8 @@ typedef struct frl_rollout_args {
     int host_explore;        /* 0: exploration inside the act launch — per vector step ONE D2H (env actions) and ONE H2D (the
                               * env outputs), records assembled on the device; 1: round 1's loop (host generator, obs H2D +
                               * action D2H + staged records H2D) kept for comparison */
-    int explore_kind;        /* -1: the algorithm's loop default (DQN epsilon-greedy, DDPG/TD3 Gaussian, SAC none), else frl_explore_kind */
+    int explore_kind;        /* 0 (a zero-initialised struct) or -1: the algorithm's loop default (DQN epsilon-greedy, DDPG/TD3
+                              * Gaussian, SAC none); FRL_EXPLORE_EPS_GREEDY / _GAUSS / _OU: that rule; FRL_EXPLORE_OFF: none */
     float gauss_init_scale, gauss_final_scale;   /* with max_episodes > 0: a learner's noise multiplier decays with ITS finished episodes, */
     int max_episodes;                            /* scale = final + (init - final) * max(0, max_episodes - episodes) / max_episodes (TD3.py:425-427, SAC.py:548-556) */
     float ou_theta, ou_sigma, ou_dt;             /* OUNoise(theta 0.15, sigma, dt) (SAC.py:334-356) */
@@ -372,6 +374,24 @@ int frl_ppo_rollout(frl_engine* e, frl_envpool* p, const frl_ppo_rollout_args* a
 
 /* Algorithmic flops / bytes of one frl_ppo_learn over all learners (the figure a PPO roofline fraction is computed from). */
 int frl_ppo_work(const frl_engine* e, int horizon, int k_epochs, double* flops_out, double* bytes_out);
+
+/* ---------------------------------------------------------------- multi-GPU: the path's ONE collective
+ * The reference is single-process / single-device and has no distributed code (its only trace is the dead import
+ * DDPG_file/misc(lose).py:4): independent seeds / env-instance sets are sharded one process per GPU and nothing on the data
+ * path is exchanged.  What IS exchanged is a short metrics vector per reporting interval — counters summed, wall-clock maxed —
+ * by ncclAllReduce over RCCL (xGMI inside a node).  Bootstrap like NCCL's: ONE rank calls frl_comm_unique_id and ships the
+ * 128 bytes to the others by any host channel (freerl_amd/dist.py: the launcher's store); every rank then calls
+ * frl_comm_create collectively.  RCCL is bound at run time (dlopen), so the library loads on a box without it. */
+#define FRL_COMM_ID_BYTES 128
+#define FRL_COMM_MAX_VALUES 64
+typedef struct frl_comm frl_comm;
+int frl_comm_unique_id(uint8_t* id_out /* [FRL_COMM_ID_BYTES] */);
+int frl_comm_create(const uint8_t* id, int rank, int world, int device_id, frl_comm** out);
+int frl_comm_destroy(frl_comm* c);
+int frl_comm_info(const frl_comm* c, int* rank_out, int* world_out);      /* NULL comm: rank 0 of 1 */
+/* sums[n_sum] <- sum over ranks, maxes[n_max] <- max over ranks, in place (float64: counters exact to 2^53); at most
+ * FRL_COMM_MAX_VALUES each.  comm == NULL: the single-process case, the vectors are already the job's totals.  Synchronous. */
+int frl_metrics_allreduce(frl_comm* c, double* sums, int n_sum, double* maxes, int n_max);
 
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);

@@ -55,6 +55,90 @@ def test_ctypes_structs_match_c_layout(native, tmp_path):
     assert got == want
 
 
+def _gcc_layout(tmp_path, structs):
+    """{struct: (sizeof, {field: offset})} measured by compiling a probe against include/freerl_hip.h."""
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "freerl_hip.h"', 'int main(void){']
+    for name, fields in structs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (name, name))
+        for f, _ in fields:
+            lines.append('printf(" %s=%%zu", offsetof(%s, %s));' % (f, name, f))
+        lines.append('printf("\\n");')
+    lines.append('return 0;}')
+    probe = tmp_path / "layout.c"
+    probe.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
+    out = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        parts = line.split()
+        out[parts[0]] = (int(parts[1]), {kv.split("=")[0]: int(kv.split("=")[1]) for kv in parts[2:]})
+    return out
+
+
+def _load_stub_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_ctypes_stub", os.path.join(ROOT, "tools", "gen_ctypes_stub.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_integration_md_stub_matches_the_header(tmp_path):
+    """INTEGRATION.md's ctypes block is what a maintainer copies: execute it and compare every struct's size and every
+    field's offset with the C compiler's view of include/freerl_hip.h (round 2's hand-written block was 24 bytes short)."""
+    tool = _load_stub_tool()
+    assert tool.main(["--check"]) == 0, "INTEGRATION.md is stale: python tools/gen_ctypes_stub.py"
+    structs, _ = tool.parse_structs()
+    assert {n for n, _ in structs} >= {"frl_config", "frl_learn_args", "frl_ppo_args", "frl_rollout_args", "frl_record_layout"}
+    ns = {}
+    exec(tool.extract(), ns)
+    want = _gcc_layout(tmp_path, structs)
+    for name, fields in structs:
+        cls = ns[name]
+        assert C.sizeof(cls) == want[name][0], name
+        for f, _ in fields:
+            assert getattr(cls, f).offset == want[name][1][f], (name, f)
+
+
+def test_native_binding_field_offsets(native, tmp_path):
+    """freerl_amd/_native.py's mirrors, field by field (the size-only test above this one would miss two swapped ints)."""
+    tool = _load_stub_tool()
+    structs, _ = tool.parse_structs()
+    want = _gcc_layout(tmp_path, structs)
+    mirror = {"frl_config": native.Config, "frl_record_layout": native.RecordLayout, "frl_learn_args": native.LearnArgs,
+              "frl_ppo_args": native.PpoArgs, "frl_explore_args": native.ExploreArgs, "frl_rollout_args": native.RolloutArgs,
+              "frl_rollout_stats": native.RolloutStats, "frl_ppo_rollout_args": native.PpoRolloutArgs}
+    assert set(mirror) == {n for n, _ in structs}
+    for name, fields in structs:
+        cls = mirror[name]
+        assert C.sizeof(cls) == want[name][0], name
+        assert [f for f, _ in cls._fields_] == [f for f, _ in fields], name
+        for f, _ in fields:
+            assert getattr(cls, f).offset == want[name][1][f], (name, f)
+
+
+def test_metrics_allreduce_abi_without_device(native):
+    """The collective's C entry point: NULL communicator = the single-process identity; argument checks; a communicator
+    cannot be created without a HIP device (no CPU fallback for the RCCL path either)."""
+    L = native.lib()
+    sums = (C.c_double * 3)(1.0, 2.0, 3.0)
+    mx = (C.c_double * 2)(4.0, 5.0)
+    assert L.frl_metrics_allreduce(None, sums, 3, mx, 2) == 0
+    assert list(sums) == [1.0, 2.0, 3.0] and list(mx) == [4.0, 5.0]
+    assert L.frl_metrics_allreduce(None, sums, native.FRL_COMM_MAX_VALUES + 1, mx, 2) == 1
+    assert L.frl_metrics_allreduce(None, None, 3, mx, 2) == 1
+    rank, world = C.c_int(-1), C.c_int(-1)
+    assert L.frl_comm_info(None, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+    import torch
+    if not torch.cuda.is_available():
+        uid = (C.c_uint8 * native.FRL_COMM_ID_BYTES)()
+        h = C.c_void_p()
+        assert L.frl_comm_create(uid, 0, 1, 0, C.byref(h)) == 3                 # FRL_ERR_NO_DEVICE
+        assert b"no HIP device" in L.frl_last_error()
+        assert L.frl_comm_create(uid, 2, 2, 0, C.byref(h)) == 1                 # rank outside world
+    assert L.frl_comm_destroy(None) == 0
+
+
 def test_header_is_plain_c(tmp_path):
     probe = tmp_path / "c.c"
     probe.write_text('#include "freerl_hip.h"\nint main(void){return FRL_OK;}\n')
