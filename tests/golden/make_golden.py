@@ -998,6 +998,94 @@ def gen_traj_ppo(out):
 
 
 # ----------------------------------------------------------------------------- harness self-check
+# ----------------------------------------------------------------------------- long-horizon curves (losses only)
+def gen_long_dqn(out):
+    from tests.golden import long_cases as LC
+    c = LC.LONG["long_dqn"]
+    inp = LC.dqn_inputs(c)
+    mod = import_reference("DQN_file", "DQN")
+    pol = mod.DQN([c["obs_dim"], c["n_actions"]], False, c["lr"], c["capacity"], CPU)
+    load(pol.agent.Qnet, inp["params"]["Qnet"])
+    load(pol.agent.Qnet_target, inp["params"]["Qnet"])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_Qnet"])
+    with inject(np.random, "choice", feeder(inp["idx"])):
+        for _ in range(c["n_calls"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["loss"] = np.array(rec["update_Qnet"], dtype=np.float32)
+    out["Qnet_l1_weight_sum"] = np.float64(pol.agent.Qnet.state_dict()["l1.weight"].double().sum().item())
+
+
+def gen_long_ac(name, out):
+    from tests.golden import long_cases as LC
+    import torch.distributions.normal as tdn
+    c = LC.LONG[name]
+    inp = LC.ac_inputs(c)
+    dims = [c["obs_dim"], c["act_dim"]]
+    if c["kind"] == "ddpg":
+        mod = import_reference("DDPG_file", "DDPG_simple")
+        pol = mod.DDPG(dims, True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU)
+    elif c["kind"] == "td3":
+        mod = import_reference("TD3_file", "TD3")
+        pol = mod.TD3(dims, True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU, trick=None,
+                      realize={"clip_double": True, "policy_noise": True, "twin_delay": True})
+    else:
+        mod = import_reference("SAC_file", "SAC")
+        pol = mod.SAC(dims, True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU,
+                      trick={"ObsNorm": False, "Batch_ObsNorm": False, "OUNoise": False, "GaussNoise": False})
+    for net in ("actor", "critic"):
+        load(getattr(pol.agent, net), inp["params"][net])
+        load(getattr(pol.agent, net + "_target"), inp["params"][net])
+    fill(pol, inp["table"])
+    rec = wrap_losses(pol.agent, ["update_critic", "update_actor"])
+    with contextlib.ExitStack() as st:
+        st.enter_context(inject(np.random, "choice", feeder(inp["idx"])))
+        if c["kind"] == "td3":
+            st.enter_context(inject(torch, "randn_like", feeder([torch.as_tensor(n0) for n0, _ in inp["noise"]])))
+        elif c["kind"] == "sac":
+            st.enter_context(inject(tdn, "_standard_normal", feeder([torch.as_tensor(e) for pair in inp["noise"] for e in pair])))
+        alphas = []
+        for _ in range(c["n_calls"]):
+            if c["kind"] == "ddpg":
+                pol.learn(c["batch"], c["gamma"], c["tau"])
+            elif c["kind"] == "td3":
+                pol.learn(c["batch"], c["gamma"], c["tau"], c["policy_noise"], c["noise_clip"], c["max_action"],
+                          c["policy_freq"], c["policy_noise_scale"])
+            else:
+                pol.learn(c["batch"], c["gamma"], c["tau"])
+                alphas.append(np.float32(pol.alphas.alpha.item()))
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    if alphas:
+        out["alpha"] = np.array(alphas, dtype=np.float32)
+
+
+def gen_long_ppo_c3(out):
+    from tests.golden import long_cases as LC
+    c = LC.LONG["long_ppo_c3"]
+    inp = LC.ppo_inputs(c)
+    mod = import_reference("PPO_file", "PPO_with_tricks")
+    pol = mod.PPO([c["obs_dim"], c["act_dim"]], True, c["actor_lr"], c["critic_lr"], c["horizon"], CPU,
+                  trick=dict(c["trick"]), beta=False)
+    load(pol.agent.actor, inp["params"]["actor"])
+    load(pol.agent.critic, inp["params"]["critic"])
+    tab = inp["table"]
+    for i in range(c["horizon"]):
+        pol.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]),
+                tab["logp"][i], bool(tab["adv_done"][i]))
+    rec = wrap_losses(pol.agent, ["update_actor", "update_critic"])
+    proxy = _NpProxy(inp["perms"])
+    mod.np = proxy
+    try:
+        pol.learn(c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    finally:
+        mod.np = np
+    out["loss_actor"] = np.array(rec["update_actor"], dtype=np.float32)
+    out["loss_critic"] = np.array(rec["update_critic"], dtype=np.float32)
+    out["adv_raw"] = proxy.captured[0].astype(np.float32)
+
+
+
 def survey_known_answers():
     """SURVEY.md §8(c) recorded `DQN.learn` losses for torch-seeded init + legacy-RNG indices.
     If this harness does not reproduce them, the harness (not a kernel) is wrong."""
@@ -1029,6 +1117,8 @@ def main():
         "traj_td3": lambda o: gen_traj_ac("td3", o), "traj_sac": lambda o: gen_traj_ac("sac", o),
         "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_matd3": gen_traj_matd3,
         "traj_ppo": gen_traj_ppo,
+        "long_dqn": gen_long_dqn, "long_ddpg": lambda o: gen_long_ac("long_ddpg", o), "long_td3_c2": lambda o: gen_long_ac("long_td3_c2", o),
+        "long_sac": lambda o: gen_long_ac("long_sac", o), "long_ppo_c3": gen_long_ppo_c3,
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]

@@ -122,13 +122,15 @@ def test_c3_ppo_halfcheetah_shape(N):
     np.testing.assert_allclose(out["adv"][0], orc.adv_raw.reshape(-1), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(out["v_target"][0], orc.v_target.reshape(-1), rtol=2e-4, atol=2e-5)
     n_mb = T // mb
-    # 64 sequential Adam steps per net and epoch: compare the loss trace with a tolerance that grows with the step
-    got_a, want_a = out["trace"][0, :, 0], np.array(orc.actor_losses)
+    # 64 sequential Adam steps per net and epoch, through both epochs at rounding level (tests/test_gpu_longrun.py holds the
+    # K = 10 run of this shape to 1e-5 / 1e-4 against the reference's own curve); the surrogate loss crosses zero, so the
+    # actor's error is taken relative to the mean |loss|
+    got_a, want_a = out["trace"][0, :, 0].astype(np.float64), np.array(orc.actor_losses, np.float64)
     got_c, want_c = out["trace"][0, :, 1], np.array(orc.critic_losses)
     assert got_a.shape == (K * n_mb,)
-    np.testing.assert_allclose(got_a[:n_mb], want_a[:n_mb], rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(got_c[:n_mb], want_c[:n_mb], rtol=2e-3)
-    np.testing.assert_allclose(got_c, want_c, rtol=2e-2)
+    a_err = np.abs(got_a - want_a).max() / np.mean(np.abs(want_a))
+    c_err = (np.abs(got_c.astype(np.float64) - want_c) / np.abs(want_c)).max()
+    assert c_err <= 1e-4 and a_err <= 1e-3, (c_err, a_err)
     assert e.opt_step(0) == K * n_mb and e.cursor(0) == (0, 0)
     e.close()
 

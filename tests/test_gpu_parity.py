@@ -41,8 +41,16 @@ def _dump_report():
     yield
     out = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_report.json"), "w") as f:
-        json.dump(REPORT, f, indent=1, sort_keys=True)
+    path = os.path.join(out, "parity_report.json")
+    merged = {}
+    if os.path.exists(path):          # a partial run (-k ...) updates its entries and keeps the others
+        try:
+            merged = json.load(open(path))
+        except Exception:
+            merged = {}
+    merged.update(REPORT)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
 
 
 def note(key, val):

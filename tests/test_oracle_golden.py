@@ -591,3 +591,78 @@ def test_ppo_py_discrete_categorical_logits():
     synth.check_digest("critic", pol.critic, fx, 5e-3, 5e-4)
     other, sel2, _ = run(False)
     assert np.max(np.abs(np.array(other.actor_losses) - fx["loss_actor"]) / np.abs(fx["loss_actor"])) > 1e-3
+
+
+# ----------------------------------------------------------------------------- long-horizon curves (tests/golden/long_*.npz)
+def _rel(got, want, floor=1e-6):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want) / np.maximum(np.abs(want), floor)
+
+
+def test_long_dqn_500_calls_vs_reference_curve():
+    """The oracle against the REFERENCE's own 500-call DQN loss curve (DQN.py:104-128): no actor-through-critic feedback, so
+    the whole curve holds at rounding level."""
+    from tests.golden import long_cases as LC
+    c = LC.LONG["long_dqn"]
+    inp = LC.dqn_inputs(c)
+    fx = gold("long_dqn")
+    orc = algos.DQN(inp["params"]["Qnet"], c["obs_dim"], c["n_actions"], c["lr"], c["capacity"])
+    fill(orc, inp["table"], discrete=True)
+    for k in range(c["n_calls"]):
+        orc.learn_with(inp["idx"][k], c["gamma"], c["tau"])
+    assert len(fx["loss"]) == c["n_calls"] == 500
+    assert _rel(orc.losses, fx["loss"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["long_ddpg", "long_td3_c2", "long_sac"])
+def test_long_actor_critic_vs_reference_curve(name):
+    """100 calls at rounding level (<= 1e-4: north_star's tolerance); over the remaining 400 the actor-critic feedback amplifies
+    one-ulp differences and the envelope is 5e-2."""
+    from tests.golden import long_cases as LC
+    c = LC.LONG[name]
+    inp = LC.ac_inputs(c)
+    fx = gold(name)
+    O, A = c["obs_dim"], c["act_dim"]
+    a_p, c_p = inp["params"]["actor"], inp["params"]["critic"]
+    orc = {"ddpg": algos.DDPG, "td3": algos.TD3, "sac": algos.SAC}[c["kind"]](a_p, c_p, O, A, c["actor_lr"], c["critic_lr"], c["capacity"])
+    fill(orc, inp["table"])
+    cl, al = [], []
+    for k in range(c["n_calls"]):
+        n0, n1 = inp["noise"][k]
+        if c["kind"] == "ddpg":
+            out = orc.learn_with(inp["idx"][k], None, c["gamma"], c["tau"])
+        elif c["kind"] == "td3":
+            out = orc.learn_with(inp["idx"][k], n0, c["gamma"], c["tau"], c["policy_noise"], c["noise_clip"], c["max_action"],
+                                 c["policy_freq"], c["policy_noise_scale"])
+        else:
+            out = orc.learn_with(inp["idx"][k], n0, n1, c["gamma"], c["tau"])
+        cl.append(out[0])
+        if c["kind"] != "td3" or (k + 1) % c["policy_freq"] == 0:
+            al.append(out[1])
+    err = _rel(cl, fx["loss_critic"])
+    assert err[:100].max() <= 1e-4, (name, err[:100].max())
+    assert err.max() <= 5e-2, (name, err.max(), int(err.argmax()))
+    assert len(al) == len(fx["loss_actor"])
+    scale = float(np.mean(np.abs(fx["loss_critic"])))
+    a_err = np.abs(np.asarray(al, np.float64) - fx["loss_actor"].astype(np.float64)) / scale
+    assert a_err[:len(al) // 5].max() <= 1e-4 and a_err.max() <= 0.15, (name, a_err.max())
+
+
+def test_long_ppo_config3_vs_reference_curve():
+    """One PPO.learn() at BASELINE config 3's full shape (obs 17, act 6, horizon 2048, minibatch 64, K 10): all 320 actor and
+    320 critic minibatch losses against the reference's (PPO_with_tricks.py:290-354)."""
+    from tests.golden import long_cases as LC
+    c = LC.LONG["long_ppo_c3"]
+    inp = LC.ppo_inputs(c)
+    fx = gold("long_ppo_c3")
+    O, A, T = c["obs_dim"], c["act_dim"], c["horizon"]
+    orc = ppo.PPO(inp["params"]["actor"], inp["params"]["critic"], O, A, c["actor_lr"], c["critic_lr"], T, c["trick"])
+    tab = inp["table"]
+    for i in range(T):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]), tab["logp"][i],
+                bool(tab["adv_done"][i]))
+    orc.learn_with(inp["perms"], c["minibatch"], c["gamma"], c["lmbda"], c["clip"], c["k_epochs"], c["ent"])
+    assert len(fx["loss_critic"]) == 320
+    assert _rel(orc.critic_losses, fx["loss_critic"]).max() <= 1e-5
+    al = fx["loss_actor"].astype(np.float64)
+    assert (np.abs(np.asarray(orc.actor_losses, np.float64) - al) / np.mean(np.abs(al))).max() <= 1e-4
