@@ -58,39 +58,100 @@ def make_engine(N, Engine, learners, device_id, seed):
     return e
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle (NumPy port of TD3.learn, incl. the reference's np.random.choice over the full
-    1e6-row buffer) timed on ONE host core: a bounded sample of the same workload."""
-    from oracle import algos
-    from tests.golden import cases, synth
+# ------------------------------------------------------------------------------------------ CPU baselines (same box)
+# The oracle (oracle/: the NumPy fp32 restatement of the reference's arithmetic, validated against the reference's own
+# outputs in tests/) timed on THIS box's host cores, in worker subprocesses of this script (`--cpu-worker`; a fork of a
+# process that holds a HIP context is not safe): one core, and all cores as independent learners — one process per core,
+# each its own seed, the same unit of parallelism the GPU engine batches ("P learners").  BLAS threads are pinned to 1 per
+# process (the 256 x 128 matrices of this workload do not scale across threads; SURVEY §8c: identical at 1 and 8 threads).
+def _cpu_worker(kind, budget_s, seed):
     try:
         import threadpoolctl
-        ctx = threadpoolctl.threadpool_limits(1)
+        threadpoolctl.threadpool_limits(1)
     except Exception:
-        ctx = None
-    actor = synth.mlp_params(1, cases.actor_layers(OBS, ACT))
-    critic = synth.mlp_params(2, cases.critic_layers(OBS + ACT, twin=True))
-    pol = algos.TD3(actor, critic, OBS, ACT, 1e-3, 1e-3, CAP)
-    g = np.random.default_rng(3)
-    b = pol.buffer
-    b.obs[:] = g.standard_normal((CAP, OBS)); b.next_obs[:] = g.standard_normal((CAP, OBS))
-    b.actions[:] = g.uniform(-1, 1, (CAP, ACT)); b.rewards[:] = g.standard_normal(CAP)
-    b.dones[:] = g.random(CAP) < 0.05
-    b._size, b._index = CAP, 0
-    np.random.seed(0)
-    noise = g.standard_normal((BATCH, ACT)).astype(np.float32)
+        pass
+    from oracle import algos
+    from tests.golden import cases, synth
+    g = np.random.default_rng(3 + seed)
+    np.random.seed(seed)
+
+    def prefill(b, rows, act_cols, discrete):
+        b.obs[:rows] = g.standard_normal((rows, OBS)); b.next_obs[:rows] = g.standard_normal((rows, OBS))
+        b.actions[:rows] = g.integers(0, 4, (rows, act_cols)) if discrete else g.uniform(-1, 1, (rows, act_cols))
+        b.rewards[:rows] = g.standard_normal(rows)
+        b.dones[:rows] = g.random(rows) < 0.05
+        b._size, b._index = rows, rows % b.capacity
+
+    if kind == "td3":
+        actor = synth.mlp_params(1 + seed, cases.actor_layers(OBS, ACT))
+        critic = synth.mlp_params(2 + seed, cases.critic_layers(OBS + ACT, twin=True))
+        pol = algos.TD3(actor, critic, OBS, ACT, 1e-3, 1e-3, CAP)
+        prefill(pol.buffer, CAP, ACT, False)
+        noise = g.standard_normal((BATCH, ACT)).astype(np.float32)
+        step = lambda: pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
+    else:                               # "dqn_loop:<rows>": the reference's DQN loop (DQN.py:294-343) on the synthetic discrete env
+        rows = int(kind.split(":")[1])
+        from freerl_amd.envs import LinearGaussianEnv
+        env = LinearGaussianEnv(discrete=True)
+        cap = max(rows, 10_000)
+        pol = algos.DQN(synth.mlp_params(5 + seed, [("l1", HIDDEN, OBS), ("l2", 4, HIDDEN)]), OBS, 4, 1e-3, cap)
+        prefill(pol.buffer, rows if rows >= cap else rows // 2, 1, True)      # 1e6: full; the small buffer: half full, filling up
+        state = {"obs": env.reset(seed=seed)[0]}
+
+        def step():
+            obs = state["obs"]
+            a = pol.select_action(obs)
+            if np.random.rand() < 0.1:                                         # DQN.py:307-310
+                a = np.random.randint(4)
+            nobs, r, term, trunc, _ = env.step(a)
+            pol.add(obs, a, r, nobs, term)
+            state["obs"] = env.reset(seed=seed)[0] if (term or trunc) else nobs
+            pol.learn(BATCH, 0.99, 0.01)                                       # np.random.choice(len(buffer), 256, replace=False) inside
     for _ in range(3):
-        pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
+        step()
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
+        step()
         n += 1
-    dt = time.perf_counter() - t0
-    if ctx is not None:
-        ctx.unregister() if hasattr(ctx, "unregister") else None
-    return {"value": n / dt, "unit": "updates/s", "cores": 1, "kind": "port",
-            "sample": "%d oracle TD3.learn() calls (1 learner, replay 1e6 full, batch 256, np.random.choice "
-                      "index draw included) in %.1f s" % (n, dt)}
+    print(json.dumps({"n": n, "dt": time.perf_counter() - t0}), flush=True)
+
+
+def _run_cpu_workers(kind, n_procs, budget_s):
+    """n_procs worker processes side by side -> (aggregate units/s, per-process counts)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, "--cpu-budget", str(budget_s),
+                               "--cpu-seed", str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for i in range(n_procs)]
+    rate, counts = 0.0, []
+    for pr in procs:
+        o, e = pr.communicate(timeout=600)
+        if pr.returncode != 0:
+            raise RuntimeError("cpu worker failed: " + e[-2000:])
+        r = json.loads(o.strip().splitlines()[-1])
+        rate += r["n"] / r["dt"]
+        counts.append(r["n"])
+    return rate, counts
+
+
+def cpu_baseline(budget_s=6.0):
+    """TD3.learn() of the bench's workload (1 learner, replay 1e6 full, batch 256, the reference's np.random.choice index
+    draw included) on one host core and on all of them; plus the DQN loop's env-steps/s (see dqn_single_learner_loop)."""
+    cores = os.cpu_count() or 1
+    n_all = min(cores, 64)              # 64 x ~250 MB of float64 ring is enough to characterise the box
+    one, c1 = _run_cpu_workers("td3", 1, budget_s)
+    allc, call = _run_cpu_workers("td3", n_all, budget_s)
+    loops = {}
+    for rows in (10_000, 1_000_000):
+        r1, _ = _run_cpu_workers("dqn_loop:%d" % rows, 1, budget_s * 0.7)
+        ra, _ = _run_cpu_workers("dqn_loop:%d" % rows, n_all, budget_s * 0.7)
+        loops["replay %d rows" % rows] = {"one_core": r1, "all_cores": ra, "processes": n_all}
+    return {"value": one, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "%d oracle TD3.learn() calls (1 learner, replay 1e6 full, batch 256, np.random.choice index draw "
+                      "included) in %.1f s on one core" % (c1[0], budget_s),
+            "all_cores": {"value": allc, "unit": "updates/s", "cores": n_all, "host_cpus": cores,
+                          "sample": "%d independent oracle learners, one process per core, %d calls in %.1f s" % (n_all, sum(call), budget_s)},
+            "dqn_loop_env_steps_per_sec": loops}
 
 
 def dropin_classes():
@@ -159,7 +220,8 @@ def dqn_single_learner_loop(P=512):
     r = rollout(e, pool, 300, **kw)
     pool.close(); e.close()
     return {"unit": "env-steps/s, one DQN learner, one learn() per vector step, replay 1e5 rows half full", **out,
-            "reference_cpu_env_steps_per_sec": {"small buffer": 560, "replay 1e6 full": 45},
+            "reference_cpu_env_steps_per_sec": "measured on this box: cpu_baseline.dqn_loop_env_steps_per_sec (BASELINE.md's 560 / 45 "
+                                               "were taken in the survey container)",
             "population": {"learners": P, "envs_per_learner": 1, "env_steps_per_sec": r["env_steps"] / r["seconds"],
                            "updates_per_sec": r["updates"] / r["seconds"]}}
 
@@ -186,12 +248,17 @@ def main():
     ap.add_argument("--learners", type=int, default=int(os.environ.get("FRL_BENCH_LEARNERS", "512")),
                     help="independent learners (seeds) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)       # internal: one CPU-baseline worker process
+    ap.add_argument("--cpu-budget", type=float, default=6.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seed", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--spawn", action="store_true",
                     help="go through the launcher even for --gpus 1 (RCCL init + the metric all-reduce with one rank)")
     ap.add_argument("--headline-only", action="store_true",
                     help="profiling runs: only the P-learner engine (no P = 1 engine, no CPU baseline), so that rocprofv3's "
                          "per-kernel averages are averages over the headline launches")
     args = ap.parse_args()
+    if args.cpu_worker:
+        return _cpu_worker(args.cpu_worker, args.cpu_budget, args.cpu_seed)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
@@ -335,6 +402,15 @@ def main():
             "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(args.learners),
             "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
         }
+        cb, dl = line["cpu_baseline"], line["dqn_single_learner_loop"]
+        if cb and dl:     # north_star's ">= 50x the reference CPU env-steps/s": same loop, same box, GPU engine / CPU port
+            small, full = cb["dqn_loop_env_steps_per_sec"]["replay 10000 rows"], cb["dqn_loop_env_steps_per_sec"]["replay 1000000 rows"]
+            dl["speedup_vs_cpu_port_same_box"] = {
+                "one learner x 1 env / one core, small buffer": dl["1 env(s)"] / small["one_core"],
+                "one learner x 1 env / one core, replay 1e6 full": dl["1 env(s)"] / full["one_core"],
+                "one learner x 8 envs / one core, small buffer": dl["8 env(s)"] / small["one_core"],
+                "population / all cores, small buffer": dl["population"]["env_steps_per_sec"] / small["all_cores"],
+                "population / all cores, replay 1e6 full": dl["population"]["env_steps_per_sec"] / full["all_cores"]}
         print(json.dumps(line), flush=True)
 
 
