@@ -274,6 +274,12 @@ def main():
                              "fallback and ranks do not share a GPU)" % (args.gpus, args.gpus, have))
         sys.exit(fdist.respawn(args.gpus, os.path.abspath(__file__), [a for a in sys.argv[1:] if a != "--spawn"]))
 
+    # ONE JSON line on stdout: RCCL and gloo print banners to fd 1 at init ("RCCL version : ...", "[Gloo] Rank 0 is connected
+    # ..."), so the real stdout is kept aside and fd 1 points at stderr for the rest of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from freerl_amd.engine import Engine
 
@@ -411,7 +417,8 @@ def main():
                 "one learner x 8 envs / one core, small buffer": dl["8 env(s)"] / small["one_core"],
                 "population / all cores, small buffer": dl["population"]["env_steps_per_sec"] / small["all_cores"],
                 "population / all cores, replay 1e6 full": dl["population"]["env_steps_per_sec"] / full["all_cores"]}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -1,8 +1,17 @@
 // One 3-layer, hidden-128, narrow-input (<= 16 columns), narrow-head (<= 16 outputs) ReLU MLP on chip, for the kernels that
 // give a whole learner to one workgroup (kernels_critic2.hip, kernels_actor2.hip): LDS images of the net in MFMA-fragment order
 // (device/chain.hpp), the chained forward of 16 (or 2 x 16) rows per wave, the backward with its three activation / delta
-// exchanges and the owners' weight-gradient accumulators, and clip + Adam (+ soft update) streamed linearly over theta / m /
-// v / target after a transpose of the accumulators through the exchange buffers.
+// exchanges and the owners' weight-gradient accumulators, and clip + Adam (+ soft update) straight from those accumulators.
+//
+// Parameter layout in HBM (NetDesc::frag, round 3): the engines these kernels serve keep theta / target / m / v of their nets in
+// the SAME fragment order as the LDS images — weight block of a layer = its 16 x 16 tiles, tile (ot, kb) at (ot * KB + kb) * 256
+// floats, element (out & 15 = f, in & 15 = 4q + e) at ((q * 16 + (f ^ q)) << 2) + e (frag_dw) — instead of Wk[in][out].  Two
+// things follow.  Staging a net is a linear 16-byte copy (round 2 gathered 4-byte words from four Wk rows per LDS slot: 80
+// loads per thread and net, 15 k cycles x 5 nets of a critic update).  And the weight gradients are accumulated TRANSPOSED
+// (dW^T[in][out] = H dZ^T: the A and B operands of round 2's dW MFMAs swapped, same fragments), so the four registers of a
+// lane's accumulator tile ARE one 16-byte slot of the image: clip + Adam + soft update run register -> global with every
+// wave-instruction covering one whole contiguous 1 KB tile — no transposes through LDS, no barriers, nothing that ties the
+// update to the workgroup's other waves (round 2: 17 % of the critic stage, every CU in it at the same time).
 #pragma once
 #include "chain.hpp"
 
@@ -15,7 +24,8 @@ struct ChainLds {
 };
 constexpr int chain_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + kChainBatch * 4 + 3 * kChainBatch + 64; }
 
-// the weight-gradient accumulators one lane owns for one 3-layer head (MFMA D layout, out = 16*ot + 4q + r, in = 16*kt + i16):
+// the weight-gradient accumulators one lane owns for one 3-layer head, TRANSPOSED (MFMA D layout of dW^T: in = 16*kt + 4q + r,
+// out = 16*ot + i16 — the lane's four registers are the 16-byte slot (q, f = i16) of image tile (ot, kt)):
 // layer 2: ot in {2w, 2w+1} x kt 0..7; layer 1 (one 16-wide input block): ot in {2w, 2w+1}; head: kt in {2w, 2w+1}
 struct HeadGrad {
     f32x4 g2[2][kHT], g1[2], g3[2];
@@ -49,50 +59,24 @@ struct ChainNet {
         tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);                  // transposed read / owner write: + ((f ^ (i16 >> 2)) << 2)
     }
 
-    // ---- one net's three layers -> LDS images (fragment order).  Engine layout: Wk[k][n] (n contiguous), then b[n_pad].
+    // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy
     __device__ __forceinline__ void stage(g_cf th, const NetDesc& N, int l0) const {
         const LayerDesc &L1 = N.L[l0], &L2 = N.L[l0 + 1], &L3 = N.L[l0 + 2];
         lds_barrier();                                                 // every wave is done with the previous images
-        // a 16-byte LDS slot holds W[out = n][in = 4*k4 .. 4*k4 + 3]: four rows of Wk[in][out] at column n — lanes walk n, so
-        // every load is a coalesced row segment; all loads of an image are issued before its stores
-        {
-            const int n = tid & 127, half = tid >> 7;                  // layer 2: 128 columns x 32 k-quads, 16 quads per thread
-            f32x4 t[16];
+        f32x4 t2[16], t1[2], t3[2];                                    // all loads of the net in flight before the first store
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k4 = 2 * j + half;
+        for (int j = 0; j < 16; ++j) t2[j] = ld4(th + L2.w_off + 4 * (tid + 256 * j));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[j][e] = th[L2.w_off + (4 * k4 + e) * kHid + n];
-            }
+        for (int j = 0; j < 2; ++j) { t1[j] = ld4(th + L1.w_off + 4 * (tid + 256 * j)); t3[j] = ld4(th + L3.w_off + 4 * (tid + 256 * j)); }
+        float bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, lsv = 0.f;
+        if (tid < kHid) { bb1 = th[L1.b_off + tid]; bb2 = th[L2.b_off + tid]; }
+        if (tid < 16) { bb3 = th[L3.b_off + tid]; lsv = (N.extra_n > 0 && tid < N.extra_n) ? th[N.extra_off + tid] : 0.f; }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k4 = 2 * j + half, kb = k4 >> 2, qq = k4 & 3;
-                st4(S.w2 + ((n >> 4) * kHT + kb) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), t[j]);
-            }
-            f32x4 u1, u1b, u3[2];                                      // layer 1: 128 columns x 4 k-quads; head: 16 columns x 32 k-quads
+        for (int j = 0; j < 16; ++j) st4(S.w2 + 4 * (tid + 256 * j), t2[j]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u1[e] = th[L1.w_off + (4 * (tid >> 7) + e) * kHid + n];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) u1b[e] = th[L1.w_off + (4 * (2 + (tid >> 7)) + e) * kHid + n];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k4 = (tid >> 4) + 16 * j;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) u3[j][e] = th[L3.w_off + (4 * k4 + e) * 16 + (tid & 15)];
-            }
-            { const int qq = tid >> 7; st4(S.w1 + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1); }
-            { const int qq = 2 + (tid >> 7); st4(S.w1 + (n >> 4) * 256 + ((qq * 16 + ((n & 15) ^ qq)) << 2), u1b); }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k4 = (tid >> 4) + 16 * j, kb = k4 >> 2, qq = k4 & 3;
-                st4(S.w3 + kb * 256 + ((qq * 16 + ((tid & 15) ^ qq)) << 2), u3[j]);
-            }
-        }
-        if (tid < kHid) { S.b1[tid] = th[L1.b_off + tid]; S.b2[tid] = th[L2.b_off + tid]; }
-        if (tid < 16) {
-            S.b3[tid] = th[L3.b_off + tid];
-            S.ls[tid] = (N.extra_n > 0 && tid < N.extra_n) ? th[N.extra_off + tid] : 0.f;
-        }
+        for (int j = 0; j < 2; ++j) { st4(S.w1 + 4 * (tid + 256 * j), t1[j]); st4(S.w3 + 4 * (tid + 256 * j), t3[j]); }
+        if (tid < kHid) { S.b1[tid] = bb1; S.b2[tid] = bb2; }
+        if (tid < 16) { S.b3[tid] = bb3; S.ls[tid] = lsv; }
         lds_barrier();
     }
 
@@ -221,7 +205,7 @@ struct ChainNet {
             const f32x4 af = get_frag(S.eb, 0, bb);
             if (w == 0) g.gb3 += (af[0] + af[1]) + (af[2] + af[3]);
 #pragma unroll
-            for (int x = 0; x < 2; ++x) g.g3[x] = mfma4(g.g3[x], af, get_frag(S.ea, 2 * w + x, bb));
+            for (int x = 0; x < 2; ++x) g.g3[x] = mfma4(g.g3[x], get_frag(S.ea, 2 * w + x, bb), af);
         }
         f32x4 d2[kHT];
         delta2(dz, h2, d2);
@@ -242,7 +226,7 @@ struct ChainNet {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], af[x], bf[kt]);
+                for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], bf[kt], af[x]);
         }
         f32x4 d1[kHT];
         delta1(d2, h1, d1);
@@ -258,7 +242,7 @@ struct ChainNet {
             for (int x = 0; x < 2; ++x) {
                 const f32x4 af = get_frag(S.eb, 2 * w + x, bb);
                 g.gb1[x] += (af[0] + af[1]) + (af[2] + af[3]);
-                g.g1[x] = mfma4(g.g1[x], af, bf);
+                g.g1[x] = mfma4(g.g1[x], bf, af);
             }
         }
     }
@@ -288,89 +272,74 @@ struct ChainNet {
         return ss;
     }
 
-    // ---- clip + Adam + soft update of one head's three layers, streamed LINEARLY over theta / m / v / target (thread t takes
-    // the float4s t, t + 256, ...: 1 KB contiguous per wave-instruction).  The accumulators are in MFMA layout — 16 input rows
-    // x 64 bytes per instruction if they went to global memory directly (measured: 187 k cycles per learner) — so they are
-    // transposed through the exchange buffers first: row-major Wk[in][out] images, 16-byte slots XOR-swizzled with the row so
-    // that the owners' ds_write_b128 and the linear ds_read_b128 are both conflict-free.  Loads of a batch before its stores:
-    // the compiler cannot prove the four arrays distinct and waits for every store before the next load.
+    // ---- clip + Adam + soft update of one head's three layers from the owners' registers.  A lane's accumulator tile is the
+    // 16-byte slot `fslot` of its image tile, and the HBM block is in image order: every load / store below is one dwordx4 per
+    // lane and one whole contiguous 1 KB tile per wave-instruction.  Loads of a batch of tiles before its stores (the compiler
+    // cannot prove the four arrays distinct and would wait for every store before the next load).  No LDS, no barriers.
+    struct AdamIn { f32x4 th, mm, vv, tg; };
+    __device__ __forceinline__ AdamIn adam_load(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o) const {
+        AdamIn X;
+        X.th = ld4((g_cf)(th + o)); X.mm = ld4((g_cf)(mA + o)); X.vv = ld4((g_cf)(vA + o));
+        X.tg = c.soft ? ld4((g_cf)(tg + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return X;
+    }
+    __device__ __forceinline__ void adam_apply(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, const f32x4& gr, const AdamIn& in) const {
+        f32x4 t4 = in.th, mm = in.mm, vv = in.vv, tt = in.tg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gi = gr[r] * c.coef;
+            if (c.wd != 0.f) gi += c.wd * t4[r];
+            float m1 = mm[r], v1 = vv[r];
+            t4[r] = adam_elem(t4[r], gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
+            mm[r] = m1; vv[r] = v1;
+            tt[r] = tt[r] * c.tk + t4[r] * c.tau;
+        }
+        st4(th + o, t4); st4(mA + o, mm); st4(vA + o, vv);
+        if (c.soft) st4(tg + o, tt);
+    }
+    __device__ __forceinline__ float adam_scalar(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, float gr) const {
+        float t1 = th[o], m1 = mA[o], v1 = vA[o];
+        float gi = gr * c.coef;
+        if (c.wd != 0.f) gi += c.wd * t1;
+        t1 = adam_elem(t1, gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
+        th[o] = t1; mA[o] = m1; vA[o] = v1;
+        if (c.soft) tg[o] = tg[o] * c.tk + t1 * c.tau;
+        return t1;
+    }
     __device__ __forceinline__ void adam_head(const HeadGrad& g, const LayerDesc& L1, const LayerDesc& L2, const LayerDesc& L3, g_f th,
                                               g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra, int extra_off, int extra_n) const {
-        struct In { f32x4 th, mm, vv, tg; };
-        auto load = [&](int o) {
-            In X;
-            X.th = ld4((g_cf)(th + o)); X.mm = ld4((g_cf)(mA + o)); X.vv = ld4((g_cf)(vA + o));
-            X.tg = c.soft ? ld4((g_cf)(tg + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            return X;
-        };
-        auto upd = [&](int o, const f32x4& gr, const In& in) {
-            f32x4 t4 = in.th, mm = in.mm, vv = in.vv, tt = in.tg;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float gi = gr[r] * c.coef;
-                if (c.wd != 0.f) gi += c.wd * t4[r];
-                float m1 = mm[r], v1 = vv[r];
-                t4[r] = adam_elem(t4[r], gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
-                mm[r] = m1; vv[r] = v1;
-                tt[r] = tt[r] * c.tk + t4[r] * c.tau;
-            }
-            st4(th + o, t4); st4(mA + o, mm); st4(vA + o, vv);
-            if (c.soft) st4(tg + o, tt);
-        };
-        lds_f GB = S.ea;                                               // ea and eb are adjacent: 16384 floats
-        // ---- round A: the 128 x 128 layer
-        lds_barrier();
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int kt = 0; kt < kHT; ++kt) {
-                const int row = kt * 16 + i16, slot = (2 * w + x) * 4 + q;
-                st4(GB + row * kHid + ((slot ^ (row & 7)) << 2), g.g2[x][kt]);
-            }
-        lds_barrier();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            In in[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) in[jj] = load(L2.w_off + 4 * (tid + 256 * (8 * half + jj)));
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int f = tid + 256 * (8 * half + jj), row = f >> 5, slot = f & 31;
-                upd(L2.w_off + 4 * f, ld4((lds_cf)(GB + row * kHid + ((slot ^ (row & 7)) << 2))), in[jj]);
-            }
-        }
-        // ---- round B: first layer (16 x 128), head (128 x 16), biases [, the net's extra parameters (log_std)]
-        lds_barrier();
+        // ---- the 128 x 128 layer: 16 tiles per lane, in two batches of 8
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            const int slot = (2 * w + x) * 4 + q;
-            st4(GB + i16 * kHid + ((slot ^ (i16 & 7)) << 2), g.g1[x]);
-            const int r3 = (2 * w + x) * 16 + i16;
-            st4(GB + 2048 + r3 * 16 + ((q ^ ((r3 >> 1) & 3)) << 2), g.g3[x]);
-            if (q == 0) { GB[4096 + (2 * w + x) * 16 + i16] = g.gb1[x]; GB[4224 + (2 * w + x) * 16 + i16] = g.gb2[x]; }
+            AdamIn in[kHT];
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) in[kt] = adam_load(th, mA, vA, tg, c, L2.w_off + ((2 * w + x) * kHT + kt) * 256 + fslot);
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) adam_apply(th, mA, vA, tg, c, L2.w_off + ((2 * w + x) * kHT + kt) * 256 + fslot, g.g2[x][kt], in[kt]);
         }
-        if (w == 0 && q == 0) GB[4352 + i16] = g.gb3;
-        if (extra_n > 0 && w == 1 && q == 0) GB[4368 + i16] = i16 < extra_n ? g_extra : 0.f;
-        lds_barrier();
+        // ---- first layer (tiles ot = 2w + x), head (tiles kb = 2w + x)
         {
-            int o[5], ga[5];                                           // global offset / LDS address of this thread's five float4s (-1: none)
+            AdamIn in[4];
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
-                const int f = tid + 256 * jj;
-                if (f < 512) { const int row = f >> 5, slot = f & 31; o[jj] = L1.w_off + 4 * f; ga[jj] = row * kHid + ((slot ^ (row & 7)) << 2); }
-                else if (f < 1024) { const int ff = f - 512, row = ff >> 2, slot = ff & 3; o[jj] = L3.w_off + 4 * ff; ga[jj] = 2048 + row * 16 + ((slot ^ ((row >> 1) & 3)) << 2); }
-                else if (f < 1056) { o[jj] = L1.b_off + 4 * (f - 1024); ga[jj] = 4096 + 4 * (f - 1024); }
-                else if (f < 1088) { o[jj] = L2.b_off + 4 * (f - 1056); ga[jj] = 4224 + 4 * (f - 1056); }
-                else if (f < 1092) { o[jj] = L3.b_off + 4 * (f - 1088); ga[jj] = 4352 + 4 * (f - 1088); }
-                else if (f < 1092 + (extra_n + 3) / 4) { o[jj] = extra_off + 4 * (f - 1092); ga[jj] = 4368 + 4 * (f - 1092); }
-                else { o[jj] = -1; ga[jj] = 0; }
+            for (int x = 0; x < 2; ++x) {
+                in[x] = adam_load(th, mA, vA, tg, c, L1.w_off + (2 * w + x) * 256 + fslot);
+                in[2 + x] = adam_load(th, mA, vA, tg, c, L3.w_off + (2 * w + x) * 256 + fslot);
             }
-            In in[5];
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj) in[jj] = load(o[jj] >= 0 ? o[jj] : 0);
+            for (int x = 0; x < 2; ++x) {
+                adam_apply(th, mA, vA, tg, c, L1.w_off + (2 * w + x) * 256 + fslot, g.g1[x], in[x]);
+                adam_apply(th, mA, vA, tg, c, L3.w_off + (2 * w + x) * 256 + fslot, g.g3[x], in[2 + x]);
+            }
+        }
+        // ---- biases (every lane group holds the full sums after grad_finish: group q == 0 writes) [, log_std]
+        if (q == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj)
-                if (o[jj] >= 0) upd(o[jj], ld4((lds_cf)(GB + ga[jj])), in[jj]);
+            for (int x = 0; x < 2; ++x) {
+                adam_scalar(th, mA, vA, tg, c, L1.b_off + (2 * w + x) * 16 + i16, g.gb1[x]);
+                adam_scalar(th, mA, vA, tg, c, L2.b_off + (2 * w + x) * 16 + i16, g.gb2[x]);
+            }
+            if (w == 0) adam_scalar(th, mA, vA, tg, c, L3.b_off + i16, g.gb3);
+            if (w == 1 && i16 < extra_n) adam_scalar(th, mA, vA, tg, c, extra_off + i16, g_extra);
         }
     }
 };

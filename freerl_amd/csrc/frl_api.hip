@@ -356,6 +356,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         }
     }
     h.learner_stride = pad32(off);
+    if (e->has_nets && chained_shape(h)) {       // kernel family (and with it the parameter layout in HBM), fixed for the engine's life
+        const char* force = getenv("FRL_CRITIC_V2");
+        if (force ? atoi(force) != 0 : h.P >= 128) h.net[0].frag = h.net[1].frag = 1;
+    }
     h.act_max = 1;
     for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);
     h.lds_kin_pad = kin;
@@ -780,7 +784,7 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
     const NetDesc& N = e->h.net[net];
     float* dev = base + (size_t)learner * e->h.learner_stride + e->h.net_off[net];
     // host order = the reference's state_dict order: per nn.Linear weight[out][in] then bias; device block =
-    // Wk[k_pad][n_pad] (frl_desc.h)
+    // Wk[k_pad][n_pad], or the fragment-image order of the register-chained engines (frl_desc.h: weight_index)
     std::vector<float> blk(N.size, 0.f);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!to_device) HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
@@ -789,7 +793,7 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
         const LayerDesc& L = N.L[i];
         for (int r = 0; r < L.n; ++r)
             for (int c = 0; c < L.k; ++c) {
-                float& d = blk[L.w_off + (size_t)c * L.n_pad + r];
+                float& d = blk[L.w_off + weight_index(N, L, r, c)];
                 if (to_device) d = host[o]; else host[o] = d;
                 ++o;
             }
@@ -1119,15 +1123,19 @@ static void launch_adam(frl_engine* e, hipStream_t st, const AdamArgs& ad, int u
 
 // One learner per workgroup, register-chained, Adam fused (kernels_critic2.hip / kernels_actor2.hip): the reference's standard
 // narrow shape at populations that give every CU a learner; everything else takes the row-chunk kernels + reduce / Adam
-// launches.  FRL_CRITIC_V2=0/1 overrides the population threshold (tests run both families on the same inputs).
-static bool chained_path(const EngineDesc& h, int batch, int pc) {
+// launches.  The family is chosen ONCE, at frl_create (chained_shape + population, FRL_CRITIC_V2=0/1 overrides the population
+// threshold — the tests run both families on the same inputs): the chained kernels keep the nets in fragment-image order in
+// HBM (NetDesc::frag), which the row-chunk kernels do not read.
+static bool chained_shape(const EngineDesc& h) {
     const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
-    const bool shape = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
-                       NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
-                       batch <= 256 && !h.obs_norm_on && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
-                       NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
-    const char* force = getenv("FRL_CRITIC_V2");
-    return shape && (force ? atoi(force) != 0 : pc >= 128);
+    return (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
+           NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
+           h.batch_max <= 256 && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
+           NA0.n_layers == 3 && NC0.n_layers == 3 * NC0.heads;
+}
+static bool chained_path(const EngineDesc& h, int batch, int pc) {
+    (void)pc;
+    return h.net[0].frag && h.net[1].frag && batch <= 256 && !h.obs_norm_on;
 }
 
 // kernels_dqn2.hip: the reference's Q-net (obs -> 128 -> n_actions, or the Dueling [V ; A] head) with the TD update of DQN.py and
@@ -1354,6 +1362,17 @@ extern "C" int frl_timer_stop(frl_engine* e, float* ms_out) {
 extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
     ENG(e);
     if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (on && e->h.net[0].frag) {
+        // Batch_ObsNorm belongs to the row-chunk family: an engine created for the register-chained kernels (parameters in
+        // fragment-image order) moves over for good — every parameter array back to Wk, through a scratch copy
+        float* scratch = nullptr;
+        HIP_TRY(hipMalloc((void**)&scratch, (size_t)4 * e->h.P * e->h.learner_stride * sizeof(float)));
+        hipLaunchKernelGGL(relayout_to_wk_kernel, dim3(e->h.P, 4), dim3(256), 0, e->stream, e->d, scratch);
+        hipError_t he = hipStreamSynchronize(e->stream);
+        hipFree(scratch);
+        if (he != hipSuccess) return fail(FRL_ERR_HIP, "relayout: %s", hipGetErrorString(he));
+        for (int i = 0; i < e->h.n_nets; ++i) e->h.net[i].frag = 0;
+    }
     e->h.obs_norm_on = on ? 1 : 0;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d, &e->h, sizeof e->h, hipMemcpyHostToDevice));

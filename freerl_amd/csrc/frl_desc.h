@@ -31,8 +31,22 @@ struct NetDesc {
     int extra_n;
     int heads;           // 1, or 2 for a twin critic (layers [0,n_layers/2) and [n_layers/2,n_layers))
     int n_shadow;        // parameter-only layers behind the forward ones: L[n_layers] = the sigma of a NoisyLinear head
+    int frag;            // 1: every weight block of this net is stored in MFMA-fragment IMAGE order instead of Wk[k][n] — 16 x 16
+                         // tiles, tile (n >> 4, k >> 4) at ((n >> 4) * (k_pad / 16) + (k >> 4)) * 256 floats, element (n & 15, k & 15)
+                         // at weight_index() below (device/chain_net.hpp: what the register-chained kernels stage linearly and
+                         // step from their accumulators).  Same offsets and sizes; biases / log_std unchanged.
     LayerDesc L[kMaxLayers];
 };
+
+// float index of W[out n][in k] inside a layer's weight block (host and device)
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline int weight_index(const NetDesc& N, const LayerDesc& L, int n, int k) {
+    if (!N.frag) return k * L.n_pad + n;
+    const int q = (k & 15) >> 2;
+    return ((n >> 4) * (L.k_pad >> 4) + (k >> 4)) * 256 + ((q * 16 + ((n & 15) ^ q)) << 2) + (k & 3);
+}
 
 // Replay record (one transition of ALL agents, 128-byte aligned stride):
 //   [ obs_0..obs_{n-1} | act_0..act_{n-1} | rew_0..rew_{n-1} | done_0..done_{n-1} | next_obs_0.. | extra ]

@@ -142,6 +142,7 @@ __global__ void noisy_sigma_grad_kernel(const EngineDesc* __restrict__ Dp);
 __global__ void noisy_draw_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, unsigned long long counter);
 
 // kernels_per.hip
+__global__ void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch);
 __global__ void per_add_kernel(PerArgs a, const int* __restrict__ bucket, int P);
 __global__ void per_set_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
 __global__ void per_sample_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);

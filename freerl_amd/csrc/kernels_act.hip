@@ -12,30 +12,11 @@
 namespace frl {
 
 
-__global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const EngineDesc& D = *Dp;
-    const int p = blockIdx.y, r0 = blockIdx.x * D.rc;
-    const NetDesc& N = D.net[a.net];
-    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
-    const int rc = D.rc, nv = min(rc, a.n_rows - r0);
-    const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
-    g_cf theta = a.use_target == 2 ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[a.net])     // noisy set 0
-                                   : as_global((a.use_target ? D.target : D.theta) + off);
-    const int nl = N.n_layers / N.heads, l0 = a.head * nl;
-    const int K = a.in_dim, kpad = N.L[l0].k_pad;
-    g_cf in = as_global(a.in + ((size_t)p * a.n_rows + r0) * K);
-    for (int e = threadIdx.x; e < rc * kpad; e += kWG) {
-        const int r = e / kpad, c = e - r * kpad;
-        S.xin[r * S.xp + c] = (r < nv && c < K) ? in[(size_t)r * K + c] : 0.f;
-    }
-    if (D.obs_norm_on && a.normalize) {          // select_action: norm(obs, update=False) (SAC.py:194-195, MADDPG.py:162-163)
-        __syncthreads();
-        const int nag = D.n_agents, j = nag > 1 ? a.net / 2 : 0;           // MADDPG: net 2j is agent j's actor
-        normalize_cols(S.xin, S.xp, nv, 0, D.rec.obs_dim[j],
-                       as_global(D.obsnorm + (((size_t)p * nag + (nag - 1)) * nag + j) * D.obsnorm_w), D.rec.obs_dim[j]);
-    }
-    __syncthreads();
+// Everything after the head's output rows are in LDS (outb[row * op + column], rows r0 .. r0 + nv of learner p): the mode's
+// action rule and, for the collectors, the exploration rule.  Shared by act_kernel (row-chunk forward, Wk parameters) and
+// act_frag_kernel (register-chained forward, fragment-image parameters).
+__device__ __forceinline__ void act_epilogue(const EngineDesc& D, const ActArgs& a, const NetDesc& N, g_cf theta, lds_f outb, int op,
+                                             int nv, int r0, int p, int nout) {
     // device-side draws of this launch: Philox keyed like draw_kernel's (seed, learner), one counter value per launch
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
     auto normal_at = [&](unsigned stream, unsigned e) {
@@ -51,17 +32,14 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
         }
         return best;
     };
-    const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;
-    mlp_fwd(N, l0, nl, theta, S, out_act);
-    const int nout = N.L[l0 + nl - 1].n;
     if (a.mode == ACTM_ARGMAX && D.c51_atoms && D.algo == ALGO_DQN) {      // argmax_a sum_i z_i p_i(s, a) (DQN_with_tricks.py:122-130)
         const float dz = (D.c51_vmax - D.c51_vmin) / (float)(D.c51_atoms - 1);
-        const int lb = c51_combine(S.outb, S.op, nv, D.n_discrete, D.c51_atoms, D.dueling != 0);
+        const int lb = c51_combine(outb, op, nv, D.n_discrete, D.c51_atoms, D.dueling != 0);
         for (int r = threadIdx.x; r < nv; r += kWG) {
             int best = 0;
             float mx = 0.f;
             for (int j = 0; j < D.n_discrete; ++j) {
-                const float q = c51_q(S.outb + r * S.op + lb + j * D.c51_atoms, D.c51_atoms, D.c51_vmin, dz, nullptr);
+                const float q = c51_q(outb + r * op + lb + j * D.c51_atoms, D.c51_atoms, D.c51_vmin, dz, nullptr);
                 if (j == 0 || q > mx) { mx = q; best = j; }
             }
             best = eps_greedy(r0 + r, best, D.n_discrete);
@@ -73,7 +51,7 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     if (a.mode == ACTM_ARGMAX) {
         const bool duel = D.dueling && D.algo == ALGO_DQN;       // Q = V + A - mean(A) (DQN_with_tricks.py:79): head = [V ; A]
         for (int r = threadIdx.x; r < nv; r += kWG) {
-            lds_cf o = S.outb + r * S.op;
+            lds_cf o = outb + r * op;
             const int nq = duel ? nout - 1 : nout;
             float mean = 0.f;
             if (duel) { for (int j = 0; j < nq; ++j) mean += o[1 + j]; mean /= (float)nq; }
@@ -91,15 +69,15 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     }
     if (a.mode == ACTM_CAT_SAMPLE) {        // PPO_with_tricks.py:249-251 (torch single-draw multinomial)
         for (int r = threadIdx.x; r < nv; r += kWG) {
-            float mx = S.outb[r * S.op];
-            for (int j = 1; j < nout; ++j) mx = fmaxf(mx, S.outb[r * S.op + j]);
+            float mx = outb[r * op];
+            for (int j = 1; j < nout; ++j) mx = fmaxf(mx, outb[r * op + j]);
             float sum = 0.f;
-            for (int j = 0; j < nout; ++j) sum += expf(S.outb[r * S.op + j] - mx);
+            for (int j = 0; j < nout; ++j) sum += expf(outb[r * op + j] - mx);
             const size_t row = (size_t)p * a.n_rows + r0 + r;
             int best = 0;
             float bestv = -1.f, pbest = 0.f, psum = 0.f;
             for (int j = 0; j < nout; ++j) {
-                const float pj = expf(S.outb[r * S.op + j] - mx) / sum;
+                const float pj = expf(outb[r * op + j] - mx) / sum;
                 psum += pj;
                 // q ~ Exp(1): injected, or -log(u) from the launch's Philox stream
                 const float qj = a.device_eps ? -logf(u01(philox4x32_10(a.rng_counter, 0x9100u, (unsigned)((r0 + r) * nout + j), key).x))
@@ -109,7 +87,7 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
             }
             a.out[row] = (float)best;
             if (a.env_out) a.env_out[row] = (float)best;
-            if (a.out_logp) a.out_logp[row] = D.cat_logits ? (S.outb[r * S.op + best] - mx) - logf(sum)          // Categorical(logits=)
+            if (a.out_logp) a.out_logp[row] = D.cat_logits ? (outb[r * op + best] - mx) - logf(sum)          // Categorical(logits=)
                                                            : logf(fminf(fmaxf(pbest / psum, 1.1920929e-07f), 1.f - 1.1920929e-07f));
         }
         return;
@@ -117,7 +95,7 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     for (int e = threadIdx.x; e < nv * nout; e += kWG) {
         const int r = e / nout, c = e - r * nout;
         const size_t o = ((size_t)p * a.n_rows + r0 + r) * nout + c;
-        float v = S.outb[r * S.op + c];
+        float v = outb[r * op + c];
         if (a.mode == ACTM_SAC_SAMPLE || a.mode == ACTM_PPO_SAMPLE) {
             const float ls = fminf(fmaxf(theta[N.extra_off + c], -20.f), 2.f);
             const float sd = expf(ls);
@@ -149,6 +127,70 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
             a.env_out[o] = fminf(fmaxf(x, -ma), ma);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.y, r0 = blockIdx.x * D.rc;
+    const NetDesc& N = D.net[a.net];
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const int rc = D.rc, nv = min(rc, a.n_rows - r0);
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
+    g_cf theta = a.use_target == 2 ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[a.net])     // noisy set 0
+                                   : as_global((a.use_target ? D.target : D.theta) + off);
+    const int nl = N.n_layers / N.heads, l0 = a.head * nl;
+    const int K = a.in_dim, kpad = N.L[l0].k_pad;
+    g_cf in = as_global(a.in + ((size_t)p * a.n_rows + r0) * K);
+    for (int e = threadIdx.x; e < rc * kpad; e += kWG) {
+        const int r = e / kpad, c = e - r * kpad;
+        S.xin[r * S.xp + c] = (r < nv && c < K) ? in[(size_t)r * K + c] : 0.f;
+    }
+    if (D.obs_norm_on && a.normalize) {          // select_action: norm(obs, update=False) (SAC.py:194-195, MADDPG.py:162-163)
+        __syncthreads();
+        const int nag = D.n_agents, j = nag > 1 ? a.net / 2 : 0;           // MADDPG: net 2j is agent j's actor
+        normalize_cols(S.xin, S.xp, nv, 0, D.rec.obs_dim[j],
+                       as_global(D.obsnorm + (((size_t)p * nag + (nag - 1)) * nag + j) * D.obsnorm_w), D.rec.obs_dim[j]);
+    }
+    __syncthreads();
+    const int out_act = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE) ? ACT_TANH : ACT_NONE;
+    mlp_fwd(N, l0, nl, theta, S, out_act);
+    act_epilogue(D, a, N, theta, S.outb, S.op, nv, r0, p, N.L[l0 + nl - 1].n);
+}
+
+// The same for the engines of the register-chained kernels (NetDesc::frag: parameters in fragment-image order): the net's
+// images staged linearly into LDS, 64 rows per workgroup carried through the MLP in registers (device/chain_net.hpp), the
+// head tile written to LDS for the shared epilogue.  Shape: 3 layers, hidden 128, <= 16 inputs and outputs, ReLU (what
+// chained_shape() admits); grid = (ceil(n_rows / 64), learners).
+__global__ __launch_bounds__(256) void act_frag_kernel(const EngineDesc* __restrict__ Dp, ActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.y, r0 = blockIdx.x * 64;
+    const NetDesc& N = D.net[a.net];
+    ChainNet C;
+    C.init(smem);
+    const int nv = min(64, a.n_rows - r0);
+    const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
+    g_cf theta = as_global((a.use_target ? D.target : D.theta) + off);
+    const int l0 = a.head * 3, K = a.in_dim;
+    const int row = 16 * C.w + C.i16;
+    f32x4 xb[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (row < nv) {
+        g_cf in = as_global(a.in + ((size_t)p * a.n_rows + r0 + row) * K);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * C.q + e < K) xb[0][e] = in[4 * C.q + e];
+    }
+    C.stage(theta, N, l0);
+    f32x4 z[1], h1[1][kHT], h2[1][kHT];
+    C.forward<1>(xb, h1, h2, z);
+    const bool th = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE);
+    lds_f outb = C.S.ea;                                               // [64][20]
+    constexpr int op = 20;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) outb[row * op + 4 * C.q + r] = th ? tanhf(z[0][r]) : z[0][r];
+    __syncthreads();
+    act_epilogue(D, a, N, theta, outb, op, nv, r0, p, N.L[l0 + 2].n);
 }
 
 }  // namespace frl

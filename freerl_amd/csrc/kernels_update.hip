@@ -303,4 +303,31 @@ __global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __re
     soft_update_net(D.net[net].size, as_global(D.target + off), as_global(D.theta + off), tau);
 }
 
+// Fragment-image order -> Wk[k][n] for every weight block of the frag nets of all learners, in all four parameter arrays: what
+// frl_obsnorm_enable does to an engine created for the register-chained kernels before it hands it to the row-chunk family
+// (those kernels read Wk; Batch_ObsNorm is theirs).  grid = (P, 4 arrays); the learner's block goes through `scratch`
+// ([P][learner_stride], the engine's reduced-gradient array: unused by the chained family).
+__global__ __launch_bounds__(256) void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch) {
+    const EngineDesc& D = *Dp;
+    const int p = blockIdx.x;
+    float* arr = blockIdx.y == 0 ? D.theta : (blockIdx.y == 1 ? D.target : (blockIdx.y == 2 ? D.m : D.v));
+    float* sc = scratch + ((size_t)blockIdx.y * D.P + p) * D.learner_stride;
+    for (int net = 0; net < D.n_nets; ++net) {
+        const NetDesc& N = D.net[net];
+        if (!N.frag) continue;
+        float* blk = arr + (size_t)p * D.learner_stride + D.net_off[net];
+        for (int li = 0; li < N.n_layers + N.n_shadow; ++li) {
+            const LayerDesc& L = N.L[li];
+            const int cnt = L.n_pad * L.k_pad;
+            for (int i = threadIdx.x; i < cnt; i += kWG) sc[i] = blk[L.w_off + i];
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt; i += kWG) {
+                const int k = i / L.n_pad, n = i - k * L.n_pad;
+                blk[L.w_off + i] = sc[weight_index(N, L, n, k)];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace frl
