@@ -4,11 +4,21 @@
 // from LDS images in MFMA-fragment order, swizzled so that the forward's ds_read_b128 fragments, the backward's
 // transposed ds_read_b32 fragments and the owners' ds_write_b32 are all bank-conflict free.
 #pragma once
+#include <type_traits>
+
 #include "net.hpp"
 
 namespace frl {
 
 constexpr int kHid = 128, kHT = kHid / 16;
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) — for bodies that index register arrays and template
+// parameters with the loop variable
+template <int I> using IC = std::integral_constant<int, I>;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
 
 // dword offset of element (f16, k16) of 16x16 fragment tile `tile` in a fragment-ordered LDS image: the 16-byte slot of
 // (q = k16 >> 2, f16) sits at q*16 + (f16 ^ q)

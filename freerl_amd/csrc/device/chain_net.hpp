@@ -19,6 +19,12 @@ namespace frl {
 
 constexpr int kChainBatch = 256;          // rows of per-row staging (actions, targets, ...) the carve provides
 
+// Parameter block of one head of the shape these kernels serve (in <= 16 -> 128 -> 128 -> out <= 16; build_net's packing:
+// W1[128 x 16] b1[128] W2[128 x 128] b2[128] W3[16 x 128] b3[16]) as compile-time offsets — the host checks a net's
+// descriptor against them before it picks this family (chained_shape), and the kernels keep ~40 scalar registers free of
+// descriptor words.  A twin critic is two such blocks; a Gaussian actor's log_std follows its single block.
+// (the constants themselves: frl_desc.h, kL1w .. kHeadFloats)
+
 struct ChainLds {
     lds_f w1, w2, w3, b1, b2, b3, ls, ea, eb, ab, yb, q1, lpn, red;
 };
@@ -32,11 +38,49 @@ struct HeadGrad {
     float gb1[2], gb2[2], gb3;
 };
 
-struct AdamCoef { float coef, step, inv_bc2s, w1, w2, beta2, eps, wd, tk, tau; bool soft; };
+// (no flags in here: the update runs inside MFMA chains, where a branch would cut the scheduling region — the soft target update is
+// a template argument of the functions below, weight decay is applied unconditionally: g + 0 * theta = g)
+struct AdamCoef { float coef, step, inv_bc2s, w1, w2, beta2, eps, wd, tk, tau; };
+
+// The four parameter arrays of one net of one learner as raw buffer resources: the update addresses them as
+// buffer_load/store_dwordx4 v, <lane offset VGPR>, s[rsrc], <tile offset: SGPR / literal> — one VGPR of address state for the
+// whole update instead of a 64-bit pointer per array and tile (which the register allocator spilled inside the MFMA chains).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+struct AdamBuf { __amdgpu_buffer_rsrc_t th, mm, vv, tg; };
+__device__ __forceinline__ AdamBuf adam_buf(g_f th, g_f mA, g_f vA, g_f tg) {
+    AdamBuf B;
+    B.th = __builtin_amdgcn_make_buffer_rsrc((float*)th, 0, 0x7fffffff, 0x00020000);
+    B.mm = __builtin_amdgcn_make_buffer_rsrc((float*)mA, 0, 0x7fffffff, 0x00020000);
+    B.vv = __builtin_amdgcn_make_buffer_rsrc((float*)vA, 0, 0x7fffffff, 0x00020000);
+    B.tg = __builtin_amdgcn_make_buffer_rsrc((float*)tg, 0, 0x7fffffff, 0x00020000);
+    return B;
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int soff, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, voff, soff, 0);
+}
+
+// A "background task" of ChainNet::forward: pre<S>() / post<S>() are called once per k-block of the 128 x 128 layer (8 per
+// forward, S counts up from the caller's SLOT0) in front of and behind that block's MFMAs.  The persistent critic kernel
+// (kernels_critic3.hip) hangs the PREVIOUS learner's clip + Adam + soft update there, one accumulator tile per slot — loads in
+// pre, arithmetic and stores in post: they are independent of the MFMA chains, so they issue in the chains' shadow (one wave
+// per SIMD: ~5 issue slots per MFMA are free) and the HBM stream of the update runs under the matrix work instead of after it.
+struct NoBackground {
+    static constexpr bool kPipelined = false;
+    template <int S> static constexpr bool has_load() { return false; }
+    template <int S> static constexpr bool has_store() { return false; }
+    template <int S> __device__ __forceinline__ void pre() {}
+    template <int S> __device__ __forceinline__ void post() {}
+};
+// scheduling-group masks of __builtin_amdgcn_sched_group_barrier
+constexpr int kSgMfma = 0x008, kSgValu = 0x002, kSgVmemRead = 0x020, kSgVmemWrite = 0x040, kSgDsRead = 0x100;
 
 struct ChainNet {
     ChainLds S;
     int tid, l, w, i16, q, fslot, tslot;
+    int lane2, lane1;      // byte offsets of this lane's slot inside its first owned tile of the 128 x 128 layer / of the two narrow layers
 
     __device__ __forceinline__ void init(float* smem) {
         lds_f p = (lds_f)smem;
@@ -57,20 +101,23 @@ struct ChainNet {
         tid = threadIdx.x; l = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6); i16 = l & 15; q = l >> 4;
         fslot = (q * 16 + (i16 ^ q)) << 2;                             // forward / exchange fragment read (16 B)
         tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);                  // transposed read / owner write: + ((f ^ (i16 >> 2)) << 2)
+        lane2 = 4 * (w * 2 * kHT * 256 + fslot);
+        lane1 = 4 * (w * 2 * 256 + fslot);
     }
 
     // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy
-    __device__ __forceinline__ void stage(g_cf th, const NetDesc& N, int l0) const {
-        const LayerDesc &L1 = N.L[l0], &L2 = N.L[l0 + 1], &L3 = N.L[l0 + 2];
+    // th = the net's block, head = which head of it; extra_n > 0: a single-head net's log_std entries behind its block
+    __device__ __forceinline__ void stage(g_cf th, int head, int extra_n = 0) const {
+        th += head * kHeadFloats;
         lds_barrier();                                                 // every wave is done with the previous images
         f32x4 t2[16], t1[2], t3[2];                                    // all loads of the net in flight before the first store
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t2[j] = ld4(th + L2.w_off + 4 * (tid + 256 * j));
+        for (int j = 0; j < 16; ++j) t2[j] = ld4(th + kL2w + 4 * (tid + 256 * j));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { t1[j] = ld4(th + L1.w_off + 4 * (tid + 256 * j)); t3[j] = ld4(th + L3.w_off + 4 * (tid + 256 * j)); }
+        for (int j = 0; j < 2; ++j) { t1[j] = ld4(th + kL1w + 4 * (tid + 256 * j)); t3[j] = ld4(th + kL3w + 4 * (tid + 256 * j)); }
         float bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, lsv = 0.f;
-        if (tid < kHid) { bb1 = th[L1.b_off + tid]; bb2 = th[L2.b_off + tid]; }
-        if (tid < 16) { bb3 = th[L3.b_off + tid]; lsv = (N.extra_n > 0 && tid < N.extra_n) ? th[N.extra_off + tid] : 0.f; }
+        if (tid < kHid) { bb1 = th[kL1b + tid]; bb2 = th[kL2b + tid]; }
+        if (tid < 16) { bb3 = th[kL3b + tid]; lsv = tid < extra_n ? th[kHeadFloats + tid] : 0.f; }
 #pragma unroll
         for (int j = 0; j < 16; ++j) st4(S.w2 + 4 * (tid + 256 * j), t2[j]);
 #pragma unroll
@@ -85,6 +132,11 @@ struct ChainNet {
     // middle, tile inner), so that consecutive MFMAs never wait for each other's result.
     template <int T>
     __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T]) const {
+        NoBackground nb;
+        forward<T, 0>(xb, h1, h2, z, nb);
+    }
+    template <int T, int SLOT0, class BG>
+    __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], BG& bg) const {
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
             const f32x4 wf = ld4((lds_cf)(S.w1 + ot * 256 + fslot)), bb = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q));
@@ -101,17 +153,61 @@ struct ChainNet {
 #pragma unroll
             for (int t = 0; t < T; ++t) h2[t][ot] = bb;
         }
+        if constexpr (!BG::kPipelined) {
+            static_for<0, kHT>([&](auto kbc) {
+                constexpr int kb = decltype(kbc)::value;
+                f32x4 wf[kHT];
 #pragma unroll
-        for (int kb = 0; kb < kHT; ++kb) {
-            f32x4 wf[kHT];
+                for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
 #pragma unroll
-            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int ot = 0; ot < kHT; ++ot)
 #pragma unroll
-                for (int ot = 0; ot < kHT; ++ot)
+                        for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
+            });
+        } else {
+            // With a background task every k-block is its own scheduling region with a pinned issue order: the task's four
+            // stores and four loads first, then each MFMA followed by three VALU slots (the task's arithmetic) and, every fourth
+            // MFMA, one fragment read of the NEXT k-block (the fragments are double-buffered in the source).  Left alone the
+            // scheduler sinks every load, multiply and store of the task behind the layer's last MFMA and serialises them
+            // there behind vmcnt(0) waits.
+            f32x4 wf[2][kHT];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
+            for (int ot = 0; ot < kHT; ++ot) wf[0][ot] = ld4((lds_cf)(S.w2 + (ot * kHT) * 256 + fslot));
+            static_for<0, kHT>([&](auto kbc) {
+                constexpr int kb = decltype(kbc)::value, S_ = SLOT0 + kb;
+                __builtin_amdgcn_sched_barrier(0);
+                // gfx9 counts loads and stores in ONE counter and they complete out of order relative to each other, so with
+                // a store outstanding ANY wait for a load is a vmcnt(0).  The task's loads and stores are therefore issued
+                // together right behind one explicit drain at the top of the block — everything outstanding then is a whole
+                // k-block (~1 k cycles) old — and nothing inside the block waits on memory again.
+                if constexpr (BG::template has_load<S_>() || BG::template has_store<S_>()) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                if constexpr (kb + 1 < kHT) {
+#pragma unroll
+                    for (int ot = 0; ot < kHT; ++ot) wf[(kb + 1) & 1][ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb + 1) * 256 + fslot));
+                }
+                bg.template pre<S_>();                                  // the background unit's loads ...
+                bg.template post<S_>();                                 // ... and the PREVIOUS unit's arithmetic + stores
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb & 1][ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
+                if constexpr (BG::template has_store<S_>()) __builtin_amdgcn_sched_group_barrier(kSgVmemWrite, 4, 0);
+                if constexpr (BG::template has_load<S_>()) __builtin_amdgcn_sched_group_barrier(kSgVmemRead, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 8 * T; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        __builtin_amdgcn_sched_group_barrier(kSgMfma, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(kSgValu, 3, 0);
+                    }
+                    if (i < 8 && kb + 1 < kHT) __builtin_amdgcn_sched_group_barrier(kSgDsRead, 1, 0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -277,70 +373,88 @@ struct ChainNet {
     // lane and one whole contiguous 1 KB tile per wave-instruction.  Loads of a batch of tiles before its stores (the compiler
     // cannot prove the four arrays distinct and would wait for every store before the next load).  No LDS, no barriers.
     struct AdamIn { f32x4 th, mm, vv, tg; };
-    __device__ __forceinline__ AdamIn adam_load(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o) const {
+    // accumulator unit J of a head block: J < 16 the 128 x 128 layer's tile (ot = 2w + J / 8, kt = J % 8), 16 / 17 the first layer's
+    // tiles ot = 2w + (J & 1), 18 / 19 the head layer's tiles kb = 2w + (J & 1).  Its 16-byte slot sits at lane offset
+    // unit_voff<J>() + the compile-time unit_soff<J>() bytes inside the head's block.
+    template <int J> __device__ __forceinline__ int unit_voff() const { return J < 16 ? lane2 : lane1; }
+    template <int J> static constexpr int unit_soff() { return 4 * (J < 16 ? kL2w + J * 256 : (J < 18 ? kL1w + (J & 1) * 256 : kL3w + (J & 1) * 256)); }
+    template <int J>
+    __device__ __forceinline__ static const f32x4& unit_grad(const HeadGrad& g) {
+        if constexpr (J < 16) return g.g2[J / 8][J % 8];
+        else if constexpr (J < 18) return g.g1[J - 16];
+        else return g.g3[J - 18];
+    }
+    // HB = byte offset of the head's block inside the net (head * kHeadFloats * 4)
+    template <bool SOFT, int J, int HB>
+    __device__ __forceinline__ AdamIn adam_load(const AdamBuf& B) const {
         AdamIn X;
-        X.th = ld4((g_cf)(th + o)); X.mm = ld4((g_cf)(mA + o)); X.vv = ld4((g_cf)(vA + o));
-        X.tg = c.soft ? ld4((g_cf)(tg + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int so = HB + unit_soff<J>();
+        const int vo = unit_voff<J>();
+        X.th = buf_ld4(B.th, vo, so); X.mm = buf_ld4(B.mm, vo, so); X.vv = buf_ld4(B.vv, vo, so);
+        if constexpr (SOFT) X.tg = buf_ld4(B.tg, vo, so); else X.tg = f32x4{0.f, 0.f, 0.f, 0.f};
         return X;
     }
-    __device__ __forceinline__ void adam_apply(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, const f32x4& gr, const AdamIn& in) const {
-        f32x4 t4 = in.th, mm = in.mm, vv = in.vv, tt = in.tg;
+    template <bool SOFT>
+    __device__ __forceinline__ AdamIn adam_compute(const AdamCoef& c, const f32x4& gr, const AdamIn& in) const {
+        AdamIn R = in;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float gi = gr[r] * c.coef;
-            if (c.wd != 0.f) gi += c.wd * t4[r];
-            float m1 = mm[r], v1 = vv[r];
-            t4[r] = adam_elem(t4[r], gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
-            mm[r] = m1; vv[r] = v1;
-            tt[r] = tt[r] * c.tk + t4[r] * c.tau;
+            gi += c.wd * R.th[r];
+            float m1 = R.mm[r], v1 = R.vv[r];
+            R.th[r] = adam_elem(R.th[r], gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
+            R.mm[r] = m1; R.vv[r] = v1;
+            if constexpr (SOFT) R.tg[r] = R.tg[r] * c.tk + R.th[r] * c.tau;
         }
-        st4(th + o, t4); st4(mA + o, mm); st4(vA + o, vv);
-        if (c.soft) st4(tg + o, tt);
+        return R;
     }
+    template <bool SOFT, int J, int HB>
+    __device__ __forceinline__ void adam_store(const AdamBuf& B, const AdamIn& R) const {
+        constexpr int so = HB + unit_soff<J>();
+        const int vo = unit_voff<J>();
+        buf_st4(B.th, vo, so, R.th); buf_st4(B.mm, vo, so, R.mm); buf_st4(B.vv, vo, so, R.vv);
+        if constexpr (SOFT) buf_st4(B.tg, vo, so, R.tg);
+    }
+    template <bool SOFT>
     __device__ __forceinline__ float adam_scalar(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, float gr) const {
         float t1 = th[o], m1 = mA[o], v1 = vA[o];
         float gi = gr * c.coef;
-        if (c.wd != 0.f) gi += c.wd * t1;
+        gi += c.wd * t1;
         t1 = adam_elem(t1, gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
         th[o] = t1; mA[o] = m1; vA[o] = v1;
-        if (c.soft) tg[o] = tg[o] * c.tk + t1 * c.tau;
+        if constexpr (SOFT) tg[o] = tg[o] * c.tk + t1 * c.tau;
         return t1;
     }
-    __device__ __forceinline__ void adam_head(const HeadGrad& g, const LayerDesc& L1, const LayerDesc& L2, const LayerDesc& L3, g_f th,
-                                              g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra, int extra_off, int extra_n) const {
-        // ---- the 128 x 128 layer: 16 tiles per lane, in two batches of 8
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            AdamIn in[kHT];
-#pragma unroll
-            for (int kt = 0; kt < kHT; ++kt) in[kt] = adam_load(th, mA, vA, tg, c, L2.w_off + ((2 * w + x) * kHT + kt) * 256 + fslot);
-#pragma unroll
-            for (int kt = 0; kt < kHT; ++kt) adam_apply(th, mA, vA, tg, c, L2.w_off + ((2 * w + x) * kHT + kt) * 256 + fslot, g.g2[x][kt], in[kt]);
-        }
-        // ---- first layer (tiles ot = 2w + x), head (tiles kb = 2w + x)
-        {
-            AdamIn in[4];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                in[x] = adam_load(th, mA, vA, tg, c, L1.w_off + (2 * w + x) * 256 + fslot);
-                in[2 + x] = adam_load(th, mA, vA, tg, c, L3.w_off + (2 * w + x) * 256 + fslot);
-            }
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                adam_apply(th, mA, vA, tg, c, L1.w_off + (2 * w + x) * 256 + fslot, g.g1[x], in[x]);
-                adam_apply(th, mA, vA, tg, c, L3.w_off + (2 * w + x) * 256 + fslot, g.g3[x], in[2 + x]);
-            }
-        }
-        // ---- biases (every lane group holds the full sums after grad_finish: group q == 0 writes) [, log_std]
+    // biases (every lane group holds the full sums after grad_finish: group q == 0 writes) [, log_std behind a single head]
+    template <bool SOFT>
+    __device__ __forceinline__ void adam_biases(const HeadGrad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra, int extra_n) const {
         if (q == 0) {
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                adam_scalar(th, mA, vA, tg, c, L1.b_off + (2 * w + x) * 16 + i16, g.gb1[x]);
-                adam_scalar(th, mA, vA, tg, c, L2.b_off + (2 * w + x) * 16 + i16, g.gb2[x]);
+                adam_scalar<SOFT>(th, mA, vA, tg, c, kL1b + (2 * w + x) * 16 + i16, g.gb1[x]);
+                adam_scalar<SOFT>(th, mA, vA, tg, c, kL2b + (2 * w + x) * 16 + i16, g.gb2[x]);
             }
-            if (w == 0) adam_scalar(th, mA, vA, tg, c, L3.b_off + i16, g.gb3);
-            if (w == 1 && i16 < extra_n) adam_scalar(th, mA, vA, tg, c, extra_off + i16, g_extra);
+            if (w == 0) adam_scalar<SOFT>(th, mA, vA, tg, c, kL3b + i16, g.gb3);
+            if (w == 1 && i16 < extra_n) adam_scalar<SOFT>(th, mA, vA, tg, c, kHeadFloats + i16, g_extra);
         }
+    }
+    // the whole update of head HD of a net, in the open: the 128 x 128 layer's 16 tiles in two batches of 8 (loads of a batch before
+    // its stores), then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
+    template <bool SOFT, int HD>
+    __device__ __forceinline__ void adam_head(const HeadGrad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
+                                              int extra_n = 0) const {
+        const AdamBuf B = adam_buf(th, mA, vA, tg);
+        constexpr int HB = HD * kHeadFloats * 4;
+        static_for<0, 3>([&](auto bc) {
+            constexpr int b0 = decltype(bc)::value * 8, nb = decltype(bc)::value < 2 ? 8 : 4;
+            AdamIn in[nb];
+            static_for<0, nb>([&](auto j) { in[decltype(j)::value] = adam_load<SOFT, b0 + decltype(j)::value, HB>(B); });
+            static_for<0, nb>([&](auto j) {
+                constexpr int J = b0 + decltype(j)::value;
+                adam_store<SOFT, J, HB>(B, adam_compute<SOFT>(c, unit_grad<J>(g), in[decltype(j)::value]));
+            });
+        });
+        adam_biases<SOFT>(g, th + HD * kHeadFloats, mA + HD * kHeadFloats, vA + HD * kHeadFloats, tg + HD * kHeadFloats, c, g_extra, extra_n);
     }
 };
 

@@ -25,6 +25,7 @@
 #include "kernels_ppo.hip"
 #include "kernels_ppo2.hip"
 #include "kernels_critic2.hip"
+#include "kernels_critic3.hip"
 #include "kernels_actor2.hip"
 #include "kernels_dqn2.hip"
 #include "kernels_per.hip"
@@ -105,6 +106,7 @@ struct frl_engine {
     std::vector<int> bucket_cursor;
     std::vector<int> size_flushed;        // rows valid per learner as of the last flush (PER_Buffer.add's `len(self.buffer) == 0`)
     int* d_size = nullptr;                // [2][P]: size before the flush being applied / current size
+    int n_cus = 256;                      // compute units of the device (grid of the persistent kernels)
     int* stage_bucket = nullptr;          // PER, pinned: [off[P + 1] | size_before[P] | leaf[stage_cap]] of the flush being applied
     int* d_stage_bucket = nullptr;
     float* d_per_prio = nullptr;          // [P][batch_max] float32 priorities of the last sample
@@ -274,6 +276,8 @@ static hipError_t dalloc_zero(T** p, size_t count, hipStream_t s) {
     if (e != hipSuccess) return e;
     return hipMemsetAsync(*p, 0, count * sizeof(T), s);
 }
+
+static bool chained_shape(const EngineDesc& h);
 
 extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     if (!cfg || !out) return fail(FRL_ERR_INVALID, "cfg/out is NULL");
@@ -486,6 +490,19 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->staged_per_learner.assign(P, 0);
     if (h.algo == ALGO_DQN)
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
+    if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
+        const int lb = critic2_lds_floats() * (int)sizeof(float);
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        for (auto k : {ac_critic_v3_twin_soft_kernel, ac_critic_v3_twin_hold_kernel, ac_critic_v3_twin_b128_soft_kernel, ac_critic_v3_twin_b128_hold_kernel,
+                       ac_critic_v3_single_soft_kernel, ac_critic_v3_single_hold_kernel, ac_critic_v3_single_b128_soft_kernel, ac_critic_v3_single_b128_hold_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, c.device_id));
+        e->n_cus = std::max(1, prop.multiProcessorCount);
+    }
     if (e->lds_bytes > 64 * 1024) {
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
@@ -895,8 +912,13 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     const int agent = e->h.n_agents > 1 ? net / 2 : 0;            // MADDPG: only the actors (even nets) take a single agent's obs
     a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
-    dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
-    hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
+    if (N.frag) {              // parameters in fragment-image order: the register-chained forward (kernels_act.hip)
+        hipLaunchKernelGGL(act_frag_kernel, dim3((n_rows + 63) / 64, e->h.P), dim3(256), (size_t)critic2_lds_floats() * sizeof(float),
+                           e->stream, e->d, a);
+    } else {
+        dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
+        hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
+    }
     HIP_TRY(hipGetLastError());
     return FRL_OK;
 }
@@ -1128,6 +1150,16 @@ static void launch_adam(frl_engine* e, hipStream_t st, const AdamArgs& ad, int u
 // HBM (NetDesc::frag), which the row-chunk kernels do not read.
 static bool chained_shape(const EngineDesc& h) {
     const NetDesc &NA0 = h.net[0], &NC0 = h.net[1];
+    auto packed = [](const NetDesc& N) {          // every head block at the offsets the kernels hard-code (frl_desc.h: kL1w ...)
+        for (int hd = 0; hd < N.heads; ++hd) {
+            const LayerDesc* L = N.L + 3 * hd;
+            const int b = hd * kHeadFloats;
+            if (L[0].w_off != b + kL1w || L[0].b_off != b + kL1b || L[1].w_off != b + kL2w || L[1].b_off != b + kL2b ||
+                L[2].w_off != b + kL3w || L[2].b_off != b + kL3b) return false;
+        }
+        return N.extra_n == 0 || (N.heads == 1 && N.extra_off == kHeadFloats);
+    };
+    if (NA0.n_layers != 3 || NC0.n_layers != 3 * NC0.heads || h.hidden != 128 || !packed(NA0) || !packed(NC0)) return false;
     return (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
            NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
            h.batch_max <= 256 && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
@@ -1186,7 +1218,17 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
             const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
-            if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
+            const char* pe = getenv("FRL_CRITIC_PERSIST");        // developer switch: 0 = round 2's one-learner-per-workgroup launch
+            if (pe ? atoi(pe) != 0 : true) {
+                // kernels_critic3.hip: one workgroup per CU walks through its learners, each learner's update in the shadow of
+                // the next one's target passes
+                using K = void (*)(const EngineDesc*, LearnArgs);
+                const bool twin = h.net[1].heads == 2, small = a.batch <= 128, soft = a.do_actor != 0;
+                static const K table[2][2][2] = {
+                    {{ac_critic_v3_single_hold_kernel, ac_critic_v3_single_soft_kernel}, {ac_critic_v3_single_b128_hold_kernel, ac_critic_v3_single_b128_soft_kernel}},
+                    {{ac_critic_v3_twin_hold_kernel, ac_critic_v3_twin_soft_kernel}, {ac_critic_v3_twin_b128_hold_kernel, ac_critic_v3_twin_b128_soft_kernel}}};
+                hipLaunchKernelGGL(table[twin][small][soft], dim3(std::min(pc, e->n_cus)), blk, lb, st, e->d, a);
+            } else if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
             else hipLaunchKernelGGL(ac_critic_v2_single_kernel, dim3(pc), blk, lb, st, e->d, a);
             prof_end(e);
             return;

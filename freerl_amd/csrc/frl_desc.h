@@ -38,6 +38,11 @@ struct NetDesc {
     LayerDesc L[kMaxLayers];
 };
 
+// One head of the register-chained kernels' shape (device/chain_net.hpp): in <= 16 -> 128 -> 128 -> out <= 16, packed by
+// build_net as W1[128 x 16] b1[128] W2[128 x 128] b2[128] W3[16 x 128] b3[16]
+constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w + 128 * 128, kL3w = kL2b + 128,
+              kL3b = kL3w + 16 * 128, kHeadFloats = kL3b + 16;
+
 // float index of W[out n][in k] inside a layer's weight block (host and device)
 #if defined(__HIPCC__) || defined(__CUDACC__)
 __host__ __device__

@@ -123,6 +123,7 @@ constexpr int kFusedThreads = 1024, kFusedVec = 12;      // adam_fused_kernel: o
 
 // kernels_act.hip
 __global__ void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a);
+__global__ void act_frag_kernel(const EngineDesc* __restrict__ Dp, ActArgs a);
 
 // kernels_actor.hip
 __global__ void ac_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int ns);
@@ -173,6 +174,15 @@ __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau,
 // kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)
 __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+// kernels_critic3.hip: the persistent form (grid = min(learners, CUs); <twin | single critic>_<batch <= 256 | <= 128>_<soft target update in this launch | not>)
+__global__ void ac_critic_v3_twin_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_twin_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_twin_b128_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_twin_b128_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_single_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_single_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_single_b128_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v3_single_b128_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "device/c51.hpp"
 #include "device/net.hpp"
+#include "device/chain_net.hpp"
 
 namespace frl {
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void act_frag_kernel(const EngineDesc* __restr
         for (int e = 0; e < 4; ++e)
             if (4 * C.q + e < K) xb[0][e] = in[4 * C.q + e];
     }
-    C.stage(theta, N, l0);
+    C.stage(theta, a.head, N.heads == 1 ? N.extra_n : 0);
     f32x4 z[1], h1[1][kHT], h2[1][kHT];
     C.forward<1>(xb, h1, h2, z);
     const bool th = (a.mode == ACTM_TANH || a.mode == ACTM_PPO_SAMPLE);

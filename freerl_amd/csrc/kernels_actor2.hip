@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     // =========================================================== A: a = tanh(actor(s)) -> S.ab  (SAC: a = tanh(mean + std eps), sum of log pi)
     float lpsum = 0.f;
     RowIn2 nxt2 = load_obs2(0);
-    C.stage(thA, NA, 0);
+    C.stage(thA, 0, NA.extra_n);
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
         nxt2 = load_obs2(c2 + 1 < nch2 ? c2 + 1 : 0);                  // (after the last chunk: chunk 0 again, for pass B)
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     float qsum = 0.f;
     f32x4 nxt;
     for (int hd = 0; hd < nq; ++hd) {
-        C.stage(thC, NC, 3 * hd);
+        C.stage(thC, hd);
         for (int c2 = 0; c2 < nch2; ++c2) {
             const RowIn2 cur = nxt2;
             if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     // =========================================================== C: actor forward again, delta through tanh, backward into the accumulators
     HeadGrad g;
     C.grad_zero(g);
-    C.stage(thA, NA, 0);                                               // (its leading barrier also publishes dab)
+    C.stage(thA, 0, NA.extra_n);                                       // (its leading barrier also publishes dab)
     // dab lives in eb, which the backward's exchanges overwrite: this lane's four values per chunk into registers first
     f32x4 dqa[4], epsa[4];                                             // (SAC: the rows' eps as well, ahead of the loop)
 #pragma unroll
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     co.step = (float)((double)a.actor_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
-    co.tk = 1.f - a.tau; co.tau = a.tau; co.soft = true;
-    C.adam_head(g, NA.L[0], NA.L[1], NA.L[2], thA, mA, vA, tgA, co, g_extra, NA.extra_off, sac ? NA.extra_n : 0);
+    co.tk = 1.f - a.tau; co.tau = a.tau;
+    C.adam_head<true, 0>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);
     if (tid == 0) {
         steps[0] = t;
         float* st = D.stats + (size_t)p * ST_COUNT;

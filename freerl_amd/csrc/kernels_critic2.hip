@@ -110,7 +110,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // =========================================================== a' = actor_target(s') for the whole batch -> S.ab (SAC: + log pi)
     PPO_T0();
     RowIn2 nxt2 = load_row2(false, 0);
-    C.stage(tgA, NA, 0);
+    C.stage(tgA, 0, NA.extra_n);
     PPO_T(0);
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     RowIn nxt;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
-        C.stage(tgC, NC, 3 * hd);
+        C.stage(tgC, hd);
         for (int c2 = 0; c2 < nch2; ++c2) {
             const RowIn2 cur = nxt2;
             if (c2 + 1 < nch2) nxt2 = load_row2(true, c2 + 1);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         HeadGrad& g = G[hd];
         C.grad_zero(g);
         PPO_T(3);
-        C.stage(thC, NC, 3 * hd);
+        C.stage(thC, hd);
         PPO_T(0);
         for (int c = 0; c < nchunks; ++c) {
             const int row = c * 64 + 16 * w + i16;
@@ -248,10 +248,11 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     co.step = (float)((double)a.critic_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = a.critic_wd;
     co.tk = 1.f - a.tau; co.tau = a.tau;
-    co.soft = a.do_actor != 0;                                         // TD3: targets move with the delayed policy step (TD3.py:224-233)
-#pragma unroll
-    for (int hd = 0; hd < NH; ++hd)
-        C.adam_head(G[hd], NC.L[3 * hd], NC.L[3 * hd + 1], NC.L[3 * hd + 2], thC, mC, vC, tgCw, co, 0.f, 0, 0);
+    if (a.do_actor != 0) {                                             // TD3: targets move with the delayed policy step (TD3.py:224-233)
+        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+    } else {
+        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+    }
     PPO_T(7);
     PPO_TDUMP();
     if (tid == 0) {

@@ -243,8 +243,9 @@ def test_per_tree_at_depth(N):
 
 
 def test_learn_path_reports_the_kernel_family(N, monkeypatch):
-    """frl_learn_path: the chained kernels take the narrow standard shape at populations >= 128 (or when forced), the
-    row-chunk kernels everything else; the reported LDS bytes fit the CU either way."""
+    """frl_learn_path: the chained kernels take the narrow standard shape at populations >= 128 (or when forced AT CREATION:
+    the family fixes the parameter layout in HBM for the engine's life), the row-chunk kernels everything else; the reported
+    LDS bytes fit the CU either way."""
     from freerl_amd.engine import Engine
     monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
     for algo, twin in ((N.ALGO_TD3, True), (N.ALGO_SAC, True), (N.ALGO_DDPG, False)):
@@ -252,7 +253,10 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
         chained, lds, rows = small.learn_path(256)
         assert not chained and rows == small.lds_bytes()[1] and lds == small.lds_bytes()[0]
         monkeypatch.setenv("FRL_CRITIC_V2", "1")
-        assert small.learn_path(256)[0]
+        assert not small.learn_path(256)[0]                           # an existing engine keeps its family
+        forced = Engine(algo, 8, 2, 512, twin_critic=twin, batch_max=256)
+        assert forced.learn_path(256)[0]
+        forced.close()
         monkeypatch.delenv("FRL_CRITIC_V2")
         small.close()
         pop = Engine(algo, 8, 2, 512, n_learners=128, twin_critic=twin, batch_max=256)

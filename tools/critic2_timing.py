@@ -31,11 +31,13 @@ fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_longlong)]
 buf = (C.c_longlong * 16)()
 assert fn(buf) == 0
 clk = np.array(buf[:8], dtype=np.float64)
-names = ["weight staging (5 nets)", "target actor pass (4 chunks)", "target critic passes (8 chunks)", "grad zero / bias reductions",
+persist = os.environ.get("FRL_CRITIC_PERSIST", "1") != "0"
+names = ["weight staging (5 nets)", "target actor pass", "target critic passes", "grad zero / bias reductions",
          "row prefetch issue (critic pass)", "forward (critic pass, 8 chunks)", "delta + exchanges + dW + dH (critic pass, 8 chunks)",
-         "norm + transposes + clip + Adam + soft update"]
+         "norm + clip + Adam + soft update in the open (persistent: the LAST learner's only) + row index loads"]
 tot = clk[:8].sum()
-print("P=%d: %.0f cycles per learner (critic stage)" % (P, tot))
+per = max(1, -(-P // 256)) if persist else 1
+print("P=%d: %.0f cycles per workgroup = %d learner(s) (critic stage, %s)" % (P, tot, per, "persistent kernels_critic3" if persist else "kernels_critic2"))
 for i, n in enumerate(names):
     print("   %-50s %8.0f  %5.1f%%" % (n, clk[i], 100 * clk[i] / tot))
 e.close()
