@@ -1227,7 +1227,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
                 static const K table[2][2][2] = {
                     {{ac_critic_v3_single_hold_kernel, ac_critic_v3_single_soft_kernel}, {ac_critic_v3_single_b128_hold_kernel, ac_critic_v3_single_b128_soft_kernel}},
                     {{ac_critic_v3_twin_hold_kernel, ac_critic_v3_twin_soft_kernel}, {ac_critic_v3_twin_b128_hold_kernel, ac_critic_v3_twin_b128_soft_kernel}}};
-                hipLaunchKernelGGL(table[twin][small][soft], dim3(std::min(pc, e->n_cus)), blk, lb, st, e->d, a);
+                int grid = std::min(pc, e->n_cus);
+                if (const char* ge = getenv("FRL_CRITIC_GRID")) grid = std::max(1, std::min(grid, atoi(ge)));      // developer knob: fewer, longer-running workgroups
+                hipLaunchKernelGGL(table[twin][small][soft], dim3(grid), blk, lb, st, e->d, a);
             } else if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
             else hipLaunchKernelGGL(ac_critic_v2_single_kernel, dim3(pc), blk, lb, st, e->d, a);
             prof_end(e);

@@ -92,6 +92,12 @@ struct AdamBackground {
     }
 };
 
+__device__ __forceinline__ float pin_vgpr(float uniform) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+    return v;
+}
+
 struct RowIn { f32x4 x; };
 struct RowNext { f32x4 x; float rew, done; };
 
@@ -273,7 +279,15 @@ __device__ __forceinline__ void ac_critic_v3_body(const EngineDesc& D, const Lea
             NoBackground nb;
             nxt = target_phase<NH, NCH>(C, D, a, L, ridx, nb PPO_TARGS);
         } else {
-            AdamBackground<NH, SOFT> bg{C, G, prev.thC, prev.mC, prev.vC, prev.tgCw, adam_buf(prev.thC, prev.mC, prev.vC, prev.tgCw), co, {}, {}, {}};
+            // The update's coefficients as per-lane values the compiler cannot re-create: they are uniform, VALU instructions
+            // take one scalar operand each, so hipcc keeps VGPR copies of them — and (measured, round 3: single-critic build)
+            // re-materialises those copies inside the lane-group-0-only epilogue of a target pass, after which three quarters
+            // of every tile of the background update used garbage.  An opaque v_mov at full exec pins them.
+            AdamCoef cv;
+            cv.coef = pin_vgpr(co.coef); cv.step = pin_vgpr(co.step); cv.inv_bc2s = pin_vgpr(co.inv_bc2s); cv.w1 = pin_vgpr(co.w1);
+            cv.w2 = pin_vgpr(co.w2); cv.beta2 = pin_vgpr(co.beta2); cv.eps = pin_vgpr(co.eps); cv.wd = pin_vgpr(co.wd);
+            cv.tk = pin_vgpr(co.tk); cv.tau = pin_vgpr(co.tau);
+            AdamBackground<NH, SOFT> bg{C, G, prev.thC, prev.mC, prev.vC, prev.tgCw, adam_buf(prev.thC, prev.mC, prev.vC, prev.tgCw), cv, {}, {}, {}};
             nxt = target_phase<NH, NCH>(C, D, a, L, ridx, bg PPO_TARGS);
             bg.finish();
         }
