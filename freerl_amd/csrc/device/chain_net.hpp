@@ -109,27 +109,36 @@ struct ChainNet {
         lane1 = 4 * (w * 2 * 256 + fslot);
     }
 
-    // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy
+    // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy, in two
+    // halves.  stage_fetch issues every load of the net (84 registers per lane) and can sit IN FRONT of the previous net's last
+    // pass: all 256 workgroups stage at the same moment, 21 MB in one burst that HBM serves in ~9-12 k cycles — under a pass's
+    // MFMAs that costs nothing.  stage_commit waits for the other waves to be done with the old images and stores.
     // th = the net's block, head = which head of it; extra_n > 0: a single-head net's log_std entries behind its block
-    __device__ __forceinline__ void stage(g_cf th, int head, int extra_n = 0) const {
+    struct StageRegs { f32x4 t2[16], t1[2], t3[2]; float bb1, bb2, bb3, lsv; };
+    __device__ __forceinline__ StageRegs stage_fetch(g_cf th, int head, int extra_n = 0) const {
         th += head * kHeadFloats;
+        StageRegs R;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) R.t2[j] = ld4(th + kL2w + 4 * (tid + 256 * j));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { R.t1[j] = ld4(th + kL1w + 4 * (tid + 256 * j)); R.t3[j] = ld4(th + kL3w + 4 * (tid + 256 * j)); }
+        R.bb1 = R.bb2 = R.bb3 = R.lsv = 0.f;
+        if (tid < kHid) { R.bb1 = th[kL1b + tid]; R.bb2 = th[kL2b + tid]; }
+        if (tid < 16) { R.bb3 = th[kL3b + tid]; R.lsv = tid < extra_n ? th[kHeadFloats + tid] : 0.f; }
+        __builtin_amdgcn_sched_barrier(0);                             // the loads stay here: hipcc would sink them to the stores
+        return R;
+    }
+    __device__ __forceinline__ void stage_commit(const StageRegs& R) const {
         lds_barrier();                                                 // every wave is done with the previous images
-        f32x4 t2[16], t1[2], t3[2];                                    // all loads of the net in flight before the first store
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t2[j] = ld4(th + kL2w + 4 * (tid + 256 * j));
+        for (int j = 0; j < 16; ++j) st4(S.w2 + 4 * (tid + 256 * j), R.t2[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { t1[j] = ld4(th + kL1w + 4 * (tid + 256 * j)); t3[j] = ld4(th + kL3w + 4 * (tid + 256 * j)); }
-        float bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, lsv = 0.f;
-        if (tid < kHid) { bb1 = th[kL1b + tid]; bb2 = th[kL2b + tid]; }
-        if (tid < 16) { bb3 = th[kL3b + tid]; lsv = tid < extra_n ? th[kHeadFloats + tid] : 0.f; }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st4(S.w2 + 4 * (tid + 256 * j), t2[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { st4(S.w1 + 4 * (tid + 256 * j), t1[j]); st4(S.w3 + 4 * (tid + 256 * j), t3[j]); }
-        if (tid < kHid) { S.b1[tid] = bb1; S.b2[tid] = bb2; }
-        if (tid < 16) { S.b3[tid] = bb3; S.ls[tid] = lsv; }
+        for (int j = 0; j < 2; ++j) { st4(S.w1 + 4 * (tid + 256 * j), R.t1[j]); st4(S.w3 + 4 * (tid + 256 * j), R.t3[j]); }
+        if (tid < kHid) { S.b1[tid] = R.bb1; S.b2[tid] = R.bb2; }
+        if (tid < 16) { S.b3[tid] = R.bb3; S.ls[tid] = R.lsv; }
         lds_barrier();
     }
+    __device__ __forceinline__ void stage(g_cf th, int head, int extra_n = 0) const { stage_commit(stage_fetch(th, head, extra_n)); }
 
     // ---- the chained forward of T x 16 rows per wave: x (B operand of layer 1) -> h1, h2 -> head tile z.  A tile's 32 MFMAs
     // per layer are ONE dependent accumulator chain: the 8 T chains of a layer run side by side (k-block outer, k-step
@@ -182,10 +191,10 @@ struct ChainNet {
             static_for<0, kHT>([&](auto kbc) {
                 constexpr int kb = decltype(kbc)::value, S_ = SLOT0 + kb;
                 __builtin_amdgcn_sched_barrier(0);
-                // gfx9 counts loads and stores in ONE counter and they complete out of order relative to each other, so with
-                // a store outstanding ANY wait for a load is a vmcnt(0).  The task's loads and stores are therefore issued
-                // together right behind one explicit drain at the top of the block — everything outstanding then is a whole
-                // k-block (~1 k cycles) old — and nothing inside the block waits on memory again.
+                // The task's loads and stores are issued together right behind ONE explicit drain at the top of the block:
+                // everything outstanding then is at least a whole k-block (~1 k cycles) old, the unit computed in this block finds
+                // its operands landed, and nothing inside the block waits on memory again (gfx9 has one counter for loads and
+                // stores: a wait placed between them by the compiler becomes a vmcnt(0) in the middle of the MFMA chain).
                 if constexpr (BG::template has_load<S_>() || BG::template has_store<S_>()) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
                 if constexpr (kb + 1 < kHT) {
 #pragma unroll
@@ -453,10 +462,10 @@ struct ChainNet {
             constexpr int b0 = decltype(bc)::value * 8, nb = decltype(bc)::value < 2 ? 8 : 4;
             AdamIn in[nb];
             static_for<0, nb>([&](auto j) { in[decltype(j)::value] = adam_load<SOFT, b0 + decltype(j)::value, HB>(B); });
-            // Every load of the batch has landed before its first store is issued.  The compiler counts loads and stores of
-            // this target in ONE in-order counter and would wait for "all but the N youngest" once stores are in flight behind
-            // a load; measured on MI355X (tools/r03_dbg.py, round 3) that wait returns early — the stores retire ahead of
-            // older loads — and the last array loaded of a tile (the target copy) was consumed before it arrived.
+            // Every load of the batch has landed before its first store is issued: gfx9 counts loads and stores in one counter,
+            // and with both kinds in flight hipcc's "all but the N youngest" waits rest on their retiring strictly in issue
+            // order.  Nothing measured says they do not (the corruption first blamed on it was the store-data hazard, see
+            // buf_st4) — the drain costs nothing here and takes the question off the table.
             __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
             static_for<0, nb>([&](auto j) {
                 constexpr int J = b0 + decltype(j)::value;

@@ -1218,8 +1218,10 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
             const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
-            const char* pe = getenv("FRL_CRITIC_PERSIST");        // developer switch: 0 = round 2's one-learner-per-workgroup launch
-            if (pe ? atoi(pe) != 0 : true) {
+            // FRL_CRITIC_PERSIST=1: the persistent form (kernels_critic3.hip).  Correct (bitwise equal to the launch below) but, as
+            // measured in round 3, not faster yet: see DESIGN.md §8 — the update in the MFMA shadow stalls on its own loads
+            const char* pe = getenv("FRL_CRITIC_PERSIST");
+            if (pe ? atoi(pe) != 0 : false) {
                 // kernels_critic3.hip: one workgroup per CU walks through its learners, each learner's update in the shadow of
                 // the next one's target passes
                 using K = void (*)(const EngineDesc*, LearnArgs);

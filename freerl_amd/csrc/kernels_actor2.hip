@@ -16,6 +16,7 @@
 #include "kernels.h"
 #include "device/chain_net.hpp"
 #include "device/update_common.hpp"
+#include "device/ppo_timing.hpp"
 
 namespace frl {
 
@@ -88,11 +89,17 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
 
     // =========================================================== A: a = tanh(actor(s)) -> S.ab  (SAC: a = tanh(mean + std eps), sum of log pi)
     float lpsum = 0.f;
+    PPO_T0();
     RowIn2 nxt2 = load_obs2(0);
-    C.stage(thA, 0, NA.extra_n);
+    // every net's image is fetched (global -> registers) in front of the last pass over the previous net: only the first staging
+    // waits for HBM in the open
+    ChainNet::StageRegs pend = C.stage_fetch((g_cf)thA, 0, NA.extra_n);
+    C.stage_commit(pend);
+    PPO_T(0);
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
         nxt2 = load_obs2(c2 + 1 < nch2 ? c2 + 1 : 0);                  // (after the last chunk: chunk 0 again, for pass B)
+        if (c2 + 1 == nch2) pend = C.stage_fetch(thC, 0);
         f32x4 z[2], h1[2][kHT], h2[2][kHT];
         C.forward<2>(cur.x, h1, h2, z);
 #pragma unroll
@@ -121,13 +128,16 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     // =========================================================== B: Q(s, a) and dQ/da through the frozen critic (TD3.py:227: Q1 only; SAC.py:250: both heads)
     float qsum = 0.f;
     f32x4 nxt;
+    PPO_T(1);
     for (int hd = 0; hd < nq; ++hd) {
-        C.stage(thC, hd);
+        C.stage_commit(pend);
+        PPO_T(0);
         for (int c2 = 0; c2 < nch2; ++c2) {
             const RowIn2 cur = nxt2;
             if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
             else if (hd + 1 < nq) nxt2 = load_obs2(0);                 // the next head starts over
             else nxt = load_obs(0);                                    // first chunk of pass C
+            if (c2 + 1 == nch2) pend = hd + 1 < nq ? C.stage_fetch(thC, hd + 1) : C.stage_fetch((g_cf)thA, 0, NA.extra_n);
             f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -157,11 +167,14 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
                 }
             }
         }
+        PPO_T(2);
     }
     // =========================================================== C: actor forward again, delta through tanh, backward into the accumulators
     HeadGrad g;
+    PPO_T(2);
     C.grad_zero(g);
-    C.stage(thA, 0, NA.extra_n);                                       // (its leading barrier also publishes dab)
+    C.stage_commit(pend);                                              // (its leading barrier also publishes dab)
+    PPO_T(0);
     // dab lives in eb, which the backward's exchanges overwrite: this lane's four values per chunk into registers first
     f32x4 dqa[4], epsa[4];                                             // (SAC: the rows' eps as well, ahead of the loop)
 #pragma unroll
@@ -180,7 +193,9 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         const int row = c * 64 + 16 * w + i16;
         f32x4 xb[1] = {nxt}, z[1], h1[1][kHT], h2[1][kHT];
         nxt = load_obs(c + 1 < nchunks ? c + 1 : 0);
+        PPO_T(5);
         C.forward<1>(xb, h1, h2, z);
+        PPO_T(3);
         const f32x4 dq = c == 0 ? dqa[0] : (c == 1 ? dqa[1] : (c == 2 ? dqa[2] : dqa[3]));
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
         if (q == 0 && row < B) {
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
             }
         }
         C.backward(g, xb[0], h1[0], h2[0], dz);
+        PPO_T(4);
     }
     C.grad_finish(g);
     // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target
@@ -242,7 +258,10 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     co.step = (float)((double)a.actor_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
     co.tk = 1.f - a.tau; co.tau = a.tau;
+    PPO_T(5);
     C.adam_head<true, 0>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);
+    PPO_T(6);
+    PPO_TDUMP();
     if (tid == 0) {
         steps[0] = t;
         float* st = D.stats + (size_t)p * ST_COUNT;

@@ -110,11 +110,28 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // =========================================================== a' = actor_target(s') for the whole batch -> S.ab (SAC: + log pi)
     PPO_T0();
     RowIn2 nxt2 = load_row2(false, 0);
-    C.stage(tgA, 0, NA.extra_n);
+    // the target actor's noise of this lane's rows (lane group 0 finalises the rows), loaded ahead of the pass: inside the epilogue
+    // every load was an exposed HBM round trip (~2 k cycles, four per 128-row chunk)
+    f32x4 nzr[4];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        nzr[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16;
+        if (q == 0 && row < B && (sac || a.use_policy_noise)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < A) nzr[j4][r] = noise0[(size_t)row * am + r];
+        }
+    }
+    // every net's image is FETCHED (global -> registers) in front of the last pass over the previous net and committed to LDS
+    // when that pass is done: of the five stagings of a critic update only the first waits for HBM in the open
+    ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
+    C.stage_commit(pend);
     PPO_T(0);
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
         nxt2 = load_row2(true, c2 + 1 < nch2 ? c2 + 1 : 0);            // (after the last chunk: chunk 0 of the target-critic pass)
+        if (c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
         f32x4 z[2], h1[2][kHT], h2[2][kHT];
         C.forward<2>(cur.x, h1, h2, z);
 #pragma unroll
@@ -124,13 +141,14 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             if (q == 0 && row < kChainBatch) {                         // act_dim <= 4: the head's outputs sit on lane group 0
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
                 float lp = 0.f;
+                const f32x4 nr = c2 == 0 ? nzr[t] : nzr[2 + t];
                 if (valid) {
                     if (sac) {                                         // SAC.py:70-97 on actor_target (SAC.py:227)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (r < A) {
                                 const float ls = fminf(fmaxf(S.ls[r], -20.f), 2.f), sd = expf(ls);
-                                const float u = z[t][r] + sd * noise0[(size_t)row * am + r], du = u - z[t][r];
+                                const float u = z[t][r] + sd * nr[r], du = u - z[t][r];
                                 lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
                                 lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
                                 an[r] = tanhf(u);
@@ -142,7 +160,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                             if (r < A) {
                                 float v = tanhf(z[t][r]);
                                 if (a.use_policy_noise) {              // TD3.py:196-198
-                                    float nz = a.policy_noise_scale * (noise0[(size_t)row * am + r] * a.policy_noise);
+                                    float nz = a.policy_noise_scale * (nr[r] * a.policy_noise);
                                     nz = fminf(fmaxf(nz, -a.noise_clip), a.noise_clip);
                                     v = fminf(fmaxf(v * a.max_action + nz, -a.max_action), a.max_action) / a.max_action;
                                 }
@@ -161,12 +179,13 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     RowIn nxt;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
-        C.stage(tgC, hd);
+        C.stage_commit(pend);
         for (int c2 = 0; c2 < nch2; ++c2) {
             const RowIn2 cur = nxt2;
             if (c2 + 1 < nch2) nxt2 = load_row2(true, c2 + 1);
             else if (hd + 1 < NH) nxt2 = load_row2(true, 0);
             else nxt = load_row(0);                                    // first chunk of the critic pass: [s | a], 64-row mapping
+            if (c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
             f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -204,13 +223,14 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         HeadGrad& g = G[hd];
         C.grad_zero(g);
         PPO_T(3);
-        C.stage(thC, hd);
+        C.stage_commit(pend);
         PPO_T(0);
         for (int c = 0; c < nchunks; ++c) {
             const int row = c * 64 + 16 * w + i16;
             const bool valid = row < B;
             const RowIn cur = nxt;
             nxt = load_row(c + 1 < nchunks ? c + 1 : 0);               // (after the last chunk: the second head re-reads chunk 0)
+            if (c + 1 == nchunks && hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
             f32x4 xb[1] = {cur.x}, z[1], h1[1][kHT], h2[1][kHT];
             PPO_T(4);
             C.forward<1>(xb, h1, h2, z);

@@ -56,12 +56,16 @@ __device__ __forceinline__ CriticLearner critic_learner(const EngineDesc& D, int
 // (pre, right behind the block's vmcnt(0): see ChainNet::forward), and does the arithmetic of tile S - 1 (post, in the MFMAs'
 // shadow), whose loads have had a whole k-block to land.  NH * 20 tiles in all — per head 16 of the 128 x 128 layer, 2 of the
 // first layer, 2 of the head layer; the biases follow in finish().
-template <int NH, bool SOFT>
+template <int NH, bool SOFT, int STRIDE>
 struct AdamBackground {
+    // STRIDE: a tile every STRIDE-th slot.  Packed into consecutive slots the update asks for 16 KB per CU and ~1 k cycles — twice
+    // what HBM delivers with all 256 CUs in step — and the MFMA chains wait at every drain; spread over the whole target phase it
+    // stays under the chip's bandwidth.
     static constexpr bool kPipelined = true;
     static constexpr int kUnits = NH * 20;
-    template <int S> static constexpr bool has_load() { return S < kUnits; }
-    template <int S> static constexpr bool has_store() { return S >= 2 && S < kUnits + 2; }
+    template <int S> static constexpr bool has_load() { return S % STRIDE == 0 && S / STRIDE < kUnits; }
+    template <int S> static constexpr bool has_store() { return S % STRIDE == 0 && S / STRIDE >= 2 && S / STRIDE < kUnits + 2; }
+    static constexpr int kSlotsNeeded = (kUnits + 1) * STRIDE + 1;
     const ChainNet& C;
     const HeadGrad (&G)[NH];
     g_f th, mA, vA, tg;                                                // the critic NET's blocks of the previous learner
@@ -71,19 +75,25 @@ struct AdamBackground {
 
     template <int S>
     __device__ __forceinline__ void pre() {
-        if constexpr (S >= 2 && S < kUnits + 2) {
-            constexpr int U = S - 2;
-            C.template adam_store<SOFT, U % 20, (U / 20) * kHeadFloats * 4>(B, res);
+        if constexpr (S % STRIDE == 0) {
+            constexpr int T = S / STRIDE;
+            if constexpr (T >= 2 && T < kUnits + 2) {
+                constexpr int U = T - 2;
+                C.template adam_store<SOFT, U % 20, (U / 20) * kHeadFloats * 4>(B, res);
+            }
+            if constexpr (T < kUnits) nxt = C.template adam_load<SOFT, T % 20, (T / 20) * kHeadFloats * 4>(B);
         }
-        if constexpr (S < kUnits) nxt = C.template adam_load<SOFT, S % 20, (S / 20) * kHeadFloats * 4>(B);
     }
     template <int S>
     __device__ __forceinline__ void post() {
-        if constexpr (S >= 1 && S < kUnits + 1) {
-            constexpr int U = S - 1;
-            res = C.template adam_compute<SOFT>(co, ChainNet::unit_grad<U % 20>(G[U / 20]), in);
+        if constexpr (S % STRIDE == 0) {
+            constexpr int T = S / STRIDE;
+            if constexpr (T >= 1 && T < kUnits + 1) {
+                constexpr int U = T - 1;
+                res = C.template adam_compute<SOFT>(co, ChainNet::unit_grad<U % 20>(G[U / 20]), in);
+            }
+            if constexpr (T < kUnits) in = nxt;
         }
-        if constexpr (S < kUnits) in = nxt;
     }
     __device__ __forceinline__ void finish() {
 #pragma unroll
@@ -246,7 +256,9 @@ __device__ __forceinline__ RowIn target_phase(const ChainNet& C, const EngineDes
 template <bool TWIN, int NCH, bool SOFT>
 __device__ __forceinline__ void ac_critic_v3_body(const EngineDesc& D, const LearnArgs& a, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
-    static_assert(8 * (1 + NH) * NCH >= NH * 20 + 2, "not enough background slots for the update's tiles");
+    constexpr int kSlots = 8 * (1 + NH) * NCH;                         // background slots of one target phase
+    constexpr int STRIDE = (kSlots - 1) / (NH * 20 + 1) > 0 ? (kSlots - 1) / (NH * 20 + 1) : 1;
+    static_assert(kSlots >= (NH * 20 + 1) * STRIDE + 1, "not enough background slots for the update's tiles");
     const RecordDesc& R = D.rec;
     ChainNet C;
     C.init(smem);
@@ -287,7 +299,7 @@ __device__ __forceinline__ void ac_critic_v3_body(const EngineDesc& D, const Lea
             cv.coef = pin_vgpr(co.coef); cv.step = pin_vgpr(co.step); cv.inv_bc2s = pin_vgpr(co.inv_bc2s); cv.w1 = pin_vgpr(co.w1);
             cv.w2 = pin_vgpr(co.w2); cv.beta2 = pin_vgpr(co.beta2); cv.eps = pin_vgpr(co.eps); cv.wd = pin_vgpr(co.wd);
             cv.tk = pin_vgpr(co.tk); cv.tau = pin_vgpr(co.tau);
-            AdamBackground<NH, SOFT> bg{C, G, prev.thC, prev.mC, prev.vC, prev.tgCw, adam_buf(prev.thC, prev.mC, prev.vC, prev.tgCw), cv, {}, {}, {}};
+            AdamBackground<NH, SOFT, STRIDE> bg{C, G, prev.thC, prev.mC, prev.vC, prev.tgCw, adam_buf(prev.thC, prev.mC, prev.vC, prev.tgCw), cv, {}, {}, {}};
             nxt = target_phase<NH, NCH>(C, D, a, L, ridx, bg PPO_TARGS);
             bg.finish();
         }

@@ -23,7 +23,7 @@ for net in range(2):
         flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
         e.set_params(net, flat, N.PARAM_ONLINE, learner=p); e.set_params(net, flat, N.PARAM_TARGET, learner=p)
 e.fill_synthetic(100_000, seed=5)
-for k in range(6):
+for k in range(7):      # (the last call is critic-only: the actor stage stamps the same clock array)
     e.learn(256, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True, policy_noise=0.2,
             noise_clip=0.5, max_action=1.0)
 fn = N.lib().frl_debug_ppo_clocks
@@ -31,7 +31,7 @@ fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_longlong)]
 buf = (C.c_longlong * 16)()
 assert fn(buf) == 0
 clk = np.array(buf[:8], dtype=np.float64)
-persist = os.environ.get("FRL_CRITIC_PERSIST", "1") != "0"
+persist = os.environ.get("FRL_CRITIC_PERSIST", "0") != "0"
 names = ["weight staging (5 nets)", "target actor pass", "target critic passes", "grad zero / bias reductions",
          "row prefetch issue (critic pass)", "forward (critic pass, 8 chunks)", "delta + exchanges + dW + dH (critic pass, 8 chunks)",
          "norm + clip + Adam + soft update in the open (persistent: the LAST learner's only) + row index loads"]
