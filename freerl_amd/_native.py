@@ -102,7 +102,7 @@ class RolloutStats(C.Structure):
                 ("return_sum", C.c_double), ("seconds", C.c_double)]
 
 
-ENV_PENDULUM, ENV_CARTPOLE, ENV_SYNLINEAR, ENV_SYNLINEAR_DISCRETE, ENV_PENDULUM_SHORT = range(5)
+ENV_PENDULUM, ENV_CARTPOLE, ENV_SYNLINEAR, ENV_SYNLINEAR_DISCRETE, ENV_PENDULUM_SHORT, ENV_SYNBAND_WIDE = range(6)
 
 _P = C.POINTER
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float

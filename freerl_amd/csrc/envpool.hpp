@@ -21,6 +21,7 @@
 namespace frl {
 
 enum EnvKind : int { ENV_PENDULUM = 0, ENV_CARTPOLE = 1, ENV_SYNLINEAR = 2, ENV_SYNLINEAR_DISCRETE = 3, ENV_PENDULUM_SHORT = 4,
+                     ENV_SYNBAND_WIDE = 5,     // Humanoid-v4's dims (obs 376, act 17) on banded linear dynamics: BASELINE config 4's rollout leg
                      ENV_CALLBACK = 100 };     // caller-supplied environments behind one vectorised step / reset callback
 
 typedef int (*EnvStepFn)(void* user, const float* actions, float* next_obs, float* reward, uint8_t* terminated, uint8_t* truncated,
@@ -62,6 +63,7 @@ inline EnvSpec env_spec(int kind) {
         case ENV_CARTPOLE: return {kind, 4, 1, 1, 2, 500, 4, 0.f};
         case ENV_SYNLINEAR: return {kind, 8, 2, 0, 0, 200, 8, 1.f};
         case ENV_SYNLINEAR_DISCRETE: return {kind, 8, 1, 1, 4, 200, 8, 0.f};
+        case ENV_SYNBAND_WIDE: return {kind, 376, 17, 0, 0, 1000, 376, 0.4f};
     }
     return {-1, 0, 0, 0, 0, 0, 0, 0.f};
 }
@@ -183,6 +185,26 @@ public:
                 const double th_thr = 12 * 2 * M_PI / 360;
                 term = x < -2.4 || x > 2.4 || th < -th_thr || th > th_thr;
                 r = 1.0;
+                break;
+            }
+            case ENV_SYNBAND_WIDE: {
+                // s'[r] = 0.6 s[r] + 0.25 s[r-1] + 0.1 s[r+1] + 0.5 a[r mod 17] + 0.05 eps: three neighbours per row instead of a
+                // 376 x 376 matrix, so that 10^4..10^5 instances step in the time real MuJoCo instances would need worker processes
+                const int O = spec.obs_dim, A = spec.act_dim;
+                double av[32];
+                for (int k = 0; k < A; ++k) { const double x = a[k] / 0.4; av[k] = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x); }
+                double prev = s[O - 1], first = s[0], sq = 0.0, mx = 0.0, aa = 0.0;
+                for (int r_ = 0; r_ < O; ++r_) {
+                    const double cur = s[r_], nxt = r_ + 1 < O ? s[r_ + 1] : first;
+                    const double v = 0.6 * cur + 0.25 * prev + 0.1 * nxt + 0.5 * av[r_ % A] + 0.05 * rng[i].normal();
+                    prev = cur;
+                    s[r_] = v;
+                    sq += v * v;
+                    mx = std::fmax(mx, std::fabs(v));
+                }
+                for (int k = 0; k < A; ++k) aa += av[k] * av[k];
+                r = -(sq / O + 0.1 * aa / A);
+                term = mx > 8.0;
                 break;
             }
             default: {

@@ -8,7 +8,7 @@ import numpy as np
 from . import _native as N
 
 KINDS = {"Pendulum-v1": N.ENV_PENDULUM, "PendulumShort-v1": N.ENV_PENDULUM_SHORT, "CartPole-v1": N.ENV_CARTPOLE,
-         "SynLinear-v0": N.ENV_SYNLINEAR, "SynLinearDiscrete-v0": N.ENV_SYNLINEAR_DISCRETE}
+         "SynLinear-v0": N.ENV_SYNLINEAR, "SynLinearDiscrete-v0": N.ENV_SYNLINEAR_DISCRETE, "SynBandWide-v0": N.ENV_SYNBAND_WIDE}
 
 
 def _fp(a):

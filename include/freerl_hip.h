@@ -289,7 +289,9 @@ int frl_per_state(frl_engine* e, int learner, double* sum_out, double* max_out, 
  * reference loop (select_action -> exploration -> env.step -> add -> learn; DQN.py:294-339,
  * TD3.py:403-450) for P learners x E instances per launch chain. */
 enum frl_env_kind { FRL_ENV_PENDULUM = 0, FRL_ENV_CARTPOLE = 1, FRL_ENV_SYNLINEAR = 2, FRL_ENV_SYNLINEAR_DISCRETE = 3,
-                    FRL_ENV_PENDULUM_SHORT = 4 };
+                    FRL_ENV_PENDULUM_SHORT = 4,
+                    FRL_ENV_SYNBAND_WIDE = 5 /* obs 376 / act 17 (Humanoid-v4's dims, SAC.py:519-576 at BASELINE config 4) on banded
+                                                linear dynamics: sizes the rollout path, not the physics */ };
 typedef struct frl_envpool frl_envpool;
 /* params: optional SynLinear matrices A[8][8] then B[8][2] (doubles), else NULL */
 int frl_envpool_create(int kind, int n_envs, int n_threads, uint64_t seed, const double* params, int n_params,

@@ -143,3 +143,22 @@ def test_threaded_pool_matches_the_single_threaded_one(native):
             for x, y in zip(one.step(act), many.step(act)):
                 np.testing.assert_array_equal(x, y)
         one.close(); many.close()
+
+
+def test_wide_synthetic_env_humanoid_dims():
+    """SynBandWide-v0 (FRL_ENV_SYNBAND_WIDE): obs 376 / act 17, the dims of BASELINE config 4; banded dynamics, deterministic per seed,
+    actions clipped to +-max_action, episodes truncated at max_steps."""
+    from freerl_amd.envpool import EnvPool
+    a = EnvPool("SynBandWide-v0", 6, n_threads=2, seed=3)
+    b = EnvPool("SynBandWide-v0", 6, n_threads=1, seed=3)
+    assert (a.obs_dim, a.act_dim, a.n_actions, a.max_steps) == (376, 17, 0, 1000) and abs(a.max_action - 0.4) < 1e-6
+    oa, ob = a.reset(), b.reset()
+    np.testing.assert_array_equal(oa, ob)
+    g = np.random.default_rng(0)
+    for _ in range(4):
+        act = g.uniform(-1, 1, (6, 17)).astype(np.float32)          # beyond max_action: clipped inside
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            np.testing.assert_array_equal(x, y)                       # the worker count does not change the trajectories
+        assert np.isfinite(ra[0]).all() and (ra[1] < 0).all()
+    a.close(); b.close()
