@@ -148,8 +148,14 @@ struct ChainNet {
         NoBackground nb;
         forward<T, 0>(xb, h1, h2, z, nb);
     }
-    template <int T, int SLOT0, class BG>
-    __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], BG& bg) const {
+    // ... with the head of hn <= 4 outputs as dot products (head_valu)
+    template <int T>
+    __device__ __forceinline__ void forward_vh(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn) const {
+        NoBackground nb;
+        forward<T, 0, NoBackground, true>(xb, h1, h2, z, nb, hn);
+    }
+    template <int T, int SLOT0, class BG, bool VH = false>
+    __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], BG& bg, int hn = 0) const {
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
             const f32x4 wf = ld4((lds_cf)(S.w1 + ot * 256 + fslot)), bb = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q));
@@ -228,6 +234,11 @@ struct ChainNet {
             for (int ot = 0; ot < kHT; ++ot)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h2[t][ot][r] = fmaxf(h2[t][ot][r], 0.f);
+        if constexpr (VH) head_valu<T>(h2, z, hn); else head_mfma<T>(h2, z);
+    }
+    // head layer as MFMA tiles: z[t][r] = output 4q + r of this lane's row (16 outputs)
+    template <int T>
+    __device__ __forceinline__ void head_mfma(const f32x4 (&h2)[T][kHT], f32x4 (&z)[T]) const {
         const f32x4 b3 = ld4((lds_cf)(S.b3 + 4 * q));
 #pragma unroll
         for (int t = 0; t < T; ++t) z[t] = b3;
@@ -237,6 +248,63 @@ struct ChainNet {
 #pragma unroll
             for (int t = 0; t < T; ++t) z[t] = mfma4(z[t], wf, h2[t][kb]);
         }
+    }
+    // A head of hn <= 4 outputs (every critic: 1; the actors: act_dim) as dot products instead of 32 T MFMAs with 1/16 .. 4/16
+    // useful columns: a lane holds 32 of its row's 128 hidden features (16 kb + 4q + r), the slot (q, f = o) of image tile kb holds
+    // exactly W3[o][16 kb + 4q .. + 3], the four lane groups' partial sums meet by two xor-shuffles.  z[t][o] lands on every lane
+    // group (the callers read it on group 0); entries o >= hn are zero.
+    template <int T>
+    __device__ __forceinline__ void head_valu(const f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn) const {
+#pragma unroll
+        for (int t = 0; t < T; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < hn) {
+                float acc[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[t] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < kHT; ++kb) {
+                    const f32x4 wv = ld4((lds_cf)(S.w3 + kb * 256 + ((q * 16 + (o ^ q)) << 2)));
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[t] = fmaf(wv[r], h2[t][kb][r], acc[t]);
+                }
+                const float bo = S.b3[o];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    float a = acc[t];
+                    a += __shfl_xor(a, 16, 64);
+                    a += __shfl_xor(a, 32, 64);
+                    z[t][o] = a + bo;
+                }
+            }
+        }
+    }
+    // dH2 = W3^T dz through the ReLU of h2 for such a head: dz[o] of the row sits on lane group 0 and is broadcast to the row's
+    // other groups; the fragments are the forward's
+    __device__ __forceinline__ void delta2_valu(const f32x4& dz, const f32x4 (&h2)[kHT], f32x4 (&d2)[kHT], int hn) const {
+        f32x4 dzb;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) dzb[o] = __shfl(dz[o], i16, 64);
+#pragma unroll
+        for (int it = 0; it < kHT; ++it) d2[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < hn) {
+#pragma unroll
+                for (int it = 0; it < kHT; ++it) {
+                    const f32x4 wv = ld4((lds_cf)(S.w3 + it * 256 + ((q * 16 + (o ^ q)) << 2)));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2[it][r] = fmaf(wv[r], dzb[o], d2[it][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kHT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2[it][r] = h2[it][r] > 0.f ? d2[it][r] : 0.f;
     }
 
     // dH2 = W3^T dz through the ReLU of h2 (A = W3^T: transposed fragment reads)
@@ -303,7 +371,8 @@ struct ChainNet {
 
     // ---- backward of one 64-row chunk (16 rows per wave) into the owners' accumulators: three exchanges through ea / eb
     // (H2 + dz -> head gradient; H1 + dz2 -> layer 2; X + dz1 -> layer 1), the dH chains in between
-    __device__ __forceinline__ void backward(HeadGrad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz) const {
+    // hn > 0: the head has hn <= 4 outputs and its dH runs as dot products (delta2_valu)
+    __device__ __forceinline__ void backward(HeadGrad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn = 0) const {
         lds_barrier();                                                 // the previous chunk's readers of ea / eb are done
 #pragma unroll
         for (int ft = 0; ft < kHT; ++ft) put_tile(S.ea, ft, h2[ft]);
@@ -317,7 +386,7 @@ struct ChainNet {
             for (int x = 0; x < 2; ++x) g.g3[x] = mfma4(g.g3[x], get_frag(S.ea, 2 * w + x, bb), af);
         }
         f32x4 d2[kHT];
-        delta2(dz, h2, d2);
+        if (hn > 0) delta2_valu(dz, h2, d2, hn); else delta2(dz, h2, d2);
         lds_barrier();
 #pragma unroll
         for (int ft = 0; ft < kHT; ++ft) { put_tile(S.ea, ft, h1[ft]); put_tile(S.eb, ft, d2[ft]); }

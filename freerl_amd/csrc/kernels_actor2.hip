@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         nxt2 = load_obs2(c2 + 1 < nch2 ? c2 + 1 : 0);                  // (after the last chunk: chunk 0 again, for pass B)
         if (c2 + 1 == nch2) pend = C.stage_fetch(thC, 0);
         f32x4 z[2], h1[2][kHT], h2[2][kHT];
-        C.forward<2>(cur.x, h1, h2, z);
+        C.forward_vh<2>(cur.x, h1, h2, z, A);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = c2 * 128 + 32 * w + 16 * t + i16;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
                     if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];
                 }
             }
-            C.forward<2>(xb, h1, h2, z);
+            C.forward_vh<2>(xb, h1, h2, z, 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int row = c2 * 128 + 32 * w + 16 * t + i16;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
                 f32x4 dz = {0.f, 0.f, 0.f, 0.f};
                 if (q == 0 && valid) { qsum += z[t][0]; dz[0] = dqv; } // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
                 f32x4 d2[kHT], d1[kHT];
-                C.delta2(dz, h2[t], d2);
+                C.delta2_valu(dz, h2[t], d2, 1);
                 C.delta1(d2, h1[t], d1);
                 const f32x4 dx = C.delta0(d1);                         // d loss / d [s | a] column 4q + r of this row
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         f32x4 xb[1] = {nxt}, z[1], h1[1][kHT], h2[1][kHT];
         nxt = load_obs(c + 1 < nchunks ? c + 1 : 0);
         PPO_T(5);
-        C.forward<1>(xb, h1, h2, z);
+        C.forward_vh<1>(xb, h1, h2, z, A);
         PPO_T(3);
         const f32x4 dq = c == 0 ? dqa[0] : (c == 1 ? dqa[1] : (c == 2 ? dqa[2] : dqa[3]));
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
                     if (r < A) { const float av = tanhf(z[0][r]); dz[r] = dq[r] * (1.f - av * av); }
             }
         }
-        C.backward(g, xb[0], h1[0], h2[0], dz);
+        C.backward(g, xb[0], h1[0], h2[0], dz, A);
         PPO_T(4);
     }
     C.grad_finish(g);

@@ -133,7 +133,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         nxt2 = load_row2(true, c2 + 1 < nch2 ? c2 + 1 : 0);            // (after the last chunk: chunk 0 of the target-critic pass)
         if (c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
         f32x4 z[2], h1[2][kHT], h2[2][kHT];
-        C.forward<2>(cur.x, h1, h2, z);
+        C.forward_vh<2>(cur.x, h1, h2, z, A);                           // (the actor head's act_dim <= 4 outputs as dot products)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = c2 * 128 + 32 * w + 16 * t + i16;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                     if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];      // a' from the target-actor pass
                 }
             }
-            C.forward<2>(xb, h1, h2, z);
+            C.forward_vh<2>(xb, h1, h2, z, 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int row = c2 * 128 + 32 * w + 16 * t + i16;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             if (c + 1 == nchunks && hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
             f32x4 xb[1] = {cur.x}, z[1], h1[1][kHT], h2[1][kHT];
             PPO_T(4);
-            C.forward<1>(xb, h1, h2, z);
+            C.forward_vh<1>(xb, h1, h2, z, 1);
             PPO_T(5);
             f32x4 dz = {0.f, 0.f, 0.f, 0.f};
             if (q == 0 && valid) {                                     // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
@@ -242,7 +242,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                 dz[0] = grow * invB;
                 lossp += lrow;
             }
-            C.backward(g, xb[0], h1[0], h2[0], dz);
+            C.backward(g, xb[0], h1[0], h2[0], dz, 1);
             PPO_T(6);
         }
         C.grad_finish(g);

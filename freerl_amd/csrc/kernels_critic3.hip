@@ -184,7 +184,7 @@ __device__ __forceinline__ RowIn target_phase(const ChainNet& C, const EngineDes
         nxt2 = load_next(C, R, L.ring, ridx, true, c + 1 < NCH ? c + 1 : 0);         // (after the last chunk: chunk 0 of the target-critic pass)
         if constexpr (c + 1 < NCH) nz_next = load_noise(c + 1);
         f32x4 xb[1] = {cur.x}, z[1], h1[1][kHT], h2[1][kHT];
-        C.template forward<1, 8 * c>(xb, h1, h2, z, bg);
+        C.template forward<1, 8 * c, BG, true>(xb, h1, h2, z, bg, A);
         const int row = c * 64 + 16 * w + i16;
         if (q == 0) {                                                  // act_dim <= 4: the head's outputs sit on lane group 0
             f32x4 an = {0.f, 0.f, 0.f, 0.f};
@@ -239,7 +239,7 @@ __device__ __forceinline__ RowIn target_phase(const ChainNet& C, const EngineDes
                 const int f = 4 * q + e;
                 if (row < B && f >= O && f < O + A) xb[0][e] = S.ab[row * 4 + f - O];          // a' from the target-actor pass
             }
-            C.template forward<1, 8 * ((1 + hd) * NCH + c)>(xb, h1, h2, z, bg);
+            C.template forward<1, 8 * ((1 + hd) * NCH + c), BG, true>(xb, h1, h2, z, bg, 1);
             if (q == 0 && row < B) {
                 float qv = z[0][0];
                 if (hd == 1) qv = fminf(S.q1[row], qv);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void ac_critic_v3_body(const EngineDesc& D, const Lea
                 nxt = load_row(C, R, L.ring, ridx, c + 1 < nchunks ? c + 1 : 0);       // (after the last chunk: the second head re-reads chunk 0)
                 f32x4 xb[1] = {cur.x}, z[1], h1[1][kHT], h2[1][kHT];
                 PPO_T(4);
-                C.template forward<1>(xb, h1, h2, z);
+                C.template forward_vh<1>(xb, h1, h2, z, 1);
                 PPO_T(5);
                 f32x4 dz = {0.f, 0.f, 0.f, 0.f};
                 if (q == 0 && valid) {                                 // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
@@ -328,7 +328,7 @@ __device__ __forceinline__ void ac_critic_v3_body(const EngineDesc& D, const Lea
                     dz[0] = grow * invB;
                     lossp += lrow;
                 }
-                C.backward(g, xb[0], h1[0], h2[0], dz);
+                C.backward(g, xb[0], h1[0], h2[0], dz, 1);
                 PPO_T(6);
             }
             C.grad_finish(g);

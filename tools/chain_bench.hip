@@ -38,6 +38,20 @@ __global__ __launch_bounds__(256) void k(const float* theta, long long* cyc, flo
             f32x4 dz = {z[0][0] * 1e-3f, 0.f, 0.f, 0.f};
             C.backward(g, x1[0], h1[0], h2[0], dz);
             x1[0][1] += 1e-6f * z[0][1];
+        } else if constexpr (MODE == 4) {
+            f32x4 z[1], h1[1][kHT], h2[1][kHT];
+            C.forward_vh<1>(x1, h1, h2, z, 1);
+            acc += z[0][0]; x1[0][1] += 1e-6f * z[0][1];
+        } else if constexpr (MODE == 5) {
+            f32x4 z[2], h1[2][kHT], h2[2][kHT];
+            C.forward_vh<2>(x2, h1, h2, z, 1);
+            acc += z[0][0] + z[1][0]; x2[0][1] += 1e-6f * z[1][1];
+        } else if constexpr (MODE == 6) {
+            f32x4 z[1], h1[1][kHT], h2[1][kHT];
+            C.forward_vh<1>(x1, h1, h2, z, 1);
+            f32x4 dz = {z[0][0] * 1e-3f, 0.f, 0.f, 0.f};
+            C.backward(g, x1[0], h1[0], h2[0], dz, 1);
+            x1[0][1] += 1e-6f * z[0][1];
         } else if constexpr (MODE == 3) {      // forward<2> + the dX-only chain of the actor stage's pass B
             f32x4 z[2], h1[2][kHT], h2[2][kHT];
             C.forward<2>(x2, h1, h2, z);
@@ -53,7 +67,7 @@ __global__ __launch_bounds__(256) void k(const float* theta, long long* cyc, flo
         }
     }
     const long long t1 = clock64();
-    if (MODE == 2) acc += C.grad_sumsq(g);
+    if (MODE == 2 || MODE == 6) acc += C.grad_sumsq(g);
     if (threadIdx.x == 0) cyc[blockIdx.x] = (t1 - t0) / reps;
     sink[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -68,9 +82,10 @@ int main() {
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.01f * (float)((i * 2654435761u) % 201) - 1.f;
     hipMemcpy(theta, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
     const size_t lds = (size_t)chain_lds_floats() * sizeof(float);
-    const char* names[4] = {"forward<1>             (320 MFMA)", "forward<2>             (640 MFMA)", "forward<1> + backward  (928 MFMA)",
-                            "forward<2> + 2 x dX    (1280 MFMA)"};
-    const int mfma[4] = {320, 640, 928, 1280};
+    const char* names[7] = {"forward<1>             (320 MFMA)", "forward<2>             (640 MFMA)", "forward<1> + backward  (928 MFMA)",
+                            "forward<2> + 2 x dX    (1280 MFMA)", "forward<1>, 1-output head on VALU (288 MFMA)",
+                            "forward<2>, 1-output head on VALU (576 MFMA)", "forward<1> + backward, head + its dH on VALU (864 MFMA)"};
+    const int mfma[7] = {320, 640, 928, 1280, 288, 576, 864};
     auto run = [&](auto kern, int mode) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int it = 0; it < 2; ++it) {
@@ -83,6 +98,6 @@ int main() {
         s /= G;
         printf("%s  %8.0f cycles per call   MFMA floor %6d   -> %.1f %% of the issue rate\n", names[mode], s, mfma[mode] * 32, 100.0 * mfma[mode] * 32 / s);
     };
-    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3);
+    run(k<0>, 0); run(k<1>, 1); run(k<2>, 2); run(k<3>, 3); run(k<4>, 4); run(k<5>, 5); run(k<6>, 6);
     return 0;
 }

@@ -17,10 +17,20 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   python $R/tools/pmc_summary.py $O/pmc$i $O/pmc$i.json
 done
 python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_kernel
+timeout 300 python $R/tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
+timeout 300 python $R/tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
+timeout 300 python $R/tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
+timeout 300 $R/tools/_bin/chain_bench > $O/chain_bench.txt 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ppo -- python $R/tools/ppo_bench.py 256 > $O/stats_ppo.log 2>&1
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dqn -- python $R/tools/dqn_bench.py 512 > $O/stats_dqn.log 2>&1
 cp $(ls $O/stats_dqn/*/*kernel_stats.csv | head -1) $O/kernel_stats_dqn.csv
-cd $R && timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+cd $R && timeout 300 python tools/config_bench.py 1 512 > $O/config_bench.txt 2>&1
+timeout 300 python tools/dqn_bench.py 1 512 2048 4096 > $O/dqn_bench.txt 2>&1
+timeout 300 python tools/ppo_bench.py 1 64 256 > $O/ppo_bench.txt 2>&1
+timeout 600 python tools/rollout_bench.py 1 512 > $O/rollout_bench.txt 2>&1
+timeout 300 python tools/config4_rollout.py 1 8 32 > $O/config4_rollout.txt 2>&1
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 300 python bench.py --spawn --headline-only --steps 10 --warmup 2 > $O/bench_spawn1.json 2> $O/bench_spawn1.err
 rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
 ls -la $O
