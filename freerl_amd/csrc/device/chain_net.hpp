@@ -156,15 +156,21 @@ struct ChainNet {
     }
     template <int T, int SLOT0, class BG, bool VH = false>
     __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], BG& bg, int hn = 0) const {
+        // first layer: all eight fragments and biases in flight before the first MFMA.  (All four k-steps are needed whatever the
+        // input width: k-step e of the fragment layout holds columns e, 4 + e, 8 + e, 12 + e, so the zero padding is spread
+        // over every step — a build that skipped "unused" steps dropped real columns and failed parity by 1 %.)
+        {
+            f32x4 w1f[kHT], b1f[kHT];
 #pragma unroll
-        for (int ot = 0; ot < kHT; ++ot) {
-            const f32x4 wf = ld4((lds_cf)(S.w1 + ot * 256 + fslot)), bb = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q));
+            for (int ot = 0; ot < kHT; ++ot) { w1f[ot] = ld4((lds_cf)(S.w1 + ot * 256 + fslot)); b1f[ot] = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q)); }
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const f32x4 acc = mfma4(bb, wf, xb[t]);
+            for (int ot = 0; ot < kHT; ++ot)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h1[t][ot][r] = fmaxf(acc[r], 0.f);
-            }
+                for (int t = 0; t < T; ++t) {
+                    const f32x4 acc = mfma4(b1f[ot], w1f[ot], xb[t]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[t][ot][r] = fmaxf(acc[r], 0.f);
+                }
         }
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
@@ -319,21 +325,24 @@ struct ChainNet {
             for (int r = 0; r < 4; ++r) d2[it][r] = h2[it][r] > 0.f ? acc[r] : 0.f;
         }
     }
-    // dH1 = W2^T dz2 through the ReLU of h1; eight accumulator chains side by side
+    // dH1 = W2^T dz2 through the ReLU of h1; eight accumulator chains side by side.  The transposed fragments of W2 are 4-byte LDS
+    // reads, eight per k-step: the reads of step s + 1 are issued in front of the MFMAs of step s (double-buffered in the source —
+    // hipcc waited for every step's reads right in front of its MFMAs: ~130 exposed cycles x 32 steps per call)
     __device__ __forceinline__ void delta1(const f32x4 (&d2)[kHT], const f32x4 (&h1)[kHT], f32x4 (&d1)[kHT]) const {
 #pragma unroll
         for (int it = 0; it < kHT; ++it) d1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float wa[2][kHT];
+        auto fetch = [&](int ob, int e, float (&dst)[kHT]) {
 #pragma unroll
-        for (int ob = 0; ob < kHT; ++ob) {
+            for (int it = 0; it < kHT; ++it) dst[it] = S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+        };
+        fetch(0, 0, wa[0]);
+        static_for<0, 4 * kHT>([&](auto sc) {
+            constexpr int s_ = decltype(sc)::value, ob = s_ >> 2, e = s_ & 3;
+            if constexpr (s_ + 1 < 4 * kHT) fetch((s_ + 1) >> 2, (s_ + 1) & 3, wa[(s_ + 1) & 1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float wa[kHT];
-#pragma unroll
-                for (int it = 0; it < kHT; ++it) wa[it] = S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-#pragma unroll
-                for (int it = 0; it < kHT; ++it) d1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[it], d2[ob][e], d1[it], 0, 0, 0);
-            }
-        }
+            for (int it = 0; it < kHT; ++it) d1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_ & 1][it], d2[ob][e], d1[it], 0, 0, 0);
+        });
 #pragma unroll
         for (int it = 0; it < kHT; ++it)
 #pragma unroll
