@@ -55,15 +55,32 @@ __device__ __forceinline__ AdamBuf adam_buf(g_f th, g_f mA, g_f vA, g_f tg) {
     B.tg = __builtin_amdgcn_make_buffer_rsrc((float*)tg, 0, 0x7fffffff, 0x00020000);
     return B;
 }
+// cache-policy bits of the update's loads / stores and of the staging loads (developer knobs: 2 = slc / non-temporal)
+#ifndef FRL_ADAM_AUX_LD
+#define FRL_ADAM_AUX_LD 2
+#endif
+#ifndef FRL_ADAM_AUX_ST
+#define FRL_ADAM_AUX_ST 2
+#endif
+#ifndef FRL_STAGE_NT
+#define FRL_STAGE_NT 0      // measured: no gain on the staging loads
+#endif
+__device__ __forceinline__ f32x4 ld4_stage(g_cf p) {
+#if FRL_STAGE_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const FRL_GLB f32x4*>(p));
+#else
+    return ld4(p);
+#endif
+}
 __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, FRL_ADAM_AUX_LD));
 }
 // Stores take their whole offset in the VGPR / immediate field, never in an SGPR soffset: a 128-bit VMEM store reads its data
 // registers over several cycles and a VALU write to them in the next issue slot corrupts a quarter wave of it (measured, round 3:
 // the target copy's store followed by the next tile's first multiply — 16 lanes of the tile held coef * gradient afterwards).
 // hipcc pads that hazard with wait states only when soffset is NOT a register (the GCN3 rule); on gfx950 it bites either way.
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int const_off, const f32x4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, voff + const_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, voff + const_off, 0, FRL_ADAM_AUX_ST);
 }
 
 // A "background task" of ChainNet::forward: pre<S>() / post<S>() are called once per k-block of the 128 x 128 layer (8 per
@@ -119,9 +136,9 @@ struct ChainNet {
         th += head * kHeadFloats;
         StageRegs R;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) R.t2[j] = ld4(th + kL2w + 4 * (tid + 256 * j));
+        for (int j = 0; j < 16; ++j) R.t2[j] = ld4_stage(th + kL2w + 4 * (tid + 256 * j));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { R.t1[j] = ld4(th + kL1w + 4 * (tid + 256 * j)); R.t3[j] = ld4(th + kL3w + 4 * (tid + 256 * j)); }
+        for (int j = 0; j < 2; ++j) { R.t1[j] = ld4_stage(th + kL1w + 4 * (tid + 256 * j)); R.t3[j] = ld4_stage(th + kL3w + 4 * (tid + 256 * j)); }
         R.bb1 = R.bb2 = R.bb3 = R.lsv = 0.f;
         if (tid < kHid) { R.bb1 = th[kL1b + tid]; R.bb2 = th[kL2b + tid]; }
         if (tid < 16) { R.bb3 = th[kL3b + tid]; R.lsv = tid < extra_n ? th[kHeadFloats + tid] : 0.f; }

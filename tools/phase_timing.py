@@ -78,7 +78,7 @@ def main():
     nblk = P * ((B + rc - 1) // rc)
     KMAX = 64
     buf = (C.c_int * (8 * 5 * KMAX))()
-    stride = max(1, nblk // 8 - 3)
+    stride = max(1, nblk // 8 - 3) if P >= 8 else 8       # P < 8: blocks 0, 8, 16 ... are unit 0's slices (update_common.hpp)
     assert fn(buf, stride) == 0
     assert fn(buf, -2 if actor else -1) == 0            # which kernel dumps its stamps
     for it in range(6):
