@@ -20,6 +20,7 @@ python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.js
 timeout 300 python $R/tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
 timeout 300 python $R/tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
 timeout 300 python $R/tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
+timeout 300 python $R/tools/ppo_timing.py 256 > $O/ppo_timing.txt 2>&1 < /dev/null
 timeout 300 $R/tools/_bin/chain_bench > $O/chain_bench.txt 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ppo -- python $R/tools/ppo_bench.py 256 > $O/stats_ppo.log 2>&1
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
@@ -30,6 +31,9 @@ timeout 300 python tools/dqn_bench.py 1 512 2048 4096 > $O/dqn_bench.txt 2>&1
 timeout 300 python tools/ppo_bench.py 1 64 256 > $O/ppo_bench.txt 2>&1
 timeout 600 python tools/rollout_bench.py 1 512 > $O/rollout_bench.txt 2>&1
 timeout 300 python tools/config4_rollout.py 1 8 32 > $O/config4_rollout.txt 2>&1
+timeout 300 python tools/single_bench.py 2000 > $O/single_bench.txt 2>&1 < /dev/null
+FRL_HIP_VARIANT=phase FRL_HIPCC_FLAGS=-DFRL_PHASE_TIMING timeout 200 python tools/phase_timing.py 1 > $O/phase_critic_p1.txt 2>&1 < /dev/null
+timeout 120 tools/_bin/clock_probe > $O/clock_probe.txt 2>&1
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --spawn --headline-only --steps 10 --warmup 2 > $O/bench_spawn1.json 2> $O/bench_spawn1.err
 rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
