@@ -27,10 +27,23 @@ def _native_comm_create(rank, world, local_rank):
     import ctypes as C
     from . import _native as N
     L = N.lib()
+    # Joining is collective (ncclCommInitRank blocks until every rank has called it): a rank that cannot get as far as the call
+    # — no librccl, no device — would leave the others waiting for ever.  Every rank probes first (making an id loads RCCL and
+    # touches the device) and the ranks agree over the process group before anyone joins.
+    buf = (C.c_uint8 * N.FRL_COMM_ID_BYTES)()
+    err = None
+    try:
+        N.check(L.frl_comm_unique_id(buf))
+    except Exception as ex:      # noqa: BLE001 - agreed on below
+        err = ex
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        ok = ok.cuda()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        raise err if err else N.FrlError("another rank cannot create the RCCL communicator")
     uid = torch.zeros(N.FRL_COMM_ID_BYTES, dtype=torch.uint8)
     if rank == 0:
-        buf = (C.c_uint8 * N.FRL_COMM_ID_BYTES)()
-        N.check(L.frl_comm_unique_id(buf))
         uid = torch.tensor(list(buf), dtype=torch.uint8)
     if dist.get_backend() == "nccl":
         uid = uid.cuda()
@@ -60,6 +73,7 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.exists("/sys/class/net/lo"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container hostname may not resolve
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")        # RCCL's bootstrap sockets: one node, loopback is enough
         want_native = backend != "gloo" and torch.cuda.is_available()
         if want_native:
             torch.cuda.set_device(local_rank)
