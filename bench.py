@@ -349,7 +349,7 @@ def main():
         kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
         # dominant kernel: the critic stage.  At this population it is ac_critic_v2_twin_kernel (kernels_critic2.hip): targets,
         # twin-critic forward / backward, clip + Adam + soft update of one learner per workgroup in ONE launch ("adam_critic"
-        # absent from the per-kernel times); below 128 learners ac_critic_kernel + adam_fused_kernel.  Its flops are the same
+        # absent from the per-kernel times); up to 128 learners ac_critic_kernel + adam_fused_kernel.  Its flops are the same
         # algorithmic figure either way (frl_learn_work): the Adam / soft-update phase adds HBM bytes, not flops.
         fused = "adam_critic" not in kern
         dominant = "ac_critic_v2_twin_kernel" if fused else "ac_critic_kernel"

@@ -362,7 +362,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     h.learner_stride = pad32(off);
     if (e->has_nets && chained_shape(h)) {       // kernel family (and with it the parameter layout in HBM), fixed for the engine's life
         const char* force = getenv("FRL_CRITIC_V2");
-        if (force ? atoi(force) != 0 : h.P >= 128) h.net[0].frag = h.net[1].frag = 1;
+        // measured (bench workload, updates/s): 128 learners are exactly one round of the row-chunk kernels' 512 resident
+        // workgroups — 484 k against 373 k for 128 one-learner workgroups on half the CUs; from 129 up the chained kernels win
+        // (160: 459 k / 393 k, 256: 694 k / 566 k) or tie (320: 472 k / 480 k)
+        if (force ? atoi(force) != 0 : h.P > 128) h.net[0].frag = h.net[1].frag = 1;
     }
     h.act_max = 1;
     for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);

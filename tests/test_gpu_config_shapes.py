@@ -243,7 +243,7 @@ def test_per_tree_at_depth(N):
 
 
 def test_learn_path_reports_the_kernel_family(N, monkeypatch):
-    """frl_learn_path: the chained kernels take the narrow standard shape at populations >= 128 (or when forced AT CREATION:
+    """frl_learn_path: the chained kernels take the narrow standard shape at populations > 128 (or when forced AT CREATION:
     the family fixes the parameter layout in HBM for the engine's life), the row-chunk kernels everything else; the reported
     LDS bytes fit the CU either way."""
     from freerl_amd.engine import Engine
@@ -259,16 +259,19 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
         forced.close()
         monkeypatch.delenv("FRL_CRITIC_V2")
         small.close()
-        pop = Engine(algo, 8, 2, 512, n_learners=128, twin_critic=twin, batch_max=256)
+        pop = Engine(algo, 8, 2, 512, n_learners=144, twin_critic=twin, batch_max=256)
         chained, lds, rows = pop.learn_path(256)
         assert chained and rows == 256 and lds <= 160 * 1024
         pop.close()
-    wide = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=128, twin_critic=True, batch_max=256)     # obs + act > 16, act > 4
+        edge = Engine(algo, 8, 2, 512, n_learners=128, twin_critic=twin, batch_max=256)      # one full round of the row-chunk kernels: theirs
+        assert not edge.learn_path(256)[0]
+        edge.close()
+    wide = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256)     # obs + act > 16, act > 4
     assert not wide.learn_path(256)[0]
     with pytest.raises(RuntimeError):
         wide.learn_path(257)
     wide.close()
-    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=128, twin_critic=True, batch_max=256, hidden=256)
+    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)
     assert not h256.learn_path(256)[0]
     h256.close()
     monkeypatch.delenv("FRL_DQN_FUSED", raising=False)

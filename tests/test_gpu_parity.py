@@ -284,7 +284,7 @@ def _check_ac_params(N, e, orc, twin, actor_names, label, actor_extra=None, lear
 @pytest.fixture(params=["rowchunk", "chained"])
 def ac_path(request, monkeypatch):
     """The critic stage of DDPG / TD3 / SAC has two implementations behind frl_learn: the row-chunk kernels + reduce / Adam
-    launches (any shape; what populations below 128 learners get) and the one-workgroup-per-learner register-chained kernel
+    launches (any shape; what populations up to 128 learners get) and the one-workgroup-per-learner register-chained kernel
     with Adam fused (kernels_critic2.hip; the bench's path).  FRL_CRITIC_V2 forces either, so both meet the same oracle."""
     monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
     monkeypatch.setenv("FRL_DQN_FUSED", "1" if request.param == "chained" else "0")      # (tests that also touch DQN: both of its paths)
@@ -757,7 +757,7 @@ def test_population_learners_are_independent(N):
 
 
 def test_bench_sized_population_takes_the_chained_kernels_and_matches(N, monkeypatch):
-    """At >= 128 learners frl_learn selects the one-workgroup-per-learner chained kernels on its own (what bench.py runs):
+    """Above 128 learners frl_learn selects the one-workgroup-per-learner chained kernels on its own (what bench.py runs):
     144 learners, no override; four of them (first, last, two in between — different workgroups / CUs) against their own
     oracles with their own indices and noise, actor step included."""
     from oracle import algos
