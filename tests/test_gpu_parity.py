@@ -801,6 +801,39 @@ def test_bench_sized_population_takes_the_chained_kernels_and_matches(N, monkeyp
     e.close()
 
 
+def test_chained_population_is_deterministic_and_independent_of_its_size(N, monkeypatch):
+    """The bench's kernel family (one workgroup per learner, device-drawn indices and noise) on its own terms: the same seed gives
+    bit-identical parameters twice, and learner p's parameters do not depend on how many other learners share the launch (144
+    learners = one partial round of workgroups, 300 = two): its Philox key is (seed, p), its ring and nets are its own."""
+    from freerl_amd.engine import Engine
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    watch = (0, 5, 77, 143)
+
+    def run(P):
+        e = Engine(N.ALGO_TD3, 8, 2, 4096, n_learners=P, twin_critic=True, batch_max=256, seed=77)
+        assert e.learn_path(256)[0]
+        for p in range(P):
+            rng = np.random.default_rng(1000 + p)
+            for net in (0, 1):
+                flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
+                e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
+                e.set_params(net, flat, N.PARAM_TARGET, learner=p)
+        e.fill_synthetic(4096, seed=3)
+        for k in range(6):
+            e.learn(256, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True,
+                    policy_noise=0.2, noise_clip=0.5, max_action=1.0)
+        out = [np.concatenate([e.get_params(net, kind, learner=p) for net in (0, 1)
+                               for kind in (N.PARAM_ONLINE, N.PARAM_TARGET, N.PARAM_ADAM_M, N.PARAM_ADAM_V)]) for p in watch]
+        e.close()
+        return out
+    a, b, c = run(144), run(144), run(300)
+    for x, y, z in zip(a, b, c):
+        assert np.all(np.isfinite(x))
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, z)
+    assert not np.array_equal(a[0], a[1])
+
+
 def test_full_size_device_rng_properties(N):
     """BASELINE config-2 scale (replay 1e6 rows, batch 256), device-drawn indices and noise.
     Size-independent properties: (1) bitwise determinism from the seed; (2) tau = 1 makes the
