@@ -869,6 +869,47 @@ def test_full_size_device_rng_properties(N):
     np.testing.assert_array_equal(r1["c"], r1["ct"])
 
 
+def test_full_size_chained_population_properties(N, monkeypatch):
+    """The bench's configuration in full: replay 1e6 rows per learner, batch 256, 160 learners on the chained kernels (fragment-image
+    parameters), device-drawn indices and noise.  Size-independent properties: tau = 1 makes every target net equal its online
+    net after a policy step (through two different parameter layouts in HBM: frl_params_get translates both); a zero learning
+    rate moves the Adam moments but not the parameters; the rings survive untouched; losses are finite and positive."""
+    from freerl_amd.engine import Engine
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    cap, P, watch = 1_000_000, 160, (0, 81, 159)
+    e = Engine(N.ALGO_TD3, 8, 2, cap, n_learners=P, twin_critic=True, batch_max=256, seed=4321)
+    assert e.learn_path(256)[0]
+    rng = np.random.default_rng(6)
+    start = {}
+    for p in range(P):
+        for net in (0, 1):
+            flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
+            e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
+            e.set_params(net, flat, N.PARAM_TARGET, learner=p)
+            if p in watch:
+                start[p, net] = flat
+    e.fill_synthetic(cap, seed=98)
+    before = [e.read_rows(p, 654321, 32) for p in watch]
+    kw = dict(gamma=0.99, use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, want_stats=True)
+    st = e.learn(256, tau=0.005, actor_lr=0.0, critic_lr=0.0, do_actor=True, **kw)          # lr = 0: nothing but m, v and the targets move
+    assert np.all(np.isfinite(st)) and np.all(st[:, 0, N.STAT_CRITIC_LOSS] > 0)
+    for p in watch:
+        for net in (0, 1):
+            np.testing.assert_array_equal(e.get_params(net, learner=p), start[p, net])
+            assert np.abs(e.get_params(net, N.PARAM_ADAM_M, learner=p)).max() > 0
+    for k in range(3):
+        st = e.learn(256, tau=1.0, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k == 2), **kw)
+        assert np.all(np.isfinite(st))
+    for p in watch:
+        for net in (0, 1):
+            th = e.get_params(net, learner=p)
+            assert not np.array_equal(th, start[p, net])
+            np.testing.assert_array_equal(th, e.get_params(net, N.PARAM_TARGET, learner=p))
+    for p, b in zip(watch, before):
+        np.testing.assert_array_equal(b, e.read_rows(p, 654321, 32))
+    e.close()
+
+
 def test_device_index_draw_is_a_uniform_subset_without_replacement(N):
     """The device-side stand-in for `np.random.choice(len(buffer), B, replace=False)` (DQN.py:97) at its hardest point,
     len(buffer) == 2 * B (every second draw collides and is redrawn): distinct rows, all in range, every row equally
