@@ -77,7 +77,7 @@ struct Lds {
 
 // Carve the dynamic LDS region; must mirror lds_bytes() in the host code.
 __device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int kin_pad_max, int out_pad_max,
-                                         int batch_pad, int act_pad) {
+                                         int batch_pad, int act_pad, int hbufs) {
     Lds S;
     S.rc = rc;
     S.xp = kin_pad_max + 4;
@@ -87,7 +87,8 @@ __device__ __forceinline__ Lds carve_lds(float* smem, int rc, int hidden, int ki
     lds_f p = (lds_f)smem;
     S.xin = p; p += rc * S.xp;
     S.h1 = p; p += rc * S.hp;
-    S.h2 = p; p += rc * S.hp;
+    S.h2 = p;                      // (hbufs == 1: an alias nobody touches — a net of two layers goes xin -> h1 -> outb)
+    if (hbufs > 1) p += rc * S.hp;
     S.outb = p; p += rc * S.op;
     S.abuf = p; p += rc * S.ap;
     S.dabuf = p; p += rc * S.ap;

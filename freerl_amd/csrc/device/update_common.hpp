@@ -24,7 +24,7 @@ __device__ __forceinline__ void td_loss_row(const LearnArgs& a, float e, float& 
 }
 
 __device__ __forceinline__ Lds carve(const EngineDesc& D, float* smem) {
-    return carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    return carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
 }
 
 // block id -> (unit, slice): the `ns` row chunks of unit u = learner*n_agents + agent sit on

@@ -109,6 +109,7 @@ struct EngineDesc {
     int act_max;          // max act_dim over agents (row pitch of `noise`)
     // LDS carve parameters (must match between host lds_bytes() and device carve_lds())
     int lds_kin_pad, lds_out_pad, lds_batch_pad, lds_act_pad;
+    int lds_hbufs;        // hidden-activation buffers in the carve: 2, or 1 when no head of any net has more than one hidden layer (DQN's Q-net)
     int n_discrete;       // DQN: number of discrete actions (0 otherwise)
     float* isw;           // [P][batch_max] PER importance weights of the current sample (DQN_with_tricks.py:276-279)
     float* td_err;        // [P][batch_max] TD errors Q(s,a) - y left by the last DQN learn (PER priorities)

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     const EngineDesc& D = *Dp;
     const int p = blockIdx.y, r0 = blockIdx.x * D.rc;
     const NetDesc& N = D.net[a.net];
-    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
     const int rc = D.rc, nv = min(rc, a.n_rows - r0);
     const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
     g_cf theta = a.use_target == 2 ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[a.net])     // noisy set 0

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
     const int p = a.p0 + unit;
     const NetDesc& N = D.net[0];
     const RecordDesc& R = D.rec;
-    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
     const int rc = D.rc, B = a.batch, nl = N.n_layers;
     const int nchunks = (B + rc - 1) / rc, ck0 = sl * D.cps, ck1 = min(ck0 + D.cps, nchunks);
     const size_t base = (size_t)p * D.learner_stride + D.net_off[0];

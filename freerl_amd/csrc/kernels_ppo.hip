@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void ppo_values_kernel(const EngineDesc* __res
     const int nv = min(rc, T - r0);
     const NetDesc& N = D.net[1];
     const RecordDesc& R = D.rec;
-    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
     g_cf theta = as_global(D.theta + (size_t)p * D.learner_stride + D.net_off[1]);
     g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
     const int O = R.obs_dim[0], kpad = N.L[0].k_pad;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ppo_update_kernel(const EngineDesc* __res
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
     const RecordDesc& R = D.rec;
-    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad);
+    const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
     const size_t offA = (size_t)p * D.learner_stride + D.net_off[0], offC = (size_t)p * D.learner_stride + D.net_off[1];
     g_f thA = as_global(D.theta + offA);
     g_f thC = as_global(D.theta + offC);
