@@ -1253,9 +1253,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         ad.which = 0; ad.lr = a.critic_lr; ad.wd = a.critic_wd;
         ad.soft = (h.algo == ALGO_DQN) ? 1 : ((!maddpg && a.do_actor) ? 1 : 0);
         prof_begin(e, PK_ADAM_CRITIC);
-        if (h.noisy) {        // the sigma gradients are derived from the reduced gradient between the two passes
-            hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);
-            hipLaunchKernelGGL(noisy_sigma_grad_kernel, dim3(h.P), blk, 0, st, e->d);
+        if (h.noisy) {        // the two-pass chain: its reduce pass derives the sigma gradients from the head's slab sums
+            hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);      // (+ the sigma gradients)
             hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
         } else {
             launch_adam(e, st, ad, units, grid_adam);

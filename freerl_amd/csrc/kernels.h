@@ -139,7 +139,6 @@ __global__ void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, 
 
 // kernels_noisy.hip
 __global__ void noisy_materialise_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, int target_mask);
-__global__ void noisy_sigma_grad_kernel(const EngineDesc* __restrict__ Dp);
 __global__ void noisy_draw_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, unsigned long long counter);
 
 // kernels_per.hip

@@ -2,27 +2,14 @@
 // (mu_b + sigma_b * eps_b) with factorised noise eps_w = eps_out (x) eps_in, eps_b = eps_out, redrawn at EVERY forward.
 // The forward/backward kernels stay noise-agnostic: `noisy_materialise_kernel` writes the effective parameter set of one
 // forward (trunk copied, head = mu + sigma * eps) into theta_eff, the gradient w.r.t. the effective head weights lands in
-// the head's (= mu's) gradient slots, and `noisy_sigma_grad_kernel` derives d/d sigma = d/d W_eff * eps before Adam.
+// the head's (= mu's) gradient slots, and `reduce_kernel` derives d/d sigma = d/d W_eff * eps while it sums the slabs.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
 #include "device/net.hpp"
+#include "device/noisy.hpp"
 
 namespace frl {
-
-// eps of set `s` of learner p: [eps_in0[k_pad], eps_out0[n_pad], eps_in1[k_pad], eps_out1[n_pad]]
-__device__ __forceinline__ g_cf noisy_eps_of(const EngineDesc& D, const LayerDesc& H, int p, int s) {
-    return as_global(D.noisy_eps + ((size_t)p * 3 + s) * 2 * (H.k_pad + H.n_pad));
-}
-__device__ __forceinline__ float noisy_eps_w(g_cf eps, const LayerDesc& H, int split, int k, int n) {
-    const int sub = (n >= split) ? 1 : 0;
-    g_cf e = eps + sub * (H.k_pad + H.n_pad);
-    return e[k] * e[H.k_pad + n];
-}
-__device__ __forceinline__ float noisy_eps_b(g_cf eps, const LayerDesc& H, int split, int n) {
-    const int sub = (n >= split) ? 1 : 0;
-    return eps[sub * (H.k_pad + H.n_pad) + H.k_pad + n];
-}
 
 // grid (P, n_sets): set s of learner p <- (from_target[s] ? target : theta) with the head replaced by mu + sigma * eps_s.
 // The sigma used is always the ONLINE net's for the online sets and the TARGET net's for the target set (deepcopy keeps
@@ -45,22 +32,6 @@ __global__ __launch_bounds__(256) void noisy_materialise_kernel(const EngineDesc
     }
     for (int n = threadIdx.x; n < H.n_pad; n += kWG)
         dst[H.b_off + n] = src[H.b_off + n] + src[SG.b_off + n] * noisy_eps_b(eps, H, D.noisy_split, n);
-}
-
-// grad[sigma] = grad[head] * eps of the forward that was differentiated (set 2: the online net on s)
-__global__ __launch_bounds__(256) void noisy_sigma_grad_kernel(const EngineDesc* __restrict__ Dp) {
-    const EngineDesc& D = *Dp;
-    const int p = blockIdx.x;
-    const NetDesc& N = D.net[0];
-    const LayerDesc& H = N.L[N.n_layers - 1];
-    const LayerDesc& SG = N.L[N.n_layers];
-    g_f g = as_global(D.grad + (size_t)p * D.learner_stride + D.net_off[0]);
-    g_cf eps = noisy_eps_of(D, H, p, 2);
-    for (int i = threadIdx.x; i < H.k_pad * H.n_pad; i += kWG) {
-        const int k = i / H.n_pad, n = i - k * H.n_pad;
-        g[SG.w_off + i] = g[H.w_off + i] * noisy_eps_w(eps, H, D.noisy_split, k, n);
-    }
-    for (int n = threadIdx.x; n < H.n_pad; n += kWG) g[SG.b_off + n] = g[H.b_off + n] * noisy_eps_b(eps, H, D.noisy_split, n);
 }
 
 // device-drawn noise: f(x) = sign(x) sqrt(|x|) of standard normals (Noisy_net.py:72-76); padded slots stay zero

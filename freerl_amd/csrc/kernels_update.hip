@@ -22,6 +22,7 @@
 #include "device/net.hpp"
 #include "device/update_common.hpp"
 #include "kernels.h"
+#include "device/noisy.hpp"
 
 namespace frl {
 
@@ -158,12 +159,32 @@ __global__ __launch_bounds__(256) void reduce_kernel(const EngineDesc* __restric
     const size_t ls4 = (size_t)D.learner_stride / 4;
     float ss = 0.f;
     const int base = wg * (kWG * kAdamVec);
+    // NoisyLinear head (DQN only): the shadow layer's (sigma's) gradient is the head's (mu's: where the effective weights'
+    // gradient landed) times the noise of the differentiated forward — set 2, the online net on s.  Derived here from the
+    // same slab sums instead of a launch of its own between the two passes.
+    const bool noisy = D.noisy && D.algo == ALGO_DQN;
+    const LayerDesc& H = N.L[N.n_layers - 1];
+    const LayerDesc& SG = N.L[noisy ? N.n_layers : 0];
+    const int sw0 = noisy ? SG.w_off / 4 : n4, sw1 = noisy ? sw0 + H.k_pad * H.n_pad / 4 : n4;
+    const int sb0 = noisy ? SG.b_off / 4 : n4, sb1 = noisy ? sb0 + H.n_pad / 4 : n4;
+    g_cf eps = noisy ? noisy_eps_of(D, H, p, 2) : nullptr;
 #pragma unroll
     for (int j = 0; j < kAdamVec; ++j) {
         const int i = base + j * kWG + threadIdx.x;
         if (i < n4) {
-            f32x4 s = slab[i];
-            for (int k = 1; k < a.ns; ++k) s += slab[(size_t)k * ls4 + i];
+            const bool sig_w = i >= sw0 && i < sw1, sig_b = i >= sb0 && i < sb1;
+            const int src = sig_w ? H.w_off / 4 + (i - sw0) : (sig_b ? H.b_off / 4 + (i - sb0) : i);
+            f32x4 s = slab[src];
+            for (int k = 1; k < a.ns; ++k) s += slab[(size_t)k * ls4 + src];
+            if (sig_w) {
+                const int e0 = 4 * (i - sw0), kk = e0 / H.n_pad, n0 = e0 - kk * H.n_pad;        // Wk[k][n]: four outputs of one input
+                s.x *= noisy_eps_w(eps, H, D.noisy_split, kk, n0); s.y *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 1);
+                s.z *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 2); s.w *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 3);
+            } else if (sig_b) {
+                const int n0 = 4 * (i - sb0);
+                s.x *= noisy_eps_b(eps, H, D.noisy_split, n0); s.y *= noisy_eps_b(eps, H, D.noisy_split, n0 + 1);
+                s.z *= noisy_eps_b(eps, H, D.noisy_split, n0 + 2); s.w *= noisy_eps_b(eps, H, D.noisy_split, n0 + 3);
+            }
             g[i] = s;
             ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
         }
