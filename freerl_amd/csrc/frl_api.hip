@@ -1143,8 +1143,11 @@ static void launch_adam(frl_engine* e, hipStream_t st, const AdamArgs& ad, int u
         const int net = (h.algo == ALGO_DQN) ? 0 : (ad.which == 0 ? 2 * ag + 1 : 2 * ag);
         max_n4 = std::max(max_n4, h.net[net].size / 4);
     }
-    if (max_n4 <= kFusedThreads * kFusedVec && !getenv("FRL_ADAM_TWO_PASS")) {
+    const bool two_pass = getenv("FRL_ADAM_TWO_PASS") != nullptr;
+    if (max_n4 <= kFusedThreads * kFusedVec && !h.noisy && !two_pass) {
         hipLaunchKernelGGL(adam_fused_kernel, dim3(units), dim3(kFusedThreads), 0, st, e->d, ad);
+    } else if (max_n4 <= kFusedThreads * kFusedVecWide && !two_pass) {       // (also every NoisyLinear head: the sigma gradients)
+        hipLaunchKernelGGL(adam_fused_wide_kernel, dim3(units), dim3(kFusedThreads), 0, st, e->d, ad);
     } else {
         hipLaunchKernelGGL(reduce_kernel, grid_adam, dim3(256), 0, st, e->d, ad);
         hipLaunchKernelGGL(adam_kernel, grid_adam, dim3(256), 0, st, e->d, ad);
@@ -1253,12 +1256,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         ad.which = 0; ad.lr = a.critic_lr; ad.wd = a.critic_wd;
         ad.soft = (h.algo == ALGO_DQN) ? 1 : ((!maddpg && a.do_actor) ? 1 : 0);
         prof_begin(e, PK_ADAM_CRITIC);
-        if (h.noisy) {        // the two-pass chain: its reduce pass derives the sigma gradients from the head's slab sums
-            hipLaunchKernelGGL(reduce_kernel, grid_adam, blk, 0, st, e->d, ad);      // (+ the sigma gradients)
-            hipLaunchKernelGGL(adam_kernel, grid_adam, blk, 0, st, e->d, ad);
-        } else {
-            launch_adam(e, st, ad, units, grid_adam);
-        }
+        launch_adam(e, st, ad, units, grid_adam);      // (a NoisyLinear head's sigma gradients are derived in its slab sums)
         prof_end(e);
     } else if (stage == 1) {
         if (v2) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 / SAC in one launch

@@ -120,6 +120,7 @@ struct AdamArgs {
 };
 constexpr int kAdamVec = 8;                              // float4 per thread per workgroup (reduce_kernel / adam_kernel)
 constexpr int kFusedThreads = 1024, kFusedVec = 12;      // adam_fused_kernel: one workgroup per net, gradient in registers
+constexpr int kFusedVecWide = 18;                        // adam_fused_wide_kernel: nets up to 73 k parameters (element-major slab sums)
 
 // kernels_act.hip
 __global__ void act_kernel(const EngineDesc* __restrict__ Dp, ActArgs a);
@@ -168,6 +169,7 @@ __global__ void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int
 __global__ void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void adam_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
+__global__ void adam_fused_wide_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
 __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau, int p0);
 
 // kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)

@@ -243,9 +243,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const EngineDesc* __restrict_
 // workgroup (<= kFusedVec float4 per thread: every 128-wide net of the reference): the slabs are summed into registers,
 // the norm is a block reduction, and the Adam pass takes its gradient from the registers — the reduced gradient is
 // never written, the norm partials never leave the workgroup.  11 -> 9 floats of traffic per parameter at 2 slabs.
-__global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
-    __shared__ float red[kFusedThreads / 64];
-    const EngineDesc& D = *Dp;
+template <int VEC, bool WIDE>
+__device__ __forceinline__ void adam_fused_body(const EngineDesc& D, const AdamArgs& a, float* red) {
     const int n = D.n_agents;
     const int p = a.p0 + blockIdx.x / n, ag = blockIdx.x % n;
     const int net = adam_net_index(D, a.which, ag);
@@ -256,28 +255,61 @@ __global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineD
     const size_t ls4 = (size_t)D.learner_stride / 4;
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     const int t = steps[net] + 1;                             // in flight with the slab loads
-    // slab-major: all of a thread's loads of one slab in flight together (element-major, each element's slab sum was a
-    // dependent chain of waits: 57 us for 64 learners); per element the slabs are still added in index order
-    f32x4 g[kFusedVec];
+    f32x4 g[VEC];
+    if constexpr (!WIDE) {
+        // slab-major: all of a thread's loads of one slab in flight together (element-major, each element's slab sum was a
+        // dependent chain of waits: 57 us for 64 learners); per element the slabs are still added in index order
 #pragma unroll
-    for (int j = 0; j < kFusedVec; ++j) {
-        const int i = j * kFusedThreads + threadIdx.x;
-        g[j] = (i < n4) ? slab[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int k = 1; k < a.ns; ++k) {
-        const FRL_GLB f32x4* sk = slab + (size_t)k * ls4;
-        f32x4 tmp[kFusedVec];
-#pragma unroll
-        for (int j = 0; j < kFusedVec; ++j) {
+        for (int j = 0; j < VEC; ++j) {
             const int i = j * kFusedThreads + threadIdx.x;
-            tmp[j] = (i < n4) ? sk[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            g[j] = (i < n4) ? slab[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        for (int k = 1; k < a.ns; ++k) {
+            const FRL_GLB f32x4* sk = slab + (size_t)k * ls4;
+            f32x4 tmp[VEC];
 #pragma unroll
-        for (int j = 0; j < kFusedVec; ++j) g[j] += tmp[j];
+            for (int j = 0; j < VEC; ++j) {
+                const int i = j * kFusedThreads + threadIdx.x;
+                tmp[j] = (i < n4) ? sk[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g[j] += tmp[j];
+        }
+    } else {
+        // the wide instance (nets up to 1024 x VEC float4: DQN_with_tricks' Categorical + Noisy head, 68 k parameters with its
+        // sigma layer) has no registers for a second set: element-major sums, and — like reduce_kernel — the sigma layer's
+        // gradient taken from the head's slab sums times the differentiated forward's noise
+        const bool noisy = D.noisy && D.algo == ALGO_DQN;
+        const LayerDesc& H = N.L[N.n_layers - 1];
+        const LayerDesc& SG = N.L[noisy ? N.n_layers : 0];
+        const int sw0 = noisy ? SG.w_off / 4 : n4, sw1 = noisy ? sw0 + H.k_pad * H.n_pad / 4 : n4;
+        const int sb0 = noisy ? SG.b_off / 4 : n4, sb1 = noisy ? sb0 + H.n_pad / 4 : n4;
+        g_cf eps = noisy ? noisy_eps_of(D, H, p, 2) : nullptr;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int i = j * kFusedThreads + threadIdx.x;
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+            if (i < n4) {
+                const bool sig_w = i >= sw0 && i < sw1, sig_b = i >= sb0 && i < sb1;
+                const int src = sig_w ? H.w_off / 4 + (i - sw0) : (sig_b ? H.b_off / 4 + (i - sb0) : i);
+                sv = slab[src];
+                for (int k = 1; k < a.ns; ++k) sv += slab[(size_t)k * ls4 + src];
+                if (sig_w) {
+                    const int e0 = 4 * (i - sw0), kk = e0 / H.n_pad, n0 = e0 - kk * H.n_pad;
+                    sv.x *= noisy_eps_w(eps, H, D.noisy_split, kk, n0); sv.y *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 1);
+                    sv.z *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 2); sv.w *= noisy_eps_w(eps, H, D.noisy_split, kk, n0 + 3);
+                } else if (sig_b) {
+                    const int n0 = 4 * (i - sb0);
+                    sv.x *= noisy_eps_b(eps, H, D.noisy_split, n0); sv.y *= noisy_eps_b(eps, H, D.noisy_split, n0 + 1);
+                    sv.z *= noisy_eps_b(eps, H, D.noisy_split, n0 + 2); sv.w *= noisy_eps_b(eps, H, D.noisy_split, n0 + 3);
+                }
+            }
+            g[j] = sv;
+        }
     }
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < kFusedVec; ++j) ss += g[j].x * g[j].x + g[j].y * g[j].y + g[j].z * g[j].z + g[j].w * g[j].w;
+    for (int j = 0; j < VEC; ++j) ss += g[j].x * g[j].x + g[j].y * g[j].y + g[j].z * g[j].z + g[j].w * g[j].w;
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
@@ -295,7 +327,7 @@ __global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineD
     FRL_GLB f32x4* v = (FRL_GLB f32x4*)(D.v + off);
     FRL_GLB f32x4* tg = (FRL_GLB f32x4*)(D.target + off);
 #pragma unroll
-    for (int j = 0; j < kFusedVec; ++j) {
+    for (int j = 0; j < VEC; ++j) {
         const int i = j * kFusedThreads + threadIdx.x;
         if (i < n4) {
             f32x4 gi = g[j] * coef, thi = th[i], mi = m[i], vi = v[i];
@@ -314,6 +346,15 @@ __global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineD
         steps[net] = t;
         adam_publish(D, a, p, ag, total, steps);
     }
+}
+
+__global__ __launch_bounds__(kFusedThreads) void adam_fused_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
+    __shared__ float red[kFusedThreads / 64];
+    adam_fused_body<kFusedVec, false>(*Dp, a, red);
+}
+__global__ __launch_bounds__(kFusedThreads) void adam_fused_wide_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a) {
+    __shared__ float red[kFusedThreads / 64];
+    adam_fused_body<kFusedVecWide, true>(*Dp, a, red);
 }
 
 // MADDPG.update_target (MADDPG_simple.py:188-195): every agent's actor then critic.
