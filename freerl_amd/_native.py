@@ -14,7 +14,8 @@ LIB_DIR = os.path.join(HERE, "_lib")
 # FRL_HIP_VARIANT=<name> selects a developer build (tools/phase_timing.py): lib<...>_<name>.so compiled with
 # the extra flags in FRL_HIPCC_FLAGS.  Unset = the product library.
 _VARIANT = os.environ.get("FRL_HIP_VARIANT", "")
-LIB_PATH = os.path.join(LIB_DIR, "libfreerl_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
+# (developer variants live under tools/_bin/, next to the other developer binaries: _lib/ holds the product library only)
+LIB_PATH = os.path.join(ROOT, "tools", "_bin", "libfreerl_hip_%s.so" % _VARIANT) if _VARIANT else os.path.join(LIB_DIR, "libfreerl_hip.so")
 HEADER = os.path.join(ROOT, "include", "freerl_hip.h")
 
 FRL_MAX_AGENTS = 8
@@ -209,6 +210,7 @@ def build(force=False, verbose=False, jobs=None):
     unit built with the extra flags in FRL_HIPCC_FLAGS."""
     if not force and not needs_build():
         return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     if _VARIANT:
         cmd = _HIPCC + ["-shared", "-DFRL_UNITY", "-o", LIB_PATH, os.path.join(CSRC, "frl_api.hip")] + \

@@ -83,20 +83,7 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, voff + const_off, 0, FRL_ADAM_AUX_ST);
 }
 
-// A "background task" of ChainNet::forward: pre<S>() / post<S>() are called once per k-block of the 128 x 128 layer (8 per
-// forward, S counts up from the caller's SLOT0) in front of and behind that block's MFMAs.  The persistent critic kernel
-// (kernels_critic3.hip) hangs the PREVIOUS learner's clip + Adam + soft update there, one accumulator tile per slot — loads in
-// pre, arithmetic and stores in post: they are independent of the MFMA chains, so they issue in the chains' shadow (one wave
-// per SIMD: ~5 issue slots per MFMA are free) and the HBM stream of the update runs under the matrix work instead of after it.
-struct NoBackground {
-    static constexpr bool kPipelined = false;
-    template <int S> static constexpr bool has_load() { return false; }
-    template <int S> static constexpr bool has_store() { return false; }
-    template <int S> __device__ __forceinline__ void pre() {}
-    template <int S> __device__ __forceinline__ void post() {}
-};
-// scheduling-group masks of __builtin_amdgcn_sched_group_barrier
-constexpr int kSgMfma = 0x008, kSgValu = 0x002, kSgVmemRead = 0x020, kSgVmemWrite = 0x040, kSgDsRead = 0x100;
+
 
 struct ChainNet {
     ChainLds S;
@@ -162,17 +149,15 @@ struct ChainNet {
     // middle, tile inner), so that consecutive MFMAs never wait for each other's result.
     template <int T>
     __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T]) const {
-        NoBackground nb;
-        forward<T, 0>(xb, h1, h2, z, nb);
+        forward<T, false>(xb, h1, h2, z);
     }
     // ... with the head of hn <= 4 outputs as dot products (head_valu)
     template <int T>
     __device__ __forceinline__ void forward_vh(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn) const {
-        NoBackground nb;
-        forward<T, 0, NoBackground, true>(xb, h1, h2, z, nb, hn);
+        forward<T, true>(xb, h1, h2, z, hn);
     }
-    template <int T, int SLOT0, class BG, bool VH = false>
-    __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], BG& bg, int hn = 0) const {
+    template <int T, bool VH>
+    __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn = 0) const {
         // first layer: all eight fragments and biases in flight before the first MFMA.  (All four k-steps are needed whatever the
         // input width: k-step e of the fragment layout holds columns e, 4 + e, 8 + e, 12 + e, so the zero padding is spread
         // over every step — a build that skipped "unused" steps dropped real columns and failed parity by 1 %.)
@@ -195,62 +180,18 @@ struct ChainNet {
 #pragma unroll
             for (int t = 0; t < T; ++t) h2[t][ot] = bb;
         }
-        if constexpr (!BG::kPipelined) {
-            static_for<0, kHT>([&](auto kbc) {
-                constexpr int kb = decltype(kbc)::value;
-                f32x4 wf[kHT];
+        static_for<0, kHT>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            f32x4 wf[kHT];
 #pragma unroll
-                for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int ot = 0; ot < kHT; ++ot)
+                for (int ot = 0; ot < kHT; ++ot)
 #pragma unroll
-                        for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
-            });
-        } else {
-            // With a background task every k-block is its own scheduling region with a pinned issue order: the task's four
-            // stores and four loads first, then each MFMA followed by three VALU slots (the task's arithmetic) and, every fourth
-            // MFMA, one fragment read of the NEXT k-block (the fragments are double-buffered in the source).  Left alone the
-            // scheduler sinks every load, multiply and store of the task behind the layer's last MFMA and serialises them
-            // there behind vmcnt(0) waits.
-            f32x4 wf[2][kHT];
-#pragma unroll
-            for (int ot = 0; ot < kHT; ++ot) wf[0][ot] = ld4((lds_cf)(S.w2 + (ot * kHT) * 256 + fslot));
-            static_for<0, kHT>([&](auto kbc) {
-                constexpr int kb = decltype(kbc)::value, S_ = SLOT0 + kb;
-                __builtin_amdgcn_sched_barrier(0);
-                // The task's loads and stores are issued together right behind ONE explicit drain at the top of the block:
-                // everything outstanding then is at least a whole k-block (~1 k cycles) old, the unit computed in this block finds
-                // its operands landed, and nothing inside the block waits on memory again (gfx9 has one counter for loads and
-                // stores: a wait placed between them by the compiler becomes a vmcnt(0) in the middle of the MFMA chain).
-                if constexpr (BG::template has_load<S_>() || BG::template has_store<S_>()) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-                if constexpr (kb + 1 < kHT) {
-#pragma unroll
-                    for (int ot = 0; ot < kHT; ++ot) wf[(kb + 1) & 1][ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb + 1) * 256 + fslot));
-                }
-                bg.template pre<S_>();                                  // the background unit's loads ...
-                bg.template post<S_>();                                 // ... and the PREVIOUS unit's arithmetic + stores
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int ot = 0; ot < kHT; ++ot)
-#pragma unroll
-                        for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb & 1][ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
-                if constexpr (BG::template has_store<S_>()) __builtin_amdgcn_sched_group_barrier(kSgVmemWrite, 4, 0);
-                if constexpr (BG::template has_load<S_>()) __builtin_amdgcn_sched_group_barrier(kSgVmemRead, 4, 0);
-#pragma unroll
-                for (int i = 0; i < 8 * T; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        __builtin_amdgcn_sched_group_barrier(kSgMfma, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(kSgValu, 3, 0);
-                    }
-                    if (i < 8 && kb + 1 < kHT) __builtin_amdgcn_sched_group_barrier(kSgDsRead, 1, 0);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                    for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[t][kb][e], h2[t][ot], 0, 0, 0);
+        });
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll

@@ -25,7 +25,6 @@
 #include "kernels_ppo.hip"
 #include "kernels_ppo2.hip"
 #include "kernels_critic2.hip"
-#include "kernels_critic3.hip"
 #include "kernels_actor2.hip"
 #include "kernels_dqn2.hip"
 #include "kernels_per.hip"
@@ -217,7 +216,7 @@ static int lds_bytes_for(const EngineDesc& h, int rc) {
 
 // --------------------------------------------------------------------------------- lifetime
 extern "C" const char* frl_last_error(void) { return g_err.c_str(); }
-extern "C" int frl_version(void) { return 100; }
+extern "C" int frl_version(void) { return 101; }      // 101: frl_rollout_args.explore_kind 0 = FRL_EXPLORE_DEFAULT
 
 extern "C" int frl_device_count(int* n_out) {
     if (!n_out) return fail(FRL_ERR_INVALID, "n_out is NULL");
@@ -504,9 +503,6 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        for (auto k : {ac_critic_v3_twin_soft_kernel, ac_critic_v3_twin_hold_kernel, ac_critic_v3_twin_b128_soft_kernel, ac_critic_v3_twin_b128_hold_kernel,
-                       ac_critic_v3_single_soft_kernel, ac_critic_v3_single_hold_kernel, ac_critic_v3_single_b128_soft_kernel, ac_critic_v3_single_b128_hold_kernel})
-            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, c.device_id));
         e->n_cus = std::max(1, prop.multiProcessorCount);
@@ -903,7 +899,7 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     memset(&a, 0, sizeof a);
     if (ex) {
         frl_explore_args x = ex->x;
-        if (x.kind == FRL_EXPLORE_OFF) x.kind = FRL_EXPLORE_NONE;
+        if (x.kind == FRL_EXPLORE_OFF) return fail(FRL_ERR_INVALID, "FRL_EXPLORE_OFF is a frl_rollout_args value; frl_explore_args.kind takes FRL_EXPLORE_NONE");
         if (x.kind < FRL_EXPLORE_NONE || x.kind > FRL_EXPLORE_OU) return fail(FRL_ERR_INVALID, "unknown exploration kind %d", x.kind);
         if (!ex->env_out_dev) return fail(FRL_ERR_INVALID, "exploration needs an env-action output");
         if (x.kind == FRL_EXPLORE_EPS_GREEDY && mode != FRL_ACT_ARGMAX) return fail(FRL_ERR_INVALID, "epsilon-greedy goes with FRL_ACT_ARGMAX");
@@ -1229,21 +1225,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
             const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
-            // FRL_CRITIC_PERSIST=1: the persistent form (kernels_critic3.hip).  Correct (bitwise equal to the launch below) but, as
-            // measured in round 3, not faster yet: see DESIGN.md §8 — the update in the MFMA shadow stalls on its own loads
-            const char* pe = getenv("FRL_CRITIC_PERSIST");
-            if (pe ? atoi(pe) != 0 : false) {
-                // kernels_critic3.hip: one workgroup per CU walks through its learners, each learner's update in the shadow of
-                // the next one's target passes
-                using K = void (*)(const EngineDesc*, LearnArgs);
-                const bool twin = h.net[1].heads == 2, small = a.batch <= 128, soft = a.do_actor != 0;
-                static const K table[2][2][2] = {
-                    {{ac_critic_v3_single_hold_kernel, ac_critic_v3_single_soft_kernel}, {ac_critic_v3_single_b128_hold_kernel, ac_critic_v3_single_b128_soft_kernel}},
-                    {{ac_critic_v3_twin_hold_kernel, ac_critic_v3_twin_soft_kernel}, {ac_critic_v3_twin_b128_hold_kernel, ac_critic_v3_twin_b128_soft_kernel}}};
-                int grid = std::min(pc, e->n_cus);
-                if (const char* ge = getenv("FRL_CRITIC_GRID")) grid = std::max(1, std::min(grid, atoi(ge)));      // developer knob: fewer, longer-running workgroups
-                hipLaunchKernelGGL(table[twin][small][soft], dim3(grid), blk, lb, st, e->d, a);
-            } else if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
+            if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
             else hipLaunchKernelGGL(ac_critic_v2_single_kernel, dim3(pc), blk, lb, st, e->d, a);
             prof_end(e);
             return;

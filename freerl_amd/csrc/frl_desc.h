@@ -44,7 +44,7 @@ constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w +
               kL3b = kL3w + 16 * 128, kHeadFloats = kL3b + 16;
 
 // float index of W[out n][in k] inside a layer's weight block (host and device)
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline int weight_index(const NetDesc& N, const LayerDesc& L, int n, int k) {

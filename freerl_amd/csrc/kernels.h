@@ -142,8 +142,6 @@ __global__ void dqn_grad_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, 
 __global__ void noisy_materialise_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, int target_mask);
 __global__ void noisy_draw_kernel(const EngineDesc* __restrict__ Dp, int set0, int n_sets, unsigned long long counter);
 
-// kernels_per.hip
-__global__ void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch);
 __global__ void per_add_kernel(PerArgs a, const int* __restrict__ bucket, int P);
 __global__ void per_set_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
 __global__ void per_sample_kernel(const EngineDesc* __restrict__ Dp, PerArgs a);
@@ -164,6 +162,7 @@ __global__ void replay_commit_kernel(float* __restrict__ ring, RecordDesc rec, i
 __global__ void replay_fill_kernel(float* __restrict__ ring, long long rows, RecordDesc rec, int n_discrete, unsigned long long seed);
 
 // kernels_update.hip
+__global__ void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch);      // scratch: [4][P][learner_stride]
 __global__ void draw_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int want_noise);
 __global__ void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows, int p0);
 __global__ void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
@@ -175,15 +174,6 @@ __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau,
 // kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)
 __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-// kernels_critic3.hip: the persistent form (grid = min(learners, CUs); <twin | single critic>_<batch <= 256 | <= 128>_<soft target update in this launch | not>)
-__global__ void ac_critic_v3_twin_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_twin_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_twin_b128_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_twin_b128_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_single_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_single_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_single_b128_soft_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
-__global__ void ac_critic_v3_single_b128_hold_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise

@@ -235,6 +235,8 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) S.red[16 + 4 * r + w] = gls[r];
     }
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    if (tid == 0) S.red[32] = __int_as_float(steps[0]);                // (thread 0 rewrites steps[0] after the update: the count travels with the partials)
     lds_barrier();
     // log_std gradient of component i16 (lanes i16 < A); outside the clamp [-20, 2] the gradient is zero (SAC.py:77)
     float g_extra = 0.f, ss_extra = 0.f;
@@ -252,8 +254,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     const float total = sqrtf((((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]) + ss_extra);
     const float qtot = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
     const float lptot = ((S.red[12] + S.red[13]) + S.red[14]) + S.red[15];
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t = steps[0] + 1;
+    const int t = __float_as_int(S.red[32]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     AdamCoef co;
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;

@@ -256,12 +256,15 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     ss = wave_sum(ss);
     const float lsum = wave_sum(lossp);
     lds_barrier();
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     if (l == 0) { S.red[w] = ss; S.red[8 + w] = lsum; }
+    // the step count travels through LDS with the norm partials: thread 0 rewrites steps[1] at the end of the update with no
+    // barrier in between, so a wave must not read it from global memory on its own schedule
+    if (tid == 0) S.red[16] = __int_as_float(steps[1]);
     lds_barrier();
     const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
     const float loss = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
-    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t = steps[1] + 1;
+    const int t = __float_as_int(S.red[16]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     AdamCoef co;
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;

@@ -367,8 +367,9 @@ __global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __re
 
 // Fragment-image order -> Wk[k][n] for every weight block of the frag nets of all learners, in all four parameter arrays: what
 // frl_obsnorm_enable does to an engine created for the register-chained kernels before it hands it to the row-chunk family
-// (those kernels read Wk; Batch_ObsNorm is theirs).  grid = (P, 4 arrays); the learner's block goes through `scratch`
-// ([P][learner_stride], the engine's reduced-gradient array: unused by the chained family).
+// (those kernels read Wk; Batch_ObsNorm is theirs).  grid = (P, 4 arrays); a learner's block of array y goes through
+// scratch[y][p][learner_stride] — `scratch` is FOUR times the engine's reduced-gradient array (frl_obsnorm_enable allocates it;
+// D.grad itself is too small).
 __global__ __launch_bounds__(256) void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch) {
     const EngineDesc& D = *Dp;
     const int p = blockIdx.x;

@@ -36,11 +36,7 @@ def _native_comm_create(rank, world, local_rank):
         N.check(L.frl_comm_unique_id(buf))
     except Exception as ex:      # noqa: BLE001 - agreed on below
         err = ex
-    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
-    if dist.get_backend() == "nccl":
-        ok = ok.cuda()
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
+    if not _all_ok(err is None):
         raise err if err else N.FrlError("another rank cannot create the RCCL communicator")
     uid = torch.zeros(N.FRL_COMM_ID_BYTES, dtype=torch.uint8)
     if rank == 0:
@@ -50,8 +46,29 @@ def _native_comm_create(rank, world, local_rank):
     dist.broadcast(uid, src=0)
     raw = (C.c_uint8 * N.FRL_COMM_ID_BYTES)(*[int(x) for x in uid.cpu().tolist()])
     h = C.c_void_p()
-    N.check(L.frl_comm_create(raw, int(rank), int(world), int(local_rank), C.byref(h)))
+    err = None
+    try:
+        N.check(L.frl_comm_create(raw, int(rank), int(world), int(local_rank), C.byref(h)))
+    except Exception as ex:      # noqa: BLE001 - agreed on below
+        err, h = ex, None
+    # The join can still fail on ONE rank (device_id out of range, an allocation after ncclCommInitRank, an RCCL error on one
+    # GPU).  The communicator is used by every rank or by none: a second agreement round, and the ranks that did join tear
+    # theirs down if anybody did not — otherwise barrier() / allreduce_metrics() would run ncclAllReduce on some ranks and
+    # gloo on the others and the job would hang.
+    if not _all_ok(err is None):
+        if h is not None:
+            L.frl_comm_destroy(h)
+        raise err if err else N.FrlError("another rank failed to join the RCCL communicator")
     return h
+
+
+def _all_ok(mine):
+    """True iff every rank of the process group reports success (all_reduce MIN of a flag)."""
+    ok = torch.tensor([1 if mine else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        ok = ok.cuda()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return int(ok.item()) == 1
 
 
 def init(backend=None):

@@ -323,6 +323,10 @@ int frl_envpool_step(frl_envpool* p, const float* actions, float* next_obs, floa
  * The action handed to add() is the policy's own output (continuous) or the explored index (discrete), as in the reference. */
 enum frl_explore_kind { FRL_EXPLORE_NONE = 0, FRL_EXPLORE_EPS_GREEDY = 1, FRL_EXPLORE_GAUSS = 2, FRL_EXPLORE_OU = 3,
                         FRL_EXPLORE_OFF = 4 /* frl_rollout_args.explore_kind only: explicitly no exploration noise */ };
+/* frl_rollout_args.explore_kind counts 0 differently from frl_explore_args.kind (since frl_version 101): there 0 is what a
+ * zero-initialised struct carries and selects the algorithm's loop default, so "no noise" has its own value, FRL_EXPLORE_OFF.
+ * Write FRL_EXPLORE_DEFAULT, never FRL_EXPLORE_NONE, into rollout args; frl_act_explore rejects FRL_EXPLORE_OFF. */
+#define FRL_EXPLORE_DEFAULT 0
 typedef struct frl_explore_args {
     int kind;
     float epsilon;
@@ -348,8 +352,9 @@ typedef struct frl_rollout_args {
     int host_explore;        /* 0: exploration inside the act launch — per vector step ONE D2H (env actions) and ONE H2D (the
                               * env outputs), records assembled on the device; 1: round 1's loop (host generator, obs H2D +
                               * action D2H + staged records H2D) kept for comparison */
-    int explore_kind;        /* 0 (a zero-initialised struct) or -1: the algorithm's loop default (DQN epsilon-greedy, DDPG/TD3
-                              * Gaussian, SAC none); FRL_EXPLORE_EPS_GREEDY / _GAUSS / _OU: that rule; FRL_EXPLORE_OFF: none */
+    int explore_kind;        /* FRL_EXPLORE_DEFAULT (0, a zero-initialised struct) or -1: the algorithm's loop default (DQN
+                              * epsilon-greedy, DDPG/TD3 Gaussian, SAC none); FRL_EXPLORE_EPS_GREEDY / _GAUSS / _OU: that rule;
+                              * FRL_EXPLORE_OFF: none (a deterministic evaluation rollout).  NOT FRL_EXPLORE_NONE: that is 0 */
     float gauss_init_scale, gauss_final_scale;   /* with max_episodes > 0: a learner's noise multiplier decays with ITS finished episodes, */
     int max_episodes;                            /* scale = final + (init - final) * max(0, max_episodes - episodes) / max_episodes (TD3.py:425-427, SAC.py:548-556) */
     float ou_theta, ou_sigma, ou_dt;             /* OUNoise(theta 0.15, sigma, dt) (SAC.py:334-356) */

@@ -109,3 +109,63 @@ def test_bench_refuses_world_size_mismatch():
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+
+
+JOIN_FAIL_WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from freerl_amd import dist as fd
+    from freerl_amd import _native as N
+    rank, world, local = fd.init("gloo")
+    destroyed = []
+
+    class FakeLib:                       # frl_comm_* of the C ABI: the id probe succeeds everywhere, the JOIN fails on rank 1 only
+        def frl_comm_unique_id(self, buf):
+            return 0
+        def frl_comm_create(self, raw, r, w, dev, out):
+            if r == 1:
+                return 1
+            out._obj.value = 1234
+            return 0
+        def frl_comm_destroy(self, h):
+            destroyed.append(int(h.value))
+            return 0
+
+    N.lib = lambda: FakeLib()
+    def check(rc):
+        if rc:
+            raise N.FrlError("injected join failure")
+    N.check = check
+    try:
+        fd._native_comm_create(rank, world, local)
+        outcome = "joined"
+    except N.FrlError as ex:
+        outcome = "raised: " + str(ex)
+    # every rank is back on the process group: the same collective completes on both
+    m = fd.allreduce_metrics(1.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    print(json.dumps(dict(rank=rank, outcome=outcome, destroyed=destroyed, env_steps=m["env_steps"])))
+    dist.barrier(); dist.destroy_process_group()
+''') % ROOT
+
+
+def test_join_failure_on_one_rank_leaves_no_rank_with_a_communicator(tmp_path):
+    """frl_comm_create failing on ONE rank: the ranks that joined destroy their communicator and every rank raises, so
+    init() falls back to the process group everywhere (a communicator on some ranks only would hang the next collective)."""
+    import json
+    script = tmp_path / "jf.py"
+    script.write_text(JOIN_FAIL_WORKER)
+    port = 30100 + (os.getpid() % 500)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert outs[0]["outcome"].startswith("raised") and outs[1]["outcome"].startswith("raised")
+    assert outs[0]["destroyed"] == [1234] and outs[1]["destroyed"] == []
+    assert outs[0]["env_steps"] == 2.0 and outs[1]["env_steps"] == 2.0
