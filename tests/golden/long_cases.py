@@ -2,7 +2,7 @@
 
 north_star's "TD-loss curve matching reference seed=0 to 1e-4" is a statement about hundreds of consecutive learn() calls;
 the injected-draw cases of `cases.py` are 2-8 calls long.  These cases run the imported reference for 500 (DQN,
-DDPG, TD3, SAC) calls and one full-size PPO learn() (320 + 320 minibatch steps) on seeded inputs with every legacy-RNG
+DDPG, TD3, SAC) calls, 150 MADDPG calls at config 5's shape and one full-size PPO learn() (320 + 320 minibatch steps) on seeded inputs with every legacy-RNG
 draw injected, and store the per-call LOSSES only (a few KB each).  `tests/test_gpu_longrun.py` compares the HIP engine
 DIRECTLY with these curves on every kernel family; `tests/test_oracle_golden.py` holds the oracle to them on CPU.
 
@@ -37,6 +37,11 @@ LONG = {
     # PPO_with_tricks.learn (PPO_file/PPO_with_tricks.py:290-354) at BASELINE config 3's full shape: one learn() = 320 + 320 steps
     "long_ppo_c3": dict(cases.CASES["ppo"], obs_dim=17, act_dim=6, horizon=2048, minibatch=64, k_epochs=10, table_seed=531,
                         param_seed=532, perm_seed=533, actor_lr=3e-4, critic_lr=3e-4),
+    # MADDPG_simple.learn (MADDPG_file/MADDPG_simple.py:165-195) at BASELINE config 5's full shape (simple_spread_v3: 3 agents,
+    # obs 18, act 5, batch 1024), 150 calls = 450 critic + 450 actor updates; one index set per agent and call (:169)
+    "long_maddpg_c5": dict(kind="maddpg", dims={"agent_0": [18, 5], "agent_1": [18, 5], "agent_2": [18, 5]}, batch=1024, n_table=2048,
+                           capacity=4096, n_calls=150, n_learn=150, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3,
+                           table_seed=541, param_seed=5420, idx_seed=54300),
 }
 
 
@@ -65,3 +70,11 @@ def ac_inputs(c):
 
 def ppo_inputs(c):
     return cases.ppo_inputs(c)
+
+
+def maddpg_inputs(c):
+    """tables / params per agent as cases.maddpg_inputs; idx[k][j] = agent j's index set in call k (drawn without replacement)."""
+    inp = cases.maddpg_inputs(dict(c, n_learn=0))
+    g = np.random.default_rng(c["idx_seed"])
+    inp["idx"] = [[g.choice(c["n_table"], c["batch"], replace=False).astype(np.int64) for _ in inp["ids"]] for _ in range(c["n_calls"])]
+    return inp

@@ -1085,6 +1085,33 @@ def gen_long_ppo_c3(out):
     out["adv_raw"] = proxy.captured[0].astype(np.float32)
 
 
+def gen_long_maddpg_c5(out):
+    """150 MADDPG_simple.learn calls at config 5's shape: per-agent critic / actor loss curves [150][3]."""
+    from tests.golden import long_cases as LC
+    c = LC.LONG["long_maddpg_c5"]
+    inp = LC.maddpg_inputs(c)
+    ids = inp["ids"]
+    mod = import_reference("MADDPG_file", "MADDPG_simple")
+    pol = mod.MADDPG(copy.deepcopy(c["dims"]), True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU)
+    for aid in ids:
+        ag = pol.agents[aid]
+        for net in ("actor", "critic"):
+            load(getattr(ag, net), inp["params"][aid][net])
+            load(getattr(ag, net + "_target"), inp["params"][aid][net])
+    for i in range(c["n_table"]):
+        pol.add({a: inp["tables"][a]["obs"][i] for a in ids}, {a: inp["tables"][a]["act"][i] for a in ids},
+                {a: float(inp["tables"][a]["rew"][i]) for a in ids}, {a: inp["tables"][a]["next_obs"][i] for a in ids},
+                {a: bool(inp["tables"][a]["done"][i]) for a in ids})
+    recs = {a: wrap_losses(pol.agents[a], ["update_critic", "update_actor"]) for a in ids}
+    flat_idx = [ix for per_call in inp["idx"] for ix in per_call]
+    with inject(np.random, "choice", feeder(flat_idx)):
+        for _ in range(c["n_calls"]):
+            pol.learn(c["batch"], c["gamma"], c["tau"])
+    out["loss_critic"] = np.stack([np.array(recs[a]["update_critic"], dtype=np.float32) for a in ids], axis=1)
+    out["loss_actor"] = np.stack([np.array(recs[a]["update_actor"], dtype=np.float32) for a in ids], axis=1)
+    for a in ids:
+        out["critic_l1_weight_sum/" + a] = np.float64(pol.agents[a].critic.state_dict()["l1.weight"].double().sum().item())
+
 
 def survey_known_answers():
     """SURVEY.md §8(c) recorded `DQN.learn` losses for torch-seeded init + legacy-RNG indices.
@@ -1118,7 +1145,7 @@ def main():
         "traj_ddpg_full": gen_traj_ddpg_full, "traj_maddpg": gen_traj_maddpg, "traj_matd3": gen_traj_matd3,
         "traj_ppo": gen_traj_ppo,
         "long_dqn": gen_long_dqn, "long_ddpg": lambda o: gen_long_ac("long_ddpg", o), "long_td3_c2": lambda o: gen_long_ac("long_td3_c2", o),
-        "long_sac": lambda o: gen_long_ac("long_sac", o), "long_ppo_c3": gen_long_ppo_c3,
+        "long_sac": lambda o: gen_long_ac("long_sac", o), "long_ppo_c3": gen_long_ppo_c3, "long_maddpg_c5": gen_long_maddpg_c5,
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]
