@@ -153,7 +153,7 @@ def test_c4_sac_collector_256_envs_at_humanoid_dims(N, P):
     from freerl_amd.engine import Engine
     from freerl_amd.envpool import CallbackEnvPool, rollout
     E, O, A, ma, steps = 256, 376, 17, 0.4, 5
-    envs = [_BandEnv(O, A, ma, 500 + i, limit=3 if i % 50 == 7 else 1000) for i in range(P * E)]       # some envs truncate and reset inside the run
+    envs = [_BandEnv(O, A, ma, 500 + i, limit=3 if (i % E) % 50 == 7 else 1000) for i in range(P * E)]       # some envs truncate and reset inside the run
     pool = CallbackEnvPool(envs)
     assert (pool.obs_dim, pool.act_dim, pool.n_actions) == (O, A, 0) and abs(pool.max_action - ma) < 1e-7
     e = Engine(N.ALGO_SAC, O, A, 4096, twin_critic=True, batch_max=256, n_learners=P, seed=9)
