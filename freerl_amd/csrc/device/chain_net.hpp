@@ -106,6 +106,10 @@ struct ChainNet {
         S.q1 = p; p += kChainBatch;
         S.lpn = p; p += kChainBatch;
         S.red = p; p += 64;
+        init_lanes();
+    }
+    // the lane constants alone (device/chain_wide.hpp carves its own LDS and borrows the tile helpers below)
+    __device__ __forceinline__ void init_lanes() {
         tid = threadIdx.x; l = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6); i16 = l & 15; q = l >> 4;
         fslot = (q * 16 + (i16 ^ q)) << 2;                             // forward / exchange fragment read (16 B)
         tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);                  // transposed read / owner write: + ((f ^ (i16 >> 2)) << 2)

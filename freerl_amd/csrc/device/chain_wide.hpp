@@ -1,0 +1,477 @@
+// The register-chained design (device/chain_net.hpp) for the shapes one LDS image per layer cannot hold: a FIRST LAYER of up to
+// 416 input columns (SAC at Humanoid-v4's dims: 376 + 17; MADDPG's centralised critics: 69) and heads of up to 32 outputs, hidden
+// 128 — kernels_criticw.hip / kernels_actorw.hip.  One workgroup owns one (learner, agent); parameters in fragment-image order
+// in HBM (NetDesc::frag).
+//
+//   * W1 (up to 26 k-blocks x 8 output tiles = 208 KB) never sits in LDS as a whole: the first layer of a pass runs as a SWEEP
+//     over K-slices of four k-blocks (32 KB), double-buffered — slice s + 1 travels global -> registers -> LDS under the MFMAs of
+//     slice s — with the pre-activation accumulators of up to FOUR 16-row tiles per wave (the 256 rows of a super-chunk) in
+//     registers, so a slice is fetched once per 256 rows and every fragment read from LDS feeds 4 x 4 MFMAs.  The row operand
+//     needs no LDS at all: lane (row, q) of a tile reads columns 16 kb + 4 q .. + 3 of its row straight from the replay record
+//     (or the per-row scratch that holds a policy's actions).
+//   * layers 2 and 3 run on the images of W2 (64 KB) and the head (8 - 16 KB) exactly as in chain_net.hpp; the union that held
+//     the W1 slices then serves the backward's activation / delta exchanges.
+//   * dW1 (up to 200 16 x 16 tiles) cannot live in registers next to the backward of a chunk.  The chunk loop leaves the
+//     first-layer deltas in a per-learner HBM scratch (in exchange-image order, 32 KB per 64 rows, L2-resident), and a separate
+//     pass contracts them with the rows: wave w owns output half (w & 1) and the k-tiles of parity (w >> 1) — up to 13 x 4
+//     accumulator tiles = 208 registers — and reads BOTH operands without LDS: the transposed row fragment is four dword loads
+//     per (k-tile, 16-row block), the delta fragment one dwordx4 from the scratch image.
+//   * every head's gradients go to the engine's `grad` array in image order; clip + Adam + soft update then stream the net once
+//     (the accumulators of two wide heads do not fit next to each other, and the clip coefficient needs all of them).
+#pragma once
+#include "chain_net.hpp"
+#include "update_common.hpp"
+
+namespace frl {
+
+// (the family's constants — kWideSliceKB, kWideSlice, kWideMaxKB1, kWideMaxKT, kWideApitch, kWideScratchPerRow, wide_lds_floats() —
+// are in frl_desc.h: the host sizes LDS and scratch from them)
+
+// per-(learner, agent) scratch in HBM, `bm` = batch_max rounded up to 64 rows; offsets in floats
+struct WideScratch {
+    g_f anext, apol, dqa, yb, q1, lpn, dz1, ah1, ah2;
+    __device__ __forceinline__ void init(g_f base, int bm) {
+        anext = base; apol = base + 32 * (size_t)bm; dqa = base + 64 * (size_t)bm;
+        yb = base + 96 * (size_t)bm; q1 = base + 97 * (size_t)bm; lpn = base + 98 * (size_t)bm;
+        dz1 = base + 100 * (size_t)bm; ah1 = base + 228 * (size_t)bm; ah2 = base + 356 * (size_t)bm;
+    }
+};
+
+// where the columns of one row come from: [0, OT) at po[f], [OT, XT) at pa[f] (pa is pre-shifted by -OT), zero beyond
+struct RowPtr { g_cf po, pa; };
+
+// weight-gradient accumulators of one head a lane owns next to the chunk loop (layer 2 and the head; transposed, see chain_net.hpp)
+template <int NT3>
+struct WideGrad {
+    f32x4 g2[2][kHT], g3[NT3][2];
+    float gb1[2], gb2[2], gb3[NT3];
+};
+
+struct WideNet {
+    ChainNet C;            // lane constants and the tile helpers; C.S points into the carve below (w1 / ab / yb / q1 / lpn unused)
+    lds_f u;               // the union: W1 slice buffers u, u + kWideSlice  |  exchange buffers C.S.ea = u, C.S.eb = u + 8192
+
+    __device__ __forceinline__ void init(float* smem) {
+        lds_f p = (lds_f)smem;
+        C.S.w2 = p; p += kHT * kHT * 256;
+        C.S.w3 = p; p += 2 * kHT * 256;
+        u = p; C.S.ea = p; C.S.eb = p + kHT * 4 * 256; p += 2 * kWideSlice;
+        C.S.b1 = p; p += 128;
+        C.S.b2 = p; p += 128;
+        C.S.b3 = p; p += 32;
+        C.S.ls = p; p += 32;
+        C.S.red = p; p += 64;
+        C.S.w1 = u; C.S.ab = u; C.S.yb = u; C.S.q1 = u; C.S.lpn = u;
+        C.init_lanes();
+    }
+
+    // ---- layers 2 and 3 of one head -> LDS images (linear copies, in the open), biases, log_std.  th = the net's block,
+    // L = the head's three LayerDescs, nt3 = head tiles
+    __device__ __forceinline__ void stage23(g_cf th, const LayerDesc* L, int nt3, int extra_off, int extra_n) const {
+        const int tid = C.tid;
+        f32x4 t2[16], t3[4];
+        g_cf w2 = th + L[1].w_off, w3 = th + L[2].w_off;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t2[j] = ld4(w2 + 4 * (tid + 256 * j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t3[j] = j < 2 * nt3 ? ld4(w3 + 4 * (tid + 256 * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float bb1 = 0.f, bb2 = 0.f, bb3 = 0.f, lsv = 0.f;
+        if (tid < 128) { bb1 = th[L[0].b_off + tid]; bb2 = th[L[1].b_off + tid]; }
+        if (tid < 32) {
+            if (tid < L[2].n_pad) bb3 = th[L[2].b_off + tid];
+            if (tid < extra_n) lsv = th[extra_off + tid];
+        }
+        lds_barrier();                                                 // every wave is done with the previous images
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st4(C.S.w2 + 4 * (tid + 256 * j), t2[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st4(C.S.w3 + 4 * (tid + 256 * j), t3[j]);
+        if (tid < 128) { C.S.b1[tid] = bb1; C.S.b2[tid] = bb2; }
+        if (tid < 32) { C.S.b3[tid] = bb3; C.S.ls[tid] = lsv; }
+        lds_barrier();
+    }
+
+    // ---- the row operand of k-block kb: columns 16 kb + 4 q + e of this lane's row
+    __device__ __forceinline__ f32x4 xfrag(const RowPtr& r, int kb, int OT, int XT) const {
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 16 * kb + 4 * C.q + e;
+            const int fc = f < XT ? f : XT - 1;
+            g_cf p = fc < OT ? r.po : r.pa;
+            const float v = p[fc];
+            x[e] = f < XT ? v : 0.f;
+        }
+        return x;
+    }
+
+    // ---- first layer of T x 16 rows per wave as a sweep over the K-slices of W1 (w1 = the layer's weight block in image order,
+    // tile (ot, kb) at (ot * KB1 + kb) * 256 floats) -> h1 = relu(W1 x + b1)
+    template <int T>
+    __device__ __forceinline__ void l1_sweep(f32x4 (&h1)[T][kHT], const RowPtr (&rp)[T], g_cf w1, int KB1, int OT, int XT) const {
+        const int l = C.l, w = C.w, q = C.q, fslot = C.fslot;
+        const int nsl = (KB1 + kWideSliceKB - 1) / kWideSliceKB;
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot) {
+            const f32x4 bf = ld4((lds_cf)(C.S.b1 + ot * 16 + 4 * q));
+#pragma unroll
+            for (int t = 0; t < T; ++t) h1[t][ot] = bf;
+        }
+        // slice s: wave w moves k-block 4 s + w — its eight output tiles, 1 KB contiguous each
+        f32x4 R[kHT];
+        auto fetch = [&](int s) {
+            const int kb = kWideSliceKB * s + w;
+            if (kb < KB1) {
+#pragma unroll
+                for (int j = 0; j < kHT; ++j) R[j] = ld4(w1 + ((size_t)(j * KB1 + kb) * 256 + 4 * l));
+            }
+        };
+        auto commit = [&](int s) {
+            const int kb = kWideSliceKB * s + w;
+            lds_f buf = u + (s & 1) * kWideSlice;
+            if (kb < KB1) {
+#pragma unroll
+                for (int j = 0; j < kHT; ++j) st4(buf + (j * kWideSliceKB + w) * 256 + 4 * l, R[j]);
+            }
+        };
+        fetch(0);
+        f32x4 xn[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xn[t] = xfrag(rp[t], 0, OT, XT);
+        lds_barrier();                                                 // the union's previous readers (last sweep's slice, exchanges) are done
+        for (int s = 0; s < nsl; ++s) {
+            commit(s);
+            lds_barrier();                                             // slice s visible; every wave is past slice s - 1
+            if (s + 1 < nsl) fetch(s + 1);
+            lds_cf buf = u + (s & 1) * kWideSlice;
+#pragma unroll
+            for (int kbl = 0; kbl < kWideSliceKB; ++kbl) {
+                const int kb = kWideSliceKB * s + kbl;
+                if (kb < KB1) {
+                    f32x4 wf[kHT], xc[T];
+#pragma unroll
+                    for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4(buf + (ot * kWideSliceKB + kbl) * 256 + fslot);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) xc[t] = xn[t];
+                    if (kb + 1 < KB1) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) xn[t] = xfrag(rp[t], kb + 1, OT, XT);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                            for (int t = 0; t < T; ++t) h1[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], xc[t][e], h1[t][ot], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[t][ot][r] = fmaxf(h1[t][ot][r], 0.f);
+    }
+
+    // ---- layers 2 and 3 of T tiles: h1 -> h2 = relu(W2 h1 + b2), z = W3 h2 + b3.  VH: the head has hn <= 4 outputs and runs as
+    // dot products (z[t][0][o] on every lane group, chain_net.hpp: head_valu); else NT3 MFMA tiles, z[t][o3][r] = output
+    // 16 o3 + 4 q + r of this lane's row
+    // (h1 may be a window [T0, T0 + T) of a sweep's TT tiles)
+    template <int T, int NT3, bool VH, int TT = T, int T0 = 0>
+    __device__ __forceinline__ void l23(const f32x4 (&h1)[TT][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T][NT3], int hn) const {
+        const int q = C.q, fslot = C.fslot;
+#pragma unroll
+        for (int ot = 0; ot < kHT; ++ot) {
+            const f32x4 bb = ld4((lds_cf)(C.S.b2 + ot * 16 + 4 * q));
+#pragma unroll
+            for (int t = 0; t < T; ++t) h2[t][ot] = bb;
+        }
+        static_for<0, kHT>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            f32x4 wf[kHT];
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(C.S.w2 + (ot * kHT + kb) * 256 + fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) h2[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], h1[T0 + t][kb][e], h2[t][ot], 0, 0, 0);
+        });
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[t][ot][r] = fmaxf(h2[t][ot][r], 0.f);
+        if constexpr (VH) {
+            static_assert(NT3 == 1, "a dot-product head is one tile");
+            f32x4 z1[T];
+            C.head_valu<T>(h2, z1, hn);
+#pragma unroll
+            for (int t = 0; t < T; ++t) z[t][0] = z1[t];
+        } else {
+            head_tiles<T, NT3>(h2, z);
+        }
+    }
+    template <int T, int NT3>
+    __device__ __forceinline__ void head_tiles(const f32x4 (&h2)[T][kHT], f32x4 (&z)[T][NT3]) const {
+#pragma unroll
+        for (int o3 = 0; o3 < NT3; ++o3) {
+            const f32x4 b3 = ld4((lds_cf)(C.S.b3 + 16 * o3 + 4 * C.q));
+#pragma unroll
+            for (int t = 0; t < T; ++t) z[t][o3] = b3;
+        }
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb)
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) {
+                const f32x4 wf = ld4((lds_cf)(C.S.w3 + (o3 * kHT + kb) * 256 + C.fslot));
+#pragma unroll
+                for (int t = 0; t < T; ++t) z[t][o3] = mfma4(z[t][o3], wf, h2[t][kb]);
+            }
+    }
+    // dH2 = W3^T dz through the ReLU of h2 for a head of NT3 tiles (transposed fragment reads, as ChainNet::delta2)
+    template <int NT3>
+    __device__ __forceinline__ void delta2_tiles(const f32x4 (&dz)[NT3], const f32x4 (&h2)[kHT], f32x4 (&d2)[kHT]) const {
+        const int q = C.q, i16 = C.i16, tslot = C.tslot;
+#pragma unroll
+        for (int it = 0; it < kHT; ++it) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) {
+                f32x4 wa;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wa[e] = C.S.w3[(o3 * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                acc = mfma4(acc, wa, dz[o3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2[it][r] = h2[it][r] > 0.f ? acc[r] : 0.f;
+        }
+    }
+
+    template <int NT3>
+    __device__ __forceinline__ void grad_zero(WideGrad<NT3>& g) const {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) g.g3[o3][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            g.gb1[x] = 0.f; g.gb2[x] = 0.f;
+        }
+#pragma unroll
+        for (int o3 = 0; o3 < NT3; ++o3) g.gb3[o3] = 0.f;
+    }
+
+    // ---- backward of one 64-row chunk (16 rows per wave): head and layer-2 gradients into the owners' accumulators (exchanges
+    // through ea / eb as ChainNet::backward), the first-layer deltas d1 -> `dz1_dst` (8192 floats, exchange-image order:
+    // tile (out tile, 16-row block) at (ot * 4 + bb) * 256) for the dW1 pass; their bias sums into gb1.
+    // VH: dot-product head of hn outputs (dz[0] on lane group 0)
+    template <int NT3, bool VH>
+    __device__ __forceinline__ void backward(WideGrad<NT3>& g, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4 (&dz)[NT3], int hn,
+                                             g_f dz1_dst) const {
+        const int w = C.w, tid = C.tid;
+        lds_barrier();                                                 // the union's previous readers are done
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) C.put_tile(C.S.ea, ft, h2[ft]);
+#pragma unroll
+        for (int o3 = 0; o3 < NT3; ++o3) C.put_tile(C.S.eb, o3, dz[o3]);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            f32x4 bf[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) bf[x] = C.get_frag(C.S.ea, 2 * w + x, bb);
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) {
+                const f32x4 af = C.get_frag(C.S.eb, o3, bb);
+                if (w == 0) g.gb3[o3] += (af[0] + af[1]) + (af[2] + af[3]);
+#pragma unroll
+                for (int x = 0; x < 2; ++x) g.g3[o3][x] = mfma4(g.g3[o3][x], bf[x], af);
+            }
+        }
+        f32x4 d2[kHT];
+        if constexpr (VH) C.delta2_valu(dz[0], h2, d2, hn); else delta2_tiles<NT3>(dz, h2, d2);
+        lds_barrier();
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) { C.put_tile(C.S.ea, ft, h1[ft]); C.put_tile(C.S.eb, ft, d2[ft]); }
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            f32x4 af[2], bf[kHT];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                af[x] = C.get_frag(C.S.eb, 2 * w + x, bb);
+                g.gb2[x] += (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) bf[kt] = C.get_frag(C.S.ea, kt, bb);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], bf[kt], af[x]);
+        }
+        f32x4 d1[kHT];
+        C.delta1(d2, h1, d1);
+        lds_barrier();
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) C.put_tile(C.S.eb, ft, d1[ft]);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const f32x4 af = C.get_frag(C.S.eb, 2 * w + x, bb);
+                g.gb1[x] += (af[0] + af[1]) + (af[2] + af[3]);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st4(dz1_dst + 4 * (tid + 256 * j), ld4((lds_cf)(C.S.eb + 4 * (tid + 256 * j))));
+    }
+    template <int NT3>
+    __device__ __forceinline__ void grad_finish(WideGrad<NT3>& g) const {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            g.gb1[x] += __shfl_xor(g.gb1[x], 16, 64); g.gb1[x] += __shfl_xor(g.gb1[x], 32, 64);
+            g.gb2[x] += __shfl_xor(g.gb2[x], 16, 64); g.gb2[x] += __shfl_xor(g.gb2[x], 32, 64);
+        }
+#pragma unroll
+        for (int o3 = 0; o3 < NT3; ++o3) { g.gb3[o3] += __shfl_xor(g.gb3[o3], 16, 64); g.gb3[o3] += __shfl_xor(g.gb3[o3], 32, 64); }
+    }
+
+    // ---- dW1^T of one head over the whole batch: acc[j][y] = tile (k-tile (w >> 1) + 2 j, out tile 4 (w & 1) + y).  dz1 = the
+    // scratch images the chunk loop left (one per 64-row chunk), rowptr(row) = where that batch row's columns come from.
+    template <class RowF>
+    __device__ __forceinline__ void dw1_pass(f32x4 (&acc)[kWideMaxKT][4], g_cf dz1, int nchunks, int B, int KB1, int OT, int XT, RowF rowptr) const {
+        const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
+        const int oh = w & 1, kt0 = w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
+#pragma unroll
+        for (int j = 0; j < kWideMaxKT; ++j)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[j][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto rows_of = [&](int it, RowPtr (&rp)[4]) {                  // rows 16 it + 4 q + e of the batch (clamped: their deltas are zero)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * it + 4 * q + e;
+                rp[e] = rowptr(row < B ? row : B - 1);
+            }
+        };
+        RowPtr nxt[4];
+        rows_of(0, nxt);
+        const int nit = nchunks * 4;
+        for (int it = 0; it < nit; ++it) {                             // it = 4 * chunk + 16-row block
+            RowPtr cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+            if (it + 1 < nit) rows_of(it + 1, nxt);
+            f32x4 bf[4];
+            g_cf img = dz1 + (size_t)(it >> 2) * 8192 + (it & 3) * 256 + fslot;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) bf[y] = ld4(img + (4 * oh + y) * 4 * 256);
+#pragma unroll
+            for (int j = 0; j < kWideMaxKT; ++j) {
+                if (j < nkt) {
+                    const int f = 16 * (kt0 + 2 * j) + i16;
+                    const int fc = f < XT ? f : XT - 1;
+                    f32x4 af;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g_cf p = fc < OT ? cur[e].po : cur[e].pa;
+                        const float v = p[fc];
+                        af[e] = f < XT ? v : 0.f;
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[j][y] = mfma4(acc[j][y], af, bf[y]);
+                }
+            }
+        }
+    }
+
+    // ---- one head's gradients -> the engine's grad array (image order, G = the net's block; L = the head's LayerDescs), in two
+    // parts — layers 2 / 3 and the biases before the dW1 pass, the first layer's tiles after it; each returns this lane's share of
+    // the squared norm
+    template <int NT3>
+    __device__ __forceinline__ float grad_store_23(g_f G, const LayerDesc* L, const WideGrad<NT3>& g) const {
+        const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
+        float ss = 0.f;
+        auto sq = [](const f32x4& v) { return (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); };
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) {
+                st4(G + L[1].w_off + ((2 * w + x) * kHT + kt) * 256 + fslot, g.g2[x][kt]);
+                ss += sq(g.g2[x][kt]);
+            }
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) {
+                st4(G + L[2].w_off + (o3 * kHT + 2 * w + x) * 256 + fslot, g.g3[o3][x]);
+                ss += sq(g.g3[o3][x]);
+            }
+            if (q == 0) {
+                G[L[0].b_off + (2 * w + x) * 16 + i16] = g.gb1[x];
+                G[L[1].b_off + (2 * w + x) * 16 + i16] = g.gb2[x];
+                ss += g.gb1[x] * g.gb1[x] + g.gb2[x] * g.gb2[x];
+            }
+        }
+        if (w == 0 && q == 0) {
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) { G[L[2].b_off + 16 * o3 + i16] = g.gb3[o3]; ss += g.gb3[o3] * g.gb3[o3]; }
+        }
+        return ss;
+    }
+    __device__ __forceinline__ float grad_store_1(g_f G, const LayerDesc* L, const f32x4 (&acc)[kWideMaxKT][4], int KB1) const {
+        const int w = C.w, fslot = C.fslot;
+        float ss = 0.f;
+        auto sq = [](const f32x4& v) { return (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); };
+        const int oh = w & 1, kt0 = w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
+#pragma unroll
+        for (int j = 0; j < kWideMaxKT; ++j) {
+            if (j < nkt) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    st4(G + L[0].w_off + ((size_t)((4 * oh + y) * KB1 + kt0 + 2 * j) * 256 + fslot), acc[j][y]);
+                    ss += sq(acc[j][y]);
+                }
+            }
+        }
+        return ss;
+    }
+
+    // ---- clip + Adam (+ soft target update) of a whole net, streamed: n4 = NetDesc::size / 4.  The gradient was written by this
+    // workgroup's own waves (grad_store); the caller has synchronised (vmcnt + barrier) in between.
+    template <bool SOFT>
+    __device__ __forceinline__ void adam_stream(g_f th, g_f mA, g_f vA, g_f tg, g_cf gr, int n4, const AdamCoef& c) const {
+        for (int i0 = C.tid; i0 < n4; i0 += 4 * 256) {
+            f32x4 G4[4], T4[4], M4[4], V4[4], X4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 256 * k;
+                if (i < n4) {
+                    G4[k] = ld4(gr + 4 * (size_t)i); T4[k] = ld4((g_cf)(th + 4 * (size_t)i)); M4[k] = ld4((g_cf)(mA + 4 * (size_t)i));
+                    V4[k] = ld4((g_cf)(vA + 4 * (size_t)i));
+                    if constexpr (SOFT) X4[k] = ld4((g_cf)(tg + 4 * (size_t)i));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 256 * k;
+                if (i < n4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gi = G4[k][r] * c.coef;
+                        gi += c.wd * T4[k][r];
+                        float m1 = M4[k][r], v1 = V4[k][r];
+                        T4[k][r] = adam_elem(T4[k][r], gi, m1, v1, c.w1, c.w2, c.beta2, c.inv_bc2s, c.eps, c.step);
+                        M4[k][r] = m1; V4[k][r] = v1;
+                        if constexpr (SOFT) X4[k][r] = X4[k][r] * c.tk + T4[k][r] * c.tau;
+                    }
+                    st4(th + 4 * (size_t)i, T4[k]); st4(mA + 4 * (size_t)i, M4[k]); st4(vA + 4 * (size_t)i, V4[k]);
+                    if constexpr (SOFT) st4(tg + 4 * (size_t)i, X4[k]);
+                }
+            }
+        }
+    }
+};
+
+}  // namespace frl

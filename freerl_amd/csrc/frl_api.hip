@@ -26,6 +26,8 @@
 #include "kernels_ppo2.hip"
 #include "kernels_critic2.hip"
 #include "kernels_actor2.hip"
+#include "kernels_criticw.hip"
+#include "kernels_actorw.hip"
 #include "kernels_dqn2.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
@@ -80,6 +82,8 @@ struct frl_engine {
     size_t idx_count = 0, noise_count = 0;
     unsigned long long rng_counter = 0;
     // act scratch (device)
+    float* d_act_wk = nullptr;            // [P][net size]: a fragment-image net re-laid out to Wk for act_kernel (wide chained engines)
+    size_t act_wk_cap = 0;
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
     float* d_act_out = nullptr;
@@ -240,7 +244,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_uniforms) hipFree(e->d_uniforms);
     if (e->h_noisy) hipHostFree(e->h_noisy);
     float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
-                    e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo};
+                    e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo, e->d_act_wk, e->h.wide_scr};
     for (float* p : dev) if (p) hipFree(p);
     if (e->h.idx) hipFree(e->h.idx);
     if (e->h.steps) hipFree(e->h.steps);
@@ -277,6 +281,7 @@ static hipError_t dalloc_zero(T** p, size_t count, hipStream_t s) {
 }
 
 static bool chained_shape(const EngineDesc& h);
+static bool wide_shape(const EngineDesc& h);
 
 extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     if (!cfg || !out) return fail(FRL_ERR_INVALID, "cfg/out is NULL");
@@ -365,6 +370,14 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         // workgroups — 484 k against 373 k for 128 one-learner workgroups on half the CUs; from 129 up the chained kernels win
         // (160: 459 k / 393 k, 256: 694 k / 566 k) or tie (320: 472 k / 480 k)
         if (force ? atoi(force) != 0 : h.P > 128) h.net[0].frag = h.net[1].frag = 1;
+    } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
+        const char* force = getenv("FRL_CRITIC_V2");
+        if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > 128) {
+            for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
+            h.wide = 1;
+            h.wide_bm = (h.batch_max + 63) / 64 * 64;
+            h.wide_unit = (kWideScratchPerRow * h.wide_bm + 63) / 64 * 64;
+        }
     }
     h.act_max = 1;
     for (int j = 0; j < c.n_agents; ++j) h.act_max = std::max(h.act_max, R.act_dim[j]);
@@ -474,6 +487,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
+        if (h.wide) CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
         {
             int omax = 1;
             for (int j = 0; j < c.n_agents; ++j) omax = std::max(omax, c.obs_dim[j]);
@@ -497,7 +511,12 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->staged_per_learner.assign(P, 0);
     if (h.algo == ALGO_DQN)
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
-    if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
+    if (h.wide) {
+        const int lb = wide_lds_floats() * (int)sizeof(float);
+        for (auto k : {ac_critic_wide_h1a1_kernel, ac_critic_wide_h1a2_kernel, ac_critic_wide_h2a1_kernel, ac_critic_wide_h2a2_kernel,
+                       ac_actor_wide_a1_kernel, ac_actor_wide_a2_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    } else if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
         const int lb = critic2_lds_floats() * (int)sizeof(float);
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -572,7 +591,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
     }
     const bool v2 = chained_path(e->h, batch, e->h.P);
     if (chained_out) *chained_out = v2 ? 1 : 0;
-    if (bytes_out) *bytes_out = v2 ? critic2_lds_floats() * (int)sizeof(float) : e->lds_bytes;
+    if (bytes_out) *bytes_out = v2 ? (e->h.wide ? wide_lds_floats() : critic2_lds_floats()) * (int)sizeof(float) : e->lds_bytes;
     if (rows_out) *rows_out = v2 ? batch : e->h.rc;
     return FRL_OK;
 }
@@ -916,7 +935,21 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     const int agent = e->h.n_agents > 1 ? net / 2 : 0;            // MADDPG: only the actors (even nets) take a single agent's obs
     a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
-    if (N.frag) {              // parameters in fragment-image order: the register-chained forward (kernels_act.hip)
+    if (N.frag && e->h.wide) {
+        // fragment-image parameters of a shape act_frag_kernel does not take: the net is re-laid out to Wk in a scratch copy (one
+        // small launch: the actor of config 4 is 67 k floats per learner) and act_kernel reads that
+        const size_t need = (size_t)e->h.P * N.size;
+        if (need > e->act_wk_cap) {
+            if (e->d_act_wk) hipFree(e->d_act_wk);
+            e->d_act_wk = nullptr; e->act_wk_cap = 0;
+            HIP_TRY(hipMalloc((void**)&e->d_act_wk, need * sizeof(float)));
+            e->act_wk_cap = need;
+        }
+        hipLaunchKernelGGL(frag_to_wk_kernel, dim3(e->h.P), dim3(256), 0, e->stream, e->d, net, use_target, e->d_act_wk);
+        a.theta_alt = e->d_act_wk;
+        dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
+        hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
+    } else if (N.frag) {       // parameters in fragment-image order: the register-chained forward (kernels_act.hip)
         hipLaunchKernelGGL(act_frag_kernel, dim3((n_rows + 63) / 64, e->h.P), dim3(256), (size_t)critic2_lds_floats() * sizeof(float),
                            e->stream, e->d, a);
     } else {
@@ -1174,7 +1207,29 @@ static bool chained_shape(const EngineDesc& h) {
 }
 static bool chained_path(const EngineDesc& h, int batch, int pc) {
     (void)pc;
+    if (h.wide) return !h.obs_norm_on;          // any batch <= batch_max: super-chunks of 256 rows
     return h.net[0].frag && h.net[1].frag && batch <= 256 && !h.obs_norm_on;
+}
+// The K-sliced chained family (device/chain_wide.hpp): the reference's hidden-128 ReLU actor-critic nets with first layers of up
+// to 416 input columns and actor heads of up to 32 outputs that chained_shape() does not admit — SAC / TD3 / DDPG on wide
+// observations (config 4: Humanoid's 376 + 17), MADDPG_simple's per-agent actors and centralised critics (config 5).
+// MATD3 (twin centralised critics, per-agent smoothing, delayed updates) stays with the row-chunk kernels.
+static bool wide_shape(const EngineDesc& h) {
+    const bool single = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1;
+    const bool multi = h.algo == ALGO_MADDPG && h.n_agents >= 1 && h.net[1].heads == 1;
+    if (!(single || multi) || h.hidden != 128 || h.rec.act_total > kWideApitch) return false;
+    const int nt3 = h.net[0].L[2].n_pad;
+    for (int j = 0; j < h.n_agents; ++j) {
+        const NetDesc &NA0 = h.net[2 * j], &NC0 = h.net[2 * j + 1];
+        if (NA0.n_layers != 3 || NA0.heads != 1 || NC0.n_layers != 3 * NC0.heads || NC0.heads != h.net[1].heads) return false;
+        if (NA0.hidden_act != ACT_RELU || NC0.hidden_act != ACT_RELU) return false;
+        if (NA0.L[0].k_pad > 16 * kWideMaxKB1 || NC0.L[0].k_pad > 16 * kWideMaxKB1) return false;
+        if (NA0.L[2].n_pad != nt3 || nt3 > 32) return false;                 // one head-tile count for every agent's actor
+        for (int hd = 0; hd < NC0.heads; ++hd)
+            if (NC0.L[3 * hd].n_pad != 128 || NC0.L[3 * hd + 1].n_pad != 128 || NC0.L[3 * hd + 1].k_pad != 128 || NC0.L[3 * hd + 2].n_pad != 16) return false;
+        if (NA0.L[0].n_pad != 128 || NA0.L[1].n_pad != 128 || NA0.L[1].k_pad != 128) return false;
+    }
+    return true;
 }
 
 // kernels_dqn2.hip: the reference's Q-net (obs -> 128 -> n_actions, or the Dueling [V ; A] head) with the TD update of DQN.py and
@@ -1221,6 +1276,15 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             hipLaunchKernelGGL(obsnorm_kernel, dim3(pc), blk, 0, st, e->d, a.batch, 0, p0);
         if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
             hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
+        if (v2 && h.wide) {                               // kernels_criticw.hip: one workgroup per (learner, agent)
+            prof_begin(e, PK_GRAD_CRITIC);
+            const size_t lb = (size_t)wide_lds_floats() * sizeof(float);
+            const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
+            auto k = twin ? (a2 ? ac_critic_wide_h2a2_kernel : ac_critic_wide_h2a1_kernel) : (a2 ? ac_critic_wide_h1a2_kernel : ac_critic_wide_h1a1_kernel);
+            hipLaunchKernelGGL(k, dim3(units), blk, lb, st, e->d, a);
+            prof_end(e);
+            return;
+        }
         if (v2) {
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
@@ -1241,6 +1305,13 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         launch_adam(e, st, ad, units, grid_adam);      // (a NoisyLinear head's sigma gradients are derived in its slab sums)
         prof_end(e);
     } else if (stage == 1) {
+        if (v2 && h.wide) {                               // kernels_actorw.hip
+            prof_begin(e, PK_GRAD_ACTOR);
+            auto k = h.net[0].L[2].n_pad > 16 ? ac_actor_wide_a2_kernel : ac_actor_wide_a1_kernel;
+            hipLaunchKernelGGL(k, dim3(units), blk, (size_t)wide_lds_floats() * sizeof(float), st, e->d, a);
+            prof_end(e);
+            return;
+        }
         if (v2) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 / SAC in one launch
             prof_begin(e, PK_GRAD_ACTOR);
             hipLaunchKernelGGL(ac_actor_v2_kernel, dim3(pc), blk, (size_t)critic2_lds_floats() * sizeof(float), st, e->d, a);
@@ -1405,6 +1476,7 @@ extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
         hipFree(scratch);
         if (he != hipSuccess) return fail(FRL_ERR_HIP, "relayout: %s", hipGetErrorString(he));
         for (int i = 0; i < e->h.n_nets; ++i) e->h.net[i].frag = 0;
+        e->h.wide = 0;
     }
     e->h.obs_norm_on = on ? 1 : 0;
     HIP_TRY(hipStreamSynchronize(e->stream));

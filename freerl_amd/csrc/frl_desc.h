@@ -43,6 +43,15 @@ struct NetDesc {
 constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w + 128 * 128, kL3w = kL2b + 128,
               kL3b = kL3w + 16 * 128, kHeadFloats = kL3b + 16;
 
+// The K-sliced chained family (device/chain_wide.hpp)
+constexpr int kWideSliceKB = 4;          // k-blocks of W1 per streamed slice (4 x 8 tiles x 1 KB = 32 KB)
+constexpr int kWideSlice = kWideSliceKB * 8 * 256;
+constexpr int kWideMaxKB1 = 26;          // first layer: <= 416 input columns
+constexpr int kWideMaxKT = 13;           // k-tiles of dW1 one wave owns
+constexpr int kWideApitch = 32;          // floats per row in the action scratch arrays (all agents' actions: <= 32 columns)
+constexpr int kWideScratchPerRow = 484;  // floats of scratch per batch row (WideScratch)
+constexpr int wide_lds_floats() { return 8 * 8 * 256 + 2 * 8 * 256 + 2 * kWideSlice + 128 + 128 + 32 + 32 + 64; }
+
 // float index of W[out n][in k] inside a layer's weight block (host and device)
 #if defined(__HIPCC__)
 __host__ __device__
@@ -137,6 +146,13 @@ struct EngineDesc {
     // version i, agent j) = obsnorm + ((p*n + i)*n + j) * obsnorm_w, obsnorm_w = 1 + 3*max obs_dim; the last version is the
     // state carried to the next call (and what select_action reads).  n = 1: exactly the single-agent layout.
     int obsnorm_w;
+    // The K-sliced chained family (device/chain_wide.hpp, kernels_criticw.hip / kernels_actorw.hip): per-(learner, agent) scratch —
+    // target / policy actions, TD targets, dQ/da, the first-layer deltas of the batch (exchange-image order), the actor's
+    // hidden activations between its forward and backward passes — [P][n_agents][wide_unit] floats, L2-resident
+    int wide;             // 1: this engine's actor-critic updates run on that family (every net in fragment-image order)
+    int wide_bm;          // batch_max rounded up to 64 rows
+    int wide_unit;        // floats per (learner, agent): kWideScratchPerRow * wide_bm rounded up to 64
+    float* wide_scr;
 };
 
 // Hyper-parameters of one learn() call (passed by value to the kernels).

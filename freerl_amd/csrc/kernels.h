@@ -47,6 +47,7 @@ struct ActArgs {
     const unsigned char* flags;   // [P][n_rows] bit 1: the row's episode ended on the previous step -> OU state reset first (SAC.py:546-547)
     float* env_out;      // [P][n_rows][out_dim] env-unit action = clip(a*max_action + noise, +-max_action); discrete: [P][n_rows] index
     unsigned long long rng_counter;
+    const float* theta_alt;   // non-null: [P][NetDesc::size] Wk-layout copy of the net to read instead of theta / target (frag_to_wk_kernel)
 };
 enum ExploreKind : int { EXPL_NONE = 0, EXPL_EPS_GREEDY = 1, EXPL_GAUSS = 2, EXPL_OU = 3 };
 
@@ -163,6 +164,7 @@ __global__ void replay_fill_kernel(float* __restrict__ ring, long long rows, Rec
 
 // kernels_update.hip
 __global__ void relayout_to_wk_kernel(const EngineDesc* __restrict__ Dp, float* scratch);      // scratch: [4][P][learner_stride]
+__global__ void frag_to_wk_kernel(const EngineDesc* __restrict__ Dp, int net, int use_target, float* dst);   // dst: [P][NetDesc::size]
 __global__ void draw_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, int want_noise);
 __global__ void obsnorm_kernel(const EngineDesc* __restrict__ Dp, int batch, int all_rows, int p0);
 __global__ void reduce_kernel(const EngineDesc* __restrict__ Dp, AdamArgs a);
@@ -175,6 +177,15 @@ __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau,
 __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
+
+// kernels_criticw.hip / kernels_actorw.hip: the same two stages on the K-sliced chained design (device/chain_wide.hpp) for wide
+// first layers / heads and multi-agent critics; h<critic heads>a<actor head tiles>
+__global__ void ac_critic_wide_h1a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_wide_h1a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_wide_h2a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_wide_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_actor_wide_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_actor_wide_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void act_kernel(const EngineDesc* __restrict__
     const Lds S = carve_lds(smem, D.rc, D.hidden, D.lds_kin_pad, D.lds_out_pad, D.lds_batch_pad, D.lds_act_pad, D.lds_hbufs);
     const int rc = D.rc, nv = min(rc, a.n_rows - r0);
     const size_t off = (size_t)p * D.learner_stride + D.net_off[a.net];
-    g_cf theta = a.use_target == 2 ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[a.net])     // noisy set 0
+    g_cf theta = a.theta_alt ? as_global(a.theta_alt + (size_t)p * N.size)                                             // Wk copy of a fragment-image net
+               : a.use_target == 2 ? as_global(D.theta_eff + (size_t)p * 3 * D.learner_stride + D.net_off[a.net])     // noisy set 0
                                    : as_global((a.use_target ? D.target : D.theta) + off);
     const int nl = N.n_layers / N.heads, l0 = a.head * nl;
     const int K = a.in_dim, kpad = N.L[l0].k_pad;

@@ -8,7 +8,7 @@
   MADDPG C5 3 agents x (obs 18, act 5), batch 1024    (simple_spread_v3)
 
 Device-drawn indices and noise, replay filled; weights random (timing only).  Replay capacity is 1e5 rows per learner
-here (C4's 3 KB rows x 1e6 x hundreds of learners would not fit even in 288 GB); the index draw is O(batch) on the
+here, 2e4 for C4 (its 3 KB rows x 1e6 x hundreds of learners would not fit even in 288 GB); the index draw is O(batch) on the
 device, so capacity does not enter the timing.
     python tools/config_bench.py [P ...]      (default P = 1 64 512)
 """
@@ -38,7 +38,8 @@ CASES = [
 def run(case, P, steps=20):
     name, algo, obs, act, B, H, kw = case
     twin = algo in (N.ALGO_TD3, N.ALGO_SAC)
-    e = Engine(algo, obs, act, CAP, n_learners=P, twin_critic=twin, batch_max=B, hidden=H, seed=1)
+    cap = 20_000 if name == "SAC C4" else CAP
+    e = Engine(algo, obs, act, cap, n_learners=P, twin_critic=twin, batch_max=B, hidden=H, seed=1)
     rng = np.random.default_rng(0)
     for net in range(e.n_nets):
         n = e.get_params(net, learner=0).size
@@ -49,7 +50,7 @@ def run(case, P, steps=20):
     if algo == N.ALGO_SAC:
         for p in range(P):
             e.set_alpha_state([np.log(0.01), 0, 0, 0.01], learner=p)
-    e.fill_synthetic(CAP, seed=5)
+    e.fill_synthetic(cap, seed=5)
     e.sync()
     chained, lds, rc = e.learn_path(B)
 
@@ -71,11 +72,12 @@ def run(case, P, steps=20):
 
 
 if __name__ == "__main__":
-    Ps = [int(a) for a in sys.argv[1:]] or [1, 64, 512]
+    Ps = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 64, 512]
+    only = [a for a in sys.argv[1:] if not a.isdigit()]          # e.g. "C4" "C5": substring filter on the case names
     for case in CASES:
+        if only and not any(o in case[0] for o in only):
+            continue
         for P in Ps:
-            if case[0] == "SAC C4" and P > 128:
-                P = 128                   # 100k rows x 3 KB x P learners of replay
             try:
                 run(case, P)
             except Exception as ex:      # report and go on to the next shape

@@ -1,0 +1,101 @@
+"""Developer check: the K-sliced chained kernels (kernels_criticw / _actorw, FRL_CRITIC_V2=1) against the row-chunk kernels (=0) on
+the same inputs, array by array and layer by layer — stats, theta / target / Adam moments of every net.
+    python tools/wide_ab.py [sac_c4 | td3_wide | ddpg_wide | maddpg_c5 | all] [calls]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from freerl_amd import _native as N  # noqa: E402
+from freerl_amd.engine import Engine  # noqa: E402
+
+CASES = {
+    "sac_c4": dict(algo=N.ALGO_SAC, obs=376, act=17, B=256, twin=True),
+    "td3_wide": dict(algo=N.ALGO_TD3, obs=17, act=6, B=200, twin=True),
+    "ddpg_wide": dict(algo=N.ALGO_DDPG, obs=40, act=3, B=256, twin=False),
+    "td3_b1000": dict(algo=N.ALGO_TD3, obs=30, act=5, B=1000, twin=True),
+    "maddpg_c5": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=1024, twin=False),
+    "maddpg_het": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=False),
+}
+
+
+def run(name, family, calls, P=2):
+    c = CASES[name]
+    os.environ["FRL_CRITIC_V2"] = str(family)
+    e = Engine(c["algo"], c["obs"], c["act"], 4096, n_learners=P, twin_critic=c["twin"], batch_max=c["B"], seed=3)
+    g = np.random.default_rng(0)
+    for net in range(e.n_nets):
+        for p in range(P):
+            flat = (g.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
+            e.set_params(net, flat, N.PARAM_ONLINE, learner=p)
+            e.set_params(net, flat + np.float32(0.01) * g.standard_normal(flat.size).astype(np.float32), N.PARAM_TARGET, learner=p)
+    if c["algo"] == N.ALGO_SAC:
+        for p in range(P):
+            e.set_alpha_state([np.log(0.2), 0, 0, 0.2], learner=p)
+    e.fill_synthetic(3000, seed=5)
+    na = e.n_agents
+    am = max(c["act"]) if isinstance(c["act"], list) else c["act"]
+    stats = []
+    for k in range(calls):
+        idx = np.stack([[g.choice(3000, c["B"], replace=False) for _ in range(na)] for _ in range(P)]).astype(np.int64)
+        noise = g.standard_normal((P, na, max(2, na), c["B"], am)).astype(np.float32)
+        kw = {}
+        if c["algo"] == N.ALGO_TD3:
+            kw = dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, do_actor=(k % 2 == 1))
+        if c["algo"] == N.ALGO_SAC:
+            kw = dict(alpha_lr=1e-3, target_entropy=-float(am))
+        need_noise = c["algo"] in (N.ALGO_TD3, N.ALGO_SAC)
+        st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx if na > 1 else idx[:, 0],
+                     noise=noise if need_noise else None, want_stats=True, **kw)
+        stats.append(st.copy())
+    out = dict(stats=np.stack(stats), family=e.learn_path(c["B"])[0])
+    for net in range(e.n_nets):
+        for kind, nm in ((N.PARAM_ONLINE, "theta"), (N.PARAM_TARGET, "target"), (N.PARAM_ADAM_M, "m"), (N.PARAM_ADAM_V, "v")):
+            out["%s%d" % (nm, net)] = np.stack([e.get_params(net, kind, learner=p) for p in range(P)])
+    out["layers"] = [e.net_layers(net) if hasattr(e, "net_layers") else None for net in range(e.n_nets)]
+    obs_dim = c["obs"][0] if isinstance(c["obs"], list) else c["obs"]
+    ob = g.standard_normal((P, 7, obs_dim)).astype(np.float32)
+    out["act"] = e.act(0, N.ACT_TANHHEAD, ob, out_dim=(c["act"][0] if isinstance(c["act"], list) else c["act"]))
+    e.close()
+    return out
+
+
+def compare(name, calls):
+    a, b = run(name, 0, calls), run(name, 1, calls)
+    print("== %s: families %s / %s, %d calls" % (name, a["family"], b["family"], calls))
+    sa, sb = a["stats"], b["stats"]
+    for k in range(calls):
+        for ag in range(sa.shape[2]):
+            d = np.abs(sa[k, :, ag] - sb[k, :, ag]) / np.maximum(np.abs(sa[k, :, ag]), 1e-6)
+            print("  call %d agent %d stats rel diff (critic, actor, alpha_loss, alpha, cgnorm, agnorm, ent): %s" %
+                  (k, ag, " ".join("%.1e" % x for x in d.max(axis=0)[:7])))
+            if k == calls - 1:
+                print("      values (learner 0): %s | %s" % (" ".join("%.6g" % x for x in sa[k, 0, ag, :7]), " ".join("%.6g" % x for x in sb[k, 0, ag, :7])))
+    worst = 0.0
+    for key in sorted(a):
+        if key in ("stats", "family", "layers"):
+            continue
+        x, y = a[key], b[key]
+        den = np.maximum(np.abs(x), 1e-3 * np.abs(x).max() + 1e-12)
+        rel = np.abs(x - y) / den
+        w = float(rel.max())
+        worst = max(worst, w)
+        flag = "" if w < 2e-3 else "   <-- at flat index %d (learner %d): %.6g vs %.6g" % (int(rel.argmax()) % x.shape[-1], int(rel.argmax()) // x.shape[-1],
+                                                                                        x.reshape(-1)[rel.argmax()], y.reshape(-1)[rel.argmax()])
+        print("  %-9s max rel diff %.2e  (|x| max %.3g)%s" % (key, w, np.abs(x).max(), flag))
+    print("  WORST %.2e %s" % (worst, "OK" if worst < 2e-3 else "MISMATCH"))
+    return worst < 2e-3
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    calls = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    ok = True
+    for name in (CASES if which == "all" else [which]):
+        try:
+            ok &= compare(name, calls)
+        except Exception as ex:
+            print("== %s FAILED: %r" % (name, ex))
+            ok = False
+    sys.exit(0 if ok else 1)
