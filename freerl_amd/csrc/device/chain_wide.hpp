@@ -27,18 +27,25 @@ namespace frl {
 // (the family's constants — kWideSliceKB, kWideSlice, kWideMaxKB1, kWideMaxKT, kWideApitch, kWideScratchPerRow, wide_lds_floats() —
 // are in frl_desc.h: the host sizes LDS and scratch from them)
 
-// per-(learner, agent) scratch in HBM, `bm` = batch_max rounded up to 64 rows; offsets in floats
+// per-(learner, agent) scratch in HBM (L2-resident); `bm` = batch_max rounded up to 64 rows, xp = the critic's padded input width,
+// op = the widest actor's.  xrow[row] = one critic input row, built in place: [next_obs_all | a'_all] in the critic stage,
+// [obs_all | act_all with a_i = actor_i(s_i)] in the actor stage — 16-byte aligned whatever the record's field offsets are, so
+// that the sweeps read their row operand with ONE dwordx4 per lane and k-block; xobs = an agent's observation columns, copied
+// only when they do not start on a 16-byte boundary in the record / in xrow.  Offsets in floats.
 struct WideScratch {
-    g_f anext, apol, dqa, yb, q1, lpn, dz1, ah1, ah2;
-    __device__ __forceinline__ void init(g_f base, int bm) {
-        anext = base; apol = base + 32 * (size_t)bm; dqa = base + 64 * (size_t)bm;
-        yb = base + 96 * (size_t)bm; q1 = base + 97 * (size_t)bm; lpn = base + 98 * (size_t)bm;
-        dz1 = base + 100 * (size_t)bm; ah1 = base + 228 * (size_t)bm; ah2 = base + 356 * (size_t)bm;
+    g_f xrow, xobs, dqa, yb, q1, lpn, dz1, ah1, ah2;
+    int xp, op;
+    __device__ __forceinline__ void init(g_f base, int bm, int xp_, int op_, int nag) {
+        xp = xp_; op = op_;
+        xrow = base; base += (size_t)bm * xp + 64;
+        xobs = base; base += (size_t)nag * bm * op + 64;              // (critic stage: one copy per agent that needs it)
+        dqa = base; base += (size_t)bm * kWideApitch;
+        yb = base; q1 = base + bm; lpn = base + 2 * (size_t)bm; base += 4 * (size_t)bm;
+        dz1 = base; base += 128 * (size_t)bm;
+        ah1 = base; base += 128 * (size_t)bm;
+        ah2 = base;
     }
 };
-
-// where the columns of one row come from: [0, OT) at po[f], [OT, XT) at pa[f] (pa is pre-shifted by -OT), zero beyond
-struct RowPtr { g_cf po, pa; };
 
 // weight-gradient accumulators of one head a lane owns next to the chunk loop (layer 2 and the head; transposed, see chain_net.hpp)
 template <int NT3>
@@ -63,6 +70,40 @@ struct WideNet {
         C.S.red = p; p += 64;
         C.S.w1 = u; C.S.ab = u; C.S.yb = u; C.S.q1 = u; C.S.lpn = u;
         C.init_lanes();
+    }
+
+    // ---- the batch's ring rows -> an LDS table at the start of the union (the dW1 pass has no other use for it)
+    __device__ __forceinline__ FRL_LDS int* stage_idx(g_ci idx, int B) const {
+        FRL_LDS int* tab = (FRL_LDS int*)u;
+        lds_barrier();
+        for (int i = C.tid; i < B; i += kWG) tab[i] = idx[i];
+        lds_barrier();
+        return tab;
+    }
+    // ---- columns [src_off, src_off + n) of the batch's records -> dst[row * pitch + c], any alignment (dword loads).  tab = the
+    // batch's ring rows in LDS (stage_idx).  A wave-instruction covers 64 / W rows x W columns (W = 16 / 32 / 64, the smallest
+    // that holds n; wider rows take ceil(n / 64) chunks) and eight such row groups are in flight per wave: the first build walked
+    // one row at a time behind its own index load — 780 k cycles for MADDPG's 1024 x 54 floats.
+    __device__ __forceinline__ void copy_cols(g_f dst, int pitch, g_cf ring, int stride, const FRL_LDS int* tab, int B, int src_off, int n) const {
+        const int lw = n > 32 ? 6 : (n > 16 ? 5 : 4), W = 1 << lw, rpi = 64 >> lw;      // rows per wave-instruction
+        const int sub = C.l >> lw, col = C.l & (W - 1), nc = (n + 63) >> 6;
+        const int ngroups = (B + rpi - 1) / rpi;
+        for (int g0 = C.w; g0 < ngroups; g0 += 4 * 8) {
+            for (int c = 0; c < nc; ++c) {
+                const int cc = col + 64 * c, ccl = cc < n ? cc : n - 1;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (g0 + 4 * k) * rpi + sub, rc = row < B ? row : B - 1;
+                    v[k] = ring[(size_t)tab[rc] * stride + src_off + ccl];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (g0 + 4 * k) * rpi + sub;
+                    if (row < B && cc < n) dst[(size_t)row * pitch + cc] = v[k];
+                }
+            }
+        }
     }
 
     // ---- layers 2 and 3 of one head -> LDS images (linear copies, in the open), biases, log_std.  th = the net's block,
@@ -91,26 +132,29 @@ struct WideNet {
         lds_barrier();
     }
 
-    // ---- the row operand of k-block kb: columns 16 kb + 4 q + e of this lane's row
-    __device__ __forceinline__ f32x4 xfrag(const RowPtr& r, int kb, int OT, int XT) const {
-        f32x4 x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = 16 * kb + 4 * C.q + e;
-            const int fc = f < XT ? f : XT - 1;
-            g_cf p = fc < OT ? r.po : r.pa;
-            const float v = p[fc];
-            x[e] = f < XT ? v : 0.f;
-        }
-        return x;
-    }
+    // ---- the row operand of k-block kb: columns 16 kb + 4 q .. + 3 of this lane's row, one dwordx4.  A row source is 16-byte
+    // aligned and readable for 16 KB1 columns (a replay record from its start, a scratch row): columns past the layer's real
+    // inputs hold some finite value and meet zero weights (the padding invariant of W1's image).  The first build read four
+    // dwords per lane and k-block, each wave-instruction touching 16 rows x 4 x 4 B: ~65 cycles of the CU's address unit apiece
+    // (profiles/r01/loadpat_bench.txt), 4 waves x 72 of them per slice = more than the slice's MFMA time, and the waves stall
+    // at the issue of the burst.
+    __device__ __forceinline__ f32x4 xfrag(g_cf row, int kb) const { return ld4(row + 16 * kb + 4 * C.q); }
 
     // ---- first layer of T x 16 rows per wave as a sweep over the K-slices of W1 (w1 = the layer's weight block in image order,
-    // tile (ot, kb) at (ot * KB1 + kb) * 256 floats) -> h1 = relu(W1 x + b1)
+    // tile (ot, kb) at (ot * KB1 + kb) * 256 floats) -> h1 = relu(W1 x + b1).  Both operand streams run one SLICE ahead of the
+    // MFMAs: while slice s is multiplied, the weight tiles of slice s + 1 travel global -> registers (committed to the other LDS
+    // buffer at the top of the next trip) and the row fragments of its four k-blocks global -> registers.
+    // Two rules keep that overlap alive in the ISA (both learnt from the first builds' s_waitcnt placement): (1) the loads are
+    // pinned in front of the slice's MFMAs (hipcc sinks each next to its first use); (2) NO load of the steady-state loop sits
+    // inside a conditional — gfx9 has one in-order counter for all vector memory loads, a wait for an older load is expressed
+    // as "all but the N youngest", and the compiler can only count loads that are issued unconditionally: behind a guarded
+    // prefetch every wait degenerates to vmcnt(0) and the slice waits for the prefetch it has just issued.  So the full slices
+    // run unguarded, the prefetch indices are clamped instead of guarded (the last trip re-reads a slice it does not need), and
+    // only the MFMAs of the partial tail slice are guarded.
     template <int T>
-    __device__ __forceinline__ void l1_sweep(f32x4 (&h1)[T][kHT], const RowPtr (&rp)[T], g_cf w1, int KB1, int OT, int XT) const {
+    __device__ __forceinline__ void l1_sweep(f32x4 (&h1)[T][kHT], const g_cf (&rp)[T], g_cf w1, int KB1) const {
         const int l = C.l, w = C.w, q = C.q, fslot = C.fslot;
-        const int nsl = (KB1 + kWideSliceKB - 1) / kWideSliceKB;
+        const int nfull = KB1 / kWideSliceKB, tail = KB1 - nfull * kWideSliceKB, last = KB1 - 1;
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
             const f32x4 bf = ld4((lds_cf)(C.S.b1 + ot * 16 + 4 * q));
@@ -118,53 +162,63 @@ struct WideNet {
             for (int t = 0; t < T; ++t) h1[t][ot] = bf;
         }
         // slice s: wave w moves k-block 4 s + w — its eight output tiles, 1 KB contiguous each
-        f32x4 R[kHT];
+        f32x4 R[kHT], xn[kWideSliceKB][T], xc[kWideSliceKB][T];
         auto fetch = [&](int s) {
-            const int kb = kWideSliceKB * s + w;
-            if (kb < KB1) {
+            int kb = kWideSliceKB * s + w;
+            kb = kb < last ? kb : last;
 #pragma unroll
-                for (int j = 0; j < kHT; ++j) R[j] = ld4(w1 + ((size_t)(j * KB1 + kb) * 256 + 4 * l));
-            }
+            for (int j = 0; j < kHT; ++j) R[j] = ld4(w1 + ((size_t)(j * KB1 + kb) * 256 + 4 * l));
         };
         auto commit = [&](int s) {
-            const int kb = kWideSliceKB * s + w;
             lds_f buf = u + (s & 1) * kWideSlice;
-            if (kb < KB1) {
 #pragma unroll
-                for (int j = 0; j < kHT; ++j) st4(buf + (j * kWideSliceKB + w) * 256 + 4 * l, R[j]);
-            }
+            for (int j = 0; j < kHT; ++j) st4(buf + (j * kWideSliceKB + w) * 256 + 4 * l, R[j]);
         };
-        fetch(0);
-        f32x4 xn[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) xn[t] = xfrag(rp[t], 0, OT, XT);
-        lds_barrier();                                                 // the union's previous readers (last sweep's slice, exchanges) are done
-        for (int s = 0; s < nsl; ++s) {
-            commit(s);
-            lds_barrier();                                             // slice s visible; every wave is past slice s - 1
-            if (s + 1 < nsl) fetch(s + 1);
-            lds_cf buf = u + (s & 1) * kWideSlice;
+        auto xfetch = [&](int s) {
 #pragma unroll
             for (int kbl = 0; kbl < kWideSliceKB; ++kbl) {
-                const int kb = kWideSliceKB * s + kbl;
-                if (kb < KB1) {
-                    f32x4 wf[kHT], xc[T];
+                int kb = kWideSliceKB * s + kbl;
+                kb = kb < last ? kb : last;
 #pragma unroll
-                    for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4(buf + (ot * kWideSliceKB + kbl) * 256 + fslot);
-#pragma unroll
-                    for (int t = 0; t < T; ++t) xc[t] = xn[t];
-                    if (kb + 1 < KB1) {
-#pragma unroll
-                        for (int t = 0; t < T; ++t) xn[t] = xfrag(rp[t], kb + 1, OT, XT);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int ot = 0; ot < kHT; ++ot)
-#pragma unroll
-                            for (int t = 0; t < T; ++t) h1[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], xc[t][e], h1[t][ot], 0, 0, 0);
-                }
+                for (int t = 0; t < T; ++t) xn[kbl][t] = xfrag(rp[t], kb);
             }
+        };
+        auto kblock = [&](lds_cf buf, int kbl_rt, const f32x4 (&xk)[T]) {
+            f32x4 wf[kHT];
+#pragma unroll
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4(buf + (ot * kWideSliceKB + kbl_rt) * 256 + fslot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ot = 0; ot < kHT; ++ot)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) h1[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], xk[t][e], h1[t][ot], 0, 0, 0);
+        };
+        fetch(0);
+        xfetch(0);
+        lds_barrier();                                                 // the union's previous readers (last sweep's slice, exchanges) are done
+        for (int s = 0; s < nfull; ++s) {
+            commit(s);
+            lds_barrier();                                             // slice s visible; every wave is past slice s - 1
+#pragma unroll
+            for (int kbl = 0; kbl < kWideSliceKB; ++kbl)
+#pragma unroll
+                for (int t = 0; t < T; ++t) xc[kbl][t] = xn[kbl][t];
+            fetch(s + 1);
+            xfetch(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_cf buf = u + (s & 1) * kWideSlice;
+#pragma unroll
+            for (int kbl = 0; kbl < kWideSliceKB; ++kbl) kblock(buf, kbl, xc[kbl]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tail > 0) {
+            commit(nfull);                                             // (k-blocks past the last: duplicates nobody multiplies)
+            lds_barrier();
+            lds_cf buf = u + (nfull & 1) * kWideSlice;
+#pragma unroll
+            for (int kbl = 0; kbl < kWideSliceKB - 1; ++kbl)
+                if (kbl < tail) kblock(buf, kbl, xn[kbl]);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -249,6 +303,37 @@ struct WideNet {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2[it][r] = h2[it][r] > 0.f ? acc[r] : 0.f;
         }
+    }
+
+    // dH1 = W2^T dz2 through the ReLU of h1 for T tiles at once (ChainNet::delta1 with every transposed fragment feeding T MFMAs;
+    // h1 may be a window [T0, T0 + T) of TT tiles)
+    template <int T, int TT, int T0>
+    __device__ __forceinline__ void delta1_t(const f32x4 (&d2)[T][kHT], const f32x4 (&h1)[TT][kHT], f32x4 (&d1)[T][kHT]) const {
+        const int q = C.q, i16 = C.i16, tslot = C.tslot;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < kHT; ++it) d1[t][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float wa[2][kHT];
+        auto fetch = [&](int ob, int e, float (&dst)[kHT]) {
+#pragma unroll
+            for (int it = 0; it < kHT; ++it) dst[it] = C.S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+        };
+        fetch(0, 0, wa[0]);
+        static_for<0, 4 * kHT>([&](auto sc) {
+            constexpr int s_ = decltype(sc)::value, ob = s_ >> 2, e = s_ & 3;
+            if constexpr (s_ + 1 < 4 * kHT) fetch((s_ + 1) >> 2, (s_ + 1) & 3, wa[(s_ + 1) & 1]);
+#pragma unroll
+            for (int it = 0; it < kHT; ++it)
+#pragma unroll
+                for (int t = 0; t < T; ++t) d1[t][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_ & 1][it], d2[t][ob][e], d1[t][it], 0, 0, 0);
+        });
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < kHT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d1[t][it][r] = h1[T0 + t][it][r] > 0.f ? d1[t][it][r] : 0.f;
     }
 
     template <int NT3>
@@ -340,57 +425,107 @@ struct WideNet {
         for (int o3 = 0; o3 < NT3; ++o3) { g.gb3[o3] += __shfl_xor(g.gb3[o3], 16, 64); g.gb3[o3] += __shfl_xor(g.gb3[o3], 32, 64); }
     }
 
-    // ---- dW1^T of one head over the whole batch: acc[j][y] = tile (k-tile (w >> 1) + 2 j, out tile 4 (w & 1) + y).  dz1 = the
-    // scratch images the chunk loop left (one per 64-row chunk), rowptr(row) = where that batch row's columns come from.
-    template <class RowF>
-    __device__ __forceinline__ void dw1_pass(f32x4 (&acc)[kWideMaxKT][4], g_cf dz1, int nchunks, int B, int KB1, int OT, int XT, RowF rowptr) const {
+    // ---- dW1^T of one head over the whole batch, then its tiles -> grad; returns this lane's share of the squared norm.
+    // Wave w owns out tiles 4 (w & 1) + y and the k-tiles (w >> 1) + 2 j: acc[j][y], NKT >= ceil(KB1 / 2) of them per y.
+    // dz1 = the scratch images the chunk loop left (one per 64-row chunk), rowptr(row) = that batch row's XT contiguous columns,
+    // G + L[0].w_off = the layer's block of the grad array.
+    // One trip = one 16-row block: NKT x 4 dword loads (the transposed row fragments of this wave's k-tiles) + 4 dwordx4 (the
+    // delta fragments of its out tiles) for NKT x 16 MFMAs.  The loads of block it + 1 are issued in front of the MFMAs of block
+    // it (two operand sets, alternating by name), the row pointers one block further ahead, and — as in l1_sweep — every load is
+    // unconditional: indices are clamped (a k-tile past the last re-reads the last one into accumulators nobody stores; the trip
+    // behind the last block re-reads it) instead of guarded.  The first build left the placement to the compiler: every k-tile's
+    // loads sat in front of its MFMAs, 13 exposed HBM round trips per block, 7x the MFMA time of the pass.
+    template <int NKT> struct Dw1Ops { f32x4 a[NKT], b[4]; };
+    template <int NKT, class RowF>
+    __device__ __forceinline__ float dw1_grad(g_f G, const LayerDesc* L, g_cf dz1, int nchunks, int B, int KB1, int XT, RowF rowptr) const {
         const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
         const int oh = w & 1, kt0 = w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
+        f32x4 acc[NKT][4];
 #pragma unroll
-        for (int j = 0; j < kWideMaxKT; ++j)
+        for (int j = 0; j < NKT; ++j)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[j][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto rows_of = [&](int it, RowPtr (&rp)[4]) {                  // rows 16 it + 4 q + e of the batch (clamped: their deltas are zero)
+        const int nit = nchunks * 4;                                   // it = 4 * chunk + 16-row block
+        int fcol[NKT];                                                 // this lane's column of k-tile j (clamped into the row)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            const int kt = kt0 + 2 * j < KB1 ? kt0 + 2 * j : KB1 - 1;
+            const int f = 16 * kt + i16;
+            fcol[j] = f < XT ? f : XT - 1;
+        }
+        // (rowptr reads the batch's row index from an LDS table: a GLOBAL index load here — one vmcnt counter for everything —
+        // made every trip wait for the operand loads it had just issued)
+        auto rows_of = [&](int it, g_cf (&rp)[4]) {                    // rows 16 it + 4 q + e of the batch (clamped: their deltas are zero)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = 16 * it + 4 * q + e;
+                const int row = 16 * (it < nit ? it : nit - 1) + 4 * q + e;
                 rp[e] = rowptr(row < B ? row : B - 1);
             }
         };
-        RowPtr nxt[4];
-        rows_of(0, nxt);
-        const int nit = nchunks * 4;
-        for (int it = 0; it < nit; ++it) {                             // it = 4 * chunk + 16-row block
-            RowPtr cur[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
-            if (it + 1 < nit) rows_of(it + 1, nxt);
-            f32x4 bf[4];
+        auto load_ops = [&](int it_, const g_cf (&rp)[4], Dw1Ops<NKT>& o) {
+            const int it = it_ < nit ? it_ : nit - 1;
             g_cf img = dz1 + (size_t)(it >> 2) * 8192 + (it & 3) * 256 + fslot;
 #pragma unroll
-            for (int y = 0; y < 4; ++y) bf[y] = ld4(img + (4 * oh + y) * 4 * 256);
+            for (int y = 0; y < 4; ++y) o.b[y] = ld4(img + (4 * oh + y) * 4 * 256);
 #pragma unroll
-            for (int j = 0; j < kWideMaxKT; ++j) {
-                if (j < nkt) {
-                    const int f = 16 * (kt0 + 2 * j) + i16;
-                    const int fc = f < XT ? f : XT - 1;
-                    f32x4 af;
+            for (int j = 0; j < NKT; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        g_cf p = fc < OT ? cur[e].po : cur[e].pa;
-                        const float v = p[fc];
-                        af[e] = f < XT ? v : 0.f;
-                    }
+                for (int e = 0; e < 4; ++e) o.a[j][e] = rp[e][fcol[j]];
+        };
+        auto mma = [&](const Dw1Ops<NKT>& o) {
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[j][y] = mfma4(acc[j][y], af, bf[y]);
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[j][y] = mfma4(acc[j][y], o.a[j], o.b[y]);
+        };
+        g_cf rp0[4], rp1[4];
+        Dw1Ops<NKT> A, Bo;
+        rows_of(0, rp0);
+        rows_of(1, rp1);
+        load_ops(0, rp0, A);
+        for (int it = 0; it < nit; it += 2) {                          // (nit is a multiple of 4)
+            load_ops(it + 1, rp1, Bo);
+            rows_of(it + 2, rp0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(it + 2, rp0, A);
+            rows_of(it + 3, rp1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(Bo);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // a lane's registers of tile (., kt) are input columns 16 kt + 4 q + r: the padding columns (>= XT) keep a zero gradient
+        // (their row fragments were clamped, not zeroed, at the loads)
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            if (j < nkt) {
+                const int kt = kt0 + 2 * j;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    f32x4 v = acc[j][y];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (16 * kt + 4 * q + r) < XT ? v[r] : 0.f;
+                    st4(G + L[0].w_off + ((size_t)((4 * oh + y) * KB1 + kt) * 256 + fslot), v);
+                    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
             }
         }
+        return ss;
+    }
+    // (one instantiation per size class of the first layer: a 13-tile build would make MADDPG's 5-block critics load and
+    // multiply 13 k-tiles per wave where they own 3)
+    template <class RowF>
+    __device__ __forceinline__ float dw1_grad_any(g_f G, const LayerDesc* L, g_cf dz1, int nchunks, int B, int KB1, int XT, RowF rowptr) const {
+        if (KB1 <= 2) return dw1_grad<1>(G, L, dz1, nchunks, B, KB1, XT, rowptr);
+        if (KB1 <= 6) return dw1_grad<3>(G, L, dz1, nchunks, B, KB1, XT, rowptr);
+        if (KB1 <= 14) return dw1_grad<7>(G, L, dz1, nchunks, B, KB1, XT, rowptr);
+        return dw1_grad<kWideMaxKT>(G, L, dz1, nchunks, B, KB1, XT, rowptr);
     }
 
-    // ---- one head's gradients -> the engine's grad array (image order, G = the net's block; L = the head's LayerDescs), in two
-    // parts — layers 2 / 3 and the biases before the dW1 pass, the first layer's tiles after it; each returns this lane's share of
-    // the squared norm
+    // ---- one head's layer-2 / head gradients and biases -> the engine's grad array (image order, G = the net's block; L = the
+    // head's LayerDescs), BEFORE the dW1 pass (its accumulators want the registers); returns this lane's share of the squared norm
     template <int NT3>
     __device__ __forceinline__ float grad_store_23(g_f G, const LayerDesc* L, const WideGrad<NT3>& g) const {
         const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
@@ -417,23 +552,6 @@ struct WideNet {
         if (w == 0 && q == 0) {
 #pragma unroll
             for (int o3 = 0; o3 < NT3; ++o3) { G[L[2].b_off + 16 * o3 + i16] = g.gb3[o3]; ss += g.gb3[o3] * g.gb3[o3]; }
-        }
-        return ss;
-    }
-    __device__ __forceinline__ float grad_store_1(g_f G, const LayerDesc* L, const f32x4 (&acc)[kWideMaxKT][4], int KB1) const {
-        const int w = C.w, fslot = C.fslot;
-        float ss = 0.f;
-        auto sq = [](const f32x4& v) { return (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); };
-        const int oh = w & 1, kt0 = w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
-#pragma unroll
-        for (int j = 0; j < kWideMaxKT; ++j) {
-            if (j < nkt) {
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    st4(G + L[0].w_off + ((size_t)((4 * oh + y) * KB1 + kt0 + 2 * j) * 256 + fslot), acc[j][y]);
-                    ss += sq(acc[j][y]);
-                }
-            }
         }
         return ss;
     }

@@ -376,7 +376,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
             h.wide = 1;
             h.wide_bm = (h.batch_max + 63) / 64 * 64;
-            h.wide_unit = (kWideScratchPerRow * h.wide_bm + 63) / 64 * 64;
+            h.wide_xp = h.net[1].L[0].k_pad;
+            h.wide_op = 16;
+            for (int j = 0; j < h.n_agents; ++j) h.wide_op = std::max(h.wide_op, h.net[2 * j].L[0].k_pad);
+            h.wide_unit = ((h.wide_xp + h.n_agents * h.wide_op + kWideScratchPerRow) * h.wide_bm + 128 + 63) / 64 * 64;
         }
     }
     h.act_max = 1;

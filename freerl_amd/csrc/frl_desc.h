@@ -49,7 +49,7 @@ constexpr int kWideSlice = kWideSliceKB * 8 * 256;
 constexpr int kWideMaxKB1 = 26;          // first layer: <= 416 input columns
 constexpr int kWideMaxKT = 13;           // k-tiles of dW1 one wave owns
 constexpr int kWideApitch = 32;          // floats per row in the action scratch arrays (all agents' actions: <= 32 columns)
-constexpr int kWideScratchPerRow = 484;  // floats of scratch per batch row (WideScratch)
+constexpr int kWideScratchPerRow = kWideApitch + 4 + 3 * 128;  // floats of scratch per batch row next to the two row copies (WideScratch)
 constexpr int wide_lds_floats() { return 8 * 8 * 256 + 2 * 8 * 256 + 2 * kWideSlice + 128 + 128 + 32 + 32 + 64; }
 
 // float index of W[out n][in k] inside a layer's weight block (host and device)
@@ -151,7 +151,8 @@ struct EngineDesc {
     // hidden activations between its forward and backward passes — [P][n_agents][wide_unit] floats, L2-resident
     int wide;             // 1: this engine's actor-critic updates run on that family (every net in fragment-image order)
     int wide_bm;          // batch_max rounded up to 64 rows
-    int wide_unit;        // floats per (learner, agent): kWideScratchPerRow * wide_bm rounded up to 64
+    int wide_xp, wide_op; // row pitches of the scratch's critic-input rows / observation copies (the padded first-layer widths)
+    int wide_unit;        // floats per (learner, agent): (wide_xp + n_agents * wide_op + kWideScratchPerRow) * wide_bm + 128, rounded up to 64
     float* wide_scr;
 };
 

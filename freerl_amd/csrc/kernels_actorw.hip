@@ -14,6 +14,7 @@
 
 #include "kernels.h"
 #include "device/chain_wide.hpp"
+#include "device/wide_timing.hpp"
 
 namespace frl {
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
     g_ci idx = as_global_i(D.idx + ((size_t)p * nag + ag) * D.batch_max);
     g_cf noise1 = as_global(D.noise + (((size_t)p * nag + ag) * D.noise_sets + 1) * D.batch_max * am);     // the actor stage's eps (set 1)
     WideScratch X;
-    X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm);
+    X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm, D.wide_xp, D.wide_op, nag);
     const float invB = 1.f / (float)B;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;                                 // SAC.py:250: mean of the twins; TD3.py:227 / MADDPG: Q1 only
@@ -56,25 +57,28 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
 
     // =========================================================== A: a_i = tanh(actor_i(s_i)) (SAC: tanh(mean + std eps), sum of log pi)
     float lpsum = 0.f;
+    WIDE_T0();
+    // xrow = the critic's input row [s_all | a_all], a record's first XT columns; pass A overwrites agent i's action columns with
+    // a_i (MADDPG_simple.py:183: only agent i's action is recomputed).  Agent i's observation is read in place when it starts on
+    // a 16-byte boundary of the record, from a copy otherwise.
+    const FRL_LDS int* tab0 = W.stage_idx(idx, B);                     // (the union is free until the first sweep)
+    W.copy_cols(X.xrow, X.xp, ring, R.stride, tab0, B, R.obs_off[0], XT);
+    const bool direct = ((R.obs_off[ag] - R.obs_off[0]) & 3) == 0;
+    if (!direct) W.copy_cols(X.xobs, X.op, ring, R.stride, tab0, B, R.obs_off[ag], Oi);
+    __syncthreads();
+    auto obs_of = [&](int row) {
+        const int rc = row < B ? row : B - 1;
+        return direct ? ring + (size_t)idx[rc] * R.stride + R.obs_off[ag] : (g_cf)X.xobs + (size_t)rc * X.op;
+    };
     W.stage23((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+    WIDE_T(0);
     for (int sc = 0; sc < nsc; ++sc) {
-        RowPtr rp[4];
-        g_cf recp[4];
+        g_cf rp[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { recp[t] = rec_of(row_of(sc, t)); rp[t].po = recp[t] + R.obs_off[ag]; rp[t].pa = rp[t].po; }
-        // the other agents' stored actions of the joint action row (MADDPG_simple.py:183: only agent i's action is recomputed)
-        if (nag > 1) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = row_of(sc, t);
-                if (row < B) {
-                    for (int c = q; c < AT; c += 4)
-                        if (c < aoff || c >= aoff + Ai) X.apol[(size_t)row * kWideApitch + c] = recp[t][R.act_off[0] + c];
-                }
-            }
-        }
+        for (int t = 0; t < 4; ++t) rp[t] = obs_of(row_of(sc, t));
         f32x4 h1[4][kHT];
-        W.l1_sweep<4>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a, Oi, Oi);
+        W.l1_sweep<4>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a);
+        WIDE_T(1);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -106,14 +110,15 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
                                 } else {
                                     av = tanhf(zr);
                                 }
-                                X.apol[(size_t)row * kWideApitch + aoff + c] = av;
+                                X.xrow[(size_t)row * X.xp + OT + aoff + c] = av;
                             }
                         }
                 }
             }
         });
+        WIDE_T(2);
     }
-    __syncthreads();                                                   // X.apol is read by every lane group of a row below
+    __syncthreads();                                                   // a_i in xrow is read by every lane group of a row below
 
     // =========================================================== B: Q(s, a) and dQ/da_i through the frozen critic
     float qsum = 0.f;
@@ -122,16 +127,20 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
         const LayerDesc* L = NC.L + 3 * hd;
         g_cf w1 = thC + L[0].w_off;
         W.stage23(thC, L, 1, -1, 0);
-        for (int sc = 0; sc < nsc; ++sc) {
-            RowPtr rp[4];
+        WIDE_T(0);
+        // two tiles per sweep, one tile at a time down the dX chain: h1 of four tiles next to h2, both deltas and the transposed
+        // fragments of a chain does not fit the register file (a four-tile build spilled inside the chains: 4.4x their MFMA time)
+        for (int sc2 = 0; sc2 < 2 * nsc; ++sc2) {
+            if (128 * sc2 >= B) break;
+            g_cf rp[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = row_of(sc, t);
-                rp[t].po = rec_of(row) + R.obs_off[0];
-                rp[t].pa = X.apol + (size_t)(row < B ? row : B - 1) * kWideApitch - OT;
+            for (int t = 0; t < 2; ++t) {
+                const int row = 128 * sc2 + 64 * t + 16 * w + i16;
+                rp[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp;
             }
-            f32x4 h1[4][kHT];
-            W.l1_sweep<4>(h1, rp, w1, KB1c, OT, XT);
+            f32x4 h1[2][kHT];
+            W.l1_sweep<2>(h1, rp, w1, KB1c);
+            WIDE_T(3);
             // W1's action k-blocks -> the union, tile (ot, j) at (ot * 3 + j) * 256 (the sweep is done with its slices)
             lds_barrier();
             for (int T = w; T < kHT * 3; T += 4) {
@@ -139,42 +148,45 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
                 if (j < nA) st4(W.u + T * 256 + 4 * l, ld4(w1 + ((size_t)(ot * KB1c + kbA0 + j) * 256 + 4 * l)));
             }
             lds_barrier();
-            static_for<0, 2>([&](auto hc) {
-                constexpr int half = decltype(hc)::value;
-                f32x4 h2[2][kHT], z[2][1];
-                W.l23<2, 1, true, 4, 2 * half>(h1, h2, z, 1);
+            WIDE_T(4);
+            // both tiles down the chain together: every weight fragment (forward and transposed) feeds two MFMAs
+            f32x4 h2[2][kHT], z[2][1], d2[2][kHT], d1[2][kHT];
+            W.l23<2, 1, true, 2, 0>(h1, h2, z, 1);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int tt = 2 * half + t, row = row_of(sc, tt);
-                    const bool valid = row < B;
-                    f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-                    if (q == 0 && valid) { qsum += z[t][0][0]; dz[0] = dqv; }      // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
-                    f32x4 d2[kHT], d1[kHT];
-                    C.delta2_valu(dz, h2[t], d2, 1);
-                    C.delta1(d2, h1[tt], d1);
+            for (int t = 0; t < 2; ++t) {
+                const int row = 128 * sc2 + 64 * t + 16 * w + i16;
+                f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+                if (q == 0 && row < B) { qsum += z[t][0][0]; dz[0] = dqv; }       // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
+                C.delta2_valu(dz, h2[t], d2[t], 1);
+            }
+            W.delta1_t<2, 2, 0>(d2, h1, d1);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        if (j < nA) {                                  // dX of k-block kbA0 + j = W1^T d1 (transposed fragment reads)
-                            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 3; ++j) {
+                if (j < nA) {                                          // dX of k-block kbA0 + j = W1^T d1 (transposed fragment reads)
+                    f32x4 dx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                            for (int ob = 0; ob < kHT; ++ob) {
-                                f32x4 wa;
+                    for (int ob = 0; ob < kHT; ++ob) {
+                        f32x4 wa;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) wa[e] = W.u[(ob * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-                                dx = mfma4(dx, wa, d1[ob]);
-                            }
+                        for (int e = 0; e < 4; ++e) wa[e] = W.u[(ob * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int c = 16 * (kbA0 + j) + 4 * q + r - OT - aoff;      // agent i's action component
-                                if (valid && c >= 0 && c < Ai) {
-                                    g_f dst = X.dqa + (size_t)row * kWideApitch + c;
-                                    *dst = hd == 0 ? dx[r] : *dst + dx[r];
-                                }
+                        for (int t = 0; t < 2; ++t) dx[t] = mfma4(dx[t], wa, d1[t][ob]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = 128 * sc2 + 64 * t + 16 * w + i16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = 16 * (kbA0 + j) + 4 * q + r - OT - aoff;          // agent i's action component
+                            if (row < B && c >= 0 && c < Ai) {
+                                g_f dst = X.dqa + (size_t)row * kWideApitch + c;
+                                *dst = hd == 0 ? dx[t][r] : *dst + dx[t][r];
                             }
                         }
                     }
                 }
-            });
+            }
+            WIDE_T(5);
         }
     }
     __syncthreads();
@@ -183,6 +195,7 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
     WideGrad<NT3A> g;
     W.grad_zero(g);
     W.stage23((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+    WIDE_T(0);
     float gls[NT3A][4];                                                // d loss / d log_std of this lane's action components, its rows
 #pragma unroll
     for (int o3 = 0; o3 < NT3A; ++o3)
@@ -198,6 +211,7 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
             h2[0][ot] = ld4((g_cf)(X.ah2 + ((size_t)((cg * 4 + w) * kHT + ot) * 256 + 4 * l)));
         }
         W.head_tiles<1, NT3A>(h2, z);
+        WIDE_T(6);
 #pragma unroll
         for (int o3 = 0; o3 < NT3A; ++o3) {
             dz[o3] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,7 +221,7 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
                 if (valid && c < Ai) {
                     const float dq = X.dqa[(size_t)row * kWideApitch + c];
                     if (sac) {                                         // through a = tanh(u), u = mean + exp(log_std) eps, and alpha log pi
-                        const float av = X.apol[(size_t)row * kWideApitch + aoff + c];
+                        const float av = X.xrow[(size_t)row * X.xp + OT + aoff + c];
                         const float d = dq * (1.f - av * av) + (alpha * invB) * (2.f * av);
                         const float ls = fminf(fmaxf(S.ls[c], -20.f), 2.f);
                         dz[o3][r] = d;
@@ -220,16 +234,16 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
             }
         }
         W.backward<NT3A, false>(g, h1[0], h2[0], dz, 0, X.dz1 + (size_t)cg * 8192);
+        WIDE_T(7);
     }
     W.grad_finish(g);
     float ss = W.grad_store_23<NT3A>(grA, NA.L, g);
     __syncthreads();
-    f32x4 acc[kWideMaxKT][4];
-    W.dw1_pass(acc, (g_cf)X.dz1, nchunks, B, KB1a, Oi, Oi, [&](int row) {
-        g_cf po = ring + (size_t)idx[row] * R.stride + R.obs_off[ag];
-        return RowPtr{po, po};
-    });
-    ss += W.grad_store_1(grA, NA.L, acc, KB1a);
+    {
+        const FRL_LDS int* tab = W.stage_idx(idx, B);
+        ss += W.dw1_grad_any(grA, NA.L, (g_cf)X.dz1, nchunks, B, KB1a, Oi, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[ag]; });
+    }
+    WIDE_T(8);
 
     // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target; SAC: alpha
     // log_std: sum over this wave's rows (lanes of one lane group), then over the waves through LDS
@@ -273,8 +287,11 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
     co.step = (float)((double)a.actor_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
     co.tk = 1.f - a.tau; co.tau = a.tau;
+    WIDE_T(9);
     if (nag == 1) W.adam_stream<true>(thA, mA, vA, tgA, (g_cf)grA, NA.size >> 2, co);
     else W.adam_stream<false>(thA, mA, vA, tgA, (g_cf)grA, NA.size >> 2, co);
+    WIDE_T(10);
+    WIDE_TDUMP(1);
     if (tid == 0) {
         steps[2 * ag] = tstep;
         float* st = D.stats + ((size_t)p * nag + ag) * ST_COUNT;

@@ -10,6 +10,7 @@
 
 #include "kernels.h"
 #include "device/chain_wide.hpp"
+#include "device/wide_timing.hpp"
 
 namespace frl {
 
@@ -39,29 +40,44 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
     g_ci idx = as_global_i(D.idx + ((size_t)p * nag + ag) * D.batch_max);
     g_cf noise_u = as_global(D.noise + ((size_t)p * nag + ag) * D.noise_sets * D.batch_max * am);      // this unit's sets
     WideScratch X;
-    X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm);
+    X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm, D.wide_xp, D.wide_op, nag);
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
     const int nsc = (B + 255) / 256, nchunks = (B + 63) / 64;
     const int KB1c = NC.L[0].k_pad >> 4;
     auto row_of = [&](int sc, int t) { return 256 * sc + 64 * t + 16 * w + i16; };
     auto rec_of = [&](int row) { return ring + (size_t)idx[row < B ? row : B - 1] * R.stride; };
+    auto xrow_of = [&](int row) { return (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp; };
 
-    // =========================================================== a'_j = actor_target_j(s'_j) for every agent j -> X.anext (SAC: + log pi)
+    // =========================================================== a'_j = actor_target_j(s'_j) for every agent j -> xrow = [s'_all | a'_all] (SAC: + log pi)
+    WIDE_T0();
+    const FRL_LDS int* tab0 = W.stage_idx(idx, B);                     // (the union is free until the first sweep)
+    W.copy_cols(X.xrow, X.xp, ring, R.stride, tab0, B, R.nobs_off[0], OT);        // s' of every agent: contiguous in the record
+    for (int j = 0; j < nag; ++j)                                      // ... and the agents whose columns start off a 16-byte boundary there
+        if ((R.obs_off[j] - R.obs_off[0]) & 3) W.copy_cols(X.xobs + (size_t)j * D.wide_bm * X.op, X.op, ring, R.stride, tab0, B, R.nobs_off[j], R.obs_dim[j]);
+    __syncthreads();
     for (int j = 0; j < nag; ++j) {
         const NetDesc& NA = D.net[2 * j];
         g_cf tgA = as_global(D.target + lbase + D.net_off[2 * j]);
-        const int Oj = R.obs_dim[j], Aj = R.act_dim[j], aoff = R.act_off[j] - R.act_off[0];
+        const int Oj = R.obs_dim[j], Aj = R.act_dim[j], aoff = R.act_off[j] - R.act_off[0], ooff = R.obs_off[j] - R.obs_off[0];
         const int KB1a = NA.L[0].k_pad >> 4;
         // MATD3's per-agent smoothing noise is set j of the updating agent; single agent: set 0 (TD3 policy noise / SAC eps')
         g_cf nz = noise_u + (size_t)(nag > 1 ? j : 0) * D.batch_max * am;
+        // agent j's columns of xrow, or — when they do not start on a 16-byte boundary there — a copy of them
+        const bool direct = (ooff & 3) == 0;
+
         W.stage23(tgA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+        WIDE_T(0);
         for (int sc = 0; sc < nsc; ++sc) {
-            RowPtr rp[4];
+            g_cf rp[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { rp[t].po = rec_of(row_of(sc, t)) + R.nobs_off[j]; rp[t].pa = rp[t].po; }
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t), rc = row < B ? row : B - 1;
+                rp[t] = direct ? (g_cf)X.xrow + (size_t)rc * X.xp + ooff : (g_cf)X.xobs + ((size_t)j * D.wide_bm + rc) * X.op;
+            }
             f32x4 h1[4][kHT];
-            W.l1_sweep<4>(h1, rp, tgA + NA.L[0].w_off, KB1a, Oj, Oj);
+            W.l1_sweep<4>(h1, rp, tgA + NA.L[0].w_off, KB1a);
+            WIDE_T(1);
             static_for<0, 2>([&](auto hc) {
                 constexpr int half = decltype(hc)::value;
                 f32x4 h2[2][kHT], z[2][NT3A];
@@ -107,33 +123,34 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int c = 16 * o3 + 4 * q + r;
-                                if (c < Aj) X.anext[(size_t)row * kWideApitch + aoff + c] = an[o3][r];
+                                if (c < Aj) X.xrow[(size_t)row * X.xp + OT + aoff + c] = an[o3][r];
                             }
                         if (q == 0) X.lpn[row] = lp;
                     }
                 }
             });
+            WIDE_T(2);
         }
     }
-    __syncthreads();                                                   // X.anext is read by every lane group of a row below
+    __syncthreads();                                                   // a' in xrow is read by every lane group of a row below
 
     // =========================================================== y = r + gamma (1 - d) min_h Q_target_h(s', a')  (SAC: - alpha log pi)
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         const LayerDesc* L = NC.L + 3 * hd;
         W.stage23(tgC, L, 1, -1, 0);
+        WIDE_T(0);
         for (int sc = 0; sc < nsc; ++sc) {
-            RowPtr rp[4];
-            g_cf recp[4];
+            g_cf rp[4], recp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 recp[t] = rec_of(row);
-                rp[t].po = recp[t] + R.nobs_off[0];
-                rp[t].pa = X.anext + (size_t)(row < B ? row : B - 1) * kWideApitch - OT;
+                rp[t] = xrow_of(row);
             }
             f32x4 h1[4][kHT];
-            W.l1_sweep<4>(h1, rp, tgC + L[0].w_off, KB1c, OT, XT);
+            W.l1_sweep<4>(h1, rp, tgC + L[0].w_off, KB1c);
+            WIDE_T(3);
             static_for<0, 2>([&](auto hc) {
                 constexpr int half = decltype(hc)::value;
                 f32x4 h2[2][kHT], z[2][1];
@@ -154,6 +171,7 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
                     }
                 }
             });
+            WIDE_T(4);
         }
     }
 
@@ -166,19 +184,17 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
         WideGrad<1> g;
         W.grad_zero(g);
         W.stage23((g_cf)thC, L, 1, -1, 0);
+        WIDE_T(0);
         // two tiles (chunks) per sweep here: next to the backward's live state (accumulators, h2, both deltas, the exchange
         // fragments) a third and fourth tile of first-layer activations do not fit in the register file
         for (int sc2 = 0; sc2 < 2 * nsc; ++sc2) {
             if (128 * sc2 >= B) break;
-            RowPtr rp[2];
+            g_cf rp[2];                                                // (a record's [obs | act] columns are contiguous from its start: build_record)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                g_cf rec = rec_of(128 * sc2 + 64 * t + 16 * w + i16);
-                rp[t].po = rec + R.obs_off[0];
-                rp[t].pa = rec + R.act_off[0] - OT;
-            }
+            for (int t = 0; t < 2; ++t) rp[t] = rec_of(128 * sc2 + 64 * t + 16 * w + i16) + R.obs_off[0];
             f32x4 h1[2][kHT];
-            W.l1_sweep<2>(h1, rp, (g_cf)thC + L[0].w_off, KB1c, OT, XT);
+            W.l1_sweep<2>(h1, rp, (g_cf)thC + L[0].w_off, KB1c);
+            WIDE_T(5);
             for (int c = 0; c < 2; ++c) {
                 const int cg = 2 * sc2 + c;                            // 64-row chunk of the batch
                 if (64 * cg < B) {                                     // (uniform: the chunk exists)
@@ -186,6 +202,7 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
                     const bool valid = row < B;
                     f32x4 h2[1][kHT], z[1][1];
                     W.l23<1, 1, true, 2, 0>(h1, h2, z, 1);
+                    WIDE_T(6);
                     f32x4 dz[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
                     if (q == 0 && valid) {                             // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
                         float lrow, grow;
@@ -194,6 +211,7 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
                         lossp += lrow;
                     }
                     W.backward<1, true>(g, h1[0], h2[0], dz, 1, X.dz1 + (size_t)cg * 8192);
+                    WIDE_T(7);
                 }
 #pragma unroll
                 for (int ot = 0; ot < kHT; ++ot) h1[0][ot] = h1[1][ot];
@@ -202,12 +220,11 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
         W.grad_finish(g);
         ss += W.grad_store_23<1>(grC, L, g);                           // (before the dW1 pass: its 208 accumulators want the registers)
         __syncthreads();                                               // every wave's deltas of the last chunk are in X.dz1
-        f32x4 acc[kWideMaxKT][4];
-        W.dw1_pass(acc, (g_cf)X.dz1, nchunks, B, KB1c, OT, XT, [&](int row) {
-            g_cf rec = ring + (size_t)idx[row] * R.stride;
-            return RowPtr{rec + R.obs_off[0], rec + R.act_off[0] - OT};
-        });
-        ss += W.grad_store_1(grC, L, acc, KB1c);
+        {
+            const FRL_LDS int* tab = W.stage_idx(idx, B);
+            ss += W.dw1_grad_any(grC, L, (g_cf)X.dz1, nchunks, B, KB1c, XT, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; });
+        }
+        WIDE_T(8);
         __syncthreads();                                               // X.dz1 is free for the next head
     }
 
@@ -227,10 +244,13 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
     co.step = (float)((double)a.critic_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = a.critic_wd;
     co.tk = 1.f - a.tau; co.tau = a.tau;
+    WIDE_T(9);
     // single agent: the target moves here (TD3: with the delayed policy step, TD3.py:224-233); MADDPG: soft_update_kernel afterwards
     // (every agent's workgroups read every target actor)
     if (nag == 1 && a.do_actor != 0) W.adam_stream<true>(thC, mC, vC, tgCw, (g_cf)grC, NC.size >> 2, co);
     else W.adam_stream<false>(thC, mC, vC, tgCw, (g_cf)grC, NC.size >> 2, co);
+    WIDE_T(10);
+    WIDE_TDUMP(0);
     if (tid == 0) {
         steps[2 * ag + 1] = tstep;
         float* st = D.stats + ((size_t)p * nag + ag) * ST_COUNT;
