@@ -21,7 +21,15 @@ def N():
     return _native
 
 
-def test_c4_sac_humanoid_shape(N):
+@pytest.fixture(params=["rowchunk", "chained"])
+def family(request, monkeypatch):
+    """Both kernel families on the same inputs: the row-chunk kernels (what a single learner runs) and the K-sliced chained
+    ones (kernels_criticw / _actorw: what populations of these shapes run), forced at engine creation."""
+    monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
+    return request.param == "chained"
+
+
+def test_c4_sac_humanoid_shape(N, family):
     from freerl_amd.engine import Engine
     from oracle import algos
     O, A, B, n_tab = 376, 17, 256, 600
@@ -33,6 +41,7 @@ def test_c4_sac_humanoid_shape(N):
     e = Engine(N.ALGO_SAC, O, A, 2000, twin_critic=True, batch_max=B)
     lds, rc = e.lds_bytes()
     assert lds <= 160 * 1024 and rc in (16, 32, 64)
+    assert e.learn_path(B)[0] == family and e.learn_path(B)[1] <= 160 * 1024
     for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
         e.set_params(0, flat_params(actor, an, "log_std"), kind)
         e.set_params(1, flat_params(critic, TWIN), kind)
@@ -62,7 +71,7 @@ def test_c4_sac_humanoid_shape(N):
     e.close()
 
 
-def test_c5_maddpg_spread_shape(N):
+def test_c5_maddpg_spread_shape(N, family):
     from freerl_amd.engine import Engine
     from oracle import algos
     n, O, A, B, n_tab = 3, 18, 5, 1024, 1500
@@ -72,6 +81,7 @@ def test_c5_maddpg_spread_shape(N):
     params = {a: dict(actor=synth.mlp_params(90 + 2 * j, cases.actor_layers(O, A)),
                       critic=synth.mlp_params(91 + 2 * j, cases.critic_layers(n * (O + A)))) for j, a in enumerate(ids)}
     e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, 2048, batch_max=B)
+    assert e.learn_path(B)[0] == family
     for j, a in enumerate(ids):
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
             e.set_params(2 * j, flat_params(params[a]["actor"], AC), kind)
@@ -266,11 +276,21 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
         edge = Engine(algo, 8, 2, 512, n_learners=128, twin_critic=twin, batch_max=256)      # one full round of the row-chunk kernels: theirs
         assert not edge.learn_path(256)[0]
         edge.close()
-    wide = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256)     # obs + act > 16, act > 4
-    assert not wide.learn_path(256)[0]
+    wide = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256)     # obs + act > 16, act > 4: the K-sliced chained family
+    chained, lds, rows = wide.learn_path(256)
+    assert chained and rows == 256 and 64 * 1024 < lds <= 160 * 1024
     with pytest.raises(RuntimeError):
         wide.learn_path(257)
     wide.close()
+    few = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=100, twin_critic=True, batch_max=256)      # ... from 129 (learner, agent) units up
+    assert not few.learn_path(256)[0]
+    few.close()
+    spread = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, batch_max=128)       # 192 units
+    assert spread.learn_path(128)[0]
+    spread.close()
+    matd3 = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, twin_critic=True, batch_max=128)   # MATD3: row-chunk
+    assert not matd3.learn_path(128)[0]
+    matd3.close()
     h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)
     assert not h256.learn_path(256)[0]
     h256.close()
@@ -281,3 +301,62 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     rainbow = Engine(N.ALGO_DQN, 8, 4, 512, discrete=True, batch_max=256, dueling=True, noisy=True, c51=(51, -10.0, 10.0))
     assert not rainbow.learn_path(256)[0]
     rainbow.close()
+
+
+@pytest.mark.parametrize("case", ["td3_17_6_b200", "ddpg_40_3_b256", "td3_30_5_b1000", "sac_33_17_b96"])
+def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
+    """The K-sliced chained family (kernels_criticw / _actorw, forced with FRL_CRITIC_V2=1) at shapes between the narrow standard
+    one and config 4: first layers of 2-3 k-blocks, a batch that is not a multiple of 64 (ragged last chunk), a batch of four
+    256-row super-chunks, a two-tile SAC head (17 actions) on a short batch — four learn() calls each against the oracle."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    monkeypatch.setenv("FRL_CRITIC_V2", "1")
+    kind, O, A, B = {"td3_17_6_b200": ("td3", 17, 6, 200), "ddpg_40_3_b256": ("ddpg", 40, 3, 256), "td3_30_5_b1000": ("td3", 30, 5, 1000),
+                     "sac_33_17_b96": ("sac", 33, 17, 96)}[case]
+    n_tab = 1400
+    tab = synth.transitions(401, n_tab, O, A)
+    twin = kind != "ddpg"
+    an = ["l1", "l2", "mean_layer"] if kind == "sac" else AC
+    actor = synth.mlp_params(411, cases.actor_layers(O, A, head="mean_layer" if kind == "sac" else "l3"))
+    if kind == "sac":
+        actor = dict([("log_std", np.random.default_rng(412).uniform(-0.5, 0.2, (1, A)).astype(np.float32))] + list(actor.items()))
+    critic = synth.mlp_params(413, cases.critic_layers(O + A, twin=twin))
+    algo = dict(td3=N.ALGO_TD3, ddpg=N.ALGO_DDPG, sac=N.ALGO_SAC)[kind]
+    e = Engine(algo, O, A, 2048, twin_critic=twin, batch_max=B)
+    assert e.learn_path(B)[0]
+    cn = TWIN if twin else AC
+    for k in (N.PARAM_ONLINE, N.PARAM_TARGET):
+        e.set_params(0, flat_params(actor, an, "log_std" if kind == "sac" else None), k)
+        e.set_params(1, flat_params(critic, cn), k)
+    if kind == "sac":
+        e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0)
+    e.add_batch(records([tab]))
+    orc = dict(td3=algos.TD3, ddpg=algos.DDPG, sac=algos.SAC)[kind](actor, critic, O, A, 1e-3, 1e-3, 2048)
+    for i in range(n_tab):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+    for k in range(4):
+        idx = synth.indices(420 + k, n_tab, B)
+        n0, n1 = synth.normal(430 + k, (B, A)), synth.normal(440 + k, (B, A))
+        noise = np.stack([n0, n1])[None, None]
+        if kind == "td3":
+            st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True,
+                         policy_noise=0.2, noise_clip=0.5, max_action=1.0, idx=idx, noise=noise, want_stats=True)
+            cl, al = orc.learn_with(idx, n0, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0)
+        elif kind == "ddpg":
+            st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, idx=idx, want_stats=True)
+            cl, al = orc.learn_with(idx, None, 0.99, 0.005)[:2]
+        else:
+            st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4, target_entropy=-float(A), idx=idx,
+                         noise=noise, want_stats=True)
+            cl, al, ll = orc.learn_with(idx, n0, n1, 0.99, 0.005)
+            np.testing.assert_allclose(st[0, 0, N.STAT_ALPHA_LOSS], ll, rtol=1e-4)
+        np.testing.assert_allclose(st[0, 0, N.STAT_CRITIC_LOSS], cl, rtol=1e-4)
+        if al is not None:
+            np.testing.assert_allclose(st[0, 0, N.STAT_ACTOR_LOSS], al, rtol=1e-4, atol=1e-6)
+    ga = unflat_params(e.get_params(0), orc.actor, an, "log_std" if kind == "sac" else None)
+    gc = unflat_params(e.get_params(1, N.PARAM_TARGET), orc.critic_t, cn)
+    for k in orc.actor:
+        np.testing.assert_allclose(ga[k], orc.actor[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    for k in orc.critic_t:
+        np.testing.assert_allclose(gc[k], orc.critic_t[k], rtol=1e-3, atol=1e-5, err_msg=k)
+    e.close()

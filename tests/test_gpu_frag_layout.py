@@ -35,10 +35,13 @@ def _pair(N, monkeypatch, algo, O, A, twin, P=3):
     return ec, er, g
 
 
+# (7, 3): the narrow standard shape of kernels_critic2 / _actor2 (act_frag_kernel reads the images directly); (40, 6) and (376, 17):
+# the K-sliced chained family (kernels_criticw / _actorw), whose select_action goes through a Wk copy of the net (frag_to_wk_kernel)
+@pytest.mark.parametrize("O,A", [(7, 3), (40, 6), (376, 17)])
 @pytest.mark.parametrize("algo_name,twin", [("TD3", True), ("DDPG", False), ("SAC", True)])
-def test_act_is_layout_independent(N, monkeypatch, algo_name, twin):
+def test_act_is_layout_independent(N, monkeypatch, algo_name, twin, O, A):
     algo = getattr(N, "ALGO_" + algo_name)
-    O, A, P, rows = 7, 3, 3, 150                    # 150 rows: three 64-row workgroups, the last one ragged
+    P, rows = 3, 150                                # 150 rows: three 64-row workgroups, the last one ragged
     ec, er, g = _pair(N, monkeypatch, algo, O, A, twin, P)
     obs = g.standard_normal((P, rows, O)).astype(np.float32)
     oa = g.standard_normal((P, rows, O + A)).astype(np.float32)
@@ -64,10 +67,12 @@ def test_act_is_layout_independent(N, monkeypatch, algo_name, twin):
     ec.close(); er.close()
 
 
-def test_obsnorm_enable_moves_a_chained_engine_to_the_row_chunk_family(N, monkeypatch):
+@pytest.mark.parametrize("O,A", [(6, 2), (30, 5)])
+def test_obsnorm_enable_moves_a_chained_engine_to_the_row_chunk_family(N, monkeypatch, O, A):
     """Batch_ObsNorm is the row-chunk family's: enabling it re-lays every parameter array out as Wk; parameters read back
-    unchanged and learn() then matches an engine that was row-chunk from the start."""
-    O, A, P, B = 6, 2, 2, 64
+    unchanged and learn() then matches an engine that was row-chunk from the start.  (6, 2): the narrow chained family,
+    (30, 5): the K-sliced one."""
+    P, B = 2, 64
     ec, er, g = _pair(N, monkeypatch, N.ALGO_TD3, O, A, True, P)
     before = [[ec.get_params(net, kind, learner=p) for p in range(P)] for net in range(2)
               for kind in (N.PARAM_ONLINE, N.PARAM_TARGET, N.PARAM_ADAM_M, N.PARAM_ADAM_V)]
