@@ -100,7 +100,7 @@ def init(backend=None):
             if not want_native:
                 raise
             dist.init_process_group("nccl", rank=rank, world_size=world)
-        _comm_note = "torch.distributed %s" % dist.get_backend()
+        _comm_note = "torch.distributed %s (%d rank%s)" % (dist.get_backend(), world, "" if world == 1 else "s")
         if want_native:
             try:
                 _comm = _native_comm_create(rank, world, local_rank)
