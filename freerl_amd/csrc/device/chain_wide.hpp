@@ -88,9 +88,9 @@ struct WideNet {
         const int lw = n > 32 ? 6 : (n > 16 ? 5 : 4), W = 1 << lw, rpi = 64 >> lw;      // rows per wave-instruction
         const int sub = C.l >> lw, col = C.l & (W - 1), nc = (n + 63) >> 6;
         const int ngroups = (B + rpi - 1) / rpi;
-        for (int g0 = C.w; g0 < ngroups; g0 += 4 * 8) {
-            for (int c = 0; c < nc; ++c) {
-                const int cc = col + 64 * c, ccl = cc < n ? cc : n - 1;
+        if (nc == 1) {
+            for (int g0 = C.w; g0 < ngroups; g0 += 4 * 8) {
+                const int ccl = col < n ? col : n - 1;
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -100,7 +100,28 @@ struct WideNet {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int row = (g0 + 4 * k) * rpi + sub;
-                    if (row < B && cc < n) dst[(size_t)row * pitch + cc] = v[k];
+                    if (row < B && col < n) dst[(size_t)row * pitch + col] = v[k];
+                }
+            }
+        } else {                                                       // wide rows (<= 448 columns): four rows x all chunks in flight
+            for (int r0 = C.w; r0 < B; r0 += 4 * 4) {
+                float v[4][7];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r0 + 4 * k, rc = row < B ? row : B - 1;
+                    g_cf src = ring + (size_t)tab[rc] * stride + src_off;
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) {
+                        const int cc = C.l + 64 * c;
+                        v[k][c] = src[cc < n ? cc : n - 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r0 + 4 * k;
+#pragma unroll
+                    for (int c = 0; c < 7; ++c)
+                        if (row < B && C.l + 64 * c < n) dst[(size_t)row * pitch + C.l + 64 * c] = v[k][c];
                 }
             }
         }

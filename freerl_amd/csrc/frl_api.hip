@@ -28,6 +28,8 @@
 #include "kernels_actor2.hip"
 #include "kernels_criticw.hip"
 #include "kernels_actorw.hip"
+#include "kernels_criticx.hip"
+#include "kernels_actorx.hip"
 #include "kernels_dqn2.hip"
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
@@ -374,12 +376,12 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         const char* force = getenv("FRL_CRITIC_V2");
         if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > 128) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
-            h.wide = 1;
+            h.wide = h.hidden == 256 ? 2 : 1;
             h.wide_bm = (h.batch_max + 63) / 64 * 64;
             h.wide_xp = h.net[1].L[0].k_pad;
             h.wide_op = 16;
             for (int j = 0; j < h.n_agents; ++j) h.wide_op = std::max(h.wide_op, h.net[2 * j].L[0].k_pad);
-            h.wide_unit = ((h.wide_xp + h.n_agents * h.wide_op + kWideScratchPerRow) * h.wide_bm + 128 + 63) / 64 * 64;
+            h.wide_unit = ((h.wide_xp + h.n_agents * h.wide_op + (h.wide == 2 ? kWide16ScratchPerRowHost : kWideScratchPerRow)) * h.wide_bm + 128 + 63) / 64 * 64;
         }
     }
     h.act_max = 1;
@@ -514,7 +516,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->staged_per_learner.assign(P, 0);
     if (h.algo == ALGO_DQN)
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
-    if (h.wide) {
+    if (h.wide == 2) {
+        const int lb = wide16_lds_floats_host() * (int)sizeof(float);
+        for (auto k : {ac_critic_x_h1a1_kernel, ac_critic_x_h1a2_kernel, ac_critic_x_h2a1_kernel, ac_critic_x_h2a2_kernel, ac_actor_x_a1_kernel, ac_actor_x_a2_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    } else if (h.wide) {
         const int lb = wide_lds_floats() * (int)sizeof(float);
         for (auto k : {ac_critic_wide_h1a1_kernel, ac_critic_wide_h1a2_kernel, ac_critic_wide_h2a1_kernel, ac_critic_wide_h2a2_kernel,
                        ac_actor_wide_a1_kernel, ac_actor_wide_a2_kernel})
@@ -594,7 +600,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
     }
     const bool v2 = chained_path(e->h, batch, e->h.P);
     if (chained_out) *chained_out = v2 ? 1 : 0;
-    if (bytes_out) *bytes_out = v2 ? (e->h.wide ? wide_lds_floats() : critic2_lds_floats()) * (int)sizeof(float) : e->lds_bytes;
+    if (bytes_out) *bytes_out = v2 ? (e->h.wide == 2 ? wide16_lds_floats_host() : (e->h.wide ? wide_lds_floats() : critic2_lds_floats())) * (int)sizeof(float) : e->lds_bytes;
     if (rows_out) *rows_out = v2 ? batch : e->h.rc;
     return FRL_OK;
 }
@@ -1220,7 +1226,8 @@ static bool chained_path(const EngineDesc& h, int batch, int pc) {
 static bool wide_shape(const EngineDesc& h) {
     const bool single = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1;
     const bool multi = h.algo == ALGO_MADDPG && h.n_agents >= 1 && h.net[1].heads == 1;
-    if (!(single || multi) || h.hidden != 128 || h.rec.act_total > kWideApitch) return false;
+    const int H = h.hidden;                    // 128: chain_wide.hpp; 256: chain_wide16.hpp
+    if (!(single || multi) || (H != 128 && H != 256) || h.rec.act_total > kWideApitch) return false;
     const int nt3 = h.net[0].L[2].n_pad;
     for (int j = 0; j < h.n_agents; ++j) {
         const NetDesc &NA0 = h.net[2 * j], &NC0 = h.net[2 * j + 1];
@@ -1229,8 +1236,8 @@ static bool wide_shape(const EngineDesc& h) {
         if (NA0.L[0].k_pad > 16 * kWideMaxKB1 || NC0.L[0].k_pad > 16 * kWideMaxKB1) return false;
         if (NA0.L[2].n_pad != nt3 || nt3 > 32) return false;                 // one head-tile count for every agent's actor
         for (int hd = 0; hd < NC0.heads; ++hd)
-            if (NC0.L[3 * hd].n_pad != 128 || NC0.L[3 * hd + 1].n_pad != 128 || NC0.L[3 * hd + 1].k_pad != 128 || NC0.L[3 * hd + 2].n_pad != 16) return false;
-        if (NA0.L[0].n_pad != 128 || NA0.L[1].n_pad != 128 || NA0.L[1].k_pad != 128) return false;
+            if (NC0.L[3 * hd].n_pad != H || NC0.L[3 * hd + 1].n_pad != H || NC0.L[3 * hd + 1].k_pad != H || NC0.L[3 * hd + 2].n_pad != 16) return false;
+        if (NA0.L[0].n_pad != H || NA0.L[1].n_pad != H || NA0.L[1].k_pad != H) return false;
     }
     return true;
 }
@@ -1281,9 +1288,11 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
         if (v2 && h.wide) {                               // kernels_criticw.hip: one workgroup per (learner, agent)
             prof_begin(e, PK_GRAD_CRITIC);
-            const size_t lb = (size_t)wide_lds_floats() * sizeof(float);
+            const bool x = h.wide == 2;
+            const size_t lb = (size_t)(x ? wide16_lds_floats_host() : wide_lds_floats()) * sizeof(float);
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
-            auto k = twin ? (a2 ? ac_critic_wide_h2a2_kernel : ac_critic_wide_h2a1_kernel) : (a2 ? ac_critic_wide_h1a2_kernel : ac_critic_wide_h1a1_kernel);
+            auto k = x ? (twin ? (a2 ? ac_critic_x_h2a2_kernel : ac_critic_x_h2a1_kernel) : (a2 ? ac_critic_x_h1a2_kernel : ac_critic_x_h1a1_kernel))
+                       : (twin ? (a2 ? ac_critic_wide_h2a2_kernel : ac_critic_wide_h2a1_kernel) : (a2 ? ac_critic_wide_h1a2_kernel : ac_critic_wide_h1a1_kernel));
             hipLaunchKernelGGL(k, dim3(units), blk, lb, st, e->d, a);
             prof_end(e);
             return;
@@ -1310,8 +1319,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     } else if (stage == 1) {
         if (v2 && h.wide) {                               // kernels_actorw.hip
             prof_begin(e, PK_GRAD_ACTOR);
-            auto k = h.net[0].L[2].n_pad > 16 ? ac_actor_wide_a2_kernel : ac_actor_wide_a1_kernel;
-            hipLaunchKernelGGL(k, dim3(units), blk, (size_t)wide_lds_floats() * sizeof(float), st, e->d, a);
+            const bool x = h.wide == 2, a2 = h.net[0].L[2].n_pad > 16;
+            auto k = x ? (a2 ? ac_actor_x_a2_kernel : ac_actor_x_a1_kernel) : (a2 ? ac_actor_wide_a2_kernel : ac_actor_wide_a1_kernel);
+            hipLaunchKernelGGL(k, dim3(units), blk, (size_t)(x ? wide16_lds_floats_host() : wide_lds_floats()) * sizeof(float), st, e->d, a);
             prof_end(e);
             return;
         }

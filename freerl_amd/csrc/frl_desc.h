@@ -51,6 +51,9 @@ constexpr int kWideMaxKT = 13;           // k-tiles of dW1 one wave owns
 constexpr int kWideApitch = 32;          // floats per row in the action scratch arrays (all agents' actions: <= 32 columns)
 constexpr int kWideScratchPerRow = kWideApitch + 4 + 3 * 128;  // floats of scratch per batch row next to the two row copies (WideScratch)
 constexpr int wide_lds_floats() { return 8 * 8 * 256 + 2 * 8 * 256 + 2 * kWideSlice + 128 + 128 + 32 + 32 + 64; }
+// ... at hidden 256 (device/chain_wide16.hpp: every layer streamed)
+constexpr int kWide16ScratchPerRowHost = kWideApitch + 4 + 5 * 256;
+constexpr int wide16_lds_floats_host() { return 16384 + 2 * 16 * 256 + 256 + 256 + 32 + 32 + 64; }
 
 // float index of W[out n][in k] inside a layer's weight block (host and device)
 #if defined(__HIPCC__)
@@ -149,7 +152,8 @@ struct EngineDesc {
     // The K-sliced chained family (device/chain_wide.hpp, kernels_criticw.hip / kernels_actorw.hip): per-(learner, agent) scratch —
     // target / policy actions, TD targets, dQ/da, the first-layer deltas of the batch (exchange-image order), the actor's
     // hidden activations between its forward and backward passes — [P][n_agents][wide_unit] floats, L2-resident
-    int wide;             // 1: this engine's actor-critic updates run on that family (every net in fragment-image order)
+    int wide;             // 1: this engine's actor-critic updates run on that family (every net in fragment-image order); 2: its
+                          // hidden-256 form (kernels_criticx.hip / kernels_actorx.hip)
     int wide_bm;          // batch_max rounded up to 64 rows
     int wide_xp, wide_op; // row pitches of the scratch's critic-input rows / observation copies (the padded first-layer widths)
     int wide_unit;        // floats per (learner, agent): (wide_xp + n_agents * wide_op + kWideScratchPerRow) * wide_bm + 128, rounded up to 64

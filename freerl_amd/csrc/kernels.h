@@ -187,6 +187,14 @@ __global__ void ac_critic_wide_h2a2_kernel(const EngineDesc* __restrict__ Dp, Le
 __global__ void ac_actor_wide_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_actor_wide_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 
+// kernels_criticx.hip / kernels_actorx.hip: ... and at hidden 256 (device/chain_wide16.hpp)
+__global__ void ac_critic_x_h1a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_x_h1a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_x_h2a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_x_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_actor_x_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_actor_x_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch

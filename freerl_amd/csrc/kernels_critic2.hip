@@ -21,8 +21,20 @@
 
 namespace frl {
 
-template <bool TWIN>
+// TT = 16-row tiles per wave in the target passes (4: one 256-row chunk, every weight fragment read from LDS feeds 16 MFMAs;
+// 2: 128-row chunks, for batches of <= 128 rows)
+// Developer knobs.  Measured in round 4: four tiles per wave (one 256-row chunk, 16 MFMAs per fragment read) put 256 more
+// registers of activations next to the accumulators' AGPR half — 309 spilled VGPRs with or without the fetch-ahead staging; the
+// two-tile build has none.
+#ifndef FRL_CRITIC2_TT
+#define FRL_CRITIC2_TT 2
+#endif
+#ifndef FRL_CRITIC2_AHEAD
+#define FRL_CRITIC2_AHEAD 1     // the next net's image fetched in front of a target pass's last forward (1) or behind it (0)
+#endif
+template <bool TWIN, int TT>
 __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const LearnArgs& a, float* smem) {
+    constexpr int kRowsT = 64 * TT;                                    // rows per target-pass chunk
     constexpr int NH = TWIN ? 2 : 1;
     const int p = a.p0 + blockIdx.x;
     const RecordDesc& R = D.rec;
@@ -71,22 +83,22 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         }
         return X;
     };
-    // ---- The target passes carry TWO 16-row tiles per wave (128 rows per chunk): nothing is differentiated through them, so the
-    // registers the gradient accumulators need later hold a second tile now, and every weight fragment read from LDS feeds
-    // eight MFMAs.  Row of (chunk c2, tile t) on this lane: 128 c2 + 32 w + 16 t + i16.
+    // ---- The target passes carry TT 16-row tiles per wave (64 TT rows per chunk): nothing is differentiated through them, so the
+    // registers the gradient accumulators need later hold more tiles now, and every weight fragment read from LDS feeds
+    // 4 TT MFMAs.  Row of (chunk c2, tile t) on this lane: 64 TT c2 + 16 TT w + 16 t + i16; j4 = TT c2 + t.
     int ridxT[4];
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
-        const int row = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16;
+        const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
         ridxT[j4] = row < B ? idx[row] : -1;
     }
-    struct RowIn2 { f32x4 x[2]; float rew[2], done[2]; };
-    auto load_row2 = [&](bool want_rd, int c2) {                       // s' (obs columns) [+ reward / done] of both tiles
+    struct RowIn2 { f32x4 x[TT]; float rew[TT], done[TT]; };
+    auto load_row2 = [&](bool want_rd, int c2) {                       // s' (obs columns) [+ reward / done] of the chunk's tiles
         RowIn2 X;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TT; ++t) {
             X.x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; X.rew[t] = 0.f; X.done[t] = 0.f;
-            const int ri = c2 == 0 ? ridxT[t] : ridxT[2 + t];
+            const int ri = (TT == 4 || c2 == 0) ? ridxT[t] : ridxT[(TT == 4 ? 0 : 2) + t];
             if (ri >= 0) {
                 g_cf rec = ring + (size_t)ri * R.stride;
 #pragma unroll
@@ -97,7 +109,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         }
         return X;
     };
-    const int nch2 = (B + 127) / 128;
+    const int nch2 = (B + kRowsT - 1) / kRowsT;
 
     // Developer knob (FRL_STAGGER): every workgroup runs the same ~670 k cycles and ends in the one phase that streams HBM
     // (theta / m / v / target, ~1 MB per learner), so the 256 CUs reach it together and share the chip's bandwidth (111 k
@@ -116,7 +128,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         nzr[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16;
+        const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
         if (q == 0 && row < B && (sac || a.use_policy_noise)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -131,17 +143,18 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
         nxt2 = load_row2(true, c2 + 1 < nch2 ? c2 + 1 : 0);            // (after the last chunk: chunk 0 of the target-critic pass)
-        if (c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
-        f32x4 z[2], h1[2][kHT], h2[2][kHT];
-        C.forward_vh<2>(cur.x, h1, h2, z, A);                           // (the actor head's act_dim <= 4 outputs as dot products)
+        if (FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
+        f32x4 z[TT], h1[TT][kHT], h2[TT][kHT];
+        C.forward_vh<TT>(cur.x, h1, h2, z, A);                          // (the actor head's act_dim <= 4 outputs as dot products)
+        if (!FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+        for (int t = 0; t < TT; ++t) {
+            const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
             const bool valid = row < B;
             if (q == 0 && row < kChainBatch) {                         // act_dim <= 4: the head's outputs sit on lane group 0
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
                 float lp = 0.f;
-                const f32x4 nr = c2 == 0 ? nzr[t] : nzr[2 + t];
+                const f32x4 nr = (TT == 4 || c2 == 0) ? nzr[t] : nzr[(TT == 4 ? 0 : 2) + t];
                 if (valid) {
                     if (sac) {                                         // SAC.py:70-97 on actor_target (SAC.py:227)
 #pragma unroll
@@ -185,11 +198,11 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             if (c2 + 1 < nch2) nxt2 = load_row2(true, c2 + 1);
             else if (hd + 1 < NH) nxt2 = load_row2(true, 0);
             else nxt = load_row(0);                                    // first chunk of the critic pass: [s | a], 64-row mapping
-            if (c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
-            f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
+            if (FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
+            f32x4 xb[TT], z[TT], h1[TT][kHT], h2[TT][kHT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            for (int t = 0; t < TT; ++t) {
+                const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
                 xb[t] = cur.x[t];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -197,10 +210,11 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                     if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];      // a' from the target-actor pass
                 }
             }
-            C.forward_vh<2>(xb, h1, h2, z, 1);
+            C.forward_vh<TT>(xb, h1, h2, z, 1);
+            if (!FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            for (int t = 0; t < TT; ++t) {
+                const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
                 if (q == 0 && row < B) {
                     float qv = z[t][0];
                     if (hd == 1) qv = fminf(S.q1[row], qv);
@@ -288,11 +302,11 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 
 __global__ __launch_bounds__(256) void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<true>(*Dp, a, smem);
+    ac_critic_v2_body<true, FRL_CRITIC2_TT>(*Dp, a, smem);
 }
 __global__ __launch_bounds__(256) void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<false>(*Dp, a, smem);
+    ac_critic_v2_body<false, FRL_CRITIC2_TT>(*Dp, a, smem);
 }
 
 }  // namespace frl

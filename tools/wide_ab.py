@@ -17,13 +17,16 @@ CASES = {
     "td3_b1000": dict(algo=N.ALGO_TD3, obs=30, act=5, B=1000, twin=True),
     "maddpg_c5": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=1024, twin=False),
     "maddpg_het": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=False),
+    "td3_h256": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True, hidden=256),
+    "sac_h256": dict(algo=N.ALGO_SAC, obs=40, act=17, B=200, twin=True, hidden=256),
+    "ddpg_h256": dict(algo=N.ALGO_DDPG, obs=11, act=3, B=96, twin=False, hidden=256),
 }
 
 
 def run(name, family, calls, P=2):
     c = CASES[name]
     os.environ["FRL_CRITIC_V2"] = str(family)
-    e = Engine(c["algo"], c["obs"], c["act"], 4096, n_learners=P, twin_critic=c["twin"], batch_max=c["B"], seed=3)
+    e = Engine(c["algo"], c["obs"], c["act"], 4096, n_learners=P, twin_critic=c["twin"], batch_max=c["B"], hidden=c.get("hidden", 128), seed=3)
     g = np.random.default_rng(0)
     for net in range(e.n_nets):
         for p in range(P):
