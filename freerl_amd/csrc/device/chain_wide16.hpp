@@ -44,12 +44,13 @@ struct Wide16Grad {
 
 struct WideNet16 {
     WideNet W;             // lane constants (W.C), the 64 KB union (W.u): slice buffers | exchange buffers ea, eb
-    lds_f w3, b1, b2, b3, ls, red;
+    lds_f w3, w1r, b1, b2, b3, ls, red;
 
     __device__ __forceinline__ void init(float* smem) {
         lds_f p = (lds_f)smem;
         W.u = p; W.C.S.ea = p; W.C.S.eb = p + 8192; p += 16384;
         w3 = p; p += 2 * kHT2 * 256;
+        w1r = p; p += 2 * kHT2 * 256;                                  // the first layer's image when it has <= 2 k-blocks (resident)
         b1 = p; p += 256;
         b2 = p; p += 256;
         b3 = p; p += 32;
@@ -63,10 +64,13 @@ struct WideNet16 {
     // ---- the head's image (nt3 tiles x 16 k-blocks), biases, log_std of one head -> LDS
     __device__ __forceinline__ void stage3(g_cf th, const LayerDesc* L, int nt3, int extra_off, int extra_n) const {
         const int tid = W.C.tid;
-        f32x4 t3[8];
-        g_cf wg = th + L[2].w_off;
+        f32x4 t3[8], t1[8];
+        g_cf wg = th + L[2].w_off, w1g = th + L[0].w_off;
+        const int kb1 = L[0].k_pad >> 4;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t3[j] = j < 4 * nt3 ? ld4(wg + 4 * (tid + 256 * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t1[j] = (kb1 <= 2 && j < 4 * kb1) ? ld4(w1g + 4 * (tid + 256 * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
         const float bb1 = th[L[0].b_off + tid], bb2 = th[L[1].b_off + tid];
         float bb3 = 0.f, lsv = 0.f;
         if (tid < 32) {
@@ -76,6 +80,10 @@ struct WideNet16 {
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < 8; ++j) st4(w3 + 4 * (tid + 256 * j), t3[j]);
+        if (kb1 <= 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(w1r + 4 * (tid + 256 * j), t1[j]);
+        }
         b1[tid] = bb1; b2[tid] = bb2;
         if (tid < 32) { b3[tid] = bb3; ls[tid] = lsv; }
         lds_barrier();
@@ -179,65 +187,134 @@ struct WideNet16 {
         relu<T>(h1);
     }
 
+    // ---- first layer on the RESIDENT image (KB1 <= 2: stage3 put it at w1r, tile (ot, kb) at (ot * KB1 + kb) * 256): no slice
+    // traffic, no barrier — a streamed sweep of one or two k-blocks is three dependent global round trips for 64 MFMAs
+    template <int T>
+    __device__ __forceinline__ void layer1_resident(f32x4 (&h1)[T][kHT2], const g_cf (&rp)[T], int KB1) const {
+        f32x4 x[2][T];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[kb][t] = W.xfrag(rp[t], kb < KB1 ? kb : KB1 - 1);
+        bias_init<T>(h1, (lds_cf)b1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb < KB1) {
+                f32x4 wf[kHT2];
+#pragma unroll
+                for (int ot = 0; ot < kHT2; ++ot) wf[ot] = ld4((lds_cf)(w1r + (ot * KB1 + kb) * 256 + W.C.fslot));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ot = 0; ot < kHT2; ++ot)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) h1[t][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][e], x[kb][t][e], h1[t][ot], 0, 0, 0);
+            }
+        }
+        relu<T>(h1);
+    }
+    template <int T>
+    __device__ __forceinline__ void layer1(f32x4 (&h1)[T][kHT2], const g_cf (&rp)[T], g_cf w1, int KB1) const {
+        if (KB1 <= 2) layer1_resident<T>(h1, rp, KB1); else sweep_rows<T>(h1, rp, w1, KB1);
+    }
+
     // ---- second layer: hout = relu(W2 hin + b2), the row operand in registers: hin[t][kb][e] IS the B fragment of k-block kb.
-    // Eight slices, fully unrolled (the k-block index selects registers)
+    // In two halves of eight output tiles (a slice = four k-blocks of a half: 32 tiles, its image rows are contiguous), so that
+    // the accumulators of a half (32 T registers) sit next to the 64 T of hin without spilling; four slices per half, fully
+    // unrolled (the k-block index selects registers)
     template <int T, int TT = T, int T0 = 0>
     __device__ __forceinline__ void sweep_regs(f32x4 (&hout)[T][kHT2], const f32x4 (&hin)[TT][kHT2], g_cf w2) const {
-        bias_init<T>(hout, (lds_cf)b2);
+        const int w = W.C.w, l = W.C.l, fslot = W.C.fslot, q = W.C.q;
+        // slice (hv, s): out tiles 8 hv + j, k-blocks 4 s + kbl: wave w moves k-block 4 s + w of the eight tiles -> LDS tile j * 4 + w
+        auto fetch = [&](SliceRegs& R, int hv, int s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) R.r[j] = ld4(w2 + ((size_t)((8 * hv + j) * kHT2 + 4 * s + w) * 256 + 4 * l));
+        };
+        auto put = [&](const SliceRegs& R, int n) {
+            lds_f buf = W.u + (n & 1) * 8192;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(buf + (j * 4 + w) * 256 + 4 * l, R.r[j]);
+        };
         SliceRegs R;
-        fetch_k(R, w2, kHT2, 0);
+        fetch(R, 0, 0);
         lds_barrier();
-        static_for<0, kHT2 / kSKB2>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            commit(R, s);
+        static_for<0, 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value, hv = n >> 2, s = n & 3;
+            if constexpr (s == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 bf = ld4((lds_cf)(b2 + (8 * hv + j) * 16 + 4 * q));
+#pragma unroll
+                    for (int t = 0; t < T; ++t) hout[t][8 * hv + j] = bf;
+                }
+            }
+            put(R, n);
             lds_barrier();
-            if constexpr (s + 1 < kHT2 / kSKB2) fetch_k(R, w2, kHT2, s + 1);
+            if constexpr (n + 1 < 8) fetch(R, (n + 1) >> 2, (n + 1) & 3);
             __builtin_amdgcn_sched_barrier(0);
-            lds_cf buf = W.u + (s & 1) * 8192;
+            lds_cf buf = W.u + (n & 1) * 8192;
 #pragma unroll
-            for (int kbl = 0; kbl < kSKB2; ++kbl) {
-                f32x4 xk[T];
+            for (int kbl = 0; kbl < 4; ++kbl) {
+                f32x4 wf[8];
 #pragma unroll
-                for (int t = 0; t < T; ++t) xk[t] = hin[T0 + t][kSKB2 * s + kbl];
-                kblock<T>(hout, buf, kbl, xk);
+                for (int j = 0; j < 8; ++j) wf[j] = ld4(buf + (j * 4 + kbl) * 256 + fslot);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            hout[t][8 * hv + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], hin[T0 + t][4 * s + kbl][e], hout[t][8 * hv + j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         relu<T>(hout);
     }
 
-    // ---- dH = W2^T dZ (no activation mask: the caller applies the ReLU of its h): the image sliced by output blocks, every
-    // fragment read transposed (four ds_read_b32, double-buffered one k-step ahead as ChainNet::delta1)
+    // ---- dH = W2^T dZ (no activation mask: the caller applies the ReLU of its h), fragments read transposed (four ds_read_b32,
+    // double-buffered one k-step ahead as ChainNet::delta1).  In two halves of eight INPUT tiles: slice (hv, s) = output blocks
+    // 4 s .. 4 s + 3 x input tiles 8 hv .. 8 hv + 7 (each output block's eight tiles are contiguous); wave w moves output block
+    // 4 s + w -> LDS tile j * 4 + w
     template <int T>
     __device__ __forceinline__ void sweep_t(f32x4 (&dout)[T][kHT2], const f32x4 (&din)[T][kHT2], g_cf w2) const {
-        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
+        const int w = W.C.w, l = W.C.l, q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int it = 0; it < kHT2; ++it) dout[t][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto fetch = [&](SliceRegs& R, int hv, int s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) R.r[j] = ld4(w2 + ((size_t)((4 * s + w) * kHT2 + 8 * hv + j) * 256 + 4 * l));
+        };
+        auto put = [&](const SliceRegs& R, int n) {
+            lds_f buf = W.u + (n & 1) * 8192;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(buf + (j * 4 + w) * 256 + 4 * l, R.r[j]);
+        };
         SliceRegs R;
-        fetch_o(R, w2, 0);
+        fetch(R, 0, 0);
         lds_barrier();
-        static_for<0, kHT2 / 2>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            commit(R, s);
+        static_for<0, 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value, hv = n >> 2, s = n & 3;
+            put(R, n);
             lds_barrier();
-            if constexpr (s + 1 < kHT2 / 2) fetch_o(R, w2, s + 1);
+            if constexpr (n + 1 < 8) fetch(R, (n + 1) >> 2, (n + 1) & 3);
             __builtin_amdgcn_sched_barrier(0);
-            lds_cf buf = W.u + (s & 1) * 8192;
-            float wa[2][kHT2];
-            auto fetch = [&](int obl, int e, float (&dst)[kHT2]) {
+            lds_cf buf = W.u + (n & 1) * 8192;
+            float wa[2][8];
+            auto frag = [&](int obl, int e, float (&dst)[8]) {
 #pragma unroll
-                for (int it = 0; it < kHT2; ++it) dst[it] = buf[(obl * kHT2 + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                for (int j = 0; j < 8; ++j) dst[j] = buf[(j * 4 + obl) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
             };
-            fetch(0, 0, wa[0]);
-            static_for<0, 8>([&](auto kc) {
+            frag(0, 0, wa[0]);
+            static_for<0, 16>([&](auto kc) {
                 constexpr int k_ = decltype(kc)::value, obl = k_ >> 2, e = k_ & 3;
-                if constexpr (k_ + 1 < 8) fetch((k_ + 1) >> 2, (k_ + 1) & 3, wa[(k_ + 1) & 1]);
+                if constexpr (k_ + 1 < 16) frag((k_ + 1) >> 2, (k_ + 1) & 3, wa[(k_ + 1) & 1]);
 #pragma unroll
-                for (int it = 0; it < kHT2; ++it)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int t = 0; t < T; ++t) dout[t][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k_ & 1][it], din[t][2 * s + obl][e], dout[t][it], 0, 0, 0);
+                    for (int t = 0; t < T; ++t)
+                        dout[t][8 * hv + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k_ & 1][j], din[t][4 * s + obl][e], dout[t][8 * hv + j], 0, 0, 0);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -366,56 +443,58 @@ struct WideNet16 {
         }
     }
 
-    // ---- backward of one 64-row chunk: head gradient into the owners' accumulators; h1 (row-major) and the layer-2 deltas (image)
-    // -> scratch for the dW2 pass; layer-1 deltas (image) -> scratch for the dW1 pass.  row0 = first row of the chunk.
+    // ---- backward of TWO 64-row chunks (tile t = chunk 2 pr + t) with ONE transposed sweep of W2 for both: per tile the head
+    // gradient and the layer-2 deltas (image -> scratch), then dH1 of both tiles, then per tile the ReLU mask of h1 — re-read from
+    // the row-major copy the caller stored (this lane's own row) — and the layer-1 deltas (image -> scratch).
+    // A one-tile sweep streams 256 KB of weights for 1024 MFMAs per wave: 8 B per cycle and CU, 4.9 TB/s for the chip — the
+    // first build's one-chunk backward and forward were bandwidth-bound at 35 % of the MFMA rate.
     template <int NT3, bool VH>
-    __device__ __forceinline__ void backward(Wide16Grad<NT3>& g, const f32x4 (&h1)[kHT2], const f32x4 (&h2)[kHT2], const f32x4 (&dz)[NT3], int hn,
-                                             g_cf w2, g_f h1s_row, g_f d2img, g_f dz1img) const {
+    __device__ __forceinline__ void backward_pair(Wide16Grad<NT3>& g, const f32x4 (&h2)[2][kHT2], const f32x4 (&dz)[2][NT3], int hn, g_cf w2,
+                                                  const g_cf (&h1row)[2], g_f d2img, g_f dz1img) const {
         const ChainNet& C = W.C;
         const int w = C.w;
-        // head gradient: h2's sixteen feature tiles in two halves through ea, the head deltas through eb
+        f32x4 d2[2][kHT2];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            lds_barrier();
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int ft = 0; ft < 8; ++ft) C.put_tile(C.S.ea, ft, h2[8 * hf + ft]);
-            if (hf == 0) {
+            for (int hf = 0; hf < 2; ++hf) {
+                lds_barrier();
 #pragma unroll
-                for (int o3 = 0; o3 < NT3; ++o3) C.put_tile(C.S.eb, o3, dz[o3]);
-            }
-            lds_barrier();
+                for (int ft = 0; ft < 8; ++ft) C.put_tile(C.S.ea, ft, h2[t][8 * hf + ft]);
+                if (hf == 0) {
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                f32x4 bf[2];
+                    for (int o3 = 0; o3 < NT3; ++o3) C.put_tile(C.S.eb, o3, dz[t][o3]);
+                }
+                lds_barrier();
 #pragma unroll
-                for (int x = 0; x < 2; ++x) bf[x] = C.get_frag(C.S.ea, 2 * w + x, bb);
+                for (int bb = 0; bb < 4; ++bb) {
+                    f32x4 bf[2];
 #pragma unroll
-                for (int o3 = 0; o3 < NT3; ++o3) {
-                    const f32x4 af = C.get_frag(C.S.eb, o3, bb);
-                    if (hf == 0 && w == 0) g.gb3[o3] += (af[0] + af[1]) + (af[2] + af[3]);
+                    for (int x = 0; x < 2; ++x) bf[x] = C.get_frag(C.S.ea, 2 * w + x, bb);
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) g.g3[o3][2 * hf + x] = mfma4(g.g3[o3][2 * hf + x], bf[x], af);
+                    for (int o3 = 0; o3 < NT3; ++o3) {
+                        const f32x4 af = C.get_frag(C.S.eb, o3, bb);
+                        if (hf == 0 && w == 0) g.gb3[o3] += (af[0] + af[1]) + (af[2] + af[3]);
+#pragma unroll
+                        for (int x = 0; x < 2; ++x) g.g3[o3][2 * hf + x] = mfma4(g.g3[o3][2 * hf + x], bf[x], af);
+                    }
                 }
             }
+            if constexpr (VH) delta2_valu(dz[t][0], h2[t], d2[t], hn); else delta2_tiles<NT3>(dz[t], h2[t], d2[t]);
+            exchange_out(d2[t], d2img + (size_t)t * 16384, g.gb2);
         }
-        f32x4 d2[kHT2];
-        if constexpr (VH) delta2_valu(dz[0], h2, d2, hn); else delta2_tiles<NT3>(dz, h2, d2);
-        // h1 of this lane's row, row-major (the dW2 pass reads it transposed)
+        f32x4 d1[2][kHT2];
+        sweep_t<2>(d1, d2, w2);
 #pragma unroll
-        for (int ot = 0; ot < kHT2; ++ot) st4(h1s_row + 16 * ot + 4 * C.q, h1[ot]);
-        exchange_out(d2, d2img, g.gb2);
-        f32x4 d1[kHT2];
-        {
-            f32x4 din[1][kHT2], dout[1][kHT2];
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int it = 0; it < kHT2; ++it) din[0][it] = d2[it];
-            sweep_t<1>(dout, din, w2);
+            for (int it = 0; it < kHT2; ++it) {
+                const f32x4 hm = ld4(h1row[t] + 16 * it + 4 * C.q);
 #pragma unroll
-            for (int it = 0; it < kHT2; ++it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? dout[0][it][r] : 0.f;
+                for (int r = 0; r < 4; ++r) d1[t][it][r] = hm[r] > 0.f ? d1[t][it][r] : 0.f;
+            }
+            exchange_out(d1[t], dz1img + (size_t)t * 16384, g.gb1);
         }
-        exchange_out(d1, dz1img, g.gb1);
     }
     template <int NT3>
     __device__ __forceinline__ void grad_finish(Wide16Grad<NT3>& g) const {
@@ -537,7 +616,7 @@ struct WideNet16 {
         return ss;
     }
 };
-constexpr int wide16_lds_floats() { return 16384 + 2 * kHT2 * 256 + 256 + 256 + 32 + 32 + 64; }
+constexpr int wide16_lds_floats() { return 16384 + 4 * kHT2 * 256 + 256 + 256 + 32 + 32 + 64; }
 constexpr int kWide16ScratchPerRow = kWideApitch + 4 + 5 * 256;
 
 }  // namespace frl

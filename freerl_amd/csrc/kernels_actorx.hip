@@ -65,7 +65,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
 #pragma unroll
         for (int t = 0; t < 2; ++t) rp[t] = obs_of(row2(pr, t));
         f32x4 h1[2][kHT2], h2[2][kHT2], z[2][NT3A];
-        N16.sweep_rows<2>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a);
+        N16.layer1<2>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -117,7 +117,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
 #pragma unroll
             for (int t = 0; t < 2; ++t) { const int row = row2(pr, t); rp[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp; }
             f32x4 h1[2][kHT2], d1[2][kHT2];
-            N16.sweep_rows<2>(h1, rp, w1, KB1c);
+            N16.layer1<2>(h1, rp, w1, KB1c);
             {
                 f32x4 h2[2][kHT2], z[2], d2[2][kHT2];
                 N16.sweep_regs<2>(h2, h1, w2);
@@ -183,39 +183,49 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     for (int o3 = 0; o3 < NT3A; ++o3)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gls[o3][r] = 0.f;
-    for (int cg = 0; cg < nchunks; ++cg) {
-        const int row = 64 * cg + 16 * w + i16;
-        const bool valid = row < B;
-        f32x4 h1[1][kHT2], h2[1][kHT2], z[1][NT3A], dz[NT3A];
+    for (int pr = 0; pr < npair; ++pr) {
+        g_cf h1row[2];
+        f32x4 h2[2][kHT2], z[2][NT3A], dz[2][NT3A];
 #pragma unroll
-        for (int ot = 0; ot < kHT2; ++ot) {
-            h1[0][ot] = ld4((g_cf)(X.ah1 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
-            h2[0][ot] = ld4((g_cf)(X.ah2 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
+        for (int t = 0; t < 2; ++t) {
+            const int cg = 2 * pr + t;
+            h1row[t] = (g_cf)X.h1s + (size_t)row2(pr, t) * 256;
+            // h1 back from pass A (tile order) and out again row-major: the dW2 pass reads it transposed, backward_pair its ReLU mask
+#pragma unroll
+            for (int ot = 0; ot < kHT2; ++ot) {
+                const f32x4 hv = ld4((g_cf)(X.ah1 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
+                st4((g_f)h1row[t] + 16 * ot + 4 * q, hv);
+                h2[t][ot] = ld4((g_cf)(X.ah2 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
+            }
         }
-        N16.head_tiles<1, NT3A>(h2, z);
+        N16.head_tiles<2, NT3A>(h2, z);
 #pragma unroll
-        for (int o3 = 0; o3 < NT3A; ++o3) {
-            dz[o3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 2; ++t) {
+            const int row = row2(pr, t);
+            const bool valid = row < B;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * o3 + 4 * q + r;
-                if (valid && c < Ai) {
-                    const float dq = X.dqa[(size_t)row * kWideApitch + c];
-                    if (sac) {
-                        const float av = X.xrow[(size_t)row * X.xp + OT + aoff + c];
-                        const float d = dq * (1.f - av * av) + (alpha * invB) * (2.f * av);
-                        const float lsc = fminf(fmaxf(N16.ls[c], -20.f), 2.f);
-                        dz[o3][r] = d;
-                        gls[o3][r] += d * expf(lsc) * noise1[(size_t)row * am + c] - alpha * invB;
-                    } else {
-                        const float av = tanhf(z[0][o3][r]);
-                        dz[o3][r] = dq * (1.f - av * av);
+            for (int o3 = 0; o3 < NT3A; ++o3) {
+                dz[t][o3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * o3 + 4 * q + r;
+                    if (valid && c < Ai) {
+                        const float dq = X.dqa[(size_t)row * kWideApitch + c];
+                        if (sac) {
+                            const float av = X.xrow[(size_t)row * X.xp + OT + aoff + c];
+                            const float d = dq * (1.f - av * av) + (alpha * invB) * (2.f * av);
+                            const float lsc = fminf(fmaxf(N16.ls[c], -20.f), 2.f);
+                            dz[t][o3][r] = d;
+                            gls[o3][r] += d * expf(lsc) * noise1[(size_t)row * am + c] - alpha * invB;
+                        } else {
+                            const float av = tanhf(z[t][o3][r]);
+                            dz[t][o3][r] = dq * (1.f - av * av);
+                        }
                     }
                 }
             }
         }
-        N16.backward<NT3A, false>(g, h1[0], h2[0], dz, 0, (g_cf)thA + NA.L[1].w_off, X.h1s + (size_t)row * 256, X.d2i + (size_t)cg * 16384,
-                                  X.dz1 + (size_t)cg * 16384);
+        N16.backward_pair<NT3A, false>(g, h2, dz, 0, (g_cf)thA + NA.L[1].w_off, h1row, X.d2i + (size_t)(2 * pr) * 16384, X.dz1 + (size_t)(2 * pr) * 16384);
     }
     N16.grad_finish(g);
     float ss = N16.grad_store_3<NT3A>(grA, NA.L, g);

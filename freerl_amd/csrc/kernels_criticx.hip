@@ -7,6 +7,7 @@
 
 #include "kernels.h"
 #include "device/chain_wide16.hpp"
+#include "device/wide_timing.hpp"
 
 namespace frl {
 
@@ -45,6 +46,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     auto xrow_of = [&](int row) { return (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp; };
 
     // =========================================================== a'_j = actor_target_j(s'_j) for every agent j -> xrow = [s'_all | a'_all]
+    WIDE_T0();
     const FRL_LDS int* tab0 = W.stage_idx(idx, B);
     W.copy_cols(X.xrow, X.xp, ring, R.stride, tab0, B, R.nobs_off[0], OT);
     for (int j = 0; j < nag; ++j)
@@ -58,6 +60,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         g_cf nz = noise_u + (size_t)(nag > 1 ? j : 0) * D.batch_max * am;
         const bool direct = (ooff & 3) == 0;
         N16.stage3(tgA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+        WIDE_T(0);
         for (int pr = 0; pr < npair; ++pr) {
             g_cf rp[2];
 #pragma unroll
@@ -66,8 +69,10 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                 rp[t] = direct ? (g_cf)X.xrow + (size_t)rc * X.xp + ooff : (g_cf)X.xobs + ((size_t)j * D.wide_bm + rc) * X.op;
             }
             f32x4 h1[2][kHT2], h2[2][kHT2], z[2][NT3A];
-            N16.sweep_rows<2>(h1, rp, tgA + NA.L[0].w_off, KB1a);
+            N16.layer1<2>(h1, rp, tgA + NA.L[0].w_off, KB1a);
+            WIDE_T(1);
             N16.sweep_regs<2>(h2, h1, tgA + NA.L[1].w_off);
+            WIDE_T(2);
             N16.head_tiles<2, NT3A>(h2, z);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -103,6 +108,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                 lp += __shfl_xor(lp, 32, 64);
                 if (valid && q == 0) X.lpn[row] = lp;
             }
+            WIDE_T(3);
         }
     }
     __syncthreads();                                                   // a' in xrow is read by every lane group of a row below
@@ -112,13 +118,16 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     for (int hd = 0; hd < NH; ++hd) {
         const LayerDesc* L = NC.L + 3 * hd;
         N16.stage3(tgC, L, 1, -1, 0);
+        WIDE_T(0);
         for (int pr = 0; pr < npair; ++pr) {
             g_cf rp[2], recp[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) { const int row = row2(pr, t); recp[t] = rec_of(row); rp[t] = xrow_of(row); }
             f32x4 h1[2][kHT2], h2[2][kHT2], z[2];
-            N16.sweep_rows<2>(h1, rp, tgC + L[0].w_off, KB1c);
+            N16.layer1<2>(h1, rp, tgC + L[0].w_off, KB1c);
+            WIDE_T(1);
             N16.sweep_regs<2>(h2, h1, tgC + L[1].w_off);
+            WIDE_T(2);
             N16.head_valu<2>(h2, z, 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -134,6 +143,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                     }
                 }
             }
+            WIDE_T(3);
         }
     }
 
@@ -145,28 +155,50 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         Wide16Grad<1> g;
         N16.grad_zero(g);
         N16.stage3((g_cf)thC, L, 1, -1, 0);
-        for (int cg = 0; cg < nchunks; ++cg) {
-            const int row = 64 * cg + 16 * w + i16;
-            const bool valid = row < B;
-            g_cf rp[1] = {rec_of(row) + R.obs_off[0]};                 // (a record's [obs | act] columns are contiguous from its start)
-            f32x4 h1[1][kHT2], h2[1][kHT2], z[1];
-            N16.sweep_rows<1>(h1, rp, (g_cf)thC + L[0].w_off, KB1c);
-            N16.sweep_regs<1>(h2, h1, (g_cf)thC + L[1].w_off);
-            N16.head_valu<1>(h2, z, 1);
-            f32x4 dz[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-            if (q == 0 && valid) {                                     // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
-                float lrow, grow;
-                td_loss_row(a, z[0][0] - X.yb[row], lrow, grow);
-                dz[0][0] = grow * invB;
-                lossp += lrow;
+        WIDE_T(0);
+        // pairs of chunks: tile t of pair pr = chunk 2 pr + t; one forward and one transposed sweep of W2 per pair
+        for (int pr = 0; pr < npair; ++pr) {
+            g_cf rp[2], h1row[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = row2(pr, t);
+                rp[t] = rec_of(row) + R.obs_off[0];                    // (a record's [obs | act] columns are contiguous from its start)
+                h1row[t] = (g_cf)X.h1s + (size_t)row * 256;
             }
-            N16.backward<1, true>(g, h1[0], h2[0], dz, 1, (g_cf)thC + L[1].w_off, X.h1s + (size_t)row * 256,
-                                  X.d2i + (size_t)cg * 16384, X.dz1 + (size_t)cg * 16384);
+            f32x4 h2[2][kHT2], z[2], dz[2][1];
+            {
+                f32x4 h1[2][kHT2];
+                N16.layer1<2>(h1, rp, (g_cf)thC + L[0].w_off, KB1c);
+                WIDE_T(4);
+                // h1 of this lane's rows, row-major: the dW2 pass reads it transposed, backward_pair re-reads it for the ReLU mask
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ot = 0; ot < kHT2; ++ot) st4((g_f)h1row[t] + 16 * ot + 4 * q, h1[t][ot]);
+                N16.sweep_regs<2>(h2, h1, (g_cf)thC + L[1].w_off);
+            }
+            WIDE_T(5);
+            N16.head_valu<2>(h2, z, 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = row2(pr, t);
+                dz[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q == 0 && row < B) {                               // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
+                    float lrow, grow;
+                    td_loss_row(a, z[t][0] - X.yb[row], lrow, grow);
+                    dz[t][0][0] = grow * invB;
+                    lossp += lrow;
+                }
+            }
+            N16.backward_pair<1, true>(g, h2, dz, 1, (g_cf)thC + L[1].w_off, h1row, X.d2i + (size_t)(2 * pr) * 16384, X.dz1 + (size_t)(2 * pr) * 16384);
+            WIDE_T(6);
         }
         N16.grad_finish(g);
         ss += N16.grad_store_3<1>(grC, L, g);
         __syncthreads();                                               // every wave's h1 rows and delta images are in scratch
+        WIDE_T(7);
         ss += N16.dw_grad<8>(grC + L[1].w_off, (g_cf)X.d2i, nchunks, B, kHT2, 256, [&](int row) { return (g_cf)X.h1s + (size_t)row * 256; });
+        WIDE_T(8);
         {
             const FRL_LDS int* tab = W.stage_idx(idx, B);
             auto rowf = [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; };
@@ -176,6 +208,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
             else ss += N16.dw_grad<kWideMaxKT>(grC + L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1c, XT, rowf);
         }
         __syncthreads();                                               // the scratch images are free for the next head
+        WIDE_T(9);
     }
 
     // =========================================================== clip_grad_norm_ over the whole critic net, Adam, soft update
@@ -194,8 +227,11 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     co.step = (float)((double)a.critic_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = a.critic_wd;
     co.tk = 1.f - a.tau; co.tau = a.tau;
+    WIDE_T(10);
     if (nag == 1 && a.do_actor != 0) W.adam_stream<true>(thC, mC, vC, tgCw, (g_cf)grC, NC.size >> 2, co);
     else W.adam_stream<false>(thC, mC, vC, tgCw, (g_cf)grC, NC.size >> 2, co);
+    WIDE_T(11);
+    WIDE_TDUMP(0);
     if (tid == 0) {
         steps[2 * ag + 1] = tstep;
         float* st = D.stats + ((size_t)p * nag + ag) * ST_COUNT;

@@ -303,7 +303,7 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     rainbow.close()
 
 
-@pytest.mark.parametrize("case", ["td3_17_6_b200", "ddpg_40_3_b256", "td3_30_5_b1000", "sac_33_17_b96"])
+@pytest.mark.parametrize("case", ["td3_17_6_b200", "ddpg_40_3_b256", "td3_30_5_b1000", "sac_33_17_b96", "td3_h256_11_3_b200", "sac_h256_40_17_b96"])
 def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
     """The K-sliced chained family (kernels_criticw / _actorw, forced with FRL_CRITIC_V2=1) at shapes between the narrow standard
     one and config 4: first layers of 2-3 k-blocks, a batch that is not a multiple of 64 (ragged last chunk), a batch of four
@@ -312,17 +312,18 @@ def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
     from oracle import algos
     monkeypatch.setenv("FRL_CRITIC_V2", "1")
     kind, O, A, B = {"td3_17_6_b200": ("td3", 17, 6, 200), "ddpg_40_3_b256": ("ddpg", 40, 3, 256), "td3_30_5_b1000": ("td3", 30, 5, 1000),
-                     "sac_33_17_b96": ("sac", 33, 17, 96)}[case]
+                     "sac_33_17_b96": ("sac", 33, 17, 96), "td3_h256_11_3_b200": ("td3", 11, 3, 200), "sac_h256_40_17_b96": ("sac", 40, 17, 96)}[case]
+    hidden = 256 if "h256" in case else 128         # h256: kernels_criticx / _actorx (every layer streamed; opt-in)
     n_tab = 1400
     tab = synth.transitions(401, n_tab, O, A)
     twin = kind != "ddpg"
     an = ["l1", "l2", "mean_layer"] if kind == "sac" else AC
-    actor = synth.mlp_params(411, cases.actor_layers(O, A, head="mean_layer" if kind == "sac" else "l3"))
+    actor = synth.mlp_params(411, cases.actor_layers(O, A, head="mean_layer" if kind == "sac" else "l3", hidden=hidden))
     if kind == "sac":
         actor = dict([("log_std", np.random.default_rng(412).uniform(-0.5, 0.2, (1, A)).astype(np.float32))] + list(actor.items()))
-    critic = synth.mlp_params(413, cases.critic_layers(O + A, twin=twin))
+    critic = synth.mlp_params(413, cases.critic_layers(O + A, twin=twin, hidden=hidden))
     algo = dict(td3=N.ALGO_TD3, ddpg=N.ALGO_DDPG, sac=N.ALGO_SAC)[kind]
-    e = Engine(algo, O, A, 2048, twin_critic=twin, batch_max=B)
+    e = Engine(algo, O, A, 2048, twin_critic=twin, batch_max=B, hidden=hidden)
     assert e.learn_path(B)[0]
     cn = TWIN if twin else AC
     for k in (N.PARAM_ONLINE, N.PARAM_TARGET):

@@ -20,6 +20,9 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 if case == "sac_c4":
     e = Engine(N.ALGO_SAC, 376, 17, 20_000, n_learners=P, twin_critic=True, batch_max=256, seed=1)
     B, kw = 256, dict(alpha_lr=1e-4, target_entropy=-17.0)
+elif case == "td3_h256":
+    e = Engine(N.ALGO_TD3, 8, 2, 20_000, n_learners=P, twin_critic=True, batch_max=256, hidden=256, seed=1)
+    B, kw = 256, dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0)
 else:
     e = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 20_000, n_learners=P, batch_max=1024, seed=1)
     B, kw = 1024, {}
@@ -47,6 +50,11 @@ names = [["weight staging (layers 2, 3 of every net)", "target actor(s): first-l
           "critic: first-layer sweeps on [s | a]", "action k-blocks of W1 -> LDS", "critic: layers 2-3 + dX chain -> dQ/da",
           "actor pass C: activations back + head", "actor pass C: deltas + backward", "dW1 pass (+ layer 2-3 gradient stores)",
           "dW1 stores, log_std / norm reductions", "clip + Adam + soft update stream"]]
+if case == "td3_h256":
+    names[0] = ["row copies + head staging", "target passes: first-layer sweeps", "target passes: second-layer sweeps", "target passes: heads + action rule / TD target",
+                "critic: first-layer sweeps", "critic: second-layer sweeps", "critic: head, TD delta, backward (exchanges, transposed sweep)", "head-gradient stores + sync",
+                "dW2 pass", "dW1 pass", "norm reduction", "clip + Adam (+ soft update) stream"]
+    names[1] = ["(actor stage: not stamped)"]
 for row, title in ((0, "kernels_criticw"), (1, "kernels_actorw")):
     tot = clk[row].sum()
     print("%s %s P=%d: %.0f cycles per workgroup" % (case, title, P, tot))
