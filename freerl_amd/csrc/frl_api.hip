@@ -1226,10 +1226,11 @@ static bool chained_path(const EngineDesc& h, int batch, int pc) {
 // The K-sliced chained family (device/chain_wide.hpp): the reference's hidden-128 ReLU actor-critic nets with first layers of up
 // to 416 input columns and actor heads of up to 32 outputs that chained_shape() does not admit — SAC / TD3 / DDPG on wide
 // observations (config 4: Humanoid's 376 + 17), MADDPG_simple's per-agent actors and centralised critics (config 5).
-// MATD3 (twin centralised critics, per-agent smoothing, delayed updates) stays with the row-chunk kernels.
+// MATD3 (MATD3_simple.py:195-262) is the same launch pair with twin critics, set j of the unit's noise on agent j's target action
+// and the host's delayed actor / soft-update stages.
 static bool wide_shape(const EngineDesc& h) {
     const bool single = (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1;
-    const bool multi = h.algo == ALGO_MADDPG && h.n_agents >= 1 && h.net[1].heads == 1;
+    const bool multi = h.algo == ALGO_MADDPG && h.n_agents >= 1;
     const int H = h.hidden;                    // 128: chain_wide.hpp; 256: chain_wide16.hpp
     if (!(single || multi) || (H != 128 && H != 256) || h.rec.act_total > kWideApitch) return false;
     const int nt3 = h.net[0].L[2].n_pad;

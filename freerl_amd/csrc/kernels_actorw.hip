@@ -79,10 +79,13 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
         f32x4 h1[4][kHT];
         W.l1_sweep<4>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a);
         WIDE_T(1);
+        // (only the chunks that exist: the scratch holds ceil(batch_max / 64) of them)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
+            if (64 * (4 * sc + t) < B) {
 #pragma unroll
-            for (int ot = 0; ot < kHT; ++ot) st4(X.ah1 + ((size_t)(((4 * sc + t) * 4 + w) * kHT + ot) * 256 + 4 * l), h1[t][ot]);
+                for (int ot = 0; ot < kHT; ++ot) st4(X.ah1 + ((size_t)(((4 * sc + t) * 4 + w) * kHT + ot) * 256 + 4 * l), h1[t][ot]);
+            }
         static_for<0, 2>([&](auto hc) {
             constexpr int half = decltype(hc)::value;
             f32x4 h2[2][kHT], z[2][NT3A];
@@ -90,8 +93,10 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int tt = 2 * half + t, row = row_of(sc, tt);
+                if (64 * (4 * sc + tt) < B) {
 #pragma unroll
-                for (int ot = 0; ot < kHT; ++ot) st4(X.ah2 + ((size_t)(((4 * sc + tt) * 4 + w) * kHT + ot) * 256 + 4 * l), h2[t][ot]);
+                    for (int ot = 0; ot < kHT; ++ot) st4(X.ah2 + ((size_t)(((4 * sc + tt) * 4 + w) * kHT + ot) * 256 + 4 * l), h2[t][ot]);
+                }
                 if (row < B) {
 #pragma unroll
                     for (int o3 = 0; o3 < NT3A; ++o3)

@@ -288,9 +288,12 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     spread = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, batch_max=128)       # 192 units
     assert spread.learn_path(128)[0]
     spread.close()
-    matd3 = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, twin_critic=True, batch_max=128)   # MATD3: row-chunk
-    assert not matd3.learn_path(128)[0]
+    matd3 = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, twin_critic=True, batch_max=128)   # MATD3: the same family
+    assert matd3.learn_path(128)[0]
     matd3.close()
+    h256 = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)      # hidden 256: opt-in only
+    assert not h256.learn_path(256)[0]
+    h256.close()
     h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)
     assert not h256.learn_path(256)[0]
     h256.close()

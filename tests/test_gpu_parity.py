@@ -489,7 +489,15 @@ def test_huber_td_loss_option(N, delta, ac_path):
     e.close()
 
 
-def test_maddpg_learn(N):
+@pytest.fixture(params=["rowchunk", "chained"])
+def ma_path(request, monkeypatch):
+    """MADDPG / MATD3 on both families: the row-chunk kernels and the K-sliced chained ones (kernels_criticw / _actorw: one
+    workgroup per (learner, agent); what populations of more than 128 units run)."""
+    monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
+    return request.param == "chained"
+
+
+def test_maddpg_learn(N, ma_path):
     from freerl_amd.engine import Engine
     from oracle import algos
     c = cases.CASES["maddpg"]
@@ -499,6 +507,7 @@ def test_maddpg_learn(N):
     od = [c["dims"][a][0] for a in ids]
     ad = [c["dims"][a][1] for a in ids]
     e = Engine(N.ALGO_MADDPG, od, ad, c["capacity"], batch_max=c["batch"])
+    assert e.learn_path(c["batch"])[0] == bool(ma_path)
     for j, a in enumerate(ids):
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
             e.set_params(2 * j, flat_params(inp["params"][a]["actor"], AC_NAMES), kind)
@@ -530,7 +539,7 @@ def test_maddpg_learn(N):
     e.close()
 
 
-def test_matd3_learn(N):
+def test_matd3_learn(N, ma_path):
     """MATD3_simple.learn = FRL_ALGO_MADDPG + twin_critic + policy noise on every agent's target action + do_actor."""
     from freerl_amd.engine import Engine
     from oracle import algos
@@ -543,6 +552,7 @@ def test_matd3_learn(N):
     ad = [c["dims"][a][1] for a in ids]
     am = max(ad)
     e = Engine(N.ALGO_MADDPG, od, ad, c["capacity"], batch_max=c["batch"], twin_critic=True)
+    assert e.learn_path(c["batch"])[0] == bool(ma_path)
     for j, a in enumerate(ids):
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
             e.set_params(2 * j, flat_params(inp["params"][a]["actor"], AC_NAMES), kind)
@@ -1282,8 +1292,8 @@ def test_other_row_chunks_give_the_same_answers(N, rows, monkeypatch):
     test_td3_learn(N, "td3", "rowchunk")
     test_td3_learn(N, "td3_pendulum", "rowchunk")
     test_sac_learn(N, "rowchunk")
-    test_maddpg_learn(N)
-    test_matd3_learn(N)
+    test_maddpg_learn(N, False)
+    test_matd3_learn(N, False)
 
 
 @pytest.mark.parametrize("rows,cps", [("16", "2"), ("16", "4"), ("32", "2")])
@@ -1297,8 +1307,8 @@ def test_workgroups_walking_several_row_chunks_give_the_same_answers(N, rows, cp
     test_dqn_learn_matches_oracle_and_reference(N, "rowchunk")
     test_td3_learn(N, "td3", "rowchunk")
     test_sac_learn(N, "rowchunk")
-    test_maddpg_learn(N)
-    test_matd3_learn(N)
+    test_maddpg_learn(N, False)
+    test_matd3_learn(N, False)
     test_dqn_rainbow_all_six_tricks(N)
 
 

@@ -17,6 +17,8 @@ CASES = {
     "td3_b1000": dict(algo=N.ALGO_TD3, obs=30, act=5, B=1000, twin=True),
     "maddpg_c5": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=1024, twin=False),
     "maddpg_het": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=False),
+    "matd3_het": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=True, matd3=True),
+    "matd3_c5": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=1024, twin=True, matd3=True),
     "td3_h256": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True, hidden=256),
     "sac_h256": dict(algo=N.ALGO_SAC, obs=40, act=17, B=200, twin=True, hidden=256),
     "ddpg_h256": dict(algo=N.ALGO_DDPG, obs=11, act=3, B=96, twin=False, hidden=256),
@@ -48,7 +50,9 @@ def run(name, family, calls, P=2):
             kw = dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, do_actor=(k % 2 == 1))
         if c["algo"] == N.ALGO_SAC:
             kw = dict(alpha_lr=1e-3, target_entropy=-float(am))
-        need_noise = c["algo"] in (N.ALGO_TD3, N.ALGO_SAC)
+        if c.get("matd3"):
+            kw = dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, do_actor=(k % 2 == 1))
+        need_noise = c["algo"] in (N.ALGO_TD3, N.ALGO_SAC) or c.get("matd3")
         st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx if na > 1 else idx[:, 0],
                      noise=noise if need_noise else None, want_stats=True, **kw)
         stats.append(st.copy())
