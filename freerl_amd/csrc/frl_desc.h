@@ -52,8 +52,8 @@ constexpr int kWideApitch = 32;          // floats per row in the action scratch
 constexpr int kWideScratchPerRow = kWideApitch + 4 + 3 * 128;  // floats of scratch per batch row next to the two row copies (WideScratch)
 constexpr int wide_lds_floats() { return 8 * 8 * 256 + 2 * 8 * 256 + 2 * kWideSlice + 128 + 128 + 32 + 32 + 64; }
 // ... at hidden 256 (device/chain_wide16.hpp: every layer streamed)
-constexpr int kWide16ScratchPerRowHost = kWideApitch + 4 + 5 * 256;
-constexpr int wide16_lds_floats_host() { return 16384 + 4 * 16 * 256 + 256 + 256 + 32 + 32 + 64; }
+constexpr int kWide16ScratchPerRowHost = kWideApitch + 4 + 32 + 5 * 256;      // Wide16Scratch + the actor stage's third critic tensor
+constexpr int wide16_lds_floats_host() { return 16384 + 2 * 16 * 256 + 3 * 16 * 256 + 256 + 256 + 32 + 32 + 192; }
 
 // float index of W[out n][in k] inside a layer's weight block (host and device)
 #if defined(__HIPCC__)

@@ -1,10 +1,10 @@
-// Actor stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup: kernels_actorw.hip's three passes on
-// device/chain_wide16.hpp (every layer a sweep over 32 KB slices of its image) — DDPG_simple.py:151-154, TD3.py:224-233,
-// SAC.py:244-260, MADDPG_simple.py:182-186.
-//   A  actor forward (two tiles per wave)            -> a_i into the critic's input row, h1 / h2 -> scratch
-//   B  critic forward on [s | a] + the dX chain      -> dQ/da_i (the transposed sweep of W2, then W1's action k-blocks from the union)
-//   C  actor backward from the stored activations    -> head gradient in registers, h1 rows / delta images -> scratch; dW2 and dW1
-//      passes; clip + Adam streamed over the net
+// Actor stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup on device/chain_wide16.hpp (the
+// counterpart of kernels_criticx.hip): kernels_actorw.hip's three passes with every matrix product a sweep over 32 KB weight
+// slices against four 16-row tiles per wave and the hidden activations / deltas in the unit's scratch in tile-lane order —
+// DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260, MADDPG_simple.py:182-186.
+//   A  actor forward                                   -> a_i into the critic's input row; h1, h2 stay in scratch for pass C
+//   B  critic forward on [s | a], deltas down to layer 1, dX of agent i's action columns (W1's action k-blocks in LDS) -> dQ/da_i
+//   C  actor deltas from dQ/da_i down to layer 1        -> scratch; the weight-gradient passes; clip + Adam streamed over the net
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -19,9 +19,9 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[2 * ag];
     const NetDesc& NC = D.net[2 * ag + 1];
-    WideNet16 N16;
-    N16.init(smem);
-    const WideNet& W = N16.W;
+    SweepNet N;
+    N.init(smem);
+    const WideNet& W = N.W;
     const ChainNet& C = W.C;
     const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
     const int B = a.batch, OT = R.obs_total, AT = R.act_total, XT = OT + AT, am = D.act_max;
@@ -40,13 +40,36 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     g_cf noise1 = as_global(D.noise + (((size_t)p * nag + ag) * D.noise_sets + 1) * D.batch_max * am);
     Wide16Scratch X;
     X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm, D.wide_xp, D.wide_op, nag);
+    // pass B's critic activations / deltas: behind the actor's own tensors (h1t / h2t persist from pass A to pass C)
+    g_f c1t = X.d2t, c2t = X.d1t, cdt = X.d1t + (size_t)256 * D.wide_bm;
     const float invB = 1.f / (float)B;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;
     const float dqv = sac ? -0.5f * invB : -invB;
-    const int nchunks = (B + 63) / 64, npair = (B + 127) / 128;
+    const int nsc = (B + 255) / 256, nchunks = (B + 63) / 64;
     const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
-    auto row2 = [&](int pr, int t) { return 128 * pr + 64 * t + 16 * w + i16; };
+    auto row_of = [&](int sc, int t) { return 256 * sc + 64 * t + 16 * w + i16; };
+    auto layer = [&](auto relu_c, const g_cf (&pp)[4], int kstride, g_cf wimg, int KB, lds_f bias, auto&& sink) {
+        static_for<0, 2>([&](auto hc) {
+            constexpr int hv = decltype(hc)::value;
+            f32x4 acc[4][8];
+            N.sweep_f<4, decltype(relu_c)::value>(acc, pp, kstride, wimg + (size_t)8 * hv * KB * 256, KB, (lds_cf)(bias + 128 * hv));
+            sink(acc, hv);
+        });
+    };
+    auto store_half = [&](g_f tensor, int sc) {
+        return [&, tensor, sc](const f32x4 (&acc)[4][8], int hv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (64 * (4 * sc + t) < B) {
+                    g_f tp = N.tl(tensor, 4 * sc + t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) st4(tp + (8 * hv + j) * 256, acc[t][j]);
+                }
+            }
+        };
+    };
+    std::true_type RELU;
 
     // =========================================================== A: a_i = tanh(actor_i(s_i)) (SAC: tanh(mean + std eps), sum of log pi)
     float lpsum = 0.f;
@@ -55,30 +78,28 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     const bool direct = ((R.obs_off[ag] - R.obs_off[0]) & 3) == 0;
     if (!direct) W.copy_cols(X.xobs, X.op, ring, R.stride, tab0, B, R.obs_off[ag], Oi);
     __syncthreads();
-    auto obs_of = [&](int row) {
-        const int rc = row < B ? row : B - 1;
-        return direct ? ring + (size_t)idx[rc] * R.stride + R.obs_off[ag] : (g_cf)X.xobs + (size_t)rc * X.op;
-    };
-    N16.stage3((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
-    for (int pr = 0; pr < npair; ++pr) {
-        g_cf rp[2];
+    N.stage3((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+    for (int sc = 0; sc < nsc; ++sc) {
+        g_cf px[4], ph[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) rp[t] = obs_of(row2(pr, t));
-        f32x4 h1[2][kHT2], h2[2][kHT2], z[2][NT3A];
-        N16.layer1<2>(h1, rp, (g_cf)thA + NA.L[0].w_off, KB1a);
+        for (int t = 0; t < 4; ++t) {
+            const int row = row_of(sc, t), rc = row < B ? row : B - 1;
+            px[t] = (direct ? ring + (size_t)idx[rc] * R.stride + R.obs_off[ag] : (g_cf)X.xobs + (size_t)rc * X.op) + 4 * q;
+            ph[t] = N.tl(X.h1t, 4 * sc + t);
+        }
+        layer(RELU, px, 16, (g_cf)thA + NA.L[0].w_off, KB1a, N.b1, store_half(X.h1t, sc));
+        f32x4 z[4][NT3A];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ot = 0; ot < kHT2; ++ot) st4(X.ah1 + ((size_t)(((2 * pr + t) * 4 + w) * kHT2 + ot) * 256 + 4 * l), h1[t][ot]);
-        N16.sweep_regs<2>(h2, h1, (g_cf)thA + NA.L[1].w_off);
+            for (int o3 = 0; o3 < NT3A; ++o3) z[t][o3] = ld4((lds_cf)(N.b3 + 16 * o3 + 4 * q));
+        layer(RELU, ph, 256, (g_cf)thA + NA.L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
+            store_half(X.h2t, sc)(acc, hv);
+            N.head_tiles_half<4, NT3A>(acc, hv, z);
+        });
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ot = 0; ot < kHT2; ++ot) st4(X.ah2 + ((size_t)(((2 * pr + t) * 4 + w) * kHT2 + ot) * 256 + 4 * l), h2[t][ot]);
-        N16.head_tiles<2, NT3A>(h2, z);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = row2(pr, t);
+        for (int t = 0; t < 4; ++t) {
+            const int row = row_of(sc, t);
             if (row < B) {
 #pragma unroll
                 for (int o3 = 0; o3 < NT3A; ++o3)
@@ -89,7 +110,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
                             const float zr = z[t][o3][r];
                             float av;
                             if (sac) {                                 // SAC.py:70-97
-                                const float lsc = fminf(fmaxf(N16.ls[c], -20.f), 2.f), sd = expf(lsc);
+                                const float lsc = fminf(fmaxf(N.ls[c], -20.f), 2.f), sd = expf(lsc);
                                 const float u = zr + sd * noise1[(size_t)row * am + c], du = u - zr;
                                 lpsum += -(du * du) / (2.f * sd * sd) - lsc - kLogSqrt2Pi;
                                 lpsum -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
@@ -111,134 +132,165 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     for (int hd = 0; hd < nq; ++hd) {
         const LayerDesc* L = NC.L + 3 * hd;
         g_cf w1 = thC + L[0].w_off, w2 = thC + L[1].w_off;
-        N16.stage3(thC, L, 1, -1, 0);
-        for (int pr = 0; pr < npair; ++pr) {
-            g_cf rp[2];
+        N.stage3(thC, L, 1, -1, 0);
+        // W1's action k-blocks -> LDS, tile (ot, j) at (ot * 3 + j) * 256
+        for (int T = w; T < kHT2 * 3; T += 4) {
+            const int ot = T / 3, j = T - 3 * ot;
+            if (j < nA) st4(N.w1a + T * 256 + 4 * l, ld4(w1 + ((size_t)(ot * KB1c + kbA0 + j) * 256 + 4 * l)));
+        }
+        lds_barrier();
+        for (int sc = 0; sc < nsc; ++sc) {
+            g_cf px[4], ph[4], pd[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { const int row = row2(pr, t); rp[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp; }
-            f32x4 h1[2][kHT2], d1[2][kHT2];
-            N16.layer1<2>(h1, rp, w1, KB1c);
-            {
-                f32x4 h2[2][kHT2], z[2], d2[2][kHT2];
-                N16.sweep_regs<2>(h2, h1, w2);
-                N16.head_valu<2>(h2, z, 1);
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t);
+                px[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp + 4 * q;
+                ph[t] = N.tl(c1t, 4 * sc + t);
+                pd[t] = N.tl(cdt, 4 * sc + t);
+            }
+            layer(RELU, px, 16, w1, KB1c, N.b1, store_half(c1t, sc));
+            float zp[4][4] = {};
+            layer(RELU, ph, 256, w2, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
+                store_half(c2t, sc)(acc, hv);
+                N.head_valu_half<4>(acc, hv, zp, 1);
+            });
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = row2(pr, t);
-                    f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-                    if (q == 0 && row < B) { qsum += z[t][0]; dz[0] = dqv; }       // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
-                    N16.delta2_valu(dz, h2[t], d2[t], 1);
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t), chunk = 4 * sc + t;
+                float qv = zp[t][0];
+                qv += __shfl_xor(qv, 16, 64);
+                qv += __shfl_xor(qv, 32, 64);
+                qv += N.b3[0];
+                const float dzv = row < B ? dqv : 0.f;                 // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
+                if (q == 0 && row < B) qsum += qv;
+                if (64 * chunk < B) {
+                    f32x4 none[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+                    N.delta2_tile<1, true>(none, dzv, (g_cf)N.tl(c2t, chunk), N.tl(cdt, chunk));
                 }
-                N16.sweep_t<2>(d1, d2, w2);
             }
+            f32x4 dx[4][3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int it = 0; it < kHT2; ++it)
+                for (int j = 0; j < 3; ++j) dx[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, 2>([&](auto hc) {                            // d1 = (W2^T d2) o relu'(h1), half by half, straight into the dX MFMAs
+                constexpr int hv = decltype(hc)::value;
+                f32x4 acc[4][8];
+                N.sweep_tr<4>(acc, pd, 256, w2, hv);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d1[t][it][r] = h1[t][it][r] > 0.f ? d1[t][it][r] : 0.f;
-            // W1's action k-blocks -> the union, tile (ot, j) at (ot * 3 + j) * 256 (48 tiles; the sweeps are done with their slices)
-            lds_barrier();
-            for (int T = w; T < kHT2 * 3; T += 4) {
-                const int ot = T / 3, j = T - 3 * ot;
-                if (j < nA) st4(W.u + T * 256 + 4 * l, ld4(w1 + ((size_t)(ot * KB1c + kbA0 + j) * 256 + 4 * l)));
-            }
-            lds_barrier();
+                for (int t = 0; t < 4; ++t) {
+                    g_cf hp = (g_cf)N.tl(c1t, 64 * (4 * sc + t) < B ? 4 * sc + t : 0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (j < nA) {                                          // dX of k-block kbA0 + j = W1^T d1 (transposed fragment reads)
-                    f32x4 dx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const f32x4 hm = ld4(hp + (8 * hv + jj) * 256);
 #pragma unroll
-                    for (int ob = 0; ob < kHT2; ++ob) {
-                        f32x4 wa;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) wa[e] = W.u[(ob * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) dx[t] = mfma4(dx[t], wa, d1[t][ob]);
+                        for (int r = 0; r < 4; ++r) acc[t][jj][r] = hm[r] > 0.f ? acc[t][jj][r] : 0.f;
                     }
+                }
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int row = row2(pr, t);
+                for (int j = 0; j < 3; ++j) {
+                    if (j < nA) {                                      // dX of k-block kbA0 + j += W1^T d1 over this half's output tiles
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int c = 16 * (kbA0 + j) + 4 * q + r - OT - aoff;
-                            if (row < B && c >= 0 && c < Ai) {
-                                g_f dst = X.dqa + (size_t)row * kWideApitch + c;
-                                *dst = hd == 0 ? dx[t][r] : *dst + dx[t][r];
-                            }
+                        for (int jj = 0; jj < 8; ++jj) {
+                            f32x4 wa;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) wa[e] = N.w1a[((8 * hv + jj) * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) dx[t][j] = mfma4(dx[t][j], wa, acc[t][jj]);
                         }
                     }
                 }
+            });
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * (kbA0 + j) + 4 * q + r - OT - aoff;
+                        if (j < nA && row < B && c >= 0 && c < Ai) {
+                            g_f dst = X.dqa + (size_t)row * kWideApitch + c;
+                            *dst = hd == 0 ? dx[t][j][r] : *dst + dx[t][j][r];
+                        }
+                    }
             }
         }
     }
     __syncthreads();
 
-    // =========================================================== C: backward from the stored activations
-    Wide16Grad<NT3A> g;
-    N16.grad_zero(g);
-    N16.stage3((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+    // =========================================================== C: the actor's deltas from dQ/da_i down to layer 1
+    N.stage3((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
     float gls[NT3A][4];
 #pragma unroll
     for (int o3 = 0; o3 < NT3A; ++o3)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gls[o3][r] = 0.f;
-    for (int pr = 0; pr < npair; ++pr) {
-        g_cf h1row[2];
-        f32x4 h2[2][kHT2], z[2][NT3A], dz[2][NT3A];
+    for (int sc = 0; sc < nsc; ++sc) {
+        g_cf pd[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int cg = 2 * pr + t;
-            h1row[t] = (g_cf)X.h1s + (size_t)row2(pr, t) * 256;
-            // h1 back from pass A (tile order) and out again row-major: the dW2 pass reads it transposed, backward_pair its ReLU mask
-#pragma unroll
-            for (int ot = 0; ot < kHT2; ++ot) {
-                const f32x4 hv = ld4((g_cf)(X.ah1 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
-                st4((g_f)h1row[t] + 16 * ot + 4 * q, hv);
-                h2[t][ot] = ld4((g_cf)(X.ah2 + ((size_t)((cg * 4 + w) * kHT2 + ot) * 256 + 4 * l)));
-            }
-        }
-        N16.head_tiles<2, NT3A>(h2, z);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = row2(pr, t);
+        for (int t = 0; t < 4; ++t) {
+            const int row = row_of(sc, t), chunk = 4 * sc + t;
             const bool valid = row < B;
+            pd[t] = N.tl(X.d2t, chunk);
+            f32x4 dz[NT3A];
 #pragma unroll
             for (int o3 = 0; o3 < NT3A; ++o3) {
-                dz[t][o3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dz[o3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 16 * o3 + 4 * q + r;
                     if (valid && c < Ai) {
                         const float dq = X.dqa[(size_t)row * kWideApitch + c];
-                        if (sac) {
-                            const float av = X.xrow[(size_t)row * X.xp + OT + aoff + c];
+                        const float av = X.xrow[(size_t)row * X.xp + OT + aoff + c];      // a_i (pass A)
+                        if (sac) {                                     // through a = tanh(u), u = mean + exp(log_std) eps, and alpha log pi
                             const float d = dq * (1.f - av * av) + (alpha * invB) * (2.f * av);
-                            const float lsc = fminf(fmaxf(N16.ls[c], -20.f), 2.f);
-                            dz[t][o3][r] = d;
+                            const float lsc = fminf(fmaxf(N.ls[c], -20.f), 2.f);
+                            dz[o3][r] = d;
                             gls[o3][r] += d * expf(lsc) * noise1[(size_t)row * am + c] - alpha * invB;
                         } else {
-                            const float av = tanhf(z[t][o3][r]);
-                            dz[t][o3][r] = dq * (1.f - av * av);
+                            dz[o3][r] = dq * (1.f - av * av);
                         }
                     }
                 }
             }
+            if (64 * chunk < B) {
+#pragma unroll
+                for (int o3 = 0; o3 < NT3A; ++o3) st4(N.tl(X.dzt, chunk, NT3A) + o3 * 256, dz[o3]);
+                N.delta2_tile<NT3A, false>(dz, 0.f, (g_cf)N.tl(X.h2t, chunk), N.tl(X.d2t, chunk));
+            }
         }
-        N16.backward_pair<NT3A, false>(g, h2, dz, 0, (g_cf)thA + NA.L[1].w_off, h1row, X.d2i + (size_t)(2 * pr) * 16384, X.dz1 + (size_t)(2 * pr) * 16384);
+        static_for<0, 2>([&](auto hc) {
+            constexpr int hv = decltype(hc)::value;
+            f32x4 acc[4][8];
+            N.sweep_tr<4>(acc, pd, 256, (g_cf)thA + NA.L[1].w_off, hv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (64 * (4 * sc + t) < B) {
+                    g_cf hp = (g_cf)N.tl(X.h1t, 4 * sc + t);
+                    g_f dp = N.tl(X.d1t, 4 * sc + t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4 hm = ld4(hp + (8 * hv + j) * 256);
+                        f32x4 d = acc[t][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = hm[r] > 0.f ? d[r] : 0.f;
+                        st4(dp + (8 * hv + j) * 256, d);
+                    }
+                }
+            }
+        });
     }
-    N16.grad_finish(g);
-    float ss = N16.grad_store_3<NT3A>(grA, NA.L, g);
     __syncthreads();
-    ss += N16.dw_grad<8>(grA + NA.L[1].w_off, (g_cf)X.d2i, nchunks, B, kHT2, 256, [&](int row) { return (g_cf)X.h1s + (size_t)row * 256; });
+    float ss = N.dw2(grA + NA.L[1].w_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
+    ss += N.dw3<NT3A>(grA + NA.L[2].w_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
     {
         const FRL_LDS int* tab = W.stage_idx(idx, B);
-        auto rowf = [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[ag]; };
-        if (KB1a <= 2) ss += N16.dw_grad<1>(grA + NA.L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1a, Oi, rowf);
-        else if (KB1a <= 6) ss += N16.dw_grad<3>(grA + NA.L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1a, Oi, rowf);
-        else if (KB1a <= 14) ss += N16.dw_grad<7>(grA + NA.L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1a, Oi, rowf);
-        else ss += N16.dw_grad<kWideMaxKT>(grA + NA.L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1a, Oi, rowf);
+        ss += N.dw1(grA + NA.L[0].w_off, KB1a, Oi, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[ag]; }, (g_cf)X.d1t, nchunks, B);
     }
+    ss += N.bias_pass(grA, NA.L[0].b_off, (g_cf)X.d1t, kHT2, B);
+    ss += N.bias_pass(grA, NA.L[1].b_off, (g_cf)X.d2t, kHT2, B);
+    ss += N.bias_pass(grA, NA.L[2].b_off, (g_cf)X.dzt, NT3A, B);
 
     // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target; SAC: alpha
 #pragma unroll
@@ -260,7 +312,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     lds_barrier();
     float ss_extra = 0.f;
     if (sac && tid < Ai) {                                             // outside the clamp [-20, 2] the gradient is zero (SAC.py:77)
-        const float raw = N16.ls[tid];
+        const float raw = N.ls[tid];
         const float gr = (raw >= -20.f && raw <= 2.f) ? ((lsred[tid] + lsred[32 + tid]) + lsred[64 + tid]) + lsred[96 + tid] : 0.f;
         grA[NA.extra_off + tid] = gr;
         ss_extra = gr * gr;
@@ -268,13 +320,13 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     ss = wave_sum(ss + ss_extra);
     const float qs = wave_sum(qsum), lps = wave_sum(lpsum);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    if (l == 0) { N16.red[w] = ss; N16.red[8 + w] = qs; N16.red[12 + w] = lps; }
-    if (tid == 0) N16.red[32] = __int_as_float(steps[2 * ag]);
+    if (l == 0) { N.red[w] = ss; N.red[8 + w] = qs; N.red[12 + w] = lps; }
+    if (tid == 0) N.red[32] = __int_as_float(steps[2 * ag]);
     __syncthreads();
-    const float total = sqrtf(((N16.red[0] + N16.red[1]) + N16.red[2]) + N16.red[3]);
-    const float qtot = ((N16.red[8] + N16.red[9]) + N16.red[10]) + N16.red[11];
-    const float lptot = ((N16.red[12] + N16.red[13]) + N16.red[14]) + N16.red[15];
-    const int tstep = __float_as_int(N16.red[32]) + 1;
+    const float total = sqrtf(((N.red[0] + N.red[1]) + N.red[2]) + N.red[3]);
+    const float qtot = ((N.red[8] + N.red[9]) + N.red[10]) + N.red[11];
+    const float lptot = ((N.red[12] + N.red[13]) + N.red[14]) + N.red[15];
+    const int tstep = __float_as_int(N.red[32]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, tstep), bc2 = 1.0 - powi_d((double)a.beta2, tstep);
     AdamCoef co;
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;

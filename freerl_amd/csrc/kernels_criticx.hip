@@ -1,8 +1,9 @@
-// Critic stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup: kernels_criticw.hip's structure on
-// device/chain_wide16.hpp, where every layer is a sweep over 32 KB slices of its image — DDPG_simple.py:139-149, TD3.py:193-213,
-// 235-244, SAC.py:226-238, MADDPG_simple.py:165-180 with the hidden width the reference hard-codes (TD3.py:30) doubled to north_star's
-// 256.  Target passes carry two 16-row tiles per wave (128 registers of activations per layer), the differentiated pass one;
-// the weight gradients of the first two layers are contracted in passes of their own from what the chunk loop left in scratch.
+// Critic stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup on device/chain_wide16.hpp: every
+// matrix product a sweep over 32 KB slices of its weight image against four 16-row tiles per wave, the hidden activations and
+// deltas in the unit's scratch in tile-lane order — DDPG_simple.py:139-149, TD3.py:193-213,235-244, SAC.py:226-238,
+// MADDPG_simple.py:165-180 with the hidden width the reference hard-codes (TD3.py:30) doubled to north_star's 256.
+//
+// Row mapping: tile t of wave w in super-chunk sc holds rows 256 sc + 64 t + 16 w + i16 (tile t = 64-row chunk 4 sc + t).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -17,9 +18,9 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     const int unit = blockIdx.x, p = a.p0 + unit / nag, ag = unit % nag;
     const RecordDesc& R = D.rec;
     const NetDesc& NC = D.net[2 * ag + 1];
-    WideNet16 N16;
-    N16.init(smem);
-    const WideNet& W = N16.W;
+    SweepNet N;
+    N.init(smem);
+    const WideNet& W = N.W;
     const ChainNet& C = W.C;
     const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
     const int B = a.batch, OT = R.obs_total, AT = R.act_total, XT = OT + AT, am = D.act_max;
@@ -39,11 +40,32 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm, D.wide_xp, D.wide_op, nag);
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
-    const int nchunks = (B + 63) / 64, npair = (B + 127) / 128;
+    const int nsc = (B + 255) / 256, nchunks = (B + 63) / 64;
     const int KB1c = NC.L[0].k_pad >> 4;
-    auto row2 = [&](int pr, int t) { return 128 * pr + 64 * t + 16 * w + i16; };       // tile t of wave w in 128-row pair pr = chunk 2 pr + t
+    auto row_of = [&](int sc, int t) { return 256 * sc + 64 * t + 16 * w + i16; };
     auto rec_of = [&](int row) { return ring + (size_t)idx[row < B ? row : B - 1] * R.stride; };
-    auto xrow_of = [&](int row) { return (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp; };
+    // a full 256-wide layer on the super-chunk's four tiles = two half-sweeps; sink(acc, half) consumes a half's eight output tiles
+    auto layer = [&](auto relu_c, const g_cf (&pp)[4], int kstride, g_cf wimg, int KB, lds_f bias, auto&& sink) {
+        static_for<0, 2>([&](auto hc) {
+            constexpr int hv = decltype(hc)::value;
+            f32x4 acc[4][8];
+            N.sweep_f<4, decltype(relu_c)::value>(acc, pp, kstride, wimg + (size_t)8 * hv * KB * 256, KB, (lds_cf)(bias + 128 * hv));
+            sink(acc, hv);
+        });
+    };
+    auto store_half = [&](g_f tensor, int sc) {
+        return [&, tensor, sc](const f32x4 (&acc)[4][8], int hv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (64 * (4 * sc + t) < B) {                           // (only the chunks that exist in the scratch tensors)
+                    g_f tp = N.tl(tensor, 4 * sc + t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) st4(tp + (8 * hv + j) * 256, acc[t][j]);
+                }
+            }
+        };
+    };
+    std::true_type RELU;
 
     // =========================================================== a'_j = actor_target_j(s'_j) for every agent j -> xrow = [s'_all | a'_all]
     WIDE_T0();
@@ -59,24 +81,28 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         const int KB1a = NA.L[0].k_pad >> 4;
         g_cf nz = noise_u + (size_t)(nag > 1 ? j : 0) * D.batch_max * am;
         const bool direct = (ooff & 3) == 0;
-        N16.stage3(tgA, NA.L, NT3A, NA.extra_off, NA.extra_n);
+        N.stage3(tgA, NA.L, NT3A, NA.extra_off, NA.extra_n);
         WIDE_T(0);
-        for (int pr = 0; pr < npair; ++pr) {
-            g_cf rp[2];
+        for (int sc = 0; sc < nsc; ++sc) {
+            g_cf px[4], ph[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = row2(pr, t), rc = row < B ? row : B - 1;
-                rp[t] = direct ? (g_cf)X.xrow + (size_t)rc * X.xp + ooff : (g_cf)X.xobs + ((size_t)j * D.wide_bm + rc) * X.op;
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t), rc = row < B ? row : B - 1;
+                px[t] = (direct ? (g_cf)X.xrow + (size_t)rc * X.xp + ooff : (g_cf)X.xobs + ((size_t)j * D.wide_bm + rc) * X.op) + 4 * q;
+                ph[t] = N.tl(X.h1t, 4 * sc + t);
             }
-            f32x4 h1[2][kHT2], h2[2][kHT2], z[2][NT3A];
-            N16.layer1<2>(h1, rp, tgA + NA.L[0].w_off, KB1a);
+            layer(RELU, px, 16, tgA + NA.L[0].w_off, KB1a, N.b1, store_half(X.h1t, sc));
             WIDE_T(1);
-            N16.sweep_regs<2>(h2, h1, tgA + NA.L[1].w_off);
-            WIDE_T(2);
-            N16.head_tiles<2, NT3A>(h2, z);
+            f32x4 z[4][NT3A];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = row2(pr, t);
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int o3 = 0; o3 < NT3A; ++o3) z[t][o3] = ld4((lds_cf)(N.b3 + 16 * o3 + 4 * q));
+            layer(RELU, ph, 256, tgA + NA.L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) { N.head_tiles_half<4, NT3A>(acc, hv, z); });
+            WIDE_T(2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t);
                 const bool valid = row < B;
                 float lp = 0.f;
 #pragma unroll
@@ -88,7 +114,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                             const float zr = z[t][o3][r];
                             float av;
                             if (sac) {                                 // SAC.py:70-97 on actor_target (SAC.py:227)
-                                const float lsc = fminf(fmaxf(N16.ls[c], -20.f), 2.f), sd = expf(lsc);
+                                const float lsc = fminf(fmaxf(N.ls[c], -20.f), 2.f), sd = expf(lsc);
                                 const float u = zr + sd * nz[(size_t)row * am + c], du = u - zr;
                                 lp += -(du * du) / (2.f * sd * sd) - lsc - kLogSqrt2Pi;
                                 lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
@@ -117,23 +143,30 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         const LayerDesc* L = NC.L + 3 * hd;
-        N16.stage3(tgC, L, 1, -1, 0);
+        N.stage3(tgC, L, 1, -1, 0);
         WIDE_T(0);
-        for (int pr = 0; pr < npair; ++pr) {
-            g_cf rp[2], recp[2];
+        for (int sc = 0; sc < nsc; ++sc) {
+            g_cf px[4], ph[4], recp[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { const int row = row2(pr, t); recp[t] = rec_of(row); rp[t] = xrow_of(row); }
-            f32x4 h1[2][kHT2], h2[2][kHT2], z[2];
-            N16.layer1<2>(h1, rp, tgC + L[0].w_off, KB1c);
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t);
+                recp[t] = rec_of(row);
+                px[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp + 4 * q;
+                ph[t] = N.tl(X.h1t, 4 * sc + t);
+            }
+            layer(RELU, px, 16, tgC + L[0].w_off, KB1c, N.b1, store_half(X.h1t, sc));
             WIDE_T(1);
-            N16.sweep_regs<2>(h2, h1, tgC + L[1].w_off);
+            float zp[4][4] = {};
+            layer(RELU, ph, 256, tgC + L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) { N.head_valu_half<4>(acc, hv, zp, 1); });
             WIDE_T(2);
-            N16.head_valu<2>(h2, z, 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = row2(pr, t);
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t);
+                float qv = zp[t][0];
+                qv += __shfl_xor(qv, 16, 64);
+                qv += __shfl_xor(qv, 32, 64);
+                qv += N.b3[0];
                 if (q == 0 && row < B) {
-                    float qv = z[t][0];
                     if (hd == 1) qv = fminf(X.q1[row], qv);
                     if (hd == NH - 1) {
                         const float rew = recp[t][R.rew_off + ag], done = recp[t][R.done_off + ag];
@@ -147,67 +180,87 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         }
     }
 
-    // =========================================================== critic heads: forward, TD delta, backward; gradient passes; -> grad
+    // =========================================================== critic heads: forward, TD delta, deltas down to layer 1; gradient passes
     float lossp = 0.f, ss = 0.f;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         const LayerDesc* L = NC.L + 3 * hd;
-        Wide16Grad<1> g;
-        N16.grad_zero(g);
-        N16.stage3((g_cf)thC, L, 1, -1, 0);
+        g_cf w2 = (g_cf)thC + L[1].w_off;
+        N.stage3((g_cf)thC, L, 1, -1, 0);
         WIDE_T(0);
-        // pairs of chunks: tile t of pair pr = chunk 2 pr + t; one forward and one transposed sweep of W2 per pair
-        for (int pr = 0; pr < npair; ++pr) {
-            g_cf rp[2], h1row[2];
+        for (int sc = 0; sc < nsc; ++sc) {
+            g_cf px[4], ph[4], pd[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = row2(pr, t);
-                rp[t] = rec_of(row) + R.obs_off[0];                    // (a record's [obs | act] columns are contiguous from its start)
-                h1row[t] = (g_cf)X.h1s + (size_t)row * 256;
+            for (int t = 0; t < 4; ++t) {
+                px[t] = rec_of(row_of(sc, t)) + R.obs_off[0] + 4 * q;   // (a record's [obs | act] columns are contiguous from its start)
+                ph[t] = N.tl(X.h1t, 4 * sc + t);
+                pd[t] = N.tl(X.d2t, 4 * sc + t);
             }
-            f32x4 h2[2][kHT2], z[2], dz[2][1];
-            {
-                f32x4 h1[2][kHT2];
-                N16.layer1<2>(h1, rp, (g_cf)thC + L[0].w_off, KB1c);
-                WIDE_T(4);
-                // h1 of this lane's rows, row-major: the dW2 pass reads it transposed, backward_pair re-reads it for the ReLU mask
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int ot = 0; ot < kHT2; ++ot) st4((g_f)h1row[t] + 16 * ot + 4 * q, h1[t][ot]);
-                N16.sweep_regs<2>(h2, h1, (g_cf)thC + L[1].w_off);
-            }
+            layer(RELU, px, 16, (g_cf)thC + L[0].w_off, KB1c, N.b1, store_half(X.h1t, sc));
+            WIDE_T(4);
+            float zp[4][4] = {};
+            layer(RELU, ph, 256, w2, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
+                store_half(X.h2t, sc)(acc, hv);
+                N.head_valu_half<4>(acc, hv, zp, 1);
+            });
             WIDE_T(5);
-            N16.head_valu<2>(h2, z, 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = row2(pr, t);
-                dz[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (q == 0 && row < B) {                               // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
+            for (int t = 0; t < 4; ++t) {
+                const int row = row_of(sc, t), chunk = 4 * sc + t;
+                float qv = zp[t][0];
+                qv += __shfl_xor(qv, 16, 64);
+                qv += __shfl_xor(qv, 32, 64);
+                qv += N.b3[0];
+                float dzv = 0.f;                                       // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
+                if (row < B) {
                     float lrow, grow;
-                    td_loss_row(a, z[t][0] - X.yb[row], lrow, grow);
-                    dz[t][0][0] = grow * invB;
-                    lossp += lrow;
+                    td_loss_row(a, qv - X.yb[row], lrow, grow);
+                    dzv = grow * invB;
+                    if (q == 0) lossp += lrow;
+                }
+                if (64 * chunk < B) {                                  // (uniform: the chunk exists in the scratch tensors)
+                    f32x4 dzt = {0.f, 0.f, 0.f, 0.f};
+                    if (q == 0) dzt[0] = dzv;                          // D layout of the head tile: output 0 on lane group 0, register 0
+                    st4(N.tl(X.dzt, chunk, 1), dzt);
+                    f32x4 none[1] = {dzt};
+                    N.delta2_tile<1, true>(none, dzv, (g_cf)N.tl(X.h2t, chunk), N.tl(X.d2t, chunk));
                 }
             }
-            N16.backward_pair<1, true>(g, h2, dz, 1, (g_cf)thC + L[1].w_off, h1row, X.d2i + (size_t)(2 * pr) * 16384, X.dz1 + (size_t)(2 * pr) * 16384);
             WIDE_T(6);
+            static_for<0, 2>([&](auto hc) {                            // dH1 = W2^T d2 through the ReLU of h1 -> d1t
+                constexpr int hv = decltype(hc)::value;
+                f32x4 acc[4][8];
+                N.sweep_tr<4>(acc, pd, 256, w2, hv);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (64 * (4 * sc + t) < B) {
+                        g_cf hp = (g_cf)N.tl(X.h1t, 4 * sc + t);
+                        g_f dp = N.tl(X.d1t, 4 * sc + t);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const f32x4 hm = ld4(hp + (8 * hv + j) * 256);
+                            f32x4 d = acc[t][j];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d[r] = hm[r] > 0.f ? d[r] : 0.f;
+                            st4(dp + (8 * hv + j) * 256, d);
+                        }
+                    }
+                }
+            });
+            WIDE_T(7);
         }
-        N16.grad_finish(g);
-        ss += N16.grad_store_3<1>(grC, L, g);
-        __syncthreads();                                               // every wave's h1 rows and delta images are in scratch
-        WIDE_T(7);
-        ss += N16.dw_grad<8>(grC + L[1].w_off, (g_cf)X.d2i, nchunks, B, kHT2, 256, [&](int row) { return (g_cf)X.h1s + (size_t)row * 256; });
+        __syncthreads();                                               // every wave's activations and deltas are in scratch
+        ss += N.dw2(grC + L[1].w_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
         WIDE_T(8);
+        ss += N.dw3<1>(grC + L[2].w_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
         {
             const FRL_LDS int* tab = W.stage_idx(idx, B);
-            auto rowf = [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; };
-            if (KB1c <= 2) ss += N16.dw_grad<1>(grC + L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1c, XT, rowf);
-            else if (KB1c <= 6) ss += N16.dw_grad<3>(grC + L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1c, XT, rowf);
-            else if (KB1c <= 14) ss += N16.dw_grad<7>(grC + L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1c, XT, rowf);
-            else ss += N16.dw_grad<kWideMaxKT>(grC + L[0].w_off, (g_cf)X.dz1, nchunks, B, KB1c, XT, rowf);
+            ss += N.dw1(grC + L[0].w_off, KB1c, XT, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; }, (g_cf)X.d1t, nchunks, B);
         }
-        __syncthreads();                                               // the scratch images are free for the next head
+        ss += N.bias_pass(grC, L[0].b_off, (g_cf)X.d1t, kHT2, B);
+        ss += N.bias_pass(grC, L[1].b_off, (g_cf)X.d2t, kHT2, B);
+        ss += N.bias_pass(grC, L[2].b_off, (g_cf)X.dzt, 1, B);
+        __syncthreads();                                               // the scratch tensors are free for the next head
         WIDE_T(9);
     }
 
@@ -215,12 +268,12 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     ss = wave_sum(ss);
     const float lsum = wave_sum(lossp);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    if (l == 0) { N16.red[w] = ss; N16.red[8 + w] = lsum; }
-    if (tid == 0) N16.red[16] = __int_as_float(steps[2 * ag + 1]);
+    if (l == 0) { N.red[w] = ss; N.red[8 + w] = lsum; }
+    if (tid == 0) N.red[16] = __int_as_float(steps[2 * ag + 1]);
     __syncthreads();
-    const float total = sqrtf(((N16.red[0] + N16.red[1]) + N16.red[2]) + N16.red[3]);
-    const float loss = ((N16.red[8] + N16.red[9]) + N16.red[10]) + N16.red[11];
-    const int tstep = __float_as_int(N16.red[16]) + 1;
+    const float total = sqrtf(((N.red[0] + N.red[1]) + N.red[2]) + N.red[3]);
+    const float loss = ((N.red[8] + N.red[9]) + N.red[10]) + N.red[11];
+    const int tstep = __float_as_int(N.red[16]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, tstep), bc2 = 1.0 - powi_d((double)a.beta2, tstep);
     AdamCoef co;
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;

@@ -51,9 +51,10 @@ names = [["weight staging (layers 2, 3 of every net)", "target actor(s): first-l
           "actor pass C: activations back + head", "actor pass C: deltas + backward", "dW1 pass (+ layer 2-3 gradient stores)",
           "dW1 stores, log_std / norm reductions", "clip + Adam + soft update stream"]]
 if case == "td3_h256":
-    names[0] = ["row copies + head staging", "target passes: first-layer sweeps", "target passes: second-layer sweeps", "target passes: heads + action rule / TD target",
-                "critic: first-layer sweeps", "critic: second-layer sweeps", "critic: head, TD delta, backward (exchanges, transposed sweep)", "head-gradient stores + sync",
-                "dW2 pass", "dW1 pass", "norm reduction", "clip + Adam (+ soft update) stream"]
+    names[0] = ["row copies, head staging", "target passes: first-layer sweeps (+ h1 -> scratch)", "target passes: second-layer sweeps (+ head partials)",
+                "target passes: action rule / TD target", "critic: first-layer sweeps (+ h1 -> scratch)", "critic: second-layer sweeps (+ h2 -> scratch, head partials)",
+                "critic: TD delta, layer-2 deltas -> scratch", "critic: transposed sweeps (d1 -> scratch)", "dW2 pass", "dW3, dW1, bias passes", "norm reduction",
+                "clip + Adam (+ soft update) stream"]
     names[1] = ["(actor stage: not stamped)"]
 for row, title in ((0, "kernels_criticw"), (1, "kernels_actorw")):
     tot = clk[row].sum()
