@@ -224,6 +224,255 @@ struct SweepNet {
         }
     }
 
+    // =========================================================================================================================
+    // X-stationary form of the 256-wide products.  The activations of the wave's four tiles, XR[half][t][j] = feature tile
+    // 8 half + j of row tile t (256 registers: the D layout of one layer = the B operand of the next, as in chain.hpp), stay in
+    // registers; the weight image streams through the union two output tiles (32 KB) at a time and every finished pair of
+    // output tiles goes to the caller's epilogue — so a layer reads nothing but its weights, its stores spread over the sweep,
+    // and a 256-row super-chunk runs L1 -> L2 -> head -> deltas -> W2^T without reading an activation back.
+
+    // first layer into XR: images of <= 32 tiles (KB1 <= 2) are staged whole, wider ones take the two K-outer half-sweeps
+    __device__ __forceinline__ void l1_x(f32x4 (&X)[2][4][8], const g_cf (&p)[4], g_cf w1, int KB1) const {
+        const int l = W.C.l, w = W.C.w, q = W.C.q, fslot = W.C.fslot;
+        if (KB1 <= 2) {
+            const int lastt = 16 * KB1 - 1;
+            f32x4 R[8], xin[2][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int n = w * 8 + j;
+                n = n < lastt ? n : lastt;
+                R[j] = ld4(w1 + ((size_t)n * 256 + 4 * l));
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xin[kb][t] = ld4(p[t] + (kb < KB1 ? kb : KB1 - 1) * 16);
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(W.u + (w * 8 + j) * 256 + 4 * l, R[j]);
+            lds_barrier();
+            static_for<0, 16>([&](auto oc) {
+                constexpr int ot = decltype(oc)::value;
+                const f32x4 bf = ld4((lds_cf)(b1 + ot * 16 + 4 * q));
+                f32x4 acc[4] = {bf, bf, bf, bf};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb < KB1) {
+                        const f32x4 wf = ld4((lds_cf)(W.u + (ot * KB1 + kb) * 256 + fslot));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xin[kb][t][e], acc[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[ot >> 3][t][ot & 7][r] = fmaxf(acc[t][r], 0.f);
+            });
+        } else {
+            sweep_f<4, true>(X[0], p, 16, w1, KB1, (lds_cf)b1);
+            sweep_f<4, true>(X[1], p, 16, w1 + (size_t)8 * KB1 * 256, KB1, (lds_cf)(b1 + 128));
+        }
+    }
+
+    // ReLU masks of XR: word s = tiles 2 s, 2 s + 1, bit o * 16 + t * 4 + r
+    __device__ __forceinline__ void mask_bits(const f32x4 (&X)[2][4][8], unsigned (&m)[8]) const {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            unsigned v = 0;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v |= X[(2 * s + o) >> 3][t][(2 * s + o) & 7][r] > 0.f ? 1u << (o * 16 + t * 4 + r) : 0u;
+            m[s] = v;
+        }
+    }
+    // XR -> tile-lane tensor (the super-chunk's four chunks exist: the scratch is sized in multiples of 256 rows)
+    __device__ __forceinline__ void store_x(g_f tensor, int sc, const f32x4 (&X)[2][4][8]) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            g_f tp = tl(tensor, 4 * sc + t);
+#pragma unroll
+            for (int it = 0; it < kHT2; ++it) st4(tp + it * 256, X[it >> 3][t][it & 7]);
+        }
+    }
+
+    // the sweep: for s = 0..7, acc[o][t] = sum_kb Wtile(2 s + o, kb) XR[kb][t]  (TR: sum_ob Wtile(ob, 2 s + o)^T XR[ob][t]), biases
+    // from `bias` when given; epi(s, acc) consumes the pair.  One barrier per slice, the next slice's loads pinned in front of
+    // the slice's 512 MFMAs, nothing conditional in the loop (chain_wide.hpp's rules).
+    template <bool TR, class Epi>
+    __device__ __forceinline__ void sweep_x(const f32x4 (&X)[2][4][8], g_cf w2, lds_cf bias, Epi&& epi) const {
+        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot, tslot = W.C.tslot;
+        f32x4 R[8];
+        auto fetch = [&](int s_) {
+            const int s = s_ < 7 ? s_ : 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = w * 8 + j;                               // slot n of the slice = (o = n >> 4, kb = n & 15)
+                const int tile = TR ? (n & 15) * kHT2 + 2 * s + (n >> 4) : 2 * s * kHT2 + n;
+                R[j] = ld4(w2 + ((size_t)tile * 256 + 4 * l));
+            }
+        };
+        auto commit = [&](int s) {
+            lds_f buf = W.u + (s & 1) * 8192;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(buf + (w * 8 + j) * 256 + 4 * l, R[j]);
+        };
+        fetch(0);
+        lds_barrier();
+        for (int s = 0; s < 8; ++s) {
+            commit(s);
+            lds_barrier();
+            fetch(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_cf buf = W.u + (s & 1) * 8192;
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const f32x4 bf = TR ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(bias + (2 * s + o) * 16 + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[o][t] = bf;
+            }
+            if constexpr (!TR) {
+                static_for<0, 16>([&](auto kc) {
+                    constexpr int kb = decltype(kc)::value;
+                    f32x4 wf[2];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) wf[o] = ld4(buf + (o * 16 + kb) * 256 + fslot);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int o = 0; o < 2; ++o)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[o][e], X[kb >> 3][t][kb & 7][e], acc[o][t], 0, 0, 0);
+                });
+            } else {
+                float wa[2][2];
+                auto frag = [&](int k_, float (&dst)[2]) {
+                    const int ob = k_ >> 2, e = k_ & 3;
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) dst[o] = buf[(o * 16 + ob) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                };
+                frag(0, wa[0]);
+                static_for<0, 64>([&](auto kc) {
+                    constexpr int k_ = decltype(kc)::value, ob = k_ >> 2, e = k_ & 3;
+                    if constexpr (k_ + 1 < 64) frag(k_ + 1, wa[(k_ + 1) & 1]);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k_ & 1][o], X[ob >> 3][t][ob & 7][e], acc[o][t], 0, 0, 0);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            epi(s, acc);
+        }
+    }
+
+    // layer-2 deltas into XR from the head's deltas and h2's ReLU masks: one-output dot-product head (dzv[t] = the row's delta)
+    __device__ __forceinline__ void delta2_x_valu(f32x4 (&X)[2][4][8], const unsigned (&m2)[8], const float (&dzv)[4]) const {
+        const int q = W.C.q;
+#pragma unroll
+        for (int it = 0; it < kHT2; ++it) {
+            const f32x4 wv = ld4((lds_cf)(w3 + it * 256 + ((q * 16 + q) << 2)));          // slot (q, f = 0): W3[0][16 it + 4 q ..]
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[it >> 3][t][it & 7][r] = ((m2[it >> 1] >> ((it & 1) * 16 + t * 4 + r)) & 1u) ? wv[r] * dzv[t] : 0.f;
+        }
+    }
+    // ... NT3 head tiles: W3^T dz through transposed fragments of the head image
+    template <int NT3>
+    __device__ __forceinline__ void delta2_x_tiles(f32x4 (&X)[2][4][8], const unsigned (&m2)[8], const f32x4 (&dz)[4][NT3]) const {
+        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
+#pragma unroll
+        for (int it = 0; it < kHT2; ++it) {
+            f32x4 wa[NT3];
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wa[o3][e] = w3[(o3 * kHT2 + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o3 = 0; o3 < NT3; ++o3) d = mfma4(d, wa[o3], dz[t][o3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[it >> 3][t][it & 7][r] = ((m2[it >> 1] >> ((it & 1) * 16 + t * 4 + r)) & 1u) ? d[r] : 0.f;
+            }
+        }
+    }
+    // head partials of one finished pair of h2 tiles (sweep_x epilogue): dot-product head / NT3 MFMA tiles
+    __device__ __forceinline__ void head_valu_pair(const f32x4 (&h)[2][4], int s, float (&zp)[4]) const {
+        const int q = W.C.q;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const f32x4 wv = ld4((lds_cf)(w3 + (2 * s + o) * 256 + ((q * 16 + q) << 2)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zp[t] = fmaf(wv[r], h[o][t][r], zp[t]);
+        }
+    }
+    template <int NT3>
+    __device__ __forceinline__ void head_tiles_pair(const f32x4 (&h)[2][4], int s, f32x4 (&z)[4][NT3]) const {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int o3 = 0; o3 < NT3; ++o3) {
+                const f32x4 wf = ld4((lds_cf)(w3 + (o3 * kHT2 + 2 * s + o) * 256 + W.C.fslot));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) z[t][o3] = mfma4(z[t][o3], wf, h[o][t]);
+            }
+    }
+    // the mask words travel through the slice loops by rotation (no dynamically indexed registers)
+    static __device__ __forceinline__ unsigned mask_next(unsigned (&m)[8]) {
+        const unsigned v = m[0];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) m[i] = m[i + 1];
+        m[7] = v;
+        return v;
+    }
+    static __device__ __forceinline__ void mask_push(unsigned (&m)[8], unsigned v) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) m[i] = m[i + 1];
+        m[7] = v;
+    }
+    // ReLU in place on a pair; its mask word
+    __device__ __forceinline__ unsigned relu_pair(f32x4 (&h)[2][4]) const {
+        unsigned v = 0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v |= h[o][t][r] > 0.f ? 1u << (o * 16 + t * 4 + r) : 0u;
+                    h[o][t][r] = fmaxf(h[o][t][r], 0.f);
+                }
+        return v;
+    }
+    __device__ __forceinline__ void mask_pair(f32x4 (&d)[2][4], unsigned m) const {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[o][t][r] = ((m >> (o * 16 + t * 4 + r)) & 1u) ? d[o][t][r] : 0.f;
+    }
+    __device__ __forceinline__ void store_pair(g_f tensor, int sc, int s, const f32x4 (&h)[2][4]) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            g_f tp = tl(tensor, 4 * sc + t) + (2 * s) * 256;
+            st4(tp, h[0][t]);
+            st4(tp + 256, h[1][t]);
+        }
+    }
+
     // ---- head partial sums over one half's eight hidden tiles (h = acc of sweep_f on half hv): dot-product head of hn <= 4
     // outputs (zp[t][o]: this lane's partial over its 32 features of the half; the caller sums the lane groups) / NT3 MFMA tiles
     template <int T>
@@ -292,7 +541,7 @@ struct SweepNet {
     // Tiles -> Gw (image: tile (ot, kt) at (ot * KBimg + kt) * 256), input columns >= XT zeroed; returns the lane's sum of squares.
     template <int NKT, int NY> struct DwOps { f32x4 a[NKT], b[NY]; };
     template <int NKT, int NY, bool AROWS, class RowF>
-    __device__ __forceinline__ float dw_pass(g_f Gw, int KBimg, int XT, int kt0, int kstep, int nkt, int ot0, RowF arow, g_cf atl, int NTA, g_cf btl,
+    __device__ __forceinline__ float dw_pass(g_f Gw, g_f Gb, int KBimg, int XT, int kt0, int kstep, int nkt, int ot0, RowF arow, g_cf atl, int NTA, g_cf btl,
                                              int NTB, int nchunks, int B) const {
         const int q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
         const int nit = nchunks * 4;
@@ -310,6 +559,9 @@ struct SweepNet {
         for (int j = 0; j < NKT; ++j)
 #pragma unroll
             for (int y = 0; y < NY; ++y) acc[j][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bsum[NY];                                                // the layer's bias gradient = the column sums of the B tiles
+#pragma unroll
+        for (int y = 0; y < NY; ++y) bsum[y] = 0.f;
         auto rows_of = [&](int it, g_cf (&rp)[4]) {
             if constexpr (AROWS) {
 #pragma unroll
@@ -344,6 +596,8 @@ struct SweepNet {
             for (int j = 0; j < NKT; ++j)
 #pragma unroll
                 for (int y = 0; y < NY; ++y) acc[j][y] = mfma4(acc[j][y], o.a[j], o.b[y]);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) bsum[y] += (o.b[y][0] + o.b[y][1]) + (o.b[y][2] + o.b[y][3]);
         };
         g_cf rp0[4], rp1[4];
         DwOps<NKT, NY> A, Bo;
@@ -377,55 +631,46 @@ struct SweepNet {
                 }
             }
         }
+#pragma unroll
+        for (int y = 0; y < NY; ++y) {
+            float v = bsum[y];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (Gb != nullptr && q == 0) {                             // (the caller names one owner wave per out tile)
+                Gb[(ot0 + y) * 16 + i16] = v;
+                ss += v * v;
+            }
+        }
         return ss;
     }
-    // the three uses.  dW2: wave w owns k-tiles (w >> 1) + 2 j (8 of them) x out tiles 8 hp + 4 (w & 1) + y in half-pass hp
-    __device__ __forceinline__ float dw2(g_f Gw, g_cf h1t, g_cf d2t, int nchunks, int B) const {
+    // the three uses (Gb = the layer's bias gradient).  dW2: wave w owns k-tiles (w >> 1) + 2 j (8 of them) x out tiles 8 hp + 4 (w & 1) + y in half-pass hp
+    __device__ __forceinline__ float dw2(g_f Gw, g_f Gb, g_cf h1t, g_cf d2t, int nchunks, int B) const {
         float ss = 0.f;
         auto none = [](int) { return (g_cf) nullptr; };
         for (int hp = 0; hp < 2; ++hp)
-            ss += dw_pass<8, 4, false>(Gw, kHT2, 256, W.C.w >> 1, 2, 8, 8 * hp + 4 * (W.C.w & 1), none, h1t, kHT2, d2t, kHT2, nchunks, B);
+            ss += dw_pass<8, 4, false>(Gw, (W.C.w >> 1) == 0 ? Gb : nullptr, kHT2, 256, W.C.w >> 1, 2, 8, 8 * hp + 4 * (W.C.w & 1), none, h1t, kHT2, d2t, kHT2, nchunks, B);
         return ss;
     }
     // dW3: the head's NT3 out tiles x k-tiles w, w + 4, w + 8, w + 12
     template <int NT3>
-    __device__ __forceinline__ float dw3(g_f Gw, g_cf h2t, g_cf dzt, int nchunks, int B) const {
+    __device__ __forceinline__ float dw3(g_f Gw, g_f Gb, g_cf h2t, g_cf dzt, int nchunks, int B) const {
         auto none = [](int) { return (g_cf) nullptr; };
-        return dw_pass<4, NT3, false>(Gw, kHT2, 256, W.C.w, 4, 4, 0, none, h2t, kHT2, dzt, NT3, nchunks, B);
+        return dw_pass<4, NT3, false>(Gw, W.C.w == 0 ? Gb : nullptr, kHT2, 256, W.C.w, 4, 4, 0, none, h2t, kHT2, dzt, NT3, nchunks, B);
     }
     // dW1: input rows row-major (arow through the LDS index table), deltas d1t; k-tiles (w >> 1) + 2 j, out tiles as dW2
     template <class RowF>
-    __device__ __forceinline__ float dw1(g_f Gw, int KB1, int XT, RowF arow, g_cf d1t, int nchunks, int B) const {
+    __device__ __forceinline__ float dw1(g_f Gw, g_f Gb_, int KB1, int XT, RowF arow, g_cf d1t, int nchunks, int B) const {
         float ss = 0.f;
         const int kt0 = W.C.w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
         for (int hp = 0; hp < 2; ++hp) {
             const int ot0 = 8 * hp + 4 * (W.C.w & 1);
-            if (KB1 <= 2) ss += dw_pass<1, 4, true>(Gw, KB1, XT, kt0 < KB1 ? kt0 : 0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
-            else if (KB1 <= 6) ss += dw_pass<3, 4, true>(Gw, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
-            else if (KB1 <= 14) ss += dw_pass<7, 4, true>(Gw, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
-            else ss += dw_pass<kWideMaxKT, 4, true>(Gw, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+            g_f Gb = (W.C.w >> 1) == 0 ? Gb_ : nullptr;
+            if (KB1 <= 2) ss += dw_pass<1, 4, true>(Gw, Gb, KB1, XT, kt0 < KB1 ? kt0 : 0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+            else if (KB1 <= 6) ss += dw_pass<3, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+            else if (KB1 <= 14) ss += dw_pass<7, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+            else ss += dw_pass<kWideMaxKT, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
         }
         return ss;
-    }
-
-    // ---- bias gradient of a layer = the column sums of its deltas' tile-lane tensor (NT tiles per 16-row block): thread f owns
-    // feature f < 16 NT, walks the batch's row blocks (sixteen independent loads each), -> G[b_off + f]; returns g^2
-    __device__ __forceinline__ float bias_pass(g_f G, int b_off, g_cf t, int NT, int B) const {
-        const int f = W.C.tid;
-        float g = 0.f;
-        if (f < 16 * NT) {
-            g_cf p = t + (size_t)(f >> 4) * 256 + ((((f & 15) >> 2) * 16) << 2) + (f & 3);
-            const int nrb = (B + 15) >> 4;
-            for (int rb = 0; rb < nrb; ++rb) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = p[(size_t)rb * NT * 256 + 4 * r];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g += v[r];
-            }
-            G[b_off + f] = g;
-        }
-        return g * g;
     }
 };
 

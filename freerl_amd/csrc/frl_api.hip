@@ -381,7 +381,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (force ? atoi(force) != 0 : (h.hidden == 128 && (long long)h.P * h.n_agents > 128)) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
             h.wide = h.hidden == 256 ? 2 : 1;
-            h.wide_bm = h.wide == 2 ? (h.batch_max + 127) / 128 * 128 : (h.batch_max + 63) / 64 * 64;      // (hidden 256 works in pairs of chunks)
+            h.wide_bm = h.wide == 2 ? (h.batch_max + 255) / 256 * 256 : (h.batch_max + 63) / 64 * 64;      // (hidden 256 works in super-chunks of 256 rows)
             h.wide_xp = h.net[1].L[0].k_pad;
             h.wide_op = 16;
             for (int j = 0; j < h.n_agents; ++j) h.wide_op = std::max(h.wide_op, h.net[2 * j].L[0].k_pad);

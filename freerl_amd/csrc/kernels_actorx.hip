@@ -1,9 +1,10 @@
 // Actor stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup on device/chain_wide16.hpp (the
-// counterpart of kernels_criticx.hip): kernels_actorw.hip's three passes with every matrix product a sweep over 32 KB weight
-// slices against four 16-row tiles per wave and the hidden activations / deltas in the unit's scratch in tile-lane order —
-// DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260, MADDPG_simple.py:182-186.
-//   A  actor forward                                   -> a_i into the critic's input row; h1, h2 stay in scratch for pass C
-//   B  critic forward on [s | a], deltas down to layer 1, dX of agent i's action columns (W1's action k-blocks in LDS) -> dQ/da_i
+// counterpart of kernels_criticx.hip): kernels_actorw.hip's three passes with the activations of a 256-row super-chunk in
+// registers from the first layer to the head and back (l1_x, sweep_x) — DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260,
+// MADDPG_simple.py:182-186.
+//   A  actor forward                                   -> a_i into the critic's input row; h1, h2 (tile-lane) and their ReLU masks -> scratch
+//   B  critic forward on [s | a], deltas down to layer 1, dX of agent i's action columns (W1's action k-blocks in LDS) -> dQ/da_i;
+//      nothing of the critic's leaves the registers
 //   C  actor deltas from dQ/da_i down to layer 1        -> scratch; the weight-gradient passes; clip + Adam streamed over the net
 #include <hip/hip_runtime.h>
 
@@ -40,8 +41,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     g_cf noise1 = as_global(D.noise + (((size_t)p * nag + ag) * D.noise_sets + 1) * D.batch_max * am);
     Wide16Scratch X;
     X.init(as_global(D.wide_scr + ((size_t)p * nag + ag) * D.wide_unit), D.wide_bm, D.wide_xp, D.wide_op, nag);
-    // pass B's critic activations / deltas: behind the actor's own tensors (h1t / h2t persist from pass A to pass C)
-    g_f c1t = X.d2t, c2t = X.d1t, cdt = X.d1t + (size_t)256 * D.wide_bm;
+    g_f bits = X.d1t + (size_t)256 * D.wide_bm;                       // the actor's ReLU masks, pass A -> pass C: [super-chunk][wave][lane][16]
     const float invB = 1.f / (float)B;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;
@@ -49,28 +49,6 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     const int nsc = (B + 255) / 256, nchunks = (B + 63) / 64;
     const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
     auto row_of = [&](int sc, int t) { return 256 * sc + 64 * t + 16 * w + i16; };
-    auto layer = [&](auto relu_c, const g_cf (&pp)[4], int kstride, g_cf wimg, int KB, lds_f bias, auto&& sink) {
-        static_for<0, 2>([&](auto hc) {
-            constexpr int hv = decltype(hc)::value;
-            f32x4 acc[4][8];
-            N.sweep_f<4, decltype(relu_c)::value>(acc, pp, kstride, wimg + (size_t)8 * hv * KB * 256, KB, (lds_cf)(bias + 128 * hv));
-            sink(acc, hv);
-        });
-    };
-    auto store_half = [&](g_f tensor, int sc) {
-        return [&, tensor, sc](const f32x4 (&acc)[4][8], int hv) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (64 * (4 * sc + t) < B) {
-                    g_f tp = N.tl(tensor, 4 * sc + t);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) st4(tp + (8 * hv + j) * 256, acc[t][j]);
-                }
-            }
-        };
-    };
-    std::true_type RELU;
-
     // =========================================================== A: a_i = tanh(actor_i(s_i)) (SAC: tanh(mean + std eps), sum of log pi)
     float lpsum = 0.f;
     const FRL_LDS int* tab0 = W.stage_idx(idx, B);
@@ -80,23 +58,34 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
     __syncthreads();
     N.stage3((g_cf)thA, NA.L, NT3A, NA.extra_off, NA.extra_n);
     for (int sc = 0; sc < nsc; ++sc) {
-        g_cf px[4], ph[4];
+        g_cf px[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = row_of(sc, t), rc = row < B ? row : B - 1;
             px[t] = (direct ? ring + (size_t)idx[rc] * R.stride + R.obs_off[ag] : (g_cf)X.xobs + (size_t)rc * X.op) + 4 * q;
-            ph[t] = N.tl(X.h1t, 4 * sc + t);
         }
-        layer(RELU, px, 16, (g_cf)thA + NA.L[0].w_off, KB1a, N.b1, store_half(X.h1t, sc));
+        f32x4 XR[2][4][8];
+        unsigned m1[8], m2[8] = {};
+        N.l1_x(XR, px, (g_cf)thA + NA.L[0].w_off, KB1a);
+        N.mask_bits(XR, m1);
+        N.store_x(X.h1t, sc, XR);
         f32x4 z[4][NT3A];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int o3 = 0; o3 < NT3A; ++o3) z[t][o3] = ld4((lds_cf)(N.b3 + 16 * o3 + 4 * q));
-        layer(RELU, ph, 256, (g_cf)thA + NA.L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
-            store_half(X.h2t, sc)(acc, hv);
-            N.head_tiles_half<4, NT3A>(acc, hv, z);
+        N.sweep_x<false>(XR, (g_cf)thA + NA.L[1].w_off, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+            N.mask_push(m2, N.relu_pair(acc));
+            N.store_pair(X.h2t, sc, s, acc);
+            N.head_tiles_pair<NT3A>(acc, s, z);
         });
+        {
+            g_f bp = bits + ((size_t)(sc * 4 + w) * 64 + l) * 16;
+            st4(bp, f32x4{__uint_as_float(m1[0]), __uint_as_float(m1[1]), __uint_as_float(m1[2]), __uint_as_float(m1[3])});
+            st4(bp + 4, f32x4{__uint_as_float(m1[4]), __uint_as_float(m1[5]), __uint_as_float(m1[6]), __uint_as_float(m1[7])});
+            st4(bp + 8, f32x4{__uint_as_float(m2[0]), __uint_as_float(m2[1]), __uint_as_float(m2[2]), __uint_as_float(m2[3])});
+            st4(bp + 12, f32x4{__uint_as_float(m2[4]), __uint_as_float(m2[5]), __uint_as_float(m2[6]), __uint_as_float(m2[7])});
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = row_of(sc, t);
@@ -140,63 +129,50 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
         }
         lds_barrier();
         for (int sc = 0; sc < nsc; ++sc) {
-            g_cf px[4], ph[4], pd[4];
+            g_cf px[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 px[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp + 4 * q;
-                ph[t] = N.tl(c1t, 4 * sc + t);
-                pd[t] = N.tl(cdt, 4 * sc + t);
             }
-            layer(RELU, px, 16, w1, KB1c, N.b1, store_half(c1t, sc));
-            float zp[4][4] = {};
-            layer(RELU, ph, 256, w2, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
-                store_half(c2t, sc)(acc, hv);
-                N.head_valu_half<4>(acc, hv, zp, 1);
+            f32x4 XR[2][4][8];
+            unsigned m1[8], m2[8] = {};
+            N.l1_x(XR, px, w1, KB1c);
+            N.mask_bits(XR, m1);
+            float zp[4] = {0.f, 0.f, 0.f, 0.f};
+            N.sweep_x<false>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+                N.mask_push(m2, N.relu_pair(acc));
+                N.head_valu_pair(acc, s, zp);
             });
+            float dzv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int row = row_of(sc, t), chunk = 4 * sc + t;
-                float qv = zp[t][0];
+                const int row = row_of(sc, t);
+                float qv = zp[t];
                 qv += __shfl_xor(qv, 16, 64);
                 qv += __shfl_xor(qv, 32, 64);
                 qv += N.b3[0];
-                const float dzv = row < B ? dqv : 0.f;                 // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
+                dzv[t] = row < B ? dqv : 0.f;                          // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
                 if (q == 0 && row < B) qsum += qv;
-                if (64 * chunk < B) {
-                    f32x4 none[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-                    N.delta2_tile<1, true>(none, dzv, (g_cf)N.tl(c2t, chunk), N.tl(cdt, chunk));
-                }
             }
+            N.delta2_x_valu(XR, m2, dzv);
             f32x4 dx[4][3];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) dx[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            static_for<0, 2>([&](auto hc) {                            // d1 = (W2^T d2) o relu'(h1), half by half, straight into the dX MFMAs
-                constexpr int hv = decltype(hc)::value;
-                f32x4 acc[4][8];
-                N.sweep_tr<4>(acc, pd, 256, w2, hv);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    g_cf hp = (g_cf)N.tl(c1t, 64 * (4 * sc + t) < B ? 4 * sc + t : 0);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const f32x4 hm = ld4(hp + (8 * hv + jj) * 256);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][jj][r] = hm[r] > 0.f ? acc[t][jj][r] : 0.f;
-                    }
-                }
+            N.sweep_x<true>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {      // d1 = (W2^T d2) o relu'(h1), pair by pair, straight into the dX MFMAs
+                N.mask_pair(acc, N.mask_next(m1));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    if (j < nA) {                                      // dX of k-block kbA0 + j += W1^T d1 over this half's output tiles
+                    if (j < nA) {                                      // dX of k-block kbA0 + j += W1^T d1 over this pair's output tiles
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) {
+                        for (int o = 0; o < 2; ++o) {
                             f32x4 wa;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) wa[e] = N.w1a[((8 * hv + jj) * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                            for (int e = 0; e < 4; ++e) wa[e] = N.w1a[((2 * s + o) * 3 + j) * 256 + C.tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) dx[t][j] = mfma4(dx[t][j], wa, acc[t][jj]);
+                            for (int t = 0; t < 4; ++t) dx[t][j] = mfma4(dx[t][j], wa, acc[o][t]);
                         }
                     }
                 }
@@ -227,16 +203,25 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
 #pragma unroll
         for (int r = 0; r < 4; ++r) gls[o3][r] = 0.f;
     for (int sc = 0; sc < nsc; ++sc) {
-        g_cf pd[4];
+        f32x4 XR[2][4][8];
+        unsigned m1[8], m2[8];
+        {
+            g_cf bp = (g_cf)bits + ((size_t)(sc * 4 + w) * 64 + l) * 16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f32x4 a1 = ld4(bp + 4 * k), a2 = ld4(bp + 8 + 4 * k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { m1[4 * k + r] = __float_as_uint(a1[r]); m2[4 * k + r] = __float_as_uint(a2[r]); }
+            }
+        }
+        f32x4 dz[4][NT3A];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int row = row_of(sc, t), chunk = 4 * sc + t;
+            const int row = row_of(sc, t);
             const bool valid = row < B;
-            pd[t] = N.tl(X.d2t, chunk);
-            f32x4 dz[NT3A];
 #pragma unroll
             for (int o3 = 0; o3 < NT3A; ++o3) {
-                dz[o3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dz[t][o3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 16 * o3 + 4 * q + r;
@@ -246,51 +231,30 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
                         if (sac) {                                     // through a = tanh(u), u = mean + exp(log_std) eps, and alpha log pi
                             const float d = dq * (1.f - av * av) + (alpha * invB) * (2.f * av);
                             const float lsc = fminf(fmaxf(N.ls[c], -20.f), 2.f);
-                            dz[o3][r] = d;
+                            dz[t][o3][r] = d;
                             gls[o3][r] += d * expf(lsc) * noise1[(size_t)row * am + c] - alpha * invB;
                         } else {
-                            dz[o3][r] = dq * (1.f - av * av);
+                            dz[t][o3][r] = dq * (1.f - av * av);
                         }
                     }
                 }
-            }
-            if (64 * chunk < B) {
-#pragma unroll
-                for (int o3 = 0; o3 < NT3A; ++o3) st4(N.tl(X.dzt, chunk, NT3A) + o3 * 256, dz[o3]);
-                N.delta2_tile<NT3A, false>(dz, 0.f, (g_cf)N.tl(X.h2t, chunk), N.tl(X.d2t, chunk));
+                st4(N.tl(X.dzt, 4 * sc + t, NT3A) + o3 * 256, dz[t][o3]);
             }
         }
-        static_for<0, 2>([&](auto hc) {
-            constexpr int hv = decltype(hc)::value;
-            f32x4 acc[4][8];
-            N.sweep_tr<4>(acc, pd, 256, (g_cf)thA + NA.L[1].w_off, hv);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (64 * (4 * sc + t) < B) {
-                    g_cf hp = (g_cf)N.tl(X.h1t, 4 * sc + t);
-                    g_f dp = N.tl(X.d1t, 4 * sc + t);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const f32x4 hm = ld4(hp + (8 * hv + j) * 256);
-                        f32x4 d = acc[t][j];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) d[r] = hm[r] > 0.f ? d[r] : 0.f;
-                        st4(dp + (8 * hv + j) * 256, d);
-                    }
-                }
-            }
+        N.delta2_x_tiles<NT3A>(XR, m2, dz);
+        N.store_x(X.d2t, sc, XR);
+        N.sweep_x<true>(XR, (g_cf)thA + NA.L[1].w_off, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+            N.mask_pair(acc, N.mask_next(m1));
+            N.store_pair(X.d1t, sc, s, acc);
         });
     }
     __syncthreads();
-    float ss = N.dw2(grA + NA.L[1].w_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
-    ss += N.dw3<NT3A>(grA + NA.L[2].w_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
+    float ss = N.dw2(grA + NA.L[1].w_off, grA + NA.L[1].b_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
+    ss += N.dw3<NT3A>(grA + NA.L[2].w_off, grA + NA.L[2].b_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
     {
         const FRL_LDS int* tab = W.stage_idx(idx, B);
-        ss += N.dw1(grA + NA.L[0].w_off, KB1a, Oi, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[ag]; }, (g_cf)X.d1t, nchunks, B);
+        ss += N.dw1(grA + NA.L[0].w_off, grA + NA.L[0].b_off, KB1a, Oi, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[ag]; }, (g_cf)X.d1t, nchunks, B);
     }
-    ss += N.bias_pass(grA, NA.L[0].b_off, (g_cf)X.d1t, kHT2, B);
-    ss += N.bias_pass(grA, NA.L[1].b_off, (g_cf)X.d2t, kHT2, B);
-    ss += N.bias_pass(grA, NA.L[2].b_off, (g_cf)X.dzt, NT3A, B);
 
     // =========================================================== clip_grad_norm_, Adam, soft update of the actor's target; SAC: alpha
 #pragma unroll

@@ -1,7 +1,9 @@
-// Critic stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup on device/chain_wide16.hpp: every
-// matrix product a sweep over 32 KB slices of its weight image against four 16-row tiles per wave, the hidden activations and
-// deltas in the unit's scratch in tile-lane order — DDPG_simple.py:139-149, TD3.py:193-213,235-244, SAC.py:226-238,
-// MADDPG_simple.py:165-180 with the hidden width the reference hard-codes (TD3.py:30) doubled to north_star's 256.
+// Critic stage of DDPG / TD3 / SAC / MADDPG at HIDDEN 256 for one (learner, agent) per workgroup on device/chain_wide16.hpp: the
+// activations of a 256-row super-chunk (four 16-row tiles per wave) stay in registers from the first layer to the head and back
+// down (l1_x -> sweep_x -> deltas -> sweep_x<TR>), the weight images stream through LDS 32 KB at a time, and only what the
+// weight-gradient passes need (h1, h2, d2, d1, tile-lane order) goes to the unit's scratch — DDPG_simple.py:139-149,
+// TD3.py:193-213,235-244, SAC.py:226-238, MADDPG_simple.py:165-180 with the hidden width the reference hard-codes (TD3.py:30)
+// doubled to north_star's 256.
 //
 // Row mapping: tile t of wave w in super-chunk sc holds rows 256 sc + 64 t + 16 w + i16 (tile t = 64-row chunk 4 sc + t).
 #include <hip/hip_runtime.h>
@@ -44,29 +46,6 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
     const int KB1c = NC.L[0].k_pad >> 4;
     auto row_of = [&](int sc, int t) { return 256 * sc + 64 * t + 16 * w + i16; };
     auto rec_of = [&](int row) { return ring + (size_t)idx[row < B ? row : B - 1] * R.stride; };
-    // a full 256-wide layer on the super-chunk's four tiles = two half-sweeps; sink(acc, half) consumes a half's eight output tiles
-    auto layer = [&](auto relu_c, const g_cf (&pp)[4], int kstride, g_cf wimg, int KB, lds_f bias, auto&& sink) {
-        static_for<0, 2>([&](auto hc) {
-            constexpr int hv = decltype(hc)::value;
-            f32x4 acc[4][8];
-            N.sweep_f<4, decltype(relu_c)::value>(acc, pp, kstride, wimg + (size_t)8 * hv * KB * 256, KB, (lds_cf)(bias + 128 * hv));
-            sink(acc, hv);
-        });
-    };
-    auto store_half = [&](g_f tensor, int sc) {
-        return [&, tensor, sc](const f32x4 (&acc)[4][8], int hv) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (64 * (4 * sc + t) < B) {                           // (only the chunks that exist in the scratch tensors)
-                    g_f tp = N.tl(tensor, 4 * sc + t);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) st4(tp + (8 * hv + j) * 256, acc[t][j]);
-                }
-            }
-        };
-    };
-    std::true_type RELU;
-
     // =========================================================== a'_j = actor_target_j(s'_j) for every agent j -> xrow = [s'_all | a'_all]
     WIDE_T0();
     const FRL_LDS int* tab0 = W.stage_idx(idx, B);
@@ -84,21 +63,24 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         N.stage3(tgA, NA.L, NT3A, NA.extra_off, NA.extra_n);
         WIDE_T(0);
         for (int sc = 0; sc < nsc; ++sc) {
-            g_cf px[4], ph[4];
+            g_cf px[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t), rc = row < B ? row : B - 1;
                 px[t] = (direct ? (g_cf)X.xrow + (size_t)rc * X.xp + ooff : (g_cf)X.xobs + ((size_t)j * D.wide_bm + rc) * X.op) + 4 * q;
-                ph[t] = N.tl(X.h1t, 4 * sc + t);
             }
-            layer(RELU, px, 16, tgA + NA.L[0].w_off, KB1a, N.b1, store_half(X.h1t, sc));
+            f32x4 XR[2][4][8];
+            N.l1_x(XR, px, tgA + NA.L[0].w_off, KB1a);
             WIDE_T(1);
             f32x4 z[4][NT3A];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int o3 = 0; o3 < NT3A; ++o3) z[t][o3] = ld4((lds_cf)(N.b3 + 16 * o3 + 4 * q));
-            layer(RELU, ph, 256, tgA + NA.L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) { N.head_tiles_half<4, NT3A>(acc, hv, z); });
+            N.sweep_x<false>(XR, tgA + NA.L[1].w_off, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+                N.relu_pair(acc);
+                N.head_tiles_pair<NT3A>(acc, s, z);
+            });
             WIDE_T(2);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -146,23 +128,26 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         N.stage3(tgC, L, 1, -1, 0);
         WIDE_T(0);
         for (int sc = 0; sc < nsc; ++sc) {
-            g_cf px[4], ph[4], recp[4];
+            g_cf px[4], recp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 recp[t] = rec_of(row);
                 px[t] = (g_cf)X.xrow + (size_t)(row < B ? row : B - 1) * X.xp + 4 * q;
-                ph[t] = N.tl(X.h1t, 4 * sc + t);
             }
-            layer(RELU, px, 16, tgC + L[0].w_off, KB1c, N.b1, store_half(X.h1t, sc));
+            f32x4 XR[2][4][8];
+            N.l1_x(XR, px, tgC + L[0].w_off, KB1c);
             WIDE_T(1);
-            float zp[4][4] = {};
-            layer(RELU, ph, 256, tgC + L[1].w_off, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) { N.head_valu_half<4>(acc, hv, zp, 1); });
+            float zp[4] = {0.f, 0.f, 0.f, 0.f};
+            N.sweep_x<false>(XR, tgC + L[1].w_off, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+                N.relu_pair(acc);
+                N.head_valu_pair(acc, s, zp);
+            });
             WIDE_T(2);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
-                float qv = zp[t][0];
+                float qv = zp[t];
                 qv += __shfl_xor(qv, 16, 64);
                 qv += __shfl_xor(qv, 32, 64);
                 qv += N.b3[0];
@@ -189,77 +174,58 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
         N.stage3((g_cf)thC, L, 1, -1, 0);
         WIDE_T(0);
         for (int sc = 0; sc < nsc; ++sc) {
-            g_cf px[4], ph[4], pd[4];
+            g_cf px[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                px[t] = rec_of(row_of(sc, t)) + R.obs_off[0] + 4 * q;   // (a record's [obs | act] columns are contiguous from its start)
-                ph[t] = N.tl(X.h1t, 4 * sc + t);
-                pd[t] = N.tl(X.d2t, 4 * sc + t);
-            }
-            layer(RELU, px, 16, (g_cf)thC + L[0].w_off, KB1c, N.b1, store_half(X.h1t, sc));
+            for (int t = 0; t < 4; ++t) px[t] = rec_of(row_of(sc, t)) + R.obs_off[0] + 4 * q;   // (a record's [obs | act] columns are contiguous from its start)
+            f32x4 XR[2][4][8];
+            unsigned m1[8], m2[8] = {};
+            N.l1_x(XR, px, (g_cf)thC + L[0].w_off, KB1c);
+            N.mask_bits(XR, m1);
+            N.store_x(X.h1t, sc, XR);
             WIDE_T(4);
-            float zp[4][4] = {};
-            layer(RELU, ph, 256, w2, kHT2, N.b2, [&](const f32x4 (&acc)[4][8], int hv) {
-                store_half(X.h2t, sc)(acc, hv);
-                N.head_valu_half<4>(acc, hv, zp, 1);
+            float zp[4] = {0.f, 0.f, 0.f, 0.f};
+            N.sweep_x<false>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
+                N.mask_push(m2, N.relu_pair(acc));
+                N.store_pair(X.h2t, sc, s, acc);
+                N.head_valu_pair(acc, s, zp);
             });
             WIDE_T(5);
+            float dzv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int row = row_of(sc, t), chunk = 4 * sc + t;
-                float qv = zp[t][0];
+                const int row = row_of(sc, t);
+                float qv = zp[t];
                 qv += __shfl_xor(qv, 16, 64);
                 qv += __shfl_xor(qv, 32, 64);
                 qv += N.b3[0];
-                float dzv = 0.f;                                       // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
+                dzv[t] = 0.f;                                          // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
                 if (row < B) {
                     float lrow, grow;
                     td_loss_row(a, qv - X.yb[row], lrow, grow);
-                    dzv = grow * invB;
+                    dzv[t] = grow * invB;
                     if (q == 0) lossp += lrow;
                 }
-                if (64 * chunk < B) {                                  // (uniform: the chunk exists in the scratch tensors)
-                    f32x4 dzt = {0.f, 0.f, 0.f, 0.f};
-                    if (q == 0) dzt[0] = dzv;                          // D layout of the head tile: output 0 on lane group 0, register 0
-                    st4(N.tl(X.dzt, chunk, 1), dzt);
-                    f32x4 none[1] = {dzt};
-                    N.delta2_tile<1, true>(none, dzv, (g_cf)N.tl(X.h2t, chunk), N.tl(X.d2t, chunk));
-                }
+                f32x4 dzt = {0.f, 0.f, 0.f, 0.f};
+                if (q == 0) dzt[0] = dzv[t];                           // D layout of the head tile: output 0 on lane group 0, register 0
+                st4(N.tl(X.dzt, 4 * sc + t, 1), dzt);
             }
+            N.delta2_x_valu(XR, m2, dzv);                              // d2 = (W3^T dz) o relu'(h2): the B operand of the transposed sweep
+            N.store_x(X.d2t, sc, XR);
             WIDE_T(6);
-            static_for<0, 2>([&](auto hc) {                            // dH1 = W2^T d2 through the ReLU of h1 -> d1t
-                constexpr int hv = decltype(hc)::value;
-                f32x4 acc[4][8];
-                N.sweep_tr<4>(acc, pd, 256, w2, hv);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (64 * (4 * sc + t) < B) {
-                        g_cf hp = (g_cf)N.tl(X.h1t, 4 * sc + t);
-                        g_f dp = N.tl(X.d1t, 4 * sc + t);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const f32x4 hm = ld4(hp + (8 * hv + j) * 256);
-                            f32x4 d = acc[t][j];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) d[r] = hm[r] > 0.f ? d[r] : 0.f;
-                            st4(dp + (8 * hv + j) * 256, d);
-                        }
-                    }
-                }
+            N.sweep_x<true>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {       // d1 = (W2^T d2) o relu'(h1) -> d1t
+                N.mask_pair(acc, N.mask_next(m1));
+                N.store_pair(X.d1t, sc, s, acc);
             });
             WIDE_T(7);
         }
         __syncthreads();                                               // every wave's activations and deltas are in scratch
-        ss += N.dw2(grC + L[1].w_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
+        ss += N.dw2(grC + L[1].w_off, grC + L[1].b_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);
         WIDE_T(8);
-        ss += N.dw3<1>(grC + L[2].w_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
+        ss += N.dw3<1>(grC + L[2].w_off, grC + L[2].b_off, (g_cf)X.h2t, (g_cf)X.dzt, nchunks, B);
         {
             const FRL_LDS int* tab = W.stage_idx(idx, B);
-            ss += N.dw1(grC + L[0].w_off, KB1c, XT, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; }, (g_cf)X.d1t, nchunks, B);
+            ss += N.dw1(grC + L[0].w_off, grC + L[0].b_off, KB1c, XT, [&](int row) { return ring + (size_t)tab[row] * R.stride + R.obs_off[0]; }, (g_cf)X.d1t, nchunks, B);
         }
-        ss += N.bias_pass(grC, L[0].b_off, (g_cf)X.d1t, kHT2, B);
-        ss += N.bias_pass(grC, L[1].b_off, (g_cf)X.d2t, kHT2, B);
-        ss += N.bias_pass(grC, L[2].b_off, (g_cf)X.dzt, 1, B);
         __syncthreads();                                               // the scratch tensors are free for the next head
         WIDE_T(9);
     }
