@@ -533,6 +533,81 @@ struct SweepNet {
         }
     }
 
+    // a tile written at the fragment slot, read back transposed: lane (i16, q) gets element (row 4 q + e, column i16)
+    __device__ __forceinline__ f32x4 tr_read(lds_cf tb) const {
+        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tb[tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+        return o;
+    }
+
+    // ---- dW2 (256 x 256: 16 x 16 tiles) in one cooperative pass: per 16-row block the workgroup brings the block's sixteen
+    // h1 and sixteen d2 tiles in ONCE (32 KB, eight dwordx4 per wave: waves 0, 1 the h1 tiles, 2, 3 the d2 tiles), double-
+    // buffered through the union at the fragment slot, and every wave reads its operands back transposed: wave w owns k-tiles
+    // 8 (w >> 1) + j x out tiles 8 (w & 1) + y — 64 accumulator tiles, 256 MFMAs per block and barrier.
+    __device__ __forceinline__ float dw2_coop(g_f Gw, g_f Gb, g_cf h1t, g_cf d2t, int nchunks) const {
+        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
+        const int nit = nchunks * 4, kt0 = 8 * (w >> 1), ot0 = 8 * (w & 1);
+        g_cf src = (w < 2 ? h1t + w * 8 * 256 : d2t + (w - 2) * 8 * 256) + 4 * l;
+        f32x4 acc[8][8];
+        float bsum[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            bsum[y] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 R[8];
+        auto fetch = [&](int it_) {
+            const int it = it_ < nit ? it_ : nit - 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) R[j] = ld4(src + (size_t)it * kHT2 * 256 + j * 256);
+        };
+        fetch(0);
+        lds_barrier();
+        for (int it = 0; it < nit; ++it) {
+            lds_f buf = W.u + (it & 1) * 8192;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st4(buf + (w * 8 + j) * 256 + fslot, R[j]);
+            lds_barrier();
+            fetch(it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = tr_read((lds_cf)(buf + (kt0 + j) * 256));
+#pragma unroll
+            for (int y = 0; y < 8; ++y) b[y] = tr_read((lds_cf)(buf + (kHT2 + ot0 + y) * 256));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int y = 0; y < 8; ++y) acc[j][y] = mfma4(acc[j][y], a[j], b[y]);
+#pragma unroll
+            for (int y = 0; y < 8; ++y) bsum[y] += (b[y][0] + b[y][1]) + (b[y][2] + b[y][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const f32x4 v = acc[j][y];
+                st4(Gw + ((size_t)((ot0 + y) * kHT2 + kt0 + j) * 256 + fslot), v);
+                ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            float v = bsum[y];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if ((w >> 1) == 0 && q == 0) {
+                Gb[(ot0 + y) * 16 + i16] = v;
+                ss += v * v;
+            }
+        }
+        return ss;
+    }
+
     // ---- weight-gradient pass: dW^T tiles (k-tile kt0 + kstep j, out tile ot0 + y), j < NKT, y < NY, over the whole batch:
     // acc[j][y] += sum_rows A[row][k] B[row][out].  Both operands are read transposed, four dwords per lane, 16-row block and
     // tile (lane (i16 = column of the tile, q): rows 4 q + e of the block), pinned one block ahead of the MFMAs, unconditional:
@@ -643,30 +718,170 @@ struct SweepNet {
         }
         return ss;
     }
-    // the three uses (Gb = the layer's bias gradient).  dW2: wave w owns k-tiles (w >> 1) + 2 j (8 of them) x out tiles 8 hp + 4 (w & 1) + y in half-pass hp
-    __device__ __forceinline__ float dw2(g_f Gw, g_f Gb, g_cf h1t, g_cf d2t, int nchunks, int B) const {
+    // ---- the same for SMALL products (the head's dW3; a first layer of <= 2 k-tiles), where dw_pass's sixteen short trips per
+    // wave are all latency: the waves split the ROW blocks (it = w, w + 4, ...), each accumulating all nkt x NY tiles (k-tiles
+    // 0 .. nkt - 1, out tiles 0 .. NY - 1), and the four partial sums meet in the union (waves 2, 3 -> 0, 1; wave 1 -> 0; the
+    // bias partials through the b1 / b2 slots, free between a head's main pass and the next stage3).  Wave 0 stores.
+    template <int NKT, int NY, bool AROWS, class RowF>
+    __device__ __forceinline__ float dw_rows(g_f Gw, g_f Gb, int KBimg, int XT, int nkt, RowF arow, g_cf atl, int NTA, g_cf btl, int NTB, int nchunks, int B) const {
+        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
+        int kcl[NKT], fcol[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            kcl[j] = j < nkt ? j : 0;
+            const int f = 16 * kcl[j] + i16;
+            fcol[j] = f < XT ? f : XT - 1;
+        }
+        f32x4 acc[NKT][NY];
+        float bsum[NY];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) {
+            bsum[y] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) acc[j][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // tiles come in as they lie (one dwordx4 per lane), go through this wave's own kilobytes behind the union (the head image
+        // and the actor stage's W1 blocks are idle during the gradient passes) at the fragment slot and come back transposed
+        // (chain_net.hpp: fslot / tslot) — a transposed dword gather costs the texture path several times a dwordx4
+        constexpr int NL = AROWS ? NY : NKT + NY;
+        lds_f wb = w3 + w * 20 * 256;
+        struct Raw { f32x4 t[NL]; f32x4 a[AROWS ? NKT : 1]; };
+        auto fetch = [&](int i_, Raw& r) {
+            const int it = 4 * (i_ < nchunks ? i_ : nchunks - 1) + w;
+            g_cf bb = btl + (size_t)it * NTB * 256 + 4 * l;
+#pragma unroll
+            for (int y = 0; y < NY; ++y) r.t[y] = ld4(bb + y * 256);
+            if constexpr (AROWS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * it + 4 * q + e;
+                    g_cf rp = arow(row < B ? row : B - 1);
+#pragma unroll
+                    for (int j = 0; j < NKT; ++j) r.a[j][e] = rp[fcol[j]];
+                }
+            } else {
+                g_cf ab = atl + (size_t)it * NTA * 256 + 4 * l;
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) r.t[NY + j] = ld4(ab + kcl[j] * 256);
+            }
+        };
+        auto turn = [&](const Raw& r, DwOps<NKT, NY>& o) {
+#pragma unroll
+            for (int n = 0; n < NL; ++n) st4(wb + n * 256 + fslot, r.t[n]);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) o.b[y] = tr_read((lds_cf)(wb + y * 256));
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if constexpr (AROWS) o.a[j] = r.a[j];
+                else o.a[j] = tr_read((lds_cf)(wb + (NY + j) * 256));
+            }
+        };
+        auto mma = [&](const DwOps<NKT, NY>& o) {
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int y = 0; y < NY; ++y) acc[j][y] = mfma4(acc[j][y], o.a[j], o.b[y]);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) bsum[y] += (o.b[y][0] + o.b[y][1]) + (o.b[y][2] + o.b[y][3]);
+        };
+        Raw r0, r1;
+        DwOps<NKT, NY> ops;
+        fetch(0, r0);
+        for (int i = 0; i < nchunks; i += 2) {
+            fetch(i + 1, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            turn(r0, ops);
+            mma(ops);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(i + 2, r0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < nchunks) {
+                turn(r1, ops);
+                mma(ops);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int y = 0; y < NY; ++y) {
+            bsum[y] += __shfl_xor(bsum[y], 16, 64);
+            bsum[y] += __shfl_xor(bsum[y], 32, 64);
+        }
+        lds_f bsl = b1;                                                // two slots of 256 floats (b1, b2 are adjacent)
+        auto put = [&](lds_f area, lds_f bslot) {
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int y = 0; y < NY; ++y) st4(area + (j * NY + y) * 256 + 4 * l, acc[j][y]);
+            if (q == 0) {
+#pragma unroll
+                for (int y = 0; y < NY; ++y) bslot[y * 16 + i16] = bsum[y];
+            }
+        };
+        auto add = [&](lds_cf area, lds_cf bslot) {
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int y = 0; y < NY; ++y) {
+                    const f32x4 v = ld4(area + (j * NY + y) * 256 + 4 * l);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][y][r] += v[r];
+                }
+#pragma unroll
+            for (int y = 0; y < NY; ++y) bsum[y] += bslot[y * 16 + i16];
+        };
+        lds_barrier();                                                 // every wave is through its rows (and the index table in the union)
+        if (w >= 2) put(W.u + (w - 2) * 8192, bsl + (w - 2) * 256);
+        lds_barrier();
+        if (w < 2) add((lds_cf)(W.u + w * 8192), (lds_cf)(bsl + w * 256));
+        lds_barrier();
+        if (w == 1) put(W.u, bsl);
+        lds_barrier();
         float ss = 0.f;
-        auto none = [](int) { return (g_cf) nullptr; };
-        for (int hp = 0; hp < 2; ++hp)
-            ss += dw_pass<8, 4, false>(Gw, (W.C.w >> 1) == 0 ? Gb : nullptr, kHT2, 256, W.C.w >> 1, 2, 8, 8 * hp + 4 * (W.C.w & 1), none, h1t, kHT2, d2t, kHT2, nchunks, B);
+        if (w == 0) {
+            add((lds_cf)W.u, (lds_cf)bsl);
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < nkt) {
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        f32x4 v = acc[j][y];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (16 * j + 4 * q + r) < XT ? v[r] : 0.f;
+                        st4(Gw + ((size_t)(y * KBimg + j) * 256 + fslot), v);
+                        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int y = 0; y < NY; ++y) {
+                    Gb[y * 16 + i16] = bsum[y];
+                    ss += bsum[y] * bsum[y];
+                }
+            }
+        }
         return ss;
     }
-    // dW3: the head's NT3 out tiles x k-tiles w, w + 4, w + 8, w + 12
+    // the three uses (Gb = the layer's bias gradient)
+    __device__ __forceinline__ float dw2(g_f Gw, g_f Gb, g_cf h1t, g_cf d2t, int nchunks, int B) const { return dw2_coop(Gw, Gb, h1t, d2t, nchunks); }
+    // dW3: the head's NT3 out tiles x sixteen k-tiles, rows split over the waves
     template <int NT3>
     __device__ __forceinline__ float dw3(g_f Gw, g_f Gb, g_cf h2t, g_cf dzt, int nchunks, int B) const {
         auto none = [](int) { return (g_cf) nullptr; };
-        return dw_pass<4, NT3, false>(Gw, W.C.w == 0 ? Gb : nullptr, kHT2, 256, W.C.w, 4, 4, 0, none, h2t, kHT2, dzt, NT3, nchunks, B);
+        return dw_rows<kHT2, NT3, false>(Gw, Gb, kHT2, 256, kHT2, none, h2t, kHT2, dzt, NT3, nchunks, B);
     }
-    // dW1: input rows row-major (arow through the LDS index table), deltas d1t; k-tiles (w >> 1) + 2 j, out tiles as dW2
+    // dW1: input rows row-major (arow through the LDS index table), deltas d1t; one or two k-tiles: rows split over the waves,
+    // else k-tiles (w >> 1) + 2 j, out tiles as dW2
     template <class RowF>
     __device__ __forceinline__ float dw1(g_f Gw, g_f Gb_, int KB1, int XT, RowF arow, g_cf d1t, int nchunks, int B) const {
+        if (KB1 == 1) return dw_rows<1, kHT2, true>(Gw, Gb_, KB1, XT, 1, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+        if (KB1 == 2) return dw_rows<2, kHT2, true>(Gw, Gb_, KB1, XT, 2, arow, nullptr, 0, d1t, kHT2, nchunks, B);
         float ss = 0.f;
         const int kt0 = W.C.w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
         for (int hp = 0; hp < 2; ++hp) {
             const int ot0 = 8 * hp + 4 * (W.C.w & 1);
             g_f Gb = (W.C.w >> 1) == 0 ? Gb_ : nullptr;
-            if (KB1 <= 2) ss += dw_pass<1, 4, true>(Gw, Gb, KB1, XT, kt0 < KB1 ? kt0 : 0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
-            else if (KB1 <= 6) ss += dw_pass<3, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
+            if (KB1 <= 6) ss += dw_pass<3, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
             else if (KB1 <= 14) ss += dw_pass<7, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
             else ss += dw_pass<kWideMaxKT, 4, true>(Gw, Gb, KB1, XT, kt0, 2, nkt, ot0, arow, nullptr, 0, d1t, kHT2, nchunks, B);
         }

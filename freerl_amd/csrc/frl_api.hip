@@ -374,11 +374,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (force ? atoi(force) != 0 : h.P > 128) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
-        // hidden 128: from 129 (learner, agent) units up (SAC at Humanoid dims 81.6 TFLOP/s against the row-chunk kernels' 45.8, MADDPG
-        // simple_spread 77.1 / 55.5).  Hidden 256 (chain_wide16.hpp) only when forced: at two 16-row tiles per sweep the 256 KB
-        // image of W2 is streamed at ~2.4 TB/s chip-wide and the stage measures 50.7 TFLOP/s against the row-chunk kernels' 55.4
-        // (profiles/README.md) — parity-tested, not the default
-        if (force ? atoi(force) != 0 : (h.hidden == 128 && (long long)h.P * h.n_agents > 128)) {
+        // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 84.1 TFLOP/s against the row-chunk
+        // kernels' 45.8, MADDPG simple_spread 77.1 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 69.3 / 55.4
+        // (profiles/r04)
+        if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > 128) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
             h.wide = h.hidden == 256 ? 2 : 1;
             h.wide_bm = h.wide == 2 ? (h.batch_max + 255) / 256 * 256 : (h.batch_max + 63) / 64 * 64;      // (hidden 256 works in super-chunks of 256 rows)

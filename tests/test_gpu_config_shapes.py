@@ -291,10 +291,10 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     matd3 = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, twin_critic=True, batch_max=128)   # MATD3: the same family
     assert matd3.learn_path(128)[0]
     matd3.close()
-    h256 = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)      # hidden 256: opt-in only
-    assert not h256.learn_path(256)[0]
+    h256 = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)      # hidden 256: the x-stationary kernels
+    assert h256.learn_path(256)[0]
     h256.close()
-    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)
+    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=100, twin_critic=True, batch_max=256, hidden=256)       # ... from 129 units up as well
     assert not h256.learn_path(256)[0]
     h256.close()
     monkeypatch.delenv("FRL_DQN_FUSED", raising=False)
@@ -316,7 +316,7 @@ def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
     monkeypatch.setenv("FRL_CRITIC_V2", "1")
     kind, O, A, B = {"td3_17_6_b200": ("td3", 17, 6, 200), "ddpg_40_3_b256": ("ddpg", 40, 3, 256), "td3_30_5_b1000": ("td3", 30, 5, 1000),
                      "sac_33_17_b96": ("sac", 33, 17, 96), "td3_h256_11_3_b200": ("td3", 11, 3, 200), "sac_h256_40_17_b96": ("sac", 40, 17, 96)}[case]
-    hidden = 256 if "h256" in case else 128         # h256: kernels_criticx / _actorx (every layer streamed; opt-in)
+    hidden = 256 if "h256" in case else 128         # h256: kernels_criticx / _actorx (x-stationary sweeps)
     n_tab = 1400
     tab = synth.transitions(401, n_tab, O, A)
     twin = kind != "ddpg"
