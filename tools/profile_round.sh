@@ -26,7 +26,15 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dqn -- python $R/tools/dqn_bench.py 512 > $O/stats_dqn.log 2>&1
 cp $(ls $O/stats_dqn/*/*kernel_stats.csv | head -1) $O/kernel_stats_dqn.csv
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg -- python $R/tools/config_bench.py C4 C5 h256 512 > $O/stats_cfg.log 2>&1
+cp $(ls $O/stats_cfg/*/*kernel_stats.csv | head -1) $O/kernel_stats_configs.csv
 cd $R && timeout 300 python tools/config_bench.py 1 512 > $O/config_bench.txt 2>&1
+FRL_CRITIC_V2=0 timeout 300 python tools/config_bench.py C4 C5 h256 512 > $O/config_bench_rowchunk.txt 2>&1
+# the K-sliced chained families' sections (library variant `widet`: -DFRL_WIDE_TIMING, built beforehand so that it travels)
+for c in sac_c4 maddpg_c5 td3_h256; do timeout 300 python tools/wide_timing.py $c 256 > $O/wide_timing_$c.txt 2>&1 < /dev/null; done
+timeout 300 python tools/wide_timing.py td3_h256 1 > $O/wide_timing_td3_h256_p1.txt 2>&1 < /dev/null
+for c in sac_c4 maddpg_c5 matd3_c5 td3_h256 sac_h256; do timeout 200 python tools/wide_ab.py $c 2; done > $O/wide_ab.txt 2>&1
+timeout 60 tools/_bin/icache > $O/icache_micro.txt 2>&1
 timeout 300 python tools/dqn_bench.py 1 512 2048 4096 > $O/dqn_bench.txt 2>&1
 timeout 300 python tools/ppo_bench.py 1 64 256 > $O/ppo_bench.txt 2>&1
 timeout 600 python tools/rollout_bench.py 1 512 > $O/rollout_bench.txt 2>&1
@@ -36,5 +44,5 @@ FRL_HIP_VARIANT=phase FRL_HIPCC_FLAGS=-DFRL_PHASE_TIMING timeout 200 python tool
 timeout 120 tools/_bin/clock_probe > $O/clock_probe.txt 2>&1
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --spawn --headline-only --steps 10 --warmup 2 > $O/bench_spawn1.json 2> $O/bench_spawn1.err
-rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
+rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/stats_cfg $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
 ls -la $O
