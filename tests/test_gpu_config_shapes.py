@@ -92,18 +92,25 @@ def test_c5_maddpg_spread_shape(N, family):
         orc.add({a: tabs[a]["obs"][i] for a in ids}, {a: tabs[a]["act"][i] for a in ids},
                 {a: float(tabs[a]["rew"][i]) for a in ids}, {a: tabs[a]["next_obs"][i] for a in ids},
                 {a: bool(tabs[a]["done"][i]) for a in ids})
-    idx = [synth.indices(100 + j, n_tab, B) for j in range(n)]
-    st = e.learn(B, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=np.stack(idx)[None], want_stats=True)
-    orc.learn_with(idx, 0.95, 0.01)
+    for call in range(2):                         # (the second call starts from moved parameters and non-zero Adam moments)
+        idx = [synth.indices(100 + 10 * call + j, n_tab, B) for j in range(n)]
+        st = e.learn(B, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=np.stack(idx)[None], want_stats=True)
+        orc.learn_with(idx, 0.95, 0.01)
     for j, a in enumerate(ids):
-        np.testing.assert_allclose(st[0, j, N.STAT_CRITIC_LOSS], orc.critic_losses[a][0], rtol=1e-4)
-        np.testing.assert_allclose(st[0, j, N.STAT_ACTOR_LOSS], orc.actor_losses[a][0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st[0, j, N.STAT_CRITIC_LOSS], orc.critic_losses[a][1], rtol=1e-4)
+        np.testing.assert_allclose(st[0, j, N.STAT_ACTOR_LOSS], orc.actor_losses[a][1], rtol=1e-4, atol=1e-6)
         got = unflat_params(e.get_params(2 * j + 1), orc.critic[a], AC)
         for k in orc.critic[a]:
             np.testing.assert_allclose(got[k], orc.critic[a][k], rtol=5e-4, atol=5e-6, err_msg=a + k)
         got = unflat_params(e.get_params(2 * j, N.PARAM_TARGET), orc.actor_t[a], AC)
         for k in orc.actor_t[a]:
             np.testing.assert_allclose(got[k], orc.actor_t[a][k], rtol=5e-4, atol=5e-6, err_msg=a + k)
+        # the (clipped) gradients themselves: Adam's first moment is 0.1 g_2 + 0.09 g_1, element by element — the target
+        # parameters above moved by tau * lr and would hide a gradient that is off by a per cent
+        for net, opt in ((2 * j, orc.actor_opt[a]), (2 * j + 1, orc.critic_opt[a])):
+            got = unflat_params(e.get_params(net, N.PARAM_ADAM_M), opt.m, AC)
+            for k in opt.m:
+                np.testing.assert_allclose(got[k], opt.m[k], rtol=1e-4, atol=2e-5 * float(np.abs(opt.m[k]).max()), err_msg="adam m " + a + k)
     e.close()
 
 

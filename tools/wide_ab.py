@@ -1,6 +1,6 @@
 """Developer check: the K-sliced chained kernels (kernels_criticw / _actorw, FRL_CRITIC_V2=1) against the row-chunk kernels (=0) on
 the same inputs, array by array and layer by layer — stats, theta / target / Adam moments of every net.
-    python tools/wide_ab.py [sac_c4 | td3_wide | ddpg_wide | maddpg_c5 | all] [calls]"""
+    python tools/wide_ab.py [sac_c4 | td3_wide | ddpg_wide | maddpg_c5 | ... | all] [calls] [learners]"""
 import os
 import sys
 
@@ -68,8 +68,8 @@ def run(name, family, calls, P=2):
     return out
 
 
-def compare(name, calls):
-    a, b = run(name, 0, calls), run(name, 1, calls)
+def compare(name, calls, P=2):
+    a, b = run(name, 0, calls, P), run(name, 1, calls, P)
     print("== %s: families %s / %s, %d calls" % (name, a["family"], b["family"], calls))
     sa, sb = a["stats"], b["stats"]
     for k in range(calls):
@@ -84,24 +84,31 @@ def compare(name, calls):
         if key in ("stats", "family", "layers"):
             continue
         x, y = a[key], b[key]
-        den = np.maximum(np.abs(x), 1e-3 * np.abs(x).max() + 1e-12)
-        rel = np.abs(x - y) / den
+        # against the array's largest element: an element whose gradient is rounding noise (1e-3 of the largest and below, a sum
+        # of 256-1024 cancelling terms in two different orders) gets a different Adam step m / sqrt(v) in each family — up to lr
+        # per call in theta — and a ReLU unit within an ulp of zero may open in one and not in the other; element-relative
+        # errors of such entries are large in BOTH families against the oracle and say nothing (tests/ hold each family to it)
+        rel = np.abs(x - y) / (np.abs(x).max() + 1e-30)
         w = float(rel.max())
-        worst = max(worst, w)
-        flag = "" if w < 2e-3 else "   <-- at flat index %d (learner %d): %.6g vs %.6g" % (int(rel.argmax()) % x.shape[-1], int(rel.argmax()) // x.shape[-1],
+        # theta / target: one Adam step is +-lr whatever the gradient's size, so a unit that is dead in one family and barely
+        # alive in the other moves its weights by a full lr (1e-3 here, ~5e-3 of the largest weight): 2e-2 for those arrays
+        tol = 2e-2 if key.startswith(("theta", "target")) else 2e-3
+        worst = max(worst, w * (2e-3 / tol))
+        flag = "" if w < tol else "   <-- at flat index %d (learner %d): %.6g vs %.6g" % (int(rel.argmax()) % x.shape[-1], int(rel.argmax()) // x.shape[-1],
                                                                                         x.reshape(-1)[rel.argmax()], y.reshape(-1)[rel.argmax()])
-        print("  %-9s max rel diff %.2e  (|x| max %.3g)%s" % (key, w, np.abs(x).max(), flag))
-    print("  WORST %.2e %s" % (worst, "OK" if worst < 2e-3 else "MISMATCH"))
+        print("  %-9s max |diff| / max |x| %.2e  (|x| max %.3g)%s" % (key, w, np.abs(x).max(), flag))
+    print("  WORST (scaled to a 2e-3 tolerance) %.2e %s" % (worst, "OK" if worst < 2e-3 else "MISMATCH"))
     return worst < 2e-3
 
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     ok = True
     for name in (CASES if which == "all" else [which]):
         try:
-            ok &= compare(name, calls)
+            ok &= compare(name, calls, P)
         except Exception as ex:
             print("== %s FAILED: %r" % (name, ex))
             ok = False
