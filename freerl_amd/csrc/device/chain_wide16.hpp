@@ -16,6 +16,7 @@
 // chip-wide and the kernels spilled ~1000 VGPRs: 50.7 TFLOP/s against the row-chunk kernels' 55.4 (profiles/README.md).
 #pragma once
 #include "chain_wide.hpp"
+#include "wide_timing.hpp"
 
 namespace frl {
 
@@ -234,6 +235,9 @@ struct SweepNet {
     // first layer into XR: images of <= 32 tiles (KB1 <= 2) are staged whole, wider ones take the two K-outer half-sweeps
     __device__ __forceinline__ void l1_x(f32x4 (&X)[2][4][8], const g_cf (&p)[4], g_cf w1, int KB1) const {
         const int l = W.C.l, w = W.C.w, q = W.C.q, fslot = W.C.fslot;
+#ifdef FRL_WIDE_TIMING
+        long long lc_[5] = {clock64(), 0, 0, 0, 0};
+#endif
         if (KB1 <= 2) {
             const int lastt = 16 * KB1 - 1;
             f32x4 R[8], xin[2][4];
@@ -248,9 +252,20 @@ struct SweepNet {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) xin[kb][t] = ld4(p[t] + (kb < KB1 ? kb : KB1 - 1) * 16);
             lds_barrier();
+#ifdef FRL_WIDE_TIMING
+            lc_[1] = clock64();
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) st4(W.u + (w * 8 + j) * 256 + 4 * l, R[j]);
             lds_barrier();
+#ifdef FRL_WIDE_TIMING
+            lc_[2] = clock64();
+            {
+                float probe = xin[0][0][0] + xin[0][3][3];          // wait for the row operands here, so that the next stamp is the MFMAs' alone
+                asm volatile("" :: "v"(probe));
+                lc_[3] = clock64();
+            }
+#endif
             static_for<0, 16>([&](auto oc) {
                 constexpr int ot = decltype(oc)::value;
                 const f32x4 bf = ld4((lds_cf)(b1 + ot * 16 + 4 * q));
@@ -270,6 +285,14 @@ struct SweepNet {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[ot >> 3][t][ot & 7][r] = fmaxf(acc[t][r], 0.f);
             });
+#ifdef FRL_WIDE_TIMING
+            asm volatile("" :: "v"(X[1][3][7][0]));
+            lc_[4] = clock64();
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                for (int i_ = 0; i_ < 4; ++i_) g_wide_clk[1][8 + i_] += lc_[i_ + 1] - lc_[i_];
+                g_wide_clk[1][12] += 1;
+            }
+#endif
         } else {
             sweep_f<4, true>(X[0], p, 16, w1, KB1, (lds_cf)b1);
             sweep_f<4, true>(X[1], p, 16, w1 + (size_t)8 * KB1 * 256, KB1, (lds_cf)(b1 + 128));
