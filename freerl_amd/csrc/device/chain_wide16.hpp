@@ -40,6 +40,7 @@ struct Wide16Scratch {
 };
 
 struct SweepNet {
+    struct Slice0 { f32x4 R[8]; };     // a sweep's first weight slice in flight (sweep_fetch0)
     WideNet W;             // lane constants (W.C), the 64 KB union (W.u): the sweeps' slice buffers
     lds_f w3, w1a, b1, b2, b3, ls, red;
 
@@ -266,6 +267,8 @@ struct SweepNet {
                 lc_[3] = clock64();
             }
 #endif
+            // (measured and not kept: the next tile's LDS reads issued a tile ahead and the ReLU a tile behind, pinned with
+            // sched_barrier — 17.0 k cycles for this block against 14.5 k as the compiler orders it by itself)
             static_for<0, 16>([&](auto oc) {
                 constexpr int ot = decltype(oc)::value;
                 const f32x4 bf = ld4((lds_cf)(b1 + ot * 16 + 4 * q));
@@ -326,10 +329,31 @@ struct SweepNet {
     // the sweep: for s = 0..7, acc[o][t] = sum_kb Wtile(2 s + o, kb) XR[kb][t]  (TR: sum_ob Wtile(ob, 2 s + o)^T XR[ob][t]), biases
     // from `bias` when given; epi(s, acc) consumes the pair.  One barrier per slice, the next slice's loads pinned in front of
     // the slice's 512 MFMAs, nothing conditional in the loop (chain_wide.hpp's rules).
+    // (sweep_fetch0: the first slice's loads, for callers that have something to run in front of the sweep — the mask words and
+    // tile stores of a first layer, the delta arithmetic — while they are in flight: at 256 workgroups a sweep otherwise opens
+    // with ~11 k cycles of HBM latency.  Not in front of the first layer itself: its own loads then queue behind eight more,
+    // measured +17 k cycles per call)
+    template <bool TR>
+    __device__ __forceinline__ Slice0 sweep_fetch0(g_cf w2) const {
+        Slice0 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = W.C.w * 8 + j;
+            const int tile = TR ? (n & 15) * kHT2 + (n >> 4) : n;
+            f.R[j] = ld4(w2 + ((size_t)tile * 256 + 4 * W.C.l));
+        }
+        return f;
+    }
     template <bool TR, class Epi>
     __device__ __forceinline__ void sweep_x(const f32x4 (&X)[2][4][8], g_cf w2, lds_cf bias, Epi&& epi) const {
+        sweep_x<TR>(X, w2, bias, epi, sweep_fetch0<TR>(w2));
+    }
+    template <bool TR, class Epi>
+    __device__ __forceinline__ void sweep_x(const f32x4 (&X)[2][4][8], g_cf w2, lds_cf bias, Epi&& epi, const Slice0& f0) const {
         const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot, tslot = W.C.tslot;
         f32x4 R[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) R[j] = f0.R[j];
         auto fetch = [&](int s_) {
             const int s = s_ < 7 ? s_ : 7;
 #pragma unroll
@@ -344,11 +368,23 @@ struct SweepNet {
 #pragma unroll
             for (int j = 0; j < 8; ++j) st4(buf + (w * 8 + j) * 256 + 4 * l, R[j]);
         };
-        fetch(0);
+#ifdef FRL_WIDE_TIMING
+        long long sc_[5] = {clock64(), 0, 0, 0, 0}, sa_[4] = {0, 0, 0, 0};
+#endif
         lds_barrier();
+#ifdef FRL_WIDE_TIMING
+        sc_[1] = clock64();
+        sa_[0] = sc_[1] - sc_[0];
+#endif
         for (int s = 0; s < 8; ++s) {
+#ifdef FRL_WIDE_TIMING
+            sc_[1] = clock64();
+#endif
             commit(s);
             lds_barrier();
+#ifdef FRL_WIDE_TIMING
+            sc_[2] = clock64();
+#endif
             fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             lds_cf buf = W.u + (s & 1) * 8192;
@@ -360,18 +396,26 @@ struct SweepNet {
                 for (int t = 0; t < 4; ++t) acc[o][t] = bf;
             }
             if constexpr (!TR) {
+                // fragments one k-block ahead of their MFMAs, pinned: with XR's 256 registers live hipcc otherwise reads each
+                // pair right in front of its 32 MFMAs and waits for it there (lgkmcnt(0) sixteen times per slice: -10 %)
+                f32x4 wf[2][2];
+#pragma unroll
+                for (int o = 0; o < 2; ++o) wf[0][o] = ld4(buf + (o * 16) * 256 + fslot);
                 static_for<0, 16>([&](auto kc) {
                     constexpr int kb = decltype(kc)::value;
-                    f32x4 wf[2];
+                    if constexpr (kb + 1 < 16) {
 #pragma unroll
-                    for (int o = 0; o < 2; ++o) wf[o] = ld4(buf + (o * 16 + kb) * 256 + fslot);
+                        for (int o = 0; o < 2; ++o) wf[(kb + 1) & 1][o] = ld4(buf + (o * 16 + kb + 1) * 256 + fslot);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int o = 0; o < 2; ++o)
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
-                                acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[o][e], X[kb >> 3][t][kb & 7][e], acc[o][t], 0, 0, 0);
+                                acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kb & 1][o][e], X[kb >> 3][t][kb & 7][e], acc[o][t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             } else {
                 float wa[2][2];
@@ -392,8 +436,21 @@ struct SweepNet {
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef FRL_WIDE_TIMING
+            asm volatile("" :: "v"(acc[1][3][0]), "v"(acc[0][0][0]));
+            sc_[3] = clock64();
+#endif
             epi(s, acc);
+#ifdef FRL_WIDE_TIMING
+            sc_[4] = clock64();
+            sa_[1] += sc_[2] - sc_[1]; sa_[2] += sc_[3] - sc_[2]; sa_[3] += sc_[4] - sc_[3];
+#endif
         }
+#ifdef FRL_WIDE_TIMING
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            for (int i_ = 0; i_ < 4; ++i_) g_wide_clk[1][(TR ? 4 : 0) + i_] += sa_[i_];
+        }
+#endif
     }
 
     // layer-2 deltas into XR from the head's deltas and h2's ReLU masks: one-output dot-product head (dzv[t] = the row's delta)
@@ -596,18 +653,19 @@ struct SweepNet {
             lds_barrier();
             fetch(it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 a[8], b[8];
+            f32x4 a[8], b[2];                                          // the B tile of out tile y + 1 is read behind y's 32 MFMAs (pinned)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = tr_read((lds_cf)(buf + (kt0 + j) * 256));
+            b[0] = tr_read((lds_cf)(buf + (kHT2 + ot0) * 256));
+            static_for<0, 8>([&](auto yc) {
+                constexpr int y = decltype(yc)::value;
+                if constexpr (y + 1 < 8) b[(y + 1) & 1] = tr_read((lds_cf)(buf + (kHT2 + ot0 + y + 1) * 256));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int y = 0; y < 8; ++y) b[y] = tr_read((lds_cf)(buf + (kHT2 + ot0 + y) * 256));
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int y = 0; y < 8; ++y) acc[j][y] = mfma4(acc[j][y], a[j], b[y]);
-#pragma unroll
-            for (int y = 0; y < 8; ++y) bsum[y] += (b[y][0] + b[y][1]) + (b[y][2] + b[y][3]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) acc[j][y] = mfma4(acc[j][y], a[j], b[y & 1]);
+                bsum[y] += (b[y & 1][0] + b[y & 1][1]) + (b[y & 1][2] + b[y & 1][3]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
         float ss = 0.f;
 #pragma unroll

@@ -67,6 +67,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
         f32x4 XR[2][4][8];
         unsigned m1[8], m2[8] = {};
         N.l1_x(XR, px, (g_cf)thA + NA.L[0].w_off, KB1a);
+        const SweepNet::Slice0 f0 = N.sweep_fetch0<false>((g_cf)thA + NA.L[1].w_off);
         N.mask_bits(XR, m1);
         N.store_x(X.h1t, sc, XR);
         f32x4 z[4][NT3A];
@@ -78,7 +79,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
             N.mask_push(m2, N.relu_pair(acc));
             N.store_pair(X.h2t, sc, s, acc);
             N.head_tiles_pair<NT3A>(acc, s, z);
-        });
+        }, f0);
         {
             g_f bp = bits + ((size_t)(sc * 4 + w) * 64 + l) * 16;
             st4(bp, f32x4{__uint_as_float(m1[0]), __uint_as_float(m1[1]), __uint_as_float(m1[2]), __uint_as_float(m1[3])});
@@ -138,12 +139,14 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
             f32x4 XR[2][4][8];
             unsigned m1[8], m2[8] = {};
             N.l1_x(XR, px, w1, KB1c);
+            const SweepNet::Slice0 f0 = N.sweep_fetch0<false>(w2);
             N.mask_bits(XR, m1);
             float zp[4] = {0.f, 0.f, 0.f, 0.f};
             N.sweep_x<false>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
                 N.mask_push(m2, N.relu_pair(acc));
                 N.head_valu_pair(acc, s, zp);
-            });
+            }, f0);
+            const SweepNet::Slice0 f1 = N.sweep_fetch0<true>(w2);
             float dzv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
                         }
                     }
                 }
-            });
+            }, f1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
@@ -214,6 +217,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
                 for (int r = 0; r < 4; ++r) { m1[4 * k + r] = __float_as_uint(a1[r]); m2[4 * k + r] = __float_as_uint(a2[r]); }
             }
         }
+        const SweepNet::Slice0 f1 = N.sweep_fetch0<true>((g_cf)thA + NA.L[1].w_off);
         f32x4 dz[4][NT3A];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -246,7 +250,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
         N.sweep_x<true>(XR, (g_cf)thA + NA.L[1].w_off, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {
             N.mask_pair(acc, N.mask_next(m1));
             N.store_pair(X.d1t, sc, s, acc);
-        });
+        }, f1);
     }
     __syncthreads();
     float ss = N.dw2(grA + NA.L[1].w_off, grA + NA.L[1].b_off, (g_cf)X.h1t, (g_cf)X.d2t, nchunks, B);

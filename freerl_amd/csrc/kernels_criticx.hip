@@ -180,6 +180,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
             f32x4 XR[2][4][8];
             unsigned m1[8], m2[8] = {};
             N.l1_x(XR, px, (g_cf)thC + L[0].w_off, KB1c);
+            const SweepNet::Slice0 f0 = N.sweep_fetch0<false>(w2);      // W2's first slice, in flight under the mask words and h1's stores
             N.mask_bits(XR, m1);
             N.store_x(X.h1t, sc, XR);
             WIDE_T(4);
@@ -188,8 +189,9 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                 N.mask_push(m2, N.relu_pair(acc));
                 N.store_pair(X.h2t, sc, s, acc);
                 N.head_valu_pair(acc, s, zp);
-            });
+            }, f0);
             WIDE_T(5);
+            const SweepNet::Slice0 f1 = N.sweep_fetch0<true>(w2);       // W2^T's first slice, in flight under the delta arithmetic
             float dzv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -215,7 +217,7 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
             N.sweep_x<true>(XR, w2, (lds_cf)N.b2, [&](int s, f32x4 (&acc)[2][4]) {       // d1 = (W2^T d2) o relu'(h1) -> d1t
                 N.mask_pair(acc, N.mask_next(m1));
                 N.store_pair(X.d1t, sc, s, acc);
-            });
+            }, f1);
             WIDE_T(7);
         }
         __syncthreads();                                               // every wave's activations and deltas are in scratch

@@ -55,7 +55,7 @@ if case == "td3_h256":
                 "target passes: action rule / TD target", "critic: first-layer sweeps (+ h1 -> scratch)", "critic: second-layer sweeps (+ h2 -> scratch, head partials)",
                 "critic: TD delta, layer-2 deltas -> scratch", "critic: transposed sweeps (d1 -> scratch)", "dW2 pass", "dW3, dW1, bias passes", "norm reduction",
                 "clip + Adam (+ soft update) stream"]
-    names[1] = ["-", "-", "-", "-", "-", "-", "-", "-", "l1_x: loads issued -> first barrier", "LDS staging -> second barrier", "wait for the row operands", "256 MFMAs + ReLU", "l1_x calls (all launches)"]
+    names[1] = ["sweep_x forward: first fetch -> barrier (all launches, all sweeps)", "   commit + barrier, 8 slices", "   fetch issue + 512 MFMAs, 8 slices", "   epilogue, 8 slices", "sweep_x transposed: first fetch -> barrier", "   commit + barrier", "   fetch issue + 512 MFMAs", "   epilogue", "l1_x: loads issued -> first barrier", "LDS staging -> second barrier", "wait for the row operands", "256 MFMAs + ReLU", "l1_x calls (all launches)"]
 for row, title in ((0, "kernels_criticw"), (1, "kernels_actorw")):
     tot = clk[row].sum()
     print("%s %s P=%d: %.0f cycles per workgroup" % (case, title, P, tot))
