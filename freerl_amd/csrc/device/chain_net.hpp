@@ -437,13 +437,17 @@ struct ChainNet {
         else if constexpr (J < 18) return g.g1[J - 16];
         else return g.g3[J - 18];
     }
-    // HB = byte offset of the head's block inside the net (head * kHeadFloats * 4)
-    template <bool SOFT, int J, int HB>
+    // HB = byte offset of the head's block inside the net (head * kHeadFloats * 4).  THL: theta from the head's image in LDS — the
+    // last head staged is still there, in the same slot order — instead of a second trip to HBM (the update phase is the one
+    // that streams HBM with every CU at once)
+    template <bool SOFT, int J, int HB, bool THL>
     __device__ __forceinline__ AdamIn adam_load(const AdamBuf& B) const {
         AdamIn X;
         constexpr int so = HB + unit_soff<J>();
         const int vo = unit_voff<J>();
-        X.th = buf_ld4(B.th, vo, so); X.mm = buf_ld4(B.mm, vo, so); X.vv = buf_ld4(B.vv, vo, so);
+        if constexpr (THL) X.th = ld4((lds_cf)((J < 16 ? S.w2 + (w * 2 * kHT + J) * 256 : (J < 18 ? S.w1 : S.w3) + (w * 2 + (J & 1)) * 256) + fslot));
+        else X.th = buf_ld4(B.th, vo, so);
+        X.mm = buf_ld4(B.mm, vo, so); X.vv = buf_ld4(B.vv, vo, so);
         if constexpr (SOFT) X.tg = buf_ld4(B.tg, vo, so); else X.tg = f32x4{0.f, 0.f, 0.f, 0.f};
         return X;
     }
@@ -493,7 +497,7 @@ struct ChainNet {
     }
     // the whole update of head HD of a net, in the open: the 128 x 128 layer's 16 tiles in two batches of 8 (loads of a batch before
     // its stores), then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
-    template <bool SOFT, int HD>
+    template <bool SOFT, int HD, bool THL = false>
     __device__ __forceinline__ void adam_head(const HeadGrad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
                                               int extra_n = 0) const {
         const AdamBuf B = adam_buf(th, mA, vA, tg);
@@ -501,7 +505,7 @@ struct ChainNet {
         static_for<0, 3>([&](auto bc) {
             constexpr int b0 = decltype(bc)::value * 8, nb = decltype(bc)::value < 2 ? 8 : 4;
             AdamIn in[nb];
-            static_for<0, nb>([&](auto j) { in[decltype(j)::value] = adam_load<SOFT, b0 + decltype(j)::value, HB>(B); });
+            static_for<0, nb>([&](auto j) { in[decltype(j)::value] = adam_load<SOFT, b0 + decltype(j)::value, HB, THL>(B); });
             // Every load of the batch has landed before its first store is issued: gfx9 counts loads and stores in one counter,
             // and with both kinds in flight hipcc's "all but the N youngest" waits rest on their retiring strictly in issue
             // order.  Nothing measured says they do not (the corruption first blamed on it was the store-data hazard, see

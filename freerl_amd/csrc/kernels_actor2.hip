@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
     co.tk = 1.f - a.tau; co.tau = a.tau;
     PPO_T(5);
-    C.adam_head<true, 0>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);
+    C.adam_head<true, 0, true>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);      // (theta from the actor's image, still staged from pass C)
     PPO_T(6);
     PPO_TDUMP();
     if (tid == 0) {

@@ -62,26 +62,36 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 
     // ---- this lane's rows (one per 64-row chunk) are the same in every pass: their ring addresses once, up front; a chunk's
     // record fields are loaded one chunk ahead of their use (one workgroup per CU: nobody else hides that latency)
+    // Every load below is UNCONDITIONAL — rows past the batch read the batch's last row, columns past the input read its last
+    // column — because hipcc's s_waitcnt counts only loads that are always issued: one load under an `if` turns every wait of
+    // the loop into vmcnt(0), i.e. into a wait for the chunk that was just prefetched (4.6 k cycles per target chunk pass).
+    // What the clamped lanes loaded is dropped where it is USED, a chunk later (zero_pad), not where it is loaded.
     int ridx[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int row = c * 64 + 16 * w + i16;
-        ridx[c] = row < B ? idx[row] : -1;
+        ridx[c] = idx[row < B ? row : B - 1];
+    }
+    int colx[4];                                                       // this lane's four columns of [s | a] in the record
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int f = 4 * q + e < O + A ? 4 * q + e : O + A - 1;
+        colx[e] = f < O ? R.obs_off[0] + f : R.act_off[0] + f - O;
     }
     struct RowIn { f32x4 x; };
     auto load_row = [&](int c) {                                       // [s | a] of this lane's row of chunk c
         RowIn X;
-        X.x = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ri = c == 0 ? ridx[0] : (c == 1 ? ridx[1] : (c == 2 ? ridx[2] : ridx[3]));
-        if (ri >= 0) {
-            g_cf rec = ring + (size_t)ri * R.stride;
+        g_cf rec = ring + (size_t)ri * R.stride;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 4 * q + e;
-                if (f < O + A) X.x[e] = rec[f < O ? R.obs_off[0] + f : R.act_off[0] + f - O];
-            }
-        }
+        for (int e = 0; e < 4; ++e) X.x[e] = rec[colx[e]];
         return X;
+    };
+    auto zero_pad = [&](const f32x4& x, int width) {                   // columns >= width of a loaded slice are padding: exact zeros
+        f32x4 r;                                                       // (the weight gradients of the padded columns must stay zero)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = 4 * q + e < width ? x[e] : 0.f;
+        return r;
     };
     // ---- The target passes carry TT 16-row tiles per wave (64 TT rows per chunk): nothing is differentiated through them, so the
     // registers the gradient accumulators need later hold more tiles now, and every weight fragment read from LDS feeds
@@ -90,22 +100,21 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
-        ridxT[j4] = row < B ? idx[row] : -1;
+        ridxT[j4] = idx[row < B ? row : B - 1];
     }
+    int colo[4];                                                       // ... of s' (the columns past obs_dim meet zero weight rows)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) colo[e] = R.nobs_off[0] + (4 * q + e < O ? 4 * q + e : O - 1);
     struct RowIn2 { f32x4 x[TT]; float rew[TT], done[TT]; };
     auto load_row2 = [&](bool want_rd, int c2) {                       // s' (obs columns) [+ reward / done] of the chunk's tiles
         RowIn2 X;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            X.x[t] = f32x4{0.f, 0.f, 0.f, 0.f}; X.rew[t] = 0.f; X.done[t] = 0.f;
             const int ri = (TT == 4 || c2 == 0) ? ridxT[t] : ridxT[(TT == 4 ? 0 : 2) + t];
-            if (ri >= 0) {
-                g_cf rec = ring + (size_t)ri * R.stride;
+            g_cf rec = ring + (size_t)ri * R.stride;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < O) X.x[t][e] = rec[R.nobs_off[0] + 4 * q + e];
-                if (want_rd) { X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off]; }
-            }
+            for (int e = 0; e < 4; ++e) X.x[t][e] = rec[colo[e]];
+            X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off];
         }
         return X;
     };
@@ -140,13 +149,19 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
     C.stage_commit(pend);
     PPO_T(0);
-    for (int c2 = 0; c2 < nch2; ++c2) {
+    PPO_U0();
+    // (the last chunk of every pass is a peeled copy of the loop body: the next net's fetch rides on it, and a fetch under
+    // `if (c2 + 1 == nch2)` inside the loop is a conditional load like any other)
+    auto target_actor_chunk = [&](int c2, auto last_c) {
+        constexpr bool last = decltype(last_c)::value;
         const RowIn2 cur = nxt2;
-        nxt2 = load_row2(true, c2 + 1 < nch2 ? c2 + 1 : 0);            // (after the last chunk: chunk 0 of the target-critic pass)
-        if (FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
+        nxt2 = load_row2(true, last ? 0 : c2 + 1);                     // (after the last chunk: chunk 0 of the target-critic pass)
+        if constexpr (last && FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
+        PPO_U(0);
         f32x4 z[TT], h1[TT][kHT], h2[TT][kHT];
         C.forward_vh<TT>(cur.x, h1, h2, z, A);                          // (the actor head's act_dim <= 4 outputs as dot products)
-        if (!FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = C.stage_fetch(tgC, 0);
+        PPO_U(1);
+        if constexpr (last && !FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
@@ -186,32 +201,40 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                 S.lpn[row] = lp;
             }
         }
-    }
+        PPO_U(2);
+    };
+    for (int c2 = 0; c2 + 1 < nch2; ++c2) target_actor_chunk(c2, IC<0>{});
+    target_actor_chunk(nch2 - 1, IC<1>{});
     PPO_T(1);
     // =========================================================== y = r + gamma (1 - d) min_h Q_target_h(s', a')  (SAC: - alpha log pi)
     RowIn nxt;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
+        PPO_UR();
         C.stage_commit(pend);
-        for (int c2 = 0; c2 < nch2; ++c2) {
+        PPO_U(3);
+        auto target_critic_chunk = [&](int c2, auto last_c) {
+            constexpr bool last = decltype(last_c)::value;
             const RowIn2 cur = nxt2;
-            if (c2 + 1 < nch2) nxt2 = load_row2(true, c2 + 1);
-            else if (hd + 1 < NH) nxt2 = load_row2(true, 0);
+            if constexpr (!last) nxt2 = load_row2(true, c2 + 1);
+            else if (hd + 1 < NH) nxt2 = load_row2(true, 0);           // (hd is a constant of the unrolled head loop)
             else nxt = load_row(0);                                    // first chunk of the critic pass: [s | a], 64-row mapping
-            if (FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
+            if constexpr (last && FRL_CRITIC2_AHEAD) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
             f32x4 xb[TT], z[TT], h1[TT][kHT], h2[TT][kHT];
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
-                xb[t] = cur.x[t];
+                xb[t] = zero_pad(cur.x[t], O);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int f = 4 * q + e;
                     if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];      // a' from the target-actor pass
                 }
             }
+            PPO_U(4);
             C.forward_vh<TT>(xb, h1, h2, z, 1);
-            if (!FRL_CRITIC2_AHEAD && c2 + 1 == nch2) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
+            PPO_U(5);
+            if constexpr (last && !FRL_CRITIC2_AHEAD) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
                 const int row = c2 * kRowsT + 16 * TT * w + 16 * t + i16;
@@ -226,8 +249,12 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                     }
                 }
             }
-        }
+            PPO_U(6);
+        };
+        for (int c2 = 0; c2 + 1 < nch2; ++c2) target_critic_chunk(c2, IC<0>{});
+        target_critic_chunk(nch2 - 1, IC<1>{});
     }
+    PPO_UDUMP();
     PPO_T(2);
     // =========================================================== critic heads: forward, TD delta, backward into the owners' accumulators
     HeadGrad G[NH];
@@ -239,13 +266,16 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         PPO_T(3);
         C.stage_commit(pend);
         PPO_T(0);
-        for (int c = 0; c < nchunks; ++c) {
+        auto critic_chunk = [&](int c, auto last_c) {
+            constexpr bool last = decltype(last_c)::value;
             const int row = c * 64 + 16 * w + i16;
             const bool valid = row < B;
             const RowIn cur = nxt;
-            nxt = load_row(c + 1 < nchunks ? c + 1 : 0);               // (after the last chunk: the second head re-reads chunk 0)
-            if (c + 1 == nchunks && hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
-            f32x4 xb[1] = {cur.x}, z[1], h1[1][kHT], h2[1][kHT];
+            nxt = load_row(last ? 0 : c + 1);                          // (after the last chunk: the second head re-reads chunk 0)
+            if constexpr (last) {
+                if (hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
+            }
+            f32x4 xb[1] = {zero_pad(cur.x, O + A)}, z[1], h1[1][kHT], h2[1][kHT];
             PPO_T(4);
             C.forward_vh<1>(xb, h1, h2, z, 1);
             PPO_T(5);
@@ -258,7 +288,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             }
             C.backward(g, xb[0], h1[0], h2[0], dz, 1);
             PPO_T(6);
-        }
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) critic_chunk(c, IC<0>{});
+        critic_chunk(nchunks - 1, IC<1>{});
         C.grad_finish(g);
     }
 
@@ -286,9 +318,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = a.critic_wd;
     co.tk = 1.f - a.tau; co.tau = a.tau;
     if (a.do_actor != 0) {                                             // TD3: targets move with the delayed policy step (TD3.py:224-233)
-        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
     } else {
-        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
     }
     PPO_T(7);
     PPO_TDUMP();

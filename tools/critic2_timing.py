@@ -40,4 +40,11 @@ per = max(1, -(-P // 256)) if persist else 1
 print("P=%d: %.0f cycles per workgroup = %d learner(s) (critic stage, %s)" % (P, tot, per, "persistent kernels_critic3" if persist else "kernels_critic2"))
 for i, n in enumerate(names):
     print("   %-50s %8.0f  %5.1f%%" % (n, clk[i], 100 * clk[i] / tot))
+fine = np.array(buf[8:16], dtype=np.float64)
+fnames = ["target actor: row loads + next net's fetch issued", "target actor: forward_vh<2> (2 chunks of 128 rows)", "target actor: action rule",
+          "target critics: stage_commit (2 heads)", "target critics: row loads, a' from LDS, fetch issued", "target critics: forward_vh<2> (4 chunk passes)",
+          "target critics: min / TD target"]
+print("   inside the target passes:")
+for i, n in enumerate(fnames):
+    print("      %-60s %8.0f" % (n, fine[i]))
 e.close()
