@@ -71,16 +71,18 @@ def test_c4_sac_humanoid_shape(N, family):
     e.close()
 
 
-def test_c5_maddpg_spread_shape(N, family):
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_c5_maddpg_spread_shape(N, family, hidden):
+    """hidden 256: the same centralised critics on kernels_criticx / _actorx (B = 320: a full super-chunk and a ragged one)."""
     from freerl_amd.engine import Engine
     from oracle import algos
-    n, O, A, B, n_tab = 3, 18, 5, 1024, 1500
+    n, O, A, B, n_tab = 3, 18, 5, (1024 if hidden == 128 else 320), 1500
     ids = ["agent_%d" % j for j in range(n)]
     dims = {a: [O, A] for a in ids}
     tabs = {a: synth.transitions(80 + j, n_tab, O, A) for j, a in enumerate(ids)}
-    params = {a: dict(actor=synth.mlp_params(90 + 2 * j, cases.actor_layers(O, A)),
-                      critic=synth.mlp_params(91 + 2 * j, cases.critic_layers(n * (O + A)))) for j, a in enumerate(ids)}
-    e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, 2048, batch_max=B)
+    params = {a: dict(actor=synth.mlp_params(90 + 2 * j, cases.actor_layers(O, A, hidden=hidden)),
+                      critic=synth.mlp_params(91 + 2 * j, cases.critic_layers(n * (O + A), hidden=hidden))) for j, a in enumerate(ids)}
+    e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, 2048, batch_max=B, hidden=hidden)
     assert e.learn_path(B)[0] == family
     for j, a in enumerate(ids):
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
@@ -313,7 +315,8 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     rainbow.close()
 
 
-@pytest.mark.parametrize("case", ["td3_17_6_b200", "ddpg_40_3_b256", "td3_30_5_b1000", "sac_33_17_b96", "td3_h256_11_3_b200", "sac_h256_40_17_b96"])
+@pytest.mark.parametrize("case", ["td3_17_6_b200", "ddpg_40_3_b256", "td3_30_5_b1000", "sac_33_17_b96", "td3_h256_11_3_b200", "sac_h256_40_17_b96",
+                                  "sac_h256_120_20_b256"])
 def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
     """The K-sliced chained family (kernels_criticw / _actorw, forced with FRL_CRITIC_V2=1) at shapes between the narrow standard
     one and config 4: first layers of 2-3 k-blocks, a batch that is not a multiple of 64 (ragged last chunk), a batch of four
@@ -322,7 +325,8 @@ def test_wide_chained_family_vs_oracle(N, monkeypatch, case):
     from oracle import algos
     monkeypatch.setenv("FRL_CRITIC_V2", "1")
     kind, O, A, B = {"td3_17_6_b200": ("td3", 17, 6, 200), "ddpg_40_3_b256": ("ddpg", 40, 3, 256), "td3_30_5_b1000": ("td3", 30, 5, 1000),
-                     "sac_33_17_b96": ("sac", 33, 17, 96), "td3_h256_11_3_b200": ("td3", 11, 3, 200), "sac_h256_40_17_b96": ("sac", 40, 17, 96)}[case]
+                     "sac_33_17_b96": ("sac", 33, 17, 96), "td3_h256_11_3_b200": ("td3", 11, 3, 200), "sac_h256_40_17_b96": ("sac", 40, 17, 96),
+                     "sac_h256_120_20_b256": ("sac", 120, 20, 256)}[case]        # (nine first-layer k-blocks: the K-outer first layer at hidden 256)
     hidden = 256 if "h256" in case else 128         # h256: kernels_criticx / _actorx (x-stationary sweeps)
     n_tab = 1400
     tab = synth.transitions(401, n_tab, O, A)
