@@ -374,8 +374,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (force ? atoi(force) != 0 : h.P > 128) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
-        // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 84.1 TFLOP/s against the row-chunk
-        // kernels' 45.8, MADDPG simple_spread 77.1 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 69.3 / 55.4
+        // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
+        // kernels' 46.2, MADDPG simple_spread 77.2 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 71.1 / 56.9
         // (profiles/r04)
         if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > 128) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
