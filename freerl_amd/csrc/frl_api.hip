@@ -377,7 +377,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
         // kernels' 46.2, MADDPG simple_spread 77.2 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 71.1 / 56.9
         // (profiles/r04)
-        if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > 128) {
+        // (profiles/r04/family_crossover.txt: hidden 128 ties at ~110-129 units; hidden 256 at 128 units 38.9 against 53.1, at 192
+        // 55.3 / 51.5, at 256 68.0 / 55.7 — its workgroups are twice as long, so the half-empty chip costs more: from 177 up)
+        if (force ? atoi(force) != 0 : (long long)h.P * h.n_agents > (h.hidden == 256 ? 176 : 128)) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
             h.wide = h.hidden == 256 ? 2 : 1;
             h.wide_bm = h.wide == 2 ? (h.batch_max + 255) / 256 * 256 : (h.batch_max + 63) / 64 * 64;      // (hidden 256 works in super-chunks of 256 rows)

@@ -300,10 +300,10 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     matd3 = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, twin_critic=True, batch_max=128)   # MATD3: the same family
     assert matd3.learn_path(128)[0]
     matd3.close()
-    h256 = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)      # hidden 256: the x-stationary kernels
+    h256 = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=180, twin_critic=True, batch_max=256, hidden=256)      # hidden 256: the x-stationary kernels
     assert h256.learn_path(256)[0]
     h256.close()
-    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=100, twin_critic=True, batch_max=256, hidden=256)       # ... from 129 units up as well
+    h256 = Engine(N.ALGO_TD3, 8, 2, 512, n_learners=144, twin_critic=True, batch_max=256, hidden=256)       # ... from 177 units up (twice as long per unit)
     assert not h256.learn_path(256)[0]
     h256.close()
     monkeypatch.delenv("FRL_DQN_FUSED", raising=False)
