@@ -25,6 +25,9 @@ CASES = {
     "td3_narrow_b100": dict(algo=N.ALGO_TD3, obs=8, act=2, B=100, twin=True),        # the narrow register-chained kernels, ragged batches
     "sac_narrow_b200": dict(algo=N.ALGO_SAC, obs=11, act=3, B=200, twin=True),
     "ddpg_narrow_b37": dict(algo=N.ALGO_DDPG, obs=3, act=1, B=37, twin=False),
+    "sac_380_20_b17": dict(algo=N.ALGO_SAC, obs=380, act=20, B=17, twin=True),
+    "sac_380_20_b256": dict(algo=N.ALGO_SAC, obs=380, act=20, B=256, twin=True),
+    "sac_380_20_h256": dict(algo=N.ALGO_SAC, obs=380, act=20, B=256, twin=True, hidden=256),
     "maddpg_h256": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=False, hidden=256),
     "matd3_h256": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=300, twin=True, matd3=True, hidden=256),
     "sac_h256_wide": dict(algo=N.ALGO_SAC, obs=120, act=20, B=256, twin=True, hidden=256),
