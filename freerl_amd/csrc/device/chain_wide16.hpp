@@ -1,19 +1,21 @@
 // The K-sliced chained design (device/chain_wide.hpp) at HIDDEN 256 — north_star's "dense 256 x 256 MLP GEMMs" — kernels_criticx.hip /
-// kernels_actorx.hip.  At 256 hidden units no weight image fits LDS (W2 alone is 256 KB) and the activations of even two 16-row
-// tiles per wave fill the register file (64 registers per tile and layer), so nothing is chained through registers here:
+// kernels_actorx.hip.  At 256 hidden units no weight image fits LDS (W2 alone is 256 KB); what fits the chip is the ACTIVATIONS:
 //
-//   * every matrix product is a SWEEP in the style of chain_wide.hpp's first layer — 32 KB slices of the weight image
-//     double-buffered through the 64 KB union, FOUR 16-row tiles per wave (the 256 rows of a super-chunk) against EIGHT output
-//     tiles (one half of a 256-wide layer: 128 accumulator registers) — so every weight is read once per 256 rows and pass and
-//     every fragment read from LDS feeds 16 MFMAs;
-//   * the hidden activations and deltas live in the unit's HBM scratch in TILE-LANE order — the D layout of a 16 x 16 output
-//     tile, one dwordx4 per lane: tile (row block, feature tile) at ((chunk * 4 + wave) * 16 + tile) * 256 floats — which is at
-//     once the cheapest store (1 KB contiguous per wave-instruction), the row operand of the next sweep (the chained
-//     formulation's "D of one layer is B of the next", through memory), and what the weight-gradient passes read transposed;
-//   * sweep_tr is the transposed product dH = W^T dZ from the same image sliced by output blocks, fragments read transposed.
+//   * x-stationary sweeps: the activations of a 256-row super-chunk — four 16-row tiles per wave x sixteen feature tiles, XR: 256
+//     registers in the D layout, which is the B operand of the next layer — stay in registers from the first layer to the head
+//     and back down (l1_x -> sweep_x -> deltas from the ReLU mask words -> sweep_x<TR>), while the weight image streams through the
+//     64 KB union two output tiles (32 KB) at a time, double-buffered, 512 MFMAs per slice and barrier; a finished pair of
+//     output tiles goes to the caller's epilogue (ReLU, mask word, tile-lane store, head partials).  A head's main pass reads
+//     nothing but its weights;
+//   * what the weight-gradient passes need (h1, h2, d2, d1) goes to the unit's HBM scratch in TILE-LANE order — the D layout of
+//     a 16 x 16 output tile, one dwordx4 per lane: tile (row block, feature tile) at ((chunk * 4 + wave) * 16 + tile) * 256
+//     floats, 1 KB contiguous per wave-instruction; the gradient passes bring the tiles in as they lie and transpose them
+//     through LDS (dw2_coop: once per workgroup and row block; dw_rows: per wave);
+//   * a first layer wider than two k-blocks takes chain_wide.hpp's K-outer form (sweep_f, two halves of eight output tiles).
 //
-// The first cut of this file (round 4) chained two tiles per wave through registers: 256 KB of W2 per 128 rows is 2.4 TB/s
-// chip-wide and the kernels spilled ~1000 VGPRs: 50.7 TFLOP/s against the row-chunk kernels' 55.4 (profiles/README.md).
+// Two earlier cuts of this file (round 4, profiles/README.md): two tiles per wave chained through registers with every layer
+// K-sliced (W2 re-read per 128 rows: 2.4 TB/s chip-wide, ~1000 spilled VGPRs, 50.7 TFLOP/s against the row-chunk kernels'
+// 55.4), and every product a K-outer sweep with the activations through tile-lane tensors in HBM between the layers (56.5).
 #pragma once
 #include "chain_wide.hpp"
 #include "wide_timing.hpp"
@@ -162,67 +164,6 @@ struct SweepNet {
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[t][j][r] = fmaxf(acc[t][j][r], 0.f);
-        }
-    }
-
-    // ---- transposed half-sweep: acc[t][j] = sum_ob W[ob][8 hv + j]^T d[t][ob] over the sixteen output blocks of the 256 x 256
-    // image w2 (tile (ob, it) at (ob * 16 + it) * 256); the operand d as in sweep_f (k-block = output block).  Slice s = output
-    // blocks 4 s .. 4 s + 3 x the half's eight input tiles (contiguous per output block); fragments read transposed (four
-    // ds_read_b32, one k-step ahead)
-    template <int T>
-    __device__ __forceinline__ void sweep_tr(f32x4 (&acc)[T][8], const g_cf (&p)[T], int kstride, g_cf w2, int hv) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 R[8], xn[4][T], xc[4][T];
-        auto fetch = [&](int s_) {
-            const int s = s_ < 3 ? s_ : 3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) R[j] = ld4(w2 + ((size_t)((4 * s + w) * kHT2 + 8 * hv + j) * 256 + 4 * l));
-        };
-        auto commit = [&](int s) {
-            lds_f buf = W.u + (s & 1) * 8192;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) st4(buf + (j * 4 + w) * 256 + 4 * l, R[j]);
-        };
-        auto xfetch = [&](int s_) {
-            const int s = s_ < 3 ? s_ : 3;
-#pragma unroll
-            for (int obl = 0; obl < 4; ++obl)
-#pragma unroll
-                for (int t = 0; t < T; ++t) xn[obl][t] = ld4(p[t] + (size_t)(4 * s + obl) * kstride);
-        };
-        fetch(0);
-        xfetch(0);
-        lds_barrier();
-        for (int s = 0; s < 4; ++s) {
-            commit(s);
-            lds_barrier();
-#pragma unroll
-            for (int obl = 0; obl < 4; ++obl)
-#pragma unroll
-                for (int t = 0; t < T; ++t) xc[obl][t] = xn[obl][t];
-            fetch(s + 1);
-            xfetch(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            lds_cf buf = W.u + (s & 1) * 8192;
-            float wa[2][8];
-            auto frag = [&](int obl, int e, float (&dst)[8]) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dst[j] = buf[(j * 4 + obl) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-            };
-            frag(0, 0, wa[0]);
-            static_for<0, 16>([&](auto kc) {
-                constexpr int k_ = decltype(kc)::value, obl = k_ >> 2, e = k_ & 3;
-                if constexpr (k_ + 1 < 16) frag((k_ + 1) >> 2, (k_ + 1) & 3, wa[(k_ + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k_ & 1][j], xc[obl][t][e], acc[t][j], 0, 0, 0);
-            });
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -550,66 +491,6 @@ struct SweepNet {
             g_f tp = tl(tensor, 4 * sc + t) + (2 * s) * 256;
             st4(tp, h[0][t]);
             st4(tp + 256, h[1][t]);
-        }
-    }
-
-    // ---- head partial sums over one half's eight hidden tiles (h = acc of sweep_f on half hv): dot-product head of hn <= 4
-    // outputs (zp[t][o]: this lane's partial over its 32 features of the half; the caller sums the lane groups) / NT3 MFMA tiles
-    template <int T>
-    __device__ __forceinline__ void head_valu_half(const f32x4 (&h)[T][8], int hv, float (&zp)[T][4], int hn) const {
-        const int q = W.C.q;
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            if (o < hn) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const f32x4 wv = ld4((lds_cf)(w3 + (8 * hv + j) * 256 + ((q * 16 + (o ^ q)) << 2)));
-#pragma unroll
-                    for (int t = 0; t < T; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zp[t][o] = fmaf(wv[r], h[t][j][r], zp[t][o]);
-                }
-            }
-        }
-    }
-    template <int T, int NT3>
-    __device__ __forceinline__ void head_tiles_half(const f32x4 (&h)[T][8], int hv, f32x4 (&z)[T][NT3]) const {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int o3 = 0; o3 < NT3; ++o3) {
-                const f32x4 wf = ld4((lds_cf)(w3 + (o3 * kHT2 + 8 * hv + j) * 256 + W.C.fslot));
-#pragma unroll
-                for (int t = 0; t < T; ++t) z[t][o3] = mfma4(z[t][o3], wf, h[t][j]);
-            }
-    }
-    // ---- layer-2 deltas of one tile from its head deltas, through the ReLU of h2 (re-read from the tile-lane copy), -> d2t.
-    // VH: one-output dot-product head (dzv = the row's delta, on every lane
-    // group); else NT3 tiles via transposed fragments of the head image
-    template <int NT3, bool VH>
-    __device__ __forceinline__ void delta2_tile(const f32x4 (&dz)[NT3], float dzv, g_cf h2p, g_f d2p) const {
-        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
-#pragma unroll
-        for (int it = 0; it < kHT2; ++it) {
-            const f32x4 hv4 = ld4(h2p + it * 256);
-            f32x4 d;
-            if constexpr (VH) {
-                const f32x4 wv = ld4((lds_cf)(w3 + it * 256 + ((q * 16 + q) << 2)));      // slot (q, f = 0): W3[0][16 it + 4 q ..]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = wv[r] * dzv;
-            } else {
-                d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int o3 = 0; o3 < NT3; ++o3) {
-                    f32x4 wa;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) wa[e] = w3[(o3 * kHT2 + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
-                    d = mfma4(d, wa, dz[o3]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = hv4[r] > 0.f ? d[r] : 0.f;
-            st4(d2p + it * 256, d);
         }
     }
 
