@@ -28,6 +28,8 @@ CASES = {
     "sac_380_20_b17": dict(algo=N.ALGO_SAC, obs=380, act=20, B=17, twin=True),
     "sac_380_20_b256": dict(algo=N.ALGO_SAC, obs=380, act=20, B=256, twin=True),
     "sac_380_20_h256": dict(algo=N.ALGO_SAC, obs=380, act=20, B=256, twin=True, hidden=256),
+    "sac_100_7": dict(algo=N.ALGO_SAC, obs=100, act=7, B=200, twin=True),            # seven first-layer k-blocks: the cooperative dW1 pass, 7 k-tiles per wave
+    "td3_201_12": dict(algo=N.ALGO_TD3, obs=201, act=12, B=256, twin=True),
     "maddpg_h256": dict(algo=N.ALGO_MADDPG, obs=[6, 5, 7], act=[2, 3, 2], B=64, twin=False, hidden=256),
     "matd3_h256": dict(algo=N.ALGO_MADDPG, obs=[18] * 3, act=[5] * 3, B=300, twin=True, matd3=True, hidden=256),
     "sac_h256_wide": dict(algo=N.ALGO_SAC, obs=120, act=20, B=256, twin=True, hidden=256),
