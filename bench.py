@@ -83,11 +83,12 @@ def _cpu_worker(kind, budget_s, seed):
         b.dones[:rows] = g.random(rows) < 0.05
         b._size, b._index = rows, rows % b.capacity
 
-    if kind == "td3":
+    if kind.startswith("td3"):          # "td3" (the bench's full 1e6-row ring) or "td3:<rows>"
+        cap = int(kind.split(":")[1]) if ":" in kind else CAP
         actor = synth.mlp_params(1 + seed, cases.actor_layers(OBS, ACT))
         critic = synth.mlp_params(2 + seed, cases.critic_layers(OBS + ACT, twin=True))
-        pol = algos.TD3(actor, critic, OBS, ACT, 1e-3, 1e-3, CAP)
-        prefill(pol.buffer, CAP, ACT, False)
+        pol = algos.TD3(actor, critic, OBS, ACT, 1e-3, 1e-3, cap)
+        prefill(pol.buffer, cap, ACT, False)
         noise = g.standard_normal((BATCH, ACT)).astype(np.float32)
         step = lambda: pol.learn(BATCH, 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0, noise=noise)
     else:                               # "dqn_loop:<rows>": the reference's DQN loop (DQN.py:294-343) on the synthetic discrete env
@@ -141,6 +142,9 @@ def cpu_baseline(budget_s=6.0):
     n_all = min(cores, 64)              # 64 x ~250 MB of float64 ring is enough to characterise the box
     one, c1 = _run_cpu_workers("td3", 1, budget_s)
     allc, call = _run_cpu_workers("td3", n_all, budget_s)
+    # the same learn() from a 1e4-row ring: np.random.choice(size, 256, replace=False) permutes the whole ring per call (TD3.py:183), so
+    # this point is the port's own arithmetic (~the reference's 5 ms) and the 1e6 one above mostly the permutation
+    small, cs = _run_cpu_workers("td3:10000", 1, budget_s * 0.5)
     loops = {}
     for rows in DQN_LOOP_ROWS:
         r1, _ = _run_cpu_workers("dqn_loop:%d" % rows, 1, budget_s * 0.6)
@@ -151,6 +155,9 @@ def cpu_baseline(budget_s=6.0):
     return {"value": one, "unit": "updates/s", "cores": 1, "kind": "port",
             "sample": "%d oracle TD3.learn() calls (1 learner, replay 1e6 full, batch 256, np.random.choice index draw "
                       "included) in %.1f s on one core" % (c1[0], budget_s),
+            "ring_1e4_rows": {"value": small, "unit": "updates/s", "cores": 1,
+                              "sample": "%d oracle TD3.learn() calls from a full 1e4-row ring in %.1f s on one core (separates the port's arithmetic "
+                                        "from np.random.choice's O(ring) permutation)" % (cs[0], budget_s * 0.5)},
             "all_cores": {"value": allc, "unit": "updates/s", "cores": n_all, "host_cpus": cores,
                           "sample": "%d independent oracle learners, one process per core, %d calls in %.1f s" % (n_all, sum(call), budget_s)},
             "dqn_loop_env_steps_per_sec": loops}
@@ -374,6 +381,7 @@ def main():
     if rank == 0:
         fl_a, by_a = e.learn_work(BATCH, True)
         fl_c, by_c = e.learn_work(BATCH, False)
+        fx_a, fx_c = e.learn_work_executed(BATCH, True), e.learn_work_executed(BATCH, False)
         n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
         step_s = kernel_ms * 1e-3 / args.steps
         kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
@@ -431,6 +439,12 @@ def main():
                          "note": "round 1's 0.51 was ac_critic_kernel alone (0.523 ms) with clip + Adam in a second launch (0.120 ms): "
                                  "0.41 for the stage this kernel now covers on its own",
                          "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
+                         "flops_convention": "achieved / frac: SURVEY 8(d)'s formula, 2 B sum(in x out) x (#fwd + 2 x #bwd) (frl_learn_work); "
+                                             "*_executed: the flops autograd and these kernels execute - no first-layer dX of a trained net, "
+                                             "action columns only for dQ/da (frl_learn_work_executed)",
+                         "flops_executed_per_launch": fx_c, "achieved_executed": fx_c / launch_s / 1e12,
+                         "frac_executed": fx_c / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "step_tflops_executed": (fx_a * n_act + fx_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "hbm_bound_frac": abytes / launch_s / 1e9 / HBM_PEAK_GBS,
                          "step_flops_avg": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps,
                          "step_ms_avg": step_s * 1e3,

@@ -132,6 +132,7 @@ SIGNATURES = {
     "frl_net_num_params": (_i, [_vp, _i, _ip]),
     "frl_params_get": (_i, [_vp, _i, _i, _i, _fp]),
     "frl_params_set": (_i, [_vp, _i, _i, _i, _fp]),
+    "frl_params_pad_max": (_i, [_vp, _i, _i, _i, _fp]),
     "frl_opt_step_get": (_i, [_vp, _i, _i, _ip]),
     "frl_opt_step_set": (_i, [_vp, _i, _i, _i]),
     "frl_alpha_get": (_i, [_vp, _i, _fp, _ip]),
@@ -152,6 +153,7 @@ SIGNATURES = {
     "frl_per_update": (_i, [_vp, _i, _i64p, _fp]),
     "frl_per_state": (_i, [_vp, _i, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
+    "frl_learn_work_executed": (_i, [_vp, _i, _i, _P(C.c_double)]),
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
     "frl_ppo_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
     "frl_gae": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),

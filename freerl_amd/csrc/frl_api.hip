@@ -84,8 +84,13 @@ struct frl_engine {
     size_t idx_count = 0, noise_count = 0;
     unsigned long long rng_counter = 0;
     // act scratch (device)
-    float* d_act_wk = nullptr;            // [P][net size]: a fragment-image net re-laid out to Wk for act_kernel (wide chained engines)
-    size_t act_wk_cap = 0;
+    // [slot][P][net size]: fragment-image nets re-laid out to Wk for act_kernel (wide chained engines), one slot per
+    // (net, online | target), sized once at frl_create; a slot is re-laid out only when the engine's parameters have changed since
+    // (param_version: bumped by frl_learn, frl_params_set and the obs-norm relayout)
+    float* d_act_wk = nullptr;
+    size_t act_wk_slot = 0;               // floats per slot = P * largest net
+    std::vector<unsigned long long> act_wk_version;   // [2 * n_nets], 0 = never laid out
+    unsigned long long param_version = 1;
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
     float* d_act_out = nullptr;
@@ -222,7 +227,7 @@ static int lds_bytes_for(const EngineDesc& h, int rc) {
 
 // --------------------------------------------------------------------------------- lifetime
 extern "C" const char* frl_last_error(void) { return g_err.c_str(); }
-extern "C" int frl_version(void) { return 101; }      // 101: frl_rollout_args.explore_kind 0 = FRL_EXPLORE_DEFAULT
+extern "C" int frl_version(void) { return 102; }      // 101: frl_rollout_args.explore_kind 0 = FRL_EXPLORE_DEFAULT; 102: frl_learn_work_executed
 
 extern "C" int frl_device_count(int* n_out) {
     if (!n_out) return fail(FRL_ERR_INVALID, "n_out is NULL");
@@ -497,7 +502,14 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
-        if (h.wide) CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
+        if (h.wide) {
+            CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
+            int biggest = 0;
+            for (int i = 0; i < h.n_nets; ++i) biggest = std::max(biggest, h.net[i].size);
+            e->act_wk_slot = P * (size_t)biggest;
+            e->act_wk_version.assign(2 * (size_t)h.n_nets, 0ULL);
+            CREATE_TRY(hipMalloc((void**)&e->d_act_wk, 2 * (size_t)h.n_nets * e->act_wk_slot * sizeof(float)));
+        }
         {
             int omax = 1;
             for (int j = 0; j < c.n_agents; ++j) omax = std::max(omax, c.obs_dim[j]);
@@ -862,7 +874,10 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
         if (to_device) d = host[o]; else host[o] = d;
         ++o;
     }
-    if (to_device) HIP_TRY(hipMemcpy(dev, blk.data(), (size_t)N.size * sizeof(float), hipMemcpyHostToDevice));
+    if (to_device) {
+        HIP_TRY(hipMemcpy(dev, blk.data(), (size_t)N.size * sizeof(float), hipMemcpyHostToDevice));
+        ++e->param_version;
+    }
     return FRL_OK;
 }
 
@@ -871,6 +886,32 @@ extern "C" int frl_params_get(frl_engine* e, int learner, int net, int kind, flo
 }
 extern "C" int frl_params_set(frl_engine* e, int learner, int net, int kind, const float* in_host) {
     return params_xfer(e, learner, net, kind, const_cast<float*>(in_host), true);
+}
+
+extern "C" int frl_params_pad_max(frl_engine* e, int learner, int net, int kind, float* max_abs_out) {
+    ENG(e);
+    if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
+    if (learner < 0 || learner >= e->h.P || net < 0 || net >= e->h.n_nets || !max_abs_out) return fail(FRL_ERR_INVALID, "bad argument");
+    float* base = kind_ptr(e, kind);
+    if (!base) return fail(FRL_ERR_INVALID, "bad kind");
+    const NetDesc& N = e->h.net[net];
+    std::vector<float> blk(N.size, 0.f);
+    std::vector<char> real(N.size, 0);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(blk.data(), base + (size_t)learner * e->h.learner_stride + e->h.net_off[net], (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N.n_layers + N.n_shadow; ++i) {
+        const LayerDesc& L = N.L[i];
+        for (int r = 0; r < L.n; ++r) {
+            for (int c = 0; c < L.k; ++c) real[L.w_off + weight_index(N, L, r, c)] = 1;
+            real[L.b_off + r] = 1;
+        }
+    }
+    for (int j = 0; j < N.extra_n; ++j) real[N.extra_off + j] = 1;
+    float mx = 0.f;
+    for (int i = 0; i < N.size; ++i)
+        if (!real[i]) mx = std::max(mx, std::isnan(blk[i]) ? INFINITY : std::fabs(blk[i]));
+    *max_abs_out = mx;
+    return FRL_OK;
 }
 
 extern "C" int frl_opt_step_get(frl_engine* e, int learner, int net, int* t_out) {
@@ -952,15 +993,16 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     if (N.frag && e->h.wide) {
         // fragment-image parameters of a shape act_frag_kernel does not take: the net is re-laid out to Wk in a scratch copy (one
         // small launch: the actor of config 4 is 67 k floats per learner) and act_kernel reads that
-        const size_t need = (size_t)e->h.P * N.size;
-        if (need > e->act_wk_cap) {
-            if (e->d_act_wk) hipFree(e->d_act_wk);
-            e->d_act_wk = nullptr; e->act_wk_cap = 0;
-            HIP_TRY(hipMalloc((void**)&e->d_act_wk, need * sizeof(float)));
-            e->act_wk_cap = need;
+        // (config 4 at 512 learners: 34 M floats per net — a collector that steps its envs many times between two learn() calls
+        // pays the pass once per update, not once per vector step)
+        const int slot = 2 * net + (use_target ? 1 : 0);
+        float* wk = e->d_act_wk + (size_t)slot * e->act_wk_slot;
+        if (!e->d_act_wk || slot >= (int)e->act_wk_version.size()) return fail(FRL_ERR_STATE, "wide engine without its act scratch");
+        if (e->act_wk_version[slot] != e->param_version) {
+            hipLaunchKernelGGL(frag_to_wk_kernel, dim3(e->h.P), dim3(256), 0, e->stream, e->d, net, use_target, wk);
+            e->act_wk_version[slot] = e->param_version;
         }
-        hipLaunchKernelGGL(frag_to_wk_kernel, dim3(e->h.P), dim3(256), 0, e->stream, e->d, net, use_target, e->d_act_wk);
-        a.theta_alt = e->d_act_wk;
+        a.theta_alt = wk;
         dim3 grid((n_rows + e->h.rc - 1) / e->h.rc, e->h.P);
         hipLaunchKernelGGL(act_kernel, grid, dim3(256), e->lds_bytes, e->stream, e->d, a);
     } else if (N.frag) {       // parameters in fragment-image order: the register-chained forward (kernels_act.hip)
@@ -1234,6 +1276,9 @@ static bool wide_shape(const EngineDesc& h) {
     const bool multi = h.algo == ALGO_MADDPG && h.n_agents >= 1;
     const int H = h.hidden;                    // 128: chain_wide.hpp; 256: chain_wide16.hpp
     if (!(single || multi) || (H != 128 && H != 256) || h.rec.act_total > kWideApitch) return false;
+    // WideNet::stage_idx (chain_wide.hpp; also the hidden-256 kernels') copies the batch's ring indices into the 64 KB LDS union:
+    // 2 * kWideSlice = 16384 ints.  Larger batches stay with the row-chunk family.
+    if (h.batch_max > 2 * kWideSlice) return false;
     const int nt3 = h.net[0].L[2].n_pad;
     for (int j = 0; j < h.n_agents; ++j) {
         const NetDesc &NA0 = h.net[2 * j], &NC0 = h.net[2 * j + 1];
@@ -1400,6 +1445,7 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         a.huber = 1; a.huber_delta = args->huber_delta;
     }
     a.rng_counter = e->rng_counter++;
+    ++e->param_version;                       // (select_action's re-laid-out copies of the nets are stale from here on)
     // One chain for the whole population.  Measured and rejected (profiles/README.md): two halves of the population on two
     // streams so that one half's HBM-bound reduce/Adam runs under the other half's MFMA-bound gradient kernel — unchained
     // +2.7 %, with the gradient kernels chained across the streams -8 %: the Adam workgroups do not get co-resident with
@@ -1465,6 +1511,47 @@ extern "C" int frl_learn_work(const frl_engine* e, int batch, int do_actor, doub
     return FRL_OK;
 }
 
+// Executed flops of the same launch (include/freerl_hip.h): no first-layer dX for trained nets, the agent's action columns only
+// for dQ/da.  Per (learner, agent): target actors fwd + target critic fwd + critic fwd + dW (all layers) + dX (layers 2..);
+// actor stage: actor fwd + dW + dX (layers 2..) + per Q head used by the policy loss fwd + dX (layers 2.. whole, layer 1 x act_dim).
+extern "C" int frl_learn_work_executed(const frl_engine* e, int batch, int do_actor, double* flops_out) {
+    if (!e) return fail(FRL_ERR_INVALID, "engine is NULL");
+    const EngineDesc& h = e->h;
+    auto macs = [](const NetDesc& N, int l0, int nl) { double s = 0; for (int i = l0; i < l0 + nl; ++i) s += (double)N.L[i].n * N.L[i].k; return s; };
+    auto first = [](const NetDesc& N) {            // the first layers of all heads
+        const int nl = N.n_layers / std::max(1, N.heads);
+        double s = 0;
+        for (int hd = 0; hd < N.heads; ++hd) s += (double)N.L[hd * nl].n * N.L[hd * nl].k;
+        return s;
+    };
+    double fl = 0;
+    const double B = batch;
+    if (h.algo == ALGO_DQN) {
+        const NetDesc& N = h.net[0];
+        const double m = macs(N, 0, N.n_layers);
+        fl = 2 * B * (m + m + m + (m - first(N)));     // target fwd, online fwd, dW, dX from the second layer up
+    } else if (h.algo != ALGO_PPO) {
+        const int n = h.n_agents;
+        for (int ag = 0; ag < n; ++ag) {
+            const NetDesc &NC = h.net[2 * ag + 1], &NA = h.net[2 * ag];
+            const int ql = NC.n_layers / NC.heads;
+            double f = 0;
+            for (int j = 0; j < n; ++j) f += macs(h.net[2 * j], 0, h.net[2 * j].n_layers);
+            const double mc = macs(NC, 0, NC.n_layers);
+            f += mc + mc + mc + (mc - first(NC));
+            if (do_actor) {
+                const int nq = (h.algo == ALGO_SAC) ? NC.heads : 1;
+                const double ma = macs(NA, 0, NA.n_layers);
+                f += ma + ma + (ma - first(NA));
+                f += nq * (macs(NC, 0, ql) + macs(NC, 1, ql - 1) + (double)NC.L[0].n * h.rec.act_dim[ag]);
+            }
+            fl += 2 * B * f;
+        }
+    }
+    if (flops_out) *flops_out = fl * h.P;
+    return FRL_OK;
+}
+
 // ----------------------------------------------------------------------------------- timing
 extern "C" int frl_timer_start(frl_engine* e) {
     ENG(e);
@@ -1495,6 +1582,7 @@ extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
         hipFree(scratch);
         if (he != hipSuccess) return fail(FRL_ERR_HIP, "relayout: %s", hipGetErrorString(he));
         for (int i = 0; i < e->h.n_nets; ++i) e->h.net[i].frag = 0;
+        ++e->param_version;
         e->h.wide = 0;
     }
     e->h.obs_norm_on = on ? 1 : 0;

@@ -47,6 +47,11 @@ def _native_comm_create(rank, world, local_rank):
     raw = (C.c_uint8 * N.FRL_COMM_ID_BYTES)(*[int(x) for x in uid.cpu().tolist()])
     h = C.c_void_p()
     err = None
+    # Known limit of the agreement rounds: they bracket the join, they cannot reach INSIDE it.  A rank that dies or errors inside
+    # ncclCommInitRank after its peers have entered it leaves those peers blocked in RCCL's own bootstrap, before the second
+    # _all_ok — nothing at this level can interrupt a blocked native call.  What bounds that wait is the launcher: torch.distributed.run
+    # tears the whole job down when one worker exits non-zero, and RCCL's bootstrap gives up on its socket timeout.  The first
+    # round removes the failures that can be seen from outside (no librccl, no device, an id that cannot be made).
     try:
         N.check(L.frl_comm_create(raw, int(rank), int(world), int(local_rank), C.byref(h)))
     except Exception as ex:      # noqa: BLE001 - agreed on below

@@ -141,6 +141,12 @@ class Engine:
         assert flat.size == self.num_params(net), (flat.size, self.num_params(net))
         N.check(self._L.frl_params_set(self._h, int(learner), int(net), int(kind), _fp(flat)))
 
+    def pad_max(self, net, kind=N.PARAM_ONLINE, learner=0):
+        """max |x| over the padding slots of a net's block (must stay 0: frl_params_pad_max)."""
+        v = C.c_float(0)
+        N.check(self._L.frl_params_pad_max(self._h, int(learner), int(net), int(kind), C.byref(v)))
+        return v.value
+
     def opt_step(self, net, learner=0):
         t = C.c_int(0)
         N.check(self._L.frl_opt_step_get(self._h, int(learner), int(net), C.byref(t)))
@@ -251,6 +257,12 @@ class Engine:
         fl, by = C.c_double(0), C.c_double(0)
         N.check(self._L.frl_learn_work(self._h, int(batch), int(bool(do_actor)), C.byref(fl), C.byref(by)))
         return fl.value, by.value
+
+    def learn_work_executed(self, batch, do_actor=True):
+        """Flops the launch executes (no first-layer dX of trained nets, action columns only for dQ/da): frl_learn_work_executed."""
+        fl = C.c_double(0)
+        N.check(self._L.frl_learn_work_executed(self._h, int(batch), int(bool(do_actor)), C.byref(fl)))
+        return fl.value
 
     # ------------------------------------------------------------------ noisy head
     def noisy_eps_size(self):

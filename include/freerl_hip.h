@@ -191,6 +191,12 @@ int frl_net_count(const frl_engine* e, int* n_out);
 int frl_net_num_params(const frl_engine* e, int net, int* n_out);
 int frl_params_get(frl_engine* e, int learner, int net, int kind, float* out_host);
 int frl_params_set(frl_engine* e, int learner, int net, int kind, const float* in_host);
+/* invariant check: max |x| over the PADDING slots of one net's block of `kind` (weight rows / columns and bias entries past a
+ * layer's real dims; layers are padded to multiples of 16).  The update kernels rely on the padding staying exactly zero — the
+ * K-sliced first-layer sweeps read a record for 16 * ceil(in / 16) columns and let the zero weights cancel what lies past the
+ * layer's inputs (which is why every field of a stored transition must be FINITE: 0 * inf is NaN; a non-finite value in a sampled
+ * row poisons the reference's update as well, through the TD target) — and Adam keeps it: zero gradient, zero moments, zero step. */
+int frl_params_pad_max(frl_engine* e, int learner, int net, int kind, float* max_abs_out);
 int frl_opt_step_get(frl_engine* e, int learner, int net, int* t_out);   /* Adam step count */
 int frl_opt_step_set(frl_engine* e, int learner, int net, int t);
 /* SAC Alpha (SAC.py:154-169): vals = {log_alpha, exp_avg, exp_avg_sq, alpha} */
@@ -223,8 +229,15 @@ int frl_stats_get(frl_engine* e, float* out_host);          /* [P][n_agents][FRL
 /* the ring rows the last frl_learn trained on — `indices` of `<ALGO>.sample` (DQN.py:97): uploaded, device-drawn or (per = 1)
  * the last frl_per_sample's — as host int64 [P][n_agents][batch] */
 int frl_last_indices(frl_engine* e, int batch, int64_t* out_host);
-/* algorithmic work of one frl_learn launch (for the roofline figure): flops and HBM bytes */
+/* algorithmic work of one frl_learn launch (for the roofline figure): flops and HBM bytes, by SURVEY.md 8(d)'s formula —
+ * 2 B sum(in x out) x (#forward + 2 x #backward passes), i.e. a dX is counted for every layer of every backward pass */
 int frl_learn_work(const frl_engine* e, int batch, int do_actor, double* flops_out, double* bytes_out);
+/* the same launch's EXECUTED flops: what torch autograd (and these kernels) actually compute — a trained net's backward is
+ * dW for every layer but dX only from the second layer up (nothing needs d loss / d input), and the policy loss's pass through
+ * the frozen critic (Q(s, pi(s)), TD3.py:225, SAC.py:245-249) is forward + dX with the first layer's dX on the agent's action
+ * columns only.  8(d)'s figure is 1.6 % above this at the narrow bench shape and 30 % above it at config 4's 393-column first
+ * layers; roofline fractions quote both, named. */
+int frl_learn_work_executed(const frl_engine* e, int batch, int do_actor, double* flops_out);
 
 /* ---------------------------------------------------------------- PPO (PPO_file/PPO_with_tricks.py)
  * `PPO.learn(minibatch_size, gamma, lmbda, clip_param, K_epochs, entropy_coefficient)` (:290-354):

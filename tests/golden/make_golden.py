@@ -1033,6 +1033,17 @@ def gen_long_ac(name, out):
         mod = import_reference("SAC_file", "SAC")
         pol = mod.SAC(dims, True, c["actor_lr"], c["critic_lr"], c["capacity"], CPU,
                       trick={"ObsNorm": False, "Batch_ObsNorm": False, "OUNoise": False, "GaussNoise": False})
+    if c.get("hidden", 128) != 128:
+        # the reference's nets take their widths as constructor arguments (TD3.py:53,67,86); its Agent builds them at the default
+        # (TD3.py:125-129), so the same Agent is re-armed with the reference's OWN classes at the other width: nets, targets
+        # (deepcopy, :134-135) and optimisers (torch.optim.Adam(lr), :131-132) exactly as Agent.__init__ makes them
+        assert c["kind"] == "td3"
+        w, ag = c["hidden"], pol.agent
+        ag.actor = mod.Actor(c["obs_dim"], c["act_dim"], w, w)
+        ag.critic = mod.Critic_TD3(dims, w, w)
+        ag.actor_optimizer = torch.optim.Adam(ag.actor.parameters(), lr=c["actor_lr"])
+        ag.critic_optimizer = torch.optim.Adam(ag.critic.parameters(), lr=c["critic_lr"])
+        ag.actor_target, ag.critic_target = copy.deepcopy(ag.actor), copy.deepcopy(ag.critic)
     for net in ("actor", "critic"):
         load(getattr(pol.agent, net), inp["params"][net])
         load(getattr(pol.agent, net + "_target"), inp["params"][net])
@@ -1146,6 +1157,7 @@ def main():
         "traj_ppo": gen_traj_ppo,
         "long_dqn": gen_long_dqn, "long_ddpg": lambda o: gen_long_ac("long_ddpg", o), "long_td3_c2": lambda o: gen_long_ac("long_td3_c2", o),
         "long_sac": lambda o: gen_long_ac("long_sac", o), "long_ppo_c3": gen_long_ppo_c3, "long_maddpg_c5": gen_long_maddpg_c5,
+        "long_sac_c4": lambda o: gen_long_ac("long_sac_c4", o), "long_td3_h256": lambda o: gen_long_ac("long_td3_h256", o),
     }
     torch.set_num_threads(1)
     only = sys.argv[1:]

@@ -1,0 +1,243 @@
+"""The K-sliced (kernels_criticw / _actorw) and x-stationary (kernels_criticx / _actorx) kernel families AT POPULATION SIZE, selected by
+frl_create on its own (no FRL_CRITIC_V2): what tools/config_bench.py times at P = 512.  Every other -m gpu test of these families forces
+them onto ONE learner; a per-unit scratch-base or tile-lane-offset error (WideScratch / Wide16Scratch: eleven `bm`-scaled regions per
+(learner, agent) unit) would pass all of those.
+
+Every learner has its OWN parameters and its OWN transition table; four learners spread over the grid (first, last, two in between — other
+workgroups / CUs / XCDs, and for P > 256 the second round of workgroups) are compared with four oracles run on exactly their inputs:
+losses to 1e-4, online nets and targets element-wise, and Adam's first moment element-wise (the clipped gradient itself: targets move by
+tau * lr and would hide a gradient that is off by a per cent).  Modelled on
+test_gpu_parity.py::test_bench_sized_population_takes_the_chained_kernels_and_matches (SAC_file/SAC.py:222-260, TD3_file/TD3.py:189-233,
+MADDPG_file/MADDPG_simple.py:165-195)."""
+import numpy as np
+import pytest
+
+from tests.golden import cases, synth
+from tests.hip_helpers import flat_params, records, unflat_params
+
+pytestmark = pytest.mark.gpu
+AC = ["l1", "l2", "l3"]
+TWIN = ["l1", "l2", "l3", "l4", "l5", "l6"]
+SAC_A = ["l1", "l2", "mean_layer"]
+
+
+@pytest.fixture(scope="module")
+def N():
+    from freerl_amd import _native
+    assert _native.device_count() > 0
+    return _native
+
+
+def _fill(orc, tab):
+    for i in range(len(tab["rew"])):
+        orc.add(tab["obs"][i], tab["act"][i], float(tab["rew"][i]), tab["next_obs"][i], bool(tab["done"][i]))
+
+
+def _cheap_table(base, p):
+    """A table of an unwatched learner: the base rows rotated by p and the rewards shifted — different content in every ring row,
+    without drawing P x 600 x 771 normals."""
+    return {k: (np.roll(v, 7 * p + 1, axis=0) + (np.float32(0.01 * p) if k == "rew" else 0)) if k != "done" else np.roll(v, 7 * p + 1)
+            for k, v in base.items()}
+
+
+def _watch(P):
+    return (0, P // 3, (2 * P) // 3 + 1, P - 1)
+
+
+def _assert_net(got_flat, want, names, extra, rtol, atol, label):
+    got = unflat_params(got_flat, want, names, extra)
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=rtol, atol=atol, err_msg=label + "/" + k)
+
+
+def _assert_adam_m(got_flat, opt_m, names, extra, label):
+    got = unflat_params(got_flat, opt_m, names, extra)
+    for k in opt_m:
+        np.testing.assert_allclose(got[k], opt_m[k], rtol=1e-4, atol=2e-5 * float(np.abs(opt_m[k]).max()), err_msg="adam m " + label + "/" + k)
+
+
+@pytest.mark.parametrize("P", [130, 192, 300])
+def test_sac_config4_population_vs_oracles(N, monkeypatch, P):
+    """SAC at BASELINE config 4's learn() shape (obs 376, act 17, batch 256): ac_critic_wide_h2a2_kernel + ac_actor_wide_a2_kernel.
+    130 = just past the family threshold (one partial round of workgroups), 192, 300 = more units than CUs (a second round)."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    O, A, B, n_tab, cap = 376, 17, 256, 320, 512
+    watch = _watch(P)
+    e = Engine(N.ALGO_SAC, O, A, cap, n_learners=P, twin_critic=True, batch_max=B)
+    assert e.learn_path(B)[0], "the population did not select the K-sliced chained family"
+    base = synth.transitions(900, n_tab, O, A)
+    g = np.random.default_rng(901)
+    na, nc = e.num_params(0), e.num_params(1)
+    tabs, actors, critics = {}, {}, {}
+    for p in range(P):
+        if p in watch:
+            tabs[p] = synth.transitions(910 + p, n_tab, O, A)
+            a = synth.mlp_params(2000 + p, cases.actor_layers(O, A, head="mean_layer"))
+            actors[p] = dict([("log_std", np.random.default_rng(3000 + p).uniform(-0.5, 0.2, (1, A)).astype(np.float32))] + list(a.items()))
+            critics[p] = synth.mlp_params(4000 + p, cases.critic_layers(O + A, twin=True))
+            fa, fc = flat_params(actors[p], SAC_A, "log_std"), flat_params(critics[p], TWIN)
+            tab = tabs[p]
+        else:
+            fa, fc = (g.standard_normal(na) * 0.05).astype(np.float32), (g.standard_normal(nc) * 0.05).astype(np.float32)
+            tab = _cheap_table(base, p)
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(0, fa, kind, learner=p)
+            e.set_params(1, fc, kind, learner=p)
+        e.set_alpha_state([np.log(0.01), 0, 0, 0.01], 0, learner=p)
+        recs = records([tab])
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+    orcs = {}
+    for p in watch:
+        orcs[p] = algos.SAC(actors[p], critics[p], O, A, 1e-3, 1e-3, cap)
+        _fill(orcs[p], tabs[p])
+    for k in range(2):
+        idx = np.stack([synth.indices(5000 + 100 * k + p, n_tab, B) for p in range(P)])[:, None]
+        nz = np.zeros((P, 1, 2, B, A), np.float32)
+        for p in range(P):
+            gp = np.random.default_rng(6000 + 1000 * k + p)
+            nz[p, 0] = gp.standard_normal((2, B, A)).astype(np.float32)
+        st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, alpha_lr=1e-4, target_entropy=-float(A), idx=idx, noise=nz,
+                     want_stats=True)
+        for p in watch:
+            cl, al, ll = orcs[p].learn_with(idx[p, 0], nz[p, 0, 0], nz[p, 0, 1], 0.99, 0.005)
+            np.testing.assert_allclose(st[p, 0, N.STAT_CRITIC_LOSS], cl, rtol=1e-4, err_msg="critic loss, learner %d call %d" % (p, k))
+            np.testing.assert_allclose(st[p, 0, N.STAT_ACTOR_LOSS], al, rtol=1e-4, atol=1e-5, err_msg="actor loss, learner %d call %d" % (p, k))
+            np.testing.assert_allclose(st[p, 0, N.STAT_ALPHA_LOSS], ll, rtol=1e-4, err_msg="alpha loss, learner %d call %d" % (p, k))
+    assert np.all(np.isfinite(st)), "a learner nobody watches produced a non-finite loss"
+    for p in watch:
+        o, lab = orcs[p], "sac_c4 P=%d learner %d" % (P, p)
+        _assert_net(e.get_params(1, N.PARAM_ONLINE, learner=p), o.critic, TWIN, None, 5e-4, 5e-6, lab + " critic")
+        _assert_net(e.get_params(1, N.PARAM_TARGET, learner=p), o.critic_t, TWIN, None, 5e-4, 5e-6, lab + " critic_target")
+        _assert_net(e.get_params(0, N.PARAM_ONLINE, learner=p), o.actor, SAC_A, "log_std", 5e-4, 5e-6, lab + " actor")
+        _assert_adam_m(e.get_params(1, N.PARAM_ADAM_M, learner=p), o.critic_opt.m, TWIN, None, lab + " critic")
+        _assert_adam_m(e.get_params(0, N.PARAM_ADAM_M, learner=p), o.actor_opt.m, SAC_A, "log_std", lab + " actor")
+    e.close()
+
+
+@pytest.mark.parametrize("shape", ["8_2", "17_6"])
+def test_td3_hidden256_population_vs_oracles(N, monkeypatch, shape):
+    """TD3 at hidden 256 with 180 learners (the x-stationary family starts at 177 units): ac_critic_x_h2a1_kernel + ac_actor_x_a1_kernel
+    at the bench's dims (obs 8, act 2: one first-layer k-block) and at obs 17 / act 6 (two; batch 200 = a ragged super-chunk)."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    O, A, B = {"8_2": (8, 2, 256), "17_6": (17, 6, 200)}[shape]
+    P, n_tab, cap, Hd = 180, 400, 512, 256
+    watch = _watch(P)
+    e = Engine(N.ALGO_TD3, O, A, cap, n_learners=P, twin_critic=True, batch_max=B, hidden=Hd)
+    assert e.learn_path(B)[0], "the population did not select the x-stationary family"
+    tabs, actors, critics = {}, {}, {}
+    g = np.random.default_rng(911)
+    na, nc = e.num_params(0), e.num_params(1)
+    for p in range(P):
+        tabs[p] = synth.transitions(7000 + p, n_tab, O, A)
+        if p in watch:
+            actors[p] = synth.mlp_params(7500 + p, cases.actor_layers(O, A, hidden=Hd))
+            critics[p] = synth.mlp_params(8000 + p, cases.critic_layers(O + A, twin=True, hidden=Hd))
+            fa, fc = flat_params(actors[p], AC), flat_params(critics[p], TWIN)
+        else:
+            fa, fc = (g.standard_normal(na) * 0.04).astype(np.float32), (g.standard_normal(nc) * 0.04).astype(np.float32)
+        for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+            e.set_params(0, fa, kind, learner=p)
+            e.set_params(1, fc, kind, learner=p)
+        recs = records([tabs[p]])
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+    orcs = {}
+    for p in watch:
+        orcs[p] = algos.TD3(actors[p], critics[p], O, A, 1e-3, 1e-3, cap)
+        _fill(orcs[p], tabs[p])
+    for k in range(2):
+        idx = np.stack([synth.indices(8500 + 200 * k + p, n_tab, B) for p in range(P)])[:, None]
+        nz = np.zeros((P, 1, 2, B, A), np.float32)
+        for p in range(P):
+            nz[p, 0, 0] = synth.normal(9000 + 200 * k + p, (B, A))
+        st = e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(k % 2 == 1), use_policy_noise=True, policy_noise=0.2,
+                     noise_clip=0.5, max_action=1.0, idx=idx, noise=nz, want_stats=True)
+        for p in watch:
+            cl, al = orcs[p].learn_with(idx[p, 0], nz[p, 0, 0], 0.99, 0.005, 0.2, 0.5, 1.0, 2, 1.0)
+            np.testing.assert_allclose(st[p, 0, N.STAT_CRITIC_LOSS], cl, rtol=1e-4, err_msg="critic loss, learner %d call %d" % (p, k))
+            if k % 2 == 1:
+                np.testing.assert_allclose(st[p, 0, N.STAT_ACTOR_LOSS], al, rtol=1e-4, atol=1e-6, err_msg="actor loss, learner %d" % p)
+    assert np.all(np.isfinite(st))
+    for p in watch:
+        o, lab = orcs[p], "td3_h256 %s learner %d" % (shape, p)
+        _assert_net(e.get_params(1, N.PARAM_ONLINE, learner=p), o.critic, TWIN, None, 5e-4, 5e-6, lab + " critic")
+        _assert_net(e.get_params(1, N.PARAM_TARGET, learner=p), o.critic_t, TWIN, None, 5e-4, 5e-6, lab + " critic_target")
+        _assert_net(e.get_params(0, N.PARAM_ONLINE, learner=p), o.actor, AC, None, 5e-4, 5e-6, lab + " actor")
+        _assert_net(e.get_params(0, N.PARAM_TARGET, learner=p), o.actor_t, AC, None, 5e-4, 5e-6, lab + " actor_target")
+        _assert_adam_m(e.get_params(1, N.PARAM_ADAM_M, learner=p), o.critic_opt.m, TWIN, None, lab + " critic")
+        _assert_adam_m(e.get_params(0, N.PARAM_ADAM_M, learner=p), o.actor_opt.m, AC, None, lab + " actor")
+    e.close()
+
+
+@pytest.mark.parametrize("twin", [False, True])
+def test_maddpg_config5_population_vs_oracles(N, monkeypatch, twin):
+    """MADDPG at BASELINE config 5's shape (3 agents x (18, 5), batch 1024) with 44 learners = 132 (learner, agent) units:
+    ac_critic_wide_h1a1_kernel + ac_actor_wide_a1_kernel + soft_update_kernel; twin = MATD3_simple.py's twin centralised critics
+    (ac_critic_wide_h2a1_kernel) with per-agent target smoothing and the delayed policy step."""
+    from freerl_amd.engine import Engine
+    from oracle import algos
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    n, O, A, B, n_tab, cap, P = 3, 18, 5, 1024, 1200, 2048, 44
+    ids = ["agent_%d" % j for j in range(n)]
+    dims = {a: [O, A] for a in ids}
+    watch = _watch(P)
+    e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, cap, n_learners=P, batch_max=B, twin_critic=twin)
+    assert e.learn_path(B)[0], "the population did not select the K-sliced chained family"
+    cn = TWIN if twin else AC
+    g = np.random.default_rng(921)
+    tabs, params = {}, {}
+    for p in range(P):
+        tabs[p] = {a: synth.transitions(11000 + 10 * p + j, n_tab, O, A) for j, a in enumerate(ids)}
+        if p in watch:
+            params[p] = {a: dict(actor=synth.mlp_params(12000 + 10 * p + 2 * j, cases.actor_layers(O, A)),
+                                 critic=synth.mlp_params(12001 + 10 * p + 2 * j, cases.critic_layers(n * (O + A), twin=twin))) for j, a in enumerate(ids)}
+        for j, a in enumerate(ids):
+            if p in watch:
+                fa, fc = flat_params(params[p][a]["actor"], AC), flat_params(params[p][a]["critic"], cn)
+            else:
+                fa = (g.standard_normal(e.num_params(2 * j)) * 0.05).astype(np.float32)
+                fc = (g.standard_normal(e.num_params(2 * j + 1)) * 0.05).astype(np.float32)
+            for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
+                e.set_params(2 * j, fa, kind, learner=p)
+                e.set_params(2 * j + 1, fc, kind, learner=p)
+        recs = records([tabs[p][a] for a in ids])
+        e.add_batch(recs, learners=np.full(len(recs), p, np.int32))
+    orcs = {}
+    for p in watch:
+        o = (algos.MATD3 if twin else algos.MADDPG)(params[p], dims, 1e-3, 1e-3, cap)
+        for i in range(n_tab):
+            o.add({a: tabs[p][a]["obs"][i] for a in ids}, {a: tabs[p][a]["act"][i] for a in ids}, {a: float(tabs[p][a]["rew"][i]) for a in ids},
+                  {a: tabs[p][a]["next_obs"][i] for a in ids}, {a: bool(tabs[p][a]["done"][i]) for a in ids})
+        orcs[p] = o
+    for call in range(2):
+        idx = np.stack([np.stack([synth.indices(13000 + 500 * call + 3 * p + j, n_tab, B) for j in range(n)]) for p in range(P)])
+        if twin:
+            nz = np.zeros((P, n, n, B, A), np.float32)
+            for p in range(P):
+                nz[p] = np.random.default_rng(14000 + 500 * call + p).standard_normal((n, n, B, A)).astype(np.float32)
+            st = e.learn(B, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, do_actor=(call % 2 == 1), use_policy_noise=True,
+                         policy_noise=0.2, noise_clip=0.5, max_action=1.0, policy_noise_scale=1.0, idx=idx, noise=nz, want_stats=True)
+            for p in watch:
+                orcs[p].learn_with([idx[p, j] for j in range(n)], [[nz[p, i, j] for j in range(n)] for i in range(n)], 0.95, 0.01, 1.0, 0.2, 0.5,
+                                   1.0, 2)
+        else:
+            st = e.learn(B, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx, want_stats=True)
+            for p in watch:
+                orcs[p].learn_with([idx[p, j] for j in range(n)], 0.95, 0.01)
+    assert np.all(np.isfinite(st))
+    for p in watch:
+        o = orcs[p]
+        for j, a in enumerate(ids):
+            lab = "maddpg_c5%s learner %d %s" % ("/matd3" if twin else "", p, a)
+            np.testing.assert_allclose(st[p, j, N.STAT_CRITIC_LOSS], o.critic_losses[a][-1], rtol=1e-4, err_msg=lab)
+            np.testing.assert_allclose(st[p, j, N.STAT_ACTOR_LOSS], o.actor_losses[a][-1], rtol=1e-4, atol=1e-6, err_msg=lab)
+            _assert_net(e.get_params(2 * j + 1, N.PARAM_ONLINE, learner=p), o.critic[a], cn, None, 5e-4, 5e-6, lab + " critic")
+            _assert_net(e.get_params(2 * j + 1, N.PARAM_TARGET, learner=p), o.critic_t[a], cn, None, 5e-4, 5e-6, lab + " critic_target")
+            _assert_net(e.get_params(2 * j, N.PARAM_ONLINE, learner=p), o.actor[a], AC, None, 5e-4, 5e-6, lab + " actor")
+            _assert_net(e.get_params(2 * j, N.PARAM_TARGET, learner=p), o.actor_t[a], AC, None, 5e-4, 5e-6, lab + " actor_target")
+            _assert_adam_m(e.get_params(2 * j + 1, N.PARAM_ADAM_M, learner=p), o.critic_opt[a].m, cn, None, lab + " critic")
+            _assert_adam_m(e.get_params(2 * j, N.PARAM_ADAM_M, learner=p), o.actor_opt[a].m, AC, None, lab + " actor")
+    e.close()

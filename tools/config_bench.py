@@ -66,8 +66,12 @@ def run(case, P, steps=20):
     dt = (time.perf_counter() - t0) / steps
     w1, w0 = e.learn_work(B, True), e.learn_work(B, False)          # (flops, bytes) of the whole population's learn()
     fl = (0.5 * (w1[0] + w0[0]) if algo == N.ALGO_TD3 else w1[0])
-    print("%-13s P=%4d  %-9s rows/workgroup %3d  LDS %3d KB  %8.3f ms per learn() -> %9.0f updates/s  %6.1f TFLOP/s" %
-          (name, P, "chained" if chained else "row-chunk", rc, lds // 1024, dt * 1e3, P / dt, fl / dt / 1e12), flush=True)
+    x1, x0 = e.learn_work_executed(B, True), e.learn_work_executed(B, False)
+    fx = 0.5 * (x1 + x0) if algo == N.ALGO_TD3 else x1
+    # two flop counts, named: EXECUTED (what autograd and the kernels compute: no first-layer dX of a trained net, action columns
+    # only for dQ/da) is the one fractions of the 157.3 TFLOP/s peak are taken from; SURVEY 8(d)'s formula counts a dX per layer
+    print("%-13s P=%4d  %-9s rows/workgroup %3d  LDS %3d KB  %8.3f ms per learn() -> %9.0f updates/s  executed %6.1f TFLOP/s = %.3f of peak  (8d formula %6.1f)" %
+          (name, P, "chained" if chained else "row-chunk", rc, lds // 1024, dt * 1e3, P / dt, fx / dt / 1e12, fx / dt / 1e12 / 157.3, fl / dt / 1e12), flush=True)
     e.close()
 
 
