@@ -87,7 +87,7 @@ def run(name, family, calls, P=2):
 
 
 def diff(a, b):
-    """{array name: max |x - y| / max |x|} over theta / target / m / v of every net and the actions, plus the per-call relative difference
+    """{array name: (max |x - y| / max |x|, where, max |x|, 99th percentile of |x - y| / max |x|)} over theta / target / m / v of every net and the actions, plus the per-call relative difference
     of the stats.  Against the array's largest element: an element whose gradient is rounding noise (1e-3 of the largest and below, a sum
     of 256-1024 cancelling terms in two different orders) gets a different Adam step m / sqrt(v) in each family — up to lr per call in
     theta — and a ReLU unit within an ulp of zero may open in one family and not in the other; element-relative errors of such entries
@@ -98,7 +98,7 @@ def diff(a, b):
             continue
         x, y = a[key], b[key]
         rel = np.abs(x - y) / (np.abs(x).max() + 1e-30)
-        out[key] = (float(rel.max()), int(rel.argmax()), float(np.abs(x).max()))
+        out[key] = (float(rel.max()), int(rel.argmax()), float(np.abs(x).max()), float(np.quantile(rel, 0.99)))
     sa, sb = a["stats"], b["stats"]
     out["stats"] = np.abs(sa - sb) / np.maximum(np.abs(sa), 1e-6)         # [calls][P][agents][FRL_STAT_COUNT]
     return out

@@ -44,16 +44,45 @@ def _watch(P):
     return (0, P // 3, (2 * P) // 3 + 1, P - 1)
 
 
+# Tolerances (measured, gpurun_out/c1 of round 5: the first version of this file asked rtol 5e-4 / atol 5e-6 of EVERY parameter and 2e-5
+# of max |m| of every moment, and 6 of 9 cases failed on a handful of elements while every loss agreed to 1e-4):
+#   * two fp32 implementations of the same update differ by rounding in every gradient element; Adam's step lr * m / (sqrt(v) + eps)
+#     is ~lr whatever the gradient's size, so an element whose gradient is itself rounding noise moves by up to 2 lr per call in
+#     opposite directions (seen: 1 element of 50 304 off by 1.2e-5 at SAC config 4);
+#   * a ReLU unit of the critic within rounding of zero for one sample is open in one implementation and shut in the other — that
+#     sample's dQ/da changes, and with it EVERY element of the actor's gradient by ~1/B of a per-row term (seen: 32 % of an actor's m
+#     off by <= 4e-4 of max |m|; 33 of 8 832 critic weights off by <= 4.2e-4 at MATD3) — either kernel family does this against the
+#     oracle as often as the other (profiles/r04/diag_family.txt, gpurun_out/family_ab_report.json).
+# What this file is here to catch — a (learner, agent) unit reading another unit's scratch, rows or tiles — is O(1) on whole tiles:
+# it breaks the losses (1e-4, asserted per call), moves far more than 1 % of a net's elements, and shifts m by far more than 0.2 % of
+# its largest element.  How often a unit flips: a critic update at B = 1024 evaluates ~5e5 hidden pre-activations of scale ~0.3 whose
+# rounding error is ~3e-8, so one of them changes sign between two implementations in roughly every fifth update — with 4 watched
+# learners x 3 agents x 2 calls a flip SOMEWHERE is the expected case (seen: MATD3 learner 30, one critic's l2.weight moment off by
+# 6.6e-3 of its max on < 1 % of its elements).  So: >= 99 % of a net's elements within (rtol, atol), every element within 2 lr per
+# Adam step; Adam's first moment within 2e-3 of the array's largest on >= 99 % of its elements and within 5e-2 on all of them.
+LR, CALLS = 1e-3, 2
+
+
 def _assert_net(got_flat, want, names, extra, rtol, atol, label):
     got = unflat_params(got_flat, want, names, extra)
     for k in want:
-        np.testing.assert_allclose(got[k], want[k], rtol=rtol, atol=atol, err_msg=label + "/" + k)
+        d = np.abs(got[k] - want[k])
+        bad = d > atol + rtol * np.abs(want[k])
+        assert bad.mean() <= 0.01, "%s/%s: %d of %d elements outside rtol %g atol %g (max |diff| %.3g)" % (label, k, bad.sum(), bad.size, rtol, atol, d.max())
+        assert d.max() <= 2 * LR * CALLS, "%s/%s: max |diff| %.3g is more than Adam can move an element in %d steps" % (label, k, d.max(), CALLS)
 
 
 def _assert_adam_m(got_flat, opt_m, names, extra, label):
     got = unflat_params(got_flat, opt_m, names, extra)
     for k in opt_m:
-        np.testing.assert_allclose(got[k], opt_m[k], rtol=1e-4, atol=2e-5 * float(np.abs(opt_m[k]).max()), err_msg="adam m " + label + "/" + k)
+        scale = float(np.abs(opt_m[k]).max())
+        d = np.abs(got[k] - opt_m[k]).reshape(-1)
+        if d.size < 2048:             # a bias vector: ONE flipped unit is one of its 128 elements — a whole row's term of that unit's sum,
+            assert d.max() <= 2e-2 * scale, "adam m %s/%s: max |diff| %.3g = %.2e of max |m| %.3g" % (label, k, d.max(), d.max() / max(scale, 1e-30), scale)
+            continue                  # i.e. up to ~1 / (0.1 sqrt(B)) of the largest: 2e-2 there, the quantile rule for the matrices
+        q99 = float(np.quantile(d, 0.99))
+        assert q99 <= 2e-3 * scale, "adam m %s/%s: 99th percentile of |diff| %.3g = %.2e of max |m| %.3g" % (label, k, q99, q99 / max(scale, 1e-30), scale)
+        assert d.max() <= 5e-2 * scale, "adam m %s/%s: max |diff| %.3g = %.2e of max |m| %.3g" % (label, k, d.max(), d.max() / max(scale, 1e-30), scale)
 
 
 @pytest.mark.parametrize("P", [130, 192, 300])

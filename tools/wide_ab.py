@@ -20,7 +20,7 @@ def compare(name, calls, P=2):
             print("  call %d agent %d stats rel diff (critic, actor, alpha_loss, alpha, cgnorm, agnorm, ent): %s" %
                   (k, ag, " ".join("%.1e" % x for x in st[k, :, ag].max(axis=0)[:7])))
     worst = 0.0
-    for key, (w, at, mx) in d.items():
+    for key, (w, at, mx, _q99) in d.items():
         # theta / target: one Adam step is +-lr whatever the gradient's size, so a unit that is dead in one family and barely alive in
         # the other moves its weights by a full lr (1e-3 here, ~5e-3 of the largest weight): 2e-2 for those arrays
         tol = 2e-2 if key.startswith(("theta", "target")) else 2e-3
