@@ -91,6 +91,13 @@ struct frl_engine {
     size_t act_wk_slot = 0;               // floats per slot = P * largest net
     std::vector<unsigned long long> act_wk_version;   // [2 * n_nets], 0 = never laid out
     unsigned long long param_version = 1;
+    // kernels_solo.hip (h.solo): per-workgroup gradient slabs, partial sums, the learners' grid-barrier counters
+    float* d_solo_slab = nullptr;
+    float* d_solo_part = nullptr;
+    unsigned* d_solo_bar = nullptr;
+    int* d_solo_err = nullptr;
+    unsigned solo_bar_base = 0;           // arrivals every counter has seen (2 barriers x kSoloWG per launch)
+    int solo_stride = 0;
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
     float* d_act_out = nullptr;
@@ -250,6 +257,9 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_per_prio) hipFree(e->d_per_prio);
     if (e->d_uniforms) hipFree(e->d_uniforms);
     if (e->h_noisy) hipHostFree(e->h_noisy);
+    if (e->d_solo_slab) hipFree(e->d_solo_slab);
+    if (e->d_solo_part) hipFree(e->d_solo_part);
+    if (e->d_solo_bar) hipFree(e->d_solo_bar);
     float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo, e->d_act_wk, e->h.wide_scr};
     for (float* p : dev) if (p) hipFree(p);
@@ -376,7 +386,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         // measured (bench workload, updates/s): 128 learners are exactly one round of the row-chunk kernels' 512 resident
         // workgroups — 484 k against 373 k for 128 one-learner workgroups on half the CUs; from 129 up the chained kernels win
         // (160: 459 k / 393 k, 256: 694 k / 566 k) or tie (320: 472 k / 480 k)
-        if (force ? atoi(force) != 0 : h.P > 128) h.net[0].frag = h.net[1].frag = 1;
+        // up to kSoloMaxP learners: one learner on sixteen workgroups (kernels_solo.hip; FRL_SOLO=0/1 overrides, FRL_CRITIC_V2 set
+        // means the caller asked for one of the other two families by name)
+        const char* solo = getenv("FRL_SOLO");
+        h.solo = (solo ? atoi(solo) != 0 : (!force && h.P <= kSoloMaxP)) && (long long)h.P * kSoloWG <= 256 ? 1 : 0;
+        if (h.solo || (force ? atoi(force) != 0 : h.P > 128)) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
         // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
@@ -502,6 +516,15 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
+        if (h.solo) {
+            e->solo_stride = std::max(h.net[0].size, h.net[1].size);
+            CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
+            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * 8, e->stream));
+            float* z = nullptr;
+            CREATE_TRY(dalloc_zero(&z, P + 1, e->stream));
+            e->d_solo_bar = (unsigned*)z;
+            e->d_solo_err = (int*)(z + P);
+        }
         if (h.wide) {
             CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
             int biggest = 0;
@@ -542,6 +565,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (auto k : {ac_critic_wide_h1a1_kernel, ac_critic_wide_h1a2_kernel, ac_critic_wide_h2a1_kernel, ac_critic_wide_h2a2_kernel,
                        ac_actor_wide_a1_kernel, ac_actor_wide_a2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    } else if (h.solo) {
+        const int lb = solo_lds_floats() * (int)sizeof(float);
+        for (auto k : {solo_critic_twin_kernel, solo_critic_single_kernel, solo_actor_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, critic2_lds_floats() * (int)sizeof(float)));
     } else if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
         const int lb = critic2_lds_floats() * (int)sizeof(float);
         CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -616,6 +644,12 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
         return FRL_OK;
     }
     const bool v2 = chained_path(e->h, batch, e->h.P);
+    if (v2 && e->h.solo) {                                  // kernels_solo.hip: a 16-row tile per workgroup
+        if (chained_out) *chained_out = 1;
+        if (bytes_out) *bytes_out = solo_lds_floats() * (int)sizeof(float);
+        if (rows_out) *rows_out = 16;
+        return FRL_OK;
+    }
     if (chained_out) *chained_out = v2 ? 1 : 0;
     if (bytes_out) *bytes_out = v2 ? (e->h.wide == 2 ? wide16_lds_floats_host() : (e->h.wide ? wide_lds_floats() : critic2_lds_floats())) * (int)sizeof(float) : e->lds_bytes;
     if (rows_out) *rows_out = v2 ? batch : e->h.rc;
@@ -1348,6 +1382,16 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_end(e);
             return;
         }
+        if (v2 && h.solo) {                               // kernels_solo.hip: sixteen workgroups per learner, reduce + Adam behind grid barriers
+            prof_begin(e, PK_GRAD_CRITIC);
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
+            e->solo_bar_base += 2 * kSoloWG;
+            const size_t lb = (size_t)solo_lds_floats() * sizeof(float);
+            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
+            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
+            prof_end(e);
+            return;
+        }
         if (v2) {
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
@@ -1373,6 +1417,14 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             const bool x = h.wide == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = x ? (a2 ? ac_actor_x_a2_kernel : ac_actor_x_a1_kernel) : (a2 ? ac_actor_wide_a2_kernel : ac_actor_wide_a1_kernel);
             hipLaunchKernelGGL(k, dim3(units), blk, (size_t)(x ? wide16_lds_floats_host() : wide_lds_floats()) * sizeof(float), st, e->d, a);
+            prof_end(e);
+            return;
+        }
+        if (v2 && h.solo) {
+            prof_begin(e, PK_GRAD_ACTOR);
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
+            e->solo_bar_base += 2 * kSoloWG;
+            hipLaunchKernelGGL(solo_actor_kernel, dim3(pc * kSoloWG), blk, (size_t)solo_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
         }
@@ -1584,6 +1636,7 @@ extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
         for (int i = 0; i < e->h.n_nets; ++i) e->h.net[i].frag = 0;
         ++e->param_version;
         e->h.wide = 0;
+        e->h.solo = 0;
     }
     e->h.obs_norm_on = on ? 1 : 0;
     HIP_TRY(hipStreamSynchronize(e->stream));

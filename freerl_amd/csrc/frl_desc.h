@@ -43,6 +43,11 @@ struct NetDesc {
 constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w + 128 * 128, kL3w = kL2b + 128,
               kL3b = kL3w + 16 * 128, kHeadFloats = kL3b + 16;
 
+// One learner on sixteen workgroups (device/solo.hpp, kernels_solo.hip): the single-learner latency path
+constexpr int kSoloWG = 16;              // workgroups per learner = 16-row tiles of a 256-row batch
+constexpr int kSoloMaxP = 8;             // learners per engine on this path: every workgroup of a launch must be resident (grid barrier)
+constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 128 + 16 + 16 + 4 * 8 * 256 + 256 + 128; }
+
 // The K-sliced chained family (device/chain_wide.hpp)
 constexpr int kWideSliceKB = 4;          // k-blocks of W1 per streamed slice (4 x 8 tiles x 1 KB = 32 KB)
 constexpr int kWideSlice = kWideSliceKB * 8 * 256;
@@ -158,6 +163,8 @@ struct EngineDesc {
     int wide_xp, wide_op; // row pitches of the scratch's critic-input rows / observation copies (the padded first-layer widths)
     int wide_unit;        // floats per (learner, agent): (wide_xp + n_agents * wide_op + kWideScratchPerRow) * wide_bm + 128, rounded up to 64
     float* wide_scr;
+    int solo;             // 1: DDPG / TD3 / SAC updates of this engine run on kernels_solo.hip (<= kSoloMaxP learners of the narrow standard
+                          // shape, sixteen workgroups per learner); parameters in fragment-image order like the chained family's
 };
 
 // Hyper-parameters of one learn() call (passed by value to the kernels).

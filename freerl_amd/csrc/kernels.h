@@ -197,6 +197,19 @@ __global__ void ac_actor_x_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArg
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+
+// ---- kernels_solo.hip: a single learner's DDPG / TD3 / SAC update on kSoloWG workgroups (device/solo.hpp)
+struct SoloArgs {
+    float* slab;            // [P][kSoloWG][slab_stride] partial gradients of the net being trained, fragment-image order
+    float* part;            // [P][kSoloWG][8] per-workgroup partial sums: 0 loss / Q sum, 1 log-pi sum, 2 squared gradient norm
+    unsigned* bar;          // [P] grid-barrier arrival counters (monotonic; never reset)
+    int* err;               // [1] set to 1 by a barrier that timed out (a workgroup of the learner never arrived)
+    unsigned bar_base;      // value of bar[p] when this launch starts
+    int slab_stride;
+};
+__global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }

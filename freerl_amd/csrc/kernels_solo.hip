@@ -1,0 +1,340 @@
+// DDPG / TD3 / SAC update of a SINGLE learner (or a handful) on sixteen workgroups per learner (device/solo.hpp): the critic stage
+// — TD target with the target nets, critic forward / backward, clip, Adam, soft update: DDPG_simple.py:139-149, TD3.py:193-213,235-244,
+// SAC.py:226-238 — and the actor stage — a = actor(s), Q(s, a) through the updated critic, dQ/da, actor backward, clip, Adam, soft
+// update, SAC's alpha step: DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260 — one launch each.  Same arithmetic per row as
+// kernels_critic2.hip / kernels_actor2.hip (whose row rules are restated here on the "every lane of the row" layout this
+// decomposition produces); different decomposition: rows over workgroups, output features over waves, the gradient met by a
+// deterministic slab sum behind a grid barrier.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "device/solo.hpp"
+
+namespace frl {
+
+namespace {
+
+__device__ __forceinline__ float pick4(const f32x4& v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+
+// the fields of this lane's row that every pass needs
+struct SoloRow {
+    g_cf rec;               // the row's record in the ring (the batch's last row for lanes past the batch)
+    bool valid;
+    int row;
+};
+
+// input columns 4q .. 4q + 3 of the row: observation columns [0, O) from obs0 (obs or next_obs), then A action columns from act4
+__device__ __forceinline__ f32x4 critic_input(const SoloNet& N, const f32x4& ob, const f32x4& act4, int O, int A) {
+    f32x4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int f = 4 * N.C.q + e;
+        x[e] = f < O ? ob[e] : (f < O + A ? pick4(act4, f - O) : 0.f);
+    }
+    return x;
+}
+
+}  // namespace
+
+template <bool TWIN>
+__device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
+    constexpr int NH = TWIN ? 2 : 1;
+    const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    SoloNet N;
+    N.init(smem);
+    const ChainNet& C = N.C;
+    const int tid = C.tid, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], A = R.act_dim[0], am = D.act_max;
+    const int nb = (B + 15) / 16;
+    const bool sac = (D.algo == ALGO_SAC);
+    const size_t lbase = (size_t)p * D.learner_stride;
+    g_cf tgA = as_global(D.target + lbase + D.net_off[0]);
+    g_f thC = as_global(D.theta + lbase + D.net_off[1]);
+    g_f tgC = as_global(D.target + lbase + D.net_off[1]);
+    g_f mC = as_global(D.m + lbase + D.net_off[1]);
+    g_f vC = as_global(D.v + lbase + D.net_off[1]);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
+    float* part = s.part + ((size_t)p * kSoloWG) * 8;
+    const float invB = 1.f / (float)B;
+
+    if (b < nb) {
+        g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+        g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
+        g_cf noise0 = as_global(D.noise + (size_t)p * D.noise_sets * D.batch_max * am);
+        const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+        const int row = 16 * b + i16;
+        const bool valid = row < B;
+        g_cf rec = ring + (size_t)idx[valid ? row : B - 1] * R.stride;
+        // the first image travels while the row's fields do
+        ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        f32x4 sn, so, ac = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 4 * q + e, fc = f < O ? f : O - 1;
+            sn[e] = rec[R.nobs_off[0] + fc]; so[e] = rec[R.obs_off[0] + fc];
+            if (f >= O) { sn[e] = 0.f; so[e] = 0.f; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < A) {
+                ac[r] = rec[R.act_off[0] + r];
+                if (sac || a.use_policy_noise) nz[r] = noise0[(size_t)(valid ? row : B - 1) * am + r];
+            }
+        }
+        const float rew = rec[R.rew_off], done = rec[R.done_off];
+        C.stage_commit(pend);
+        pend = C.stage_fetch((g_cf)tgC, 0);
+        // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
+        f32x4 h1o[2], h2o[2], h2f[kHT], z, an = {0.f, 0.f, 0.f, 0.f};
+        float lp = 0.f;
+        N.forward<false>(sn, h1o, h2o, h2f, z, A);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < A) {
+                if (sac) {
+                    const float ls = fminf(fmaxf(C.S.ls[r], -20.f), 2.f), sd = expf(ls);
+                    const float u = z[r] + sd * nz[r], du = u - z[r];
+                    lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                    lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                    an[r] = tanhf(u);
+                } else {
+                    float v = tanhf(z[r]);
+                    if (a.use_policy_noise) {
+                        float n1 = a.policy_noise_scale * (nz[r] * a.policy_noise);
+                        n1 = fminf(fmaxf(n1, -a.noise_clip), a.noise_clip);
+                        v = fminf(fmaxf(v * a.max_action + n1, -a.max_action), a.max_action) / a.max_action;
+                    }
+                    an[r] = v;
+                }
+            }
+        }
+        // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi)
+        float qmin = 0.f;
+#pragma unroll
+        for (int hd = 0; hd < NH; ++hd) {
+            C.stage_commit(pend);
+            pend = hd + 1 < NH ? C.stage_fetch((g_cf)tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
+            N.forward<false>(critic_input(N, sn, an, O, A), h1o, h2o, h2f, z, 1);
+            qmin = hd == 0 ? z[0] : fminf(qmin, z[0]);
+        }
+        const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);
+        // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
+        const f32x4 xin = critic_input(N, so, ac, O, A);
+        float lossp = 0.f;
+#pragma unroll
+        for (int hd = 0; hd < NH; ++hd) {
+            C.stage_commit(pend);
+            if (hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
+            N.forward<true>(xin, h1o, h2o, h2f, z, 1);
+            f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                float lrow, grow;
+                td_loss_row(a, z[0] - y, lrow, grow);
+                dz[0] = grow * invB;
+                lossp += lrow;
+            }
+            f32x4 d2o[2], d1o[2];
+            g_f hs = slab + hd * kHeadFloats;
+            N.head_bwd<true>(hs, dz, h2o, d2o, 1);
+            N.hidden_bwd<true>(hs, d2o, h1o, d1o);
+        }
+        lossp = SoloNet::rows_sum(lossp);
+        if (tid == 0) part[b * 8 + 0] = lossp;
+    }
+    solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    SoloUpdate u;
+    u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
+    u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
+    u.t_new = t_new;
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG);
+    if (b == 0 && tid == 0) {
+        float loss = 0.f;
+        for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        steps[1] = t_new;
+        float* st = D.stats + (size_t)p * ST_COUNT;
+        st[ST_CRITIC_LOSS] = loss * invB;
+        st[ST_CRITIC_GNORM] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    solo_critic_body<true>(*Dp, a, s, smem);
+}
+__global__ __launch_bounds__(256) void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    solo_critic_body<false>(*Dp, a, s, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------- actor stage
+__global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const EngineDesc& D = *Dp;
+    const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    SoloNet N;
+    N.init(smem);
+    const ChainNet& C = N.C;
+    const int tid = C.tid, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], A = R.act_dim[0], am = D.act_max;
+    const int nb = (B + 15) / 16;
+    const bool sac = (D.algo == ALGO_SAC);
+    const size_t lbase = (size_t)p * D.learner_stride;
+    g_f thA = as_global(D.theta + lbase + D.net_off[0]);
+    g_f tgA = as_global(D.target + lbase + D.net_off[0]);
+    g_f mA = as_global(D.m + lbase + D.net_off[0]);
+    g_f vA = as_global(D.v + lbase + D.net_off[0]);
+    g_cf thC = as_global(D.theta + lbase + D.net_off[1]);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t_new = steps[0] + 1;
+    float* part = s.part + ((size_t)p * kSoloWG) * 8;
+    const float invB = 1.f / (float)B;
+    const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+    const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
+
+    if (b < nb) {
+        g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+        g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
+        g_cf noise1 = as_global(D.noise + ((size_t)p * D.noise_sets + 1) * D.batch_max * am);      // the actor stage's eps (set 1)
+        const int row = 16 * b + i16;
+        const bool valid = row < B;
+        g_cf rec = ring + (size_t)idx[valid ? row : B - 1] * R.stride;
+        ChainNet::StageRegs pend = C.stage_fetch((g_cf)thA, 0, NA.extra_n);
+        f32x4 so, ep = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = 4 * q + e, fc = f < O ? f : O - 1;
+            so[e] = rec[R.obs_off[0] + fc];
+            if (f >= O) so[e] = 0.f;
+        }
+        if (sac) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < A) ep[r] = noise1[(size_t)(valid ? row : B - 1) * am + r];
+        }
+        C.stage_commit(pend);
+        pend = C.stage_fetch(thC, 0);
+        // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
+        f32x4 ah1[2], ah2[2], h2f[kHT], za, an = {0.f, 0.f, 0.f, 0.f}, lsv = {0.f, 0.f, 0.f, 0.f};
+        float lp = 0.f;
+        N.forward<true>(so, ah1, ah2, h2f, za, A);                         // (th1 / tx keep the actor's h1 and s for pass C: pass B leaves them alone)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < A) {
+                if (sac) {
+                    lsv[r] = C.S.ls[r];
+                    const float ls = fminf(fmaxf(lsv[r], -20.f), 2.f), sd = expf(ls);
+                    const float u = za[r] + sd * ep[r], du = u - za[r];
+                    lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                    lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                    an[r] = tanhf(u);
+                } else {
+                    an[r] = tanhf(za[r]);
+                }
+            }
+        }
+        // ---- B: Q(s, a) and dQ/da through the frozen (already stepped) critic
+        const f32x4 xin = critic_input(N, so, an, O, A);
+        const float dqv = sac ? -0.5f * invB : -invB;
+        float qrow = 0.f;
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                   // d loss / d a[r] of this lane's row
+        for (int hd = 0; hd < nq; ++hd) {
+            C.stage_commit(pend);
+            pend = hd + 1 < nq ? C.stage_fetch(thC, hd + 1) : C.stage_fetch((g_cf)thA, 0, NA.extra_n);
+            f32x4 h1o[2], h2o[2], z, d2o[2], d1o[2];
+            N.forward<false>(xin, h1o, h2o, h2f, z, 1);
+            f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+            if (valid) { qrow += z[0]; dz[0] = dqv; }
+            N.head_bwd<false>(nullptr, dz, h2o, d2o, 1);
+            N.hidden_bwd<false>(nullptr, d2o, h1o, d1o);
+            const f32x4 dx = N.input_bwd(d1o);                             // column 4q + r of [s | a]; a's columns sit on lanes q = (O + j) / 4
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < A) {
+                    const int f = O + r;
+                    dq[r] += __shfl(pick4(dx, f & 3), (f >> 2) * 16 + i16, 64);
+                }
+            }
+        }
+        // ---- C: through a = tanh(.) into the actor; its activations are pass A's (own tiles in registers, h1 / s transposed in LDS)
+        C.stage_commit(pend);
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+        float gls[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < A) {
+                    const float av = an[r];
+                    if (sac) {                                             // through u = mean + exp(log_std) eps, and alpha log pi
+                        const float d = dq[r] * (1.f - av * av) + (alpha * invB) * (2.f * av);
+                        const float ls = fminf(fmaxf(lsv[r], -20.f), 2.f);
+                        dz[r] = d;
+                        gls[r] = d * expf(ls) * ep[r] - alpha * invB;
+                    } else {
+                        dz[r] = dq[r] * (1.f - av * av);
+                    }
+                }
+            }
+        }
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
+        f32x4 d2o[2], d1o[2];
+        // head_bwd needs h2's own tiles and the head image: both the actor's again
+        N.head_bwd<true>(slab, dz, ah2, d2o, A);
+        N.hidden_bwd<true>(slab, d2o, ah1, d1o);
+        // log_std's gradient of this row tile (zero outside the clamp [-20, 2], SAC.py:77) behind the head block; Q and log-pi sums
+        float gl = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sgl = SoloNet::rows_sum(gls[r]);
+            if (i16 == r) gl = (sac && r < A && lsv[r] >= -20.f && lsv[r] <= 2.f) ? sgl : 0.f;
+        }
+        if (w == 0 && q == 0) slab[kHeadFloats + i16] = gl;
+        qrow = SoloNet::rows_sum(qrow);
+        lp = SoloNet::rows_sum(valid ? lp : 0.f);
+        if (tid == 0) { part[b * 8 + 0] = qrow; part[b * 8 + 1] = lp; }
+    }
+    solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    SoloUpdate u;
+    u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG);
+    if (b == 0 && tid == 0) {
+        float qtot = 0.f, lptot = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            qtot += __hip_atomic_load(part + k * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lptot += __hip_atomic_load(part + k * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        steps[0] = t_new;
+        float* st = D.stats + (size_t)p * ST_COUNT;
+        st[ST_ACTOR_LOSS] = sac ? (-(qtot * 0.5f) + alpha * lptot) * invB : -qtot * invB;   // SAC.py:251: (alpha log pi - Q).mean()
+        st[ST_ACTOR_GNORM] = total;
+        if (sac) {                                                         // alpha step on the batch's entropy (SAC.py:154-169,257-260)
+            float* al = D.alpha + p * 4;
+            const float ent_mean = -lptot * invB;
+            const float mean_term = ent_mean - a.target_entropy;
+            const float gl = alpha * mean_term;                            // d alpha_loss / d log_alpha
+            const int ta = steps[kMaxNets] + 1;
+            float mi = al[1], vi = al[2];
+            mi = mi + (gl - mi) * (1.f - a.beta1);
+            vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
+            const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
+            const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
+            al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
+            al[1] = mi;
+            al[2] = vi;
+            al[3] = expf(al[0]);
+            steps[kMaxNets] = ta;
+            st[ST_ALPHA_LOSS] = alpha * mean_term;
+            st[ST_ALPHA] = al[3];
+            st[ST_ENTROPY] = ent_mean;
+        }
+    }
+}
+
+}  // namespace frl

@@ -262,12 +262,22 @@ def test_per_tree_at_depth(N):
 
 
 def test_learn_path_reports_the_kernel_family(N, monkeypatch):
-    """frl_learn_path: the chained kernels take the narrow standard shape at populations > 128 (or when forced AT CREATION:
-    the family fixes the parameter layout in HBM for the engine's life), the row-chunk kernels everything else; the reported
-    LDS bytes fit the CU either way."""
+    """frl_learn_path: at the narrow standard shape one to eight learners take the sixteen-workgroups-per-learner kernels, populations
+    > 128 the one-workgroup-per-learner chained kernels (or when forced AT CREATION: the family fixes the parameter layout in HBM for
+    the engine's life), the row-chunk kernels everything else; the reported LDS bytes fit the CU either way."""
     from freerl_amd.engine import Engine
     monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
     for algo, twin in ((N.ALGO_TD3, True), (N.ALGO_SAC, True), (N.ALGO_DDPG, False)):
+        solo = Engine(algo, 8, 2, 512, twin_critic=twin, batch_max=256)         # one learner: sixteen workgroups of a 16-row tile each (kernels_solo.hip)
+        assert solo.learn_path(256) == (True, 117376, 16)
+        solo.close()
+        solo = Engine(algo, 8, 2, 512, n_learners=8, twin_critic=twin, batch_max=256)        # ... up to 8 learners (128 resident workgroups)
+        assert solo.learn_path(256) == (True, 117376, 16)
+        solo.close()
+        nine = Engine(algo, 8, 2, 512, n_learners=9, twin_critic=twin, batch_max=256)
+        assert not nine.learn_path(256)[0]
+        nine.close()
+        monkeypatch.setenv("FRL_CRITIC_V2", "0")                              # the row-chunk family by name
         small = Engine(algo, 8, 2, 512, twin_critic=twin, batch_max=256)
         chained, lds, rows = small.learn_path(256)
         assert not chained and rows == small.lds_bytes()[1] and lds == small.lds_bytes()[0]
