@@ -153,6 +153,7 @@ SIGNATURES = {
     "frl_per_update": (_i, [_vp, _i, _i64p, _fp]),
     "frl_per_state": (_i, [_vp, _i, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "frl_learn_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),
+    "frl_solo_debug_read": (_i, [_vp, _fp, _i]),
     "frl_learn_work_executed": (_i, [_vp, _i, _i, _P(C.c_double)]),
     "frl_ppo_learn": (_i, [_vp, _P(PpoArgs)]),
     "frl_ppo_work": (_i, [_vp, _i, _i, _P(C.c_double), _P(C.c_double)]),

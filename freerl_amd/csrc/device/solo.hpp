@@ -30,6 +30,21 @@ namespace frl {
 
 // (SoloArgs: kernels.h)
 
+// Developer instrument (tools/solo_timing.py; kernels_solo.hip compiled with -DFRL_SOLO_TIMING): thread 0 of every workgroup leaves
+// wall-clock stamps (100 MHz ticks since its start) in the tail of its `part` row
+constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::part: 0 loss / Q sum, 1 log-pi sum, 2 squared norm, 8.. stamps
+#ifdef FRL_SOLO_TIMING
+#define SOLO_T0() const unsigned long long solo_t0_ = wall_clock64()
+#define SOLO_T(slot) do { if (threadIdx.x == 0) part[(blockIdx.x % kSoloWG) * kSoloPart + 8 + (slot)] = (float)(wall_clock64() - solo_t0_); } while (0)
+#define SOLO_TARG , solo_t0_
+#define SOLO_TARGP , part, solo_t0_
+#else
+#define SOLO_T0() do {} while (0)
+#define SOLO_T(slot) do {} while (0)
+#define SOLO_TARG
+#define SOLO_TARGP
+#endif
+
 struct SoloNet {
     ChainNet C;             // images (S.w1 / w2 / w3 / b1 / b2 / b3 / ls), lane constants, stage_fetch / stage_commit, delta0
     lds_f ea, eb;           // activation / delta exchange, MFMA D layout: tile ft at ft * 256 + 4 * lane
@@ -244,6 +259,68 @@ struct SoloNet {
     }
 };
 
+// ---- draw_indices (net.hpp) for a batch of <= 256 rows on 256 threads: `batch` distinct rows of [0, size) — the later of two equal
+// entries is redrawn, round by round, exactly as there (same Philox streams: the same indices).  The duplicate check is the cost (a
+// batch of 256 from a 5e4-row ring collides in two calls of three, so two rounds are the rule): wave w reads the entries of waves
+// 0 .. w (broadcast ds_read_b128) and keeps, per entry j, the wave's equality mask as a SCALAR — ballot(entry j == mine) AND the
+// constant mask of the lanes behind j — so a round is <= 256 v_cmp per lane and scalar ORs.  Measured inside this kernel's first
+// section (tools/solo_timing.py): net.hpp's scan of thread i's i predecessors (divergent trip count, a wait per four reads) 8.6 us; the
+// later entry of a pair flagged by the earlier one's thread (128 reads per thread, but the conditional LDS stores serialise them)
+// 16.8 us; all 256 compares as vector booleans (577 spilled SGPRs) 15.2 us.
+// lidx: 258 ints of LDS.  Returns with lidx[0 .. batch) final (and written to idx_out) behind a barrier.
+__device__ __forceinline__ void solo_draw_indices(g_i idx_out, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
+                                                  unsigned long long key
+#ifdef FRL_SOLO_TIMING
+                                                  , float* part, unsigned long long solo_t0_
+#endif
+                                                  ) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FRL_LDS int* fl = lidx + 256;                                      // "somebody redraws" of round r in fl[r & 1]
+    int mine = tid < batch ? (int)uniform_index(philox4x32_10(counter, 0u, (unsigned)tid, key), (unsigned)size) : -1 - tid;
+    lidx[tid] = mine;
+    if (tid < 2) fl[tid] = 0;
+    SOLO_T(10);
+    lds_barrier();
+    SOLO_T(11);
+    const FRL_LDS i32x4* l4 = (const FRL_LDS i32x4*)lidx;
+    for (unsigned round = 1; round < 64; ++round) {
+        // m = min over the entries in front of this thread of (entry XOR mine): zero iff one of them equals it.  Vector ALU only — the
+        // first build kept the wave's equality masks as scalars (ballot, s_and / s_or): ~35 cycles per entry behind the
+        // VALU -> SGPR -> SALU hazards, 3.7 us per round for the last wave's 256 entries
+        unsigned m = 1u;
+#pragma unroll 8
+        for (int j4 = 0; j4 < 16 * w; ++j4) {                          // entries of the waves in front of this one: every lane is behind them
+            const i32x4 v = l4[j4];
+            m = min(min(m, (unsigned)(v.x ^ mine)), min((unsigned)(v.y ^ mine), min((unsigned)(v.z ^ mine), (unsigned)(v.w ^ mine))));
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) {                              // this wave's own entries: entry 64 w + c counts for the lanes > c
+            const i32x4 v = l4[16 * w + c4];
+            m = min(m, (unsigned)(v.x ^ mine) | (unsigned)(4 * c4 >= l));
+            m = min(m, (unsigned)(v.y ^ mine) | (unsigned)(4 * c4 + 1 >= l));
+            m = min(m, (unsigned)(v.z ^ mine) | (unsigned)(4 * c4 + 2 >= l));
+            m = min(m, (unsigned)(v.w ^ mine) | (unsigned)(4 * c4 + 3 >= l));
+        }
+        const bool dup = m == 0u;
+        if (round == 1) SOLO_T(12);
+        // (__syncthreads_or took 5.6 us here — tools/solo_timing.py — against 0.1 us for a flag word between two LDS barriers)
+        if (dup) fl[round & 1] = 1;
+        lds_barrier();                                                 // everybody has compared against the old values and raised the flag
+        const int any = fl[round & 1];
+        if (round == 1) SOLO_T(13);
+        if (!any) break;
+        if (tid == 0) fl[(round + 1) & 1] = 0;
+        if (dup) {
+            mine = (int)uniform_index(philox4x32_10(counter, round * 0x10000u, (unsigned)tid, key), (unsigned)size);
+            lidx[tid] = mine;
+        }
+        lds_barrier();
+    }
+    SOLO_T(14);
+    if (tid < batch) idx_out[tid] = mine;
+}
+
 // ---- grid barrier of a learner's kSoloWG workgroups.  `bar` counts arrivals for ever; barrier number k (1, 2, ...) of a launch is
 // passed when it reaches base + k * kSoloWG.  Release / acquire at agent scope around it (__threadfence: L2 write-back and
 // invalidate, the workgroups of a learner sit on different XCDs).  A workgroup that waits ~2 s gives up and raises *err: the
@@ -275,7 +352,11 @@ struct SoloUpdate {
 // ---- behind grid barrier 1: this workgroup's sixteenth of the net — slab sum in workgroup order, partial squared norm ->
 // grid barrier 2 -> clip coefficient, Adam, soft update.  Returns the gradient norm.
 __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, int p, int b, int nb, lds_f red,
-                                             unsigned bar2_target) {
+                                             unsigned bar2_target
+#ifdef FRL_SOLO_TIMING
+                                             , unsigned long long solo_t0_
+#endif
+                                             ) {
     const int tid = threadIdx.x;
     const int n4 = u.size >> 2, per = (n4 + kSoloWG - 1) / kSoloWG, i0 = b * per, i1 = min(n4, i0 + per);
     constexpr int KM = 3;                                                  // float4 per thread: nets of up to 16 x 3 x 256 x 4 = 49 k floats
@@ -287,13 +368,31 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
         const int i = i0 + tid + kWG * k, ic = i < i1 ? i : (i1 > i0 ? i1 - 1 : 0);
         th[k] = ld4((g_cf)(u.th + 4 * ic)); mi[k] = ld4((g_cf)(u.mm + 4 * ic)); vi[k] = ld4((g_cf)(u.vv + 4 * ic)); tg[k] = ld4((g_cf)(u.tg + 4 * ic));
     }
-#pragma unroll 4
-    for (int sb = 0; sb < nb; ++sb) {
+    // every slab's share in flight at once — 16 x KM independent 16-byte loads per thread, ONE round trip to the memory side (the slabs
+    // were written by other XCDs: nothing of them is in this L2) — then summed in workgroup order.  A runtime loop over the slabs with
+    // the sum inside was four dependent round trips: 14 us of the 48 us launch (tools/solo_timing.py).
+    {
+        f32x4 sl[kSoloWG][KM];
 #pragma unroll
-        for (int k = 0; k < KM; ++k) {
-            const int i = i0 + tid + kWG * k;
-            if (i < i1) g[k] += ld4(slab + (size_t)sb * s.slab_stride + 4 * i);
+        for (int sb = 0; sb < kSoloWG; ++sb) {
+            const int sc = sb < nb ? sb : nb - 1;                          // (slabs past the batch's tiles: a harmless re-read, dropped below)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const int i = i0 + tid + kWG * k, ic = i < i1 ? i : (i1 > i0 ? i1 - 1 : 0);
+                sl[sb][k] = ld4(slab + (size_t)sc * s.slab_stride + 4 * ic);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sb = 0; sb < kSoloWG; ++sb) {
+            if (sb < nb) {
+#pragma unroll
+                for (int k = 0; k < KM; ++k) g[k] += sl[sb][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (i0 + tid + kWG * k >= i1) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float ss = 0.f;
 #pragma unroll
@@ -302,12 +401,14 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
     __syncthreads();
     if ((tid & 63) == 0) red[64 + (tid >> 6)] = ss;
     __syncthreads();
-    float* part = s.part + ((size_t)p * kSoloWG) * 8;
-    if (tid == 0) part[b * 8 + 2] = ((red[64] + red[65]) + red[66]) + red[67];
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    if (tid == 0) part[b * kSoloPart + 2] = ((red[64] + red[65]) + red[66]) + red[67];
+    SOLO_T(5);
     solo_grid_sync(s.bar + p, bar2_target, s.err);
+    SOLO_T(6);
     float tot = 0.f;
 #pragma unroll
-    for (int sb = 0; sb < kSoloWG; ++sb) tot += __hip_atomic_load(part + sb * 8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sb = 0; sb < kSoloWG; ++sb) tot += __hip_atomic_load(part + sb * kSoloPart + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float total = sqrtf(tot);
     const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     const double bc1 = 1.0 - powi_d((double)a.beta1, u.t_new), bc2 = 1.0 - powi_d((double)a.beta2, u.t_new);

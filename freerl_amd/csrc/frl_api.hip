@@ -519,7 +519,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (h.solo) {
             e->solo_stride = std::max(h.net[0].size, h.net[1].size);
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
-            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * 8, e->stream));
+            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
             float* z = nullptr;
             CREATE_TRY(dalloc_zero(&z, P + 1, e->stream));
             e->d_solo_bar = (unsigned*)z;
@@ -1362,7 +1362,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         return;
     }
     if (stage == 0) {
-        if (dev_rng) {
+        if (dev_rng && !(v2 && h.solo)) {                 // (kernels_solo.hip draws inside its critic stage)
             prof_begin(e, PK_DRAW);
             hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)2 * ((a.batch + 3) & ~3) * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
             prof_end(e);
@@ -1601,6 +1601,16 @@ extern "C" int frl_learn_work_executed(const frl_engine* e, int batch, int do_ac
         }
     }
     if (flops_out) *flops_out = fl * h.P;
+    return FRL_OK;
+}
+
+// developer read-back (tools/solo_timing.py): the single-learner kernels' per-workgroup partial sums and, in a -DFRL_SOLO_TIMING build of
+// kernels_solo.hip, their section stamps — [kSoloWG][32] floats of learner 0
+extern "C" int frl_solo_debug_read(frl_engine* e, float* out_host, int n_floats) {
+    ENG(e);
+    if (!e->h.solo || !e->d_solo_part || !out_host || n_floats < 0 || n_floats > kSoloWG * kSoloPartHost) return fail(FRL_ERR_STATE, "not a solo engine / bad size");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out_host, e->d_solo_part, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return FRL_OK;
 }
 

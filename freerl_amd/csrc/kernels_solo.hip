@@ -9,6 +9,7 @@
 
 #include "kernels.h"
 #include "device/solo.hpp"
+#include "device/rng.hpp"
 
 namespace frl {
 
@@ -58,8 +59,9 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     g_f vC = as_global(D.v + lbase + D.net_off[1]);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
-    float* part = s.part + ((size_t)p * kSoloWG) * 8;
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
+    SOLO_T0();
 
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
@@ -68,9 +70,22 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
         const int row = 16 * b + i16;
         const bool valid = row < B;
-        g_cf rec = ring + (size_t)idx[valid ? row : B - 1] * R.stride;
-        // the first image travels while the row's fields do
+        // the first image travels while the indices are drawn and the row's fields fetched
         ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        int ri;
+        const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
+        if (a.device_rng) {
+            // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
+            // rejection in its own LDS: ~1 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
+            // same values to D.idx (the actor stage and frl_last_indices read them)
+            FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
+            solo_draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, key SOLO_TARGP);
+            ri = lidx[valid ? row : B - 1];
+            SOLO_T(8);
+        } else {
+            ri = idx[valid ? row : B - 1];
+        }
+        g_cf rec = ring + (size_t)ri * R.stride;
         f32x4 sn, so, ac = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -82,11 +97,17 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         for (int r = 0; r < 4; ++r) {
             if (r < A) {
                 ac[r] = rec[R.act_off[0] + r];
-                if (sac || a.use_policy_noise) nz[r] = noise0[(size_t)(valid ? row : B - 1) * am + r];
+                if (sac || a.use_policy_noise) {
+                    const unsigned e1 = (unsigned)((valid ? row : B - 1) * am + r);
+                    if (a.device_rng) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, key), n0, n1); nz[r] = n0; }      // = draw_kernel's set 0
+                    else nz[r] = noise0[e1];
+                }
             }
         }
         const float rew = rec[R.rew_off], done = rec[R.done_off];
+        SOLO_T(9);
         C.stage_commit(pend);
+        SOLO_T(0);
         pend = C.stage_fetch((g_cf)tgC, 0);
         // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
         f32x4 h1o[2], h2o[2], h2f[kHT], z, an = {0.f, 0.f, 0.f, 0.f};
@@ -112,6 +133,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
                 }
             }
         }
+        SOLO_T(1);
         // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi)
         float qmin = 0.f;
 #pragma unroll
@@ -121,6 +143,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             N.forward<false>(critic_input(N, sn, an, O, A), h1o, h2o, h2f, z, 1);
             qmin = hd == 0 ? z[0] : fminf(qmin, z[0]);
         }
+        SOLO_T(2);
         const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);
         // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab
         g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
@@ -144,17 +167,20 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             N.hidden_bwd<true>(hs, d2o, h1o, d1o);
         }
         lossp = SoloNet::rows_sum(lossp);
-        if (tid == 0) part[b * 8 + 0] = lossp;
+        if (tid == 0) part[b * kSoloPart + 0] = lossp;
     }
+    SOLO_T(3);
     solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
     u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
     u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG);
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG SOLO_TARG);
+    SOLO_T(7);
     if (b == 0 && tid == 0) {
         float loss = 0.f;
-        for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         steps[1] = t_new;
         float* st = D.stats + (size_t)p * ST_COUNT;
         st[ST_CRITIC_LOSS] = loss * invB;
@@ -194,10 +220,11 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
     g_cf thC = as_global(D.theta + lbase + D.net_off[1]);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     const int t_new = steps[0] + 1;
-    float* part = s.part + ((size_t)p * kSoloWG) * 8;
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
+    SOLO_T0();
 
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
@@ -215,11 +242,18 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
             if (f >= O) so[e] = 0.f;
         }
         if (sac) {
+            const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < A) ep[r] = noise1[(size_t)(valid ? row : B - 1) * am + r];
+            for (int r = 0; r < 4; ++r) {
+                if (r < A) {
+                    const unsigned e1 = (unsigned)((valid ? row : B - 1) * am + r);
+                    if (a.device_rng) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, key), n0, n1); ep[r] = n1; }      // = draw_kernel's set 1
+                    else ep[r] = noise1[e1];
+                }
+            }
         }
         C.stage_commit(pend);
+        SOLO_T(0);
         pend = C.stage_fetch(thC, 0);
         // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
         f32x4 ah1[2], ah2[2], h2f[kHT], za, an = {0.f, 0.f, 0.f, 0.f}, lsv = {0.f, 0.f, 0.f, 0.f};
@@ -240,6 +274,7 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
                 }
             }
         }
+        SOLO_T(1);
         // ---- B: Q(s, a) and dQ/da through the frozen (already stepped) critic
         const f32x4 xin = critic_input(N, so, an, O, A);
         const float dqv = sac ? -0.5f * invB : -invB;
@@ -263,6 +298,7 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
                 }
             }
         }
+        SOLO_T(2);
         // ---- C: through a = tanh(.) into the actor; its activations are pass A's (own tiles in registers, h1 / s transposed in LDS)
         C.stage_commit(pend);
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
@@ -298,17 +334,20 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         if (w == 0 && q == 0) slab[kHeadFloats + i16] = gl;
         qrow = SoloNet::rows_sum(qrow);
         lp = SoloNet::rows_sum(valid ? lp : 0.f);
-        if (tid == 0) { part[b * 8 + 0] = qrow; part[b * 8 + 1] = lp; }
+        if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
     }
+    SOLO_T(3);
     solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    SOLO_T(4);
     SoloUpdate u;
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG);
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG SOLO_TARG);
+    SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;
         for (int k = 0; k < nb; ++k) {
-            qtot += __hip_atomic_load(part + k * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lptot += __hip_atomic_load(part + k * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qtot += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lptot += __hip_atomic_load(part + k * kSoloPart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         steps[0] = t_new;
         float* st = D.stats + (size_t)p * ST_COUNT;

@@ -413,6 +413,10 @@ int frl_comm_info(const frl_comm* c, int* rank_out, int* world_out);      /* NUL
  * FRL_COMM_MAX_VALUES each.  comm == NULL: the single-process case, the vectors are already the job's totals.  Synchronous. */
 int frl_metrics_allreduce(frl_comm* c, double* sums, int n_sum, double* maxes, int n_max);
 
+/* developer read-back of the single-learner kernels' per-workgroup block (partial sums; section stamps in a timing build):
+ * [16][32] floats of learner 0 (tools/solo_timing.py) */
+int frl_solo_debug_read(frl_engine* e, float* out_host, int n_floats);
+
 /* ---------------------------------------------------------------- timing on the engine stream */
 int frl_timer_start(frl_engine* e);
 int frl_timer_stop(frl_engine* e, float* ms_out);           /* synchronises */
