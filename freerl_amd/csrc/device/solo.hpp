@@ -45,6 +45,10 @@ constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::pa
 #define SOLO_TARGP
 #endif
 
+// (slab stores are plain stores.  Measured: write-through ones — global_store_dwordx4 ... sc0 sc1, so that the barrier's release fence
+// finds nothing dirty in this XCD's L2 — take 1.4 us off grid barrier 1 and put 1.1 us on the backward that issues them.)
+__device__ __forceinline__ void st4_slab(g_f p, const f32x4& v) { st4(p, v); }
+
 struct SoloNet {
     ChainNet C;             // images (S.w1 / w2 / w3 / b1 / b2 / b3 / ls), lane constants, stage_fetch / stage_commit, delta0
     lds_f ea, eb;           // activation / delta exchange, MFMA D layout: tile ft at ft * 256 + 4 * lane
@@ -176,7 +180,7 @@ struct SoloNet {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2o[x][r] = h2o[x][r] > 0.f ? acc[r] : 0.f;
-            if constexpr (WG) st4(hs + kL3w + ot * 256 + C.fslot, g3);            // the whole tile: zeros in the slots of outputs >= hn
+            if constexpr (WG) st4_slab(hs + kL3w + ot * 256 + C.fslot, g3);            // the whole tile: zeros in the slots of outputs >= hn
         }
         if constexpr (WG) {
             float gb = 0.f;
@@ -211,7 +215,7 @@ struct SoloNet {
 #pragma unroll
                 for (int kt = 0; kt < kHT; ++kt) {
                     const f32x4 g = mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, get_t(th1, kt), af);      // dW2^T tile (ot, kt): chain_net.hpp's accumulator layout
-                    st4(hs + kL2w + (ot * kHT + kt) * 256 + fslot, g);
+                    st4_slab(hs + kL2w + (ot * kHT + kt) * 256 + fslot, g);
                 }
             }
         }
@@ -241,7 +245,7 @@ struct SoloNet {
                 float gb = (af[0] + af[1]) + (af[2] + af[3]);
                 gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
                 if (q == 0) hs[kL1b + ot * 16 + i16] = gb;
-                st4(hs + kL1w + ot * 256 + fslot, mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af));
+                st4_slab(hs + kL1w + ot * 256 + fslot, mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af));
             }
         }
     }

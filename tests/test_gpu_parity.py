@@ -281,11 +281,16 @@ def _check_ac_params(N, e, orc, twin, actor_names, label, actor_extra=None, lear
     return online
 
 
-@pytest.fixture(params=["rowchunk", "chained"])
+@pytest.fixture(params=["rowchunk", "chained", "solo"])
 def ac_path(request, monkeypatch):
     """The critic stage of DDPG / TD3 / SAC has two implementations behind frl_learn: the row-chunk kernels + reduce / Adam
     launches (any shape; what populations up to 128 learners get) and the one-workgroup-per-learner register-chained kernel
     with Adam fused (kernels_critic2.hip; the bench's path).  FRL_CRITIC_V2 forces either, so both meet the same oracle."""
+    if request.param == "solo":       # nothing forced: a single learner of the narrow shape runs kernels_solo.hip (sixteen workgroups)
+        monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+        monkeypatch.delenv("FRL_SOLO", raising=False)
+        monkeypatch.delenv("FRL_DQN_FUSED", raising=False)
+        return request.param
     monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
     monkeypatch.setenv("FRL_DQN_FUSED", "1" if request.param == "chained" else "0")      # (tests that also touch DQN: both of its paths)
     return request.param
