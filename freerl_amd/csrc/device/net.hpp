@@ -657,17 +657,68 @@ __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta
 }
 
 // Draw `batch` distinct row indices in [0,size) into idx (global, this learner's slice) using
-// `lidx` (LDS int[batch]) for the duplicate check: rejection keeps the draw uniform over
-// subsets, like np.random.choice(size, batch, replace=False) (DQN.py:97).
-// lidx: 2 * round_up(batch, 4) ints of LDS
+// `lidx` (LDS) for the duplicate check: rejection keeps the draw uniform over subsets, like
+// np.random.choice(size, batch, replace=False) (DQN.py:97): the LATER of two equal entries is redrawn, round by round.
+// lidx: 2 * round_up(batch, 4) ints of LDS.  Returns with lidx[0 .. batch) final behind a barrier.
+//
+// batch <= 256 (one entry per thread; every config but MADDPG's 1024): the duplicate check is the cost — a batch of 256 from a
+// 5e4-row ring collides in two calls of three, so two rounds are the rule.  Wave w reads the entries of waves 0 .. w (broadcast
+// ds_read_b128, no stores in between: they pipeline) and keeps m = min over the entries in front of its lane of (entry XOR mine),
+// vector ALU only; "somebody redraws" is a flag word between two LDS barriers.  Measured inside kernels_solo.hip's first section
+// (tools/solo_timing.py, round 5), the whole draw: this form 3.4 us; the scan of thread i's i predecessors behind a divergent trip count
+// with __syncthreads_or (rounds 1-4, the general path below) 8.6 us — __syncthreads_or alone 5.6 us per call; the later entry of
+// a pair flagged by the earlier one's thread (128 reads per thread, but conditional LDS stores serialise them) 16.8 us; equality
+// masks kept as scalars (ballot, s_and / s_or: ~35 cycles per entry behind the VALU -> SGPR -> SALU hazards) 8 us.
 __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
                                              unsigned stream, unsigned long long key) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    if (batch <= kWG) {
+        const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nq = (batch + 3) >> 2;                                // quads of entries (the last one padded)
+        FRL_LDS int* fl = lidx + 4 * nq;                                // "somebody redraws" of round r in fl[r & 1]
+        int mine = tid < batch ? (int)uniform_index(philox4x32_10(counter, stream, (unsigned)tid, key), (unsigned)size) : -1 - tid;
+        if (tid < 4 * nq) lidx[tid] = mine;                             // (padding entries: distinct negatives, equal to nothing)
+        if (tid < 2) fl[tid] = 0;
+        lds_barrier();
+        const FRL_LDS i32x4* l4 = (const FRL_LDS i32x4*)lidx;
+        const int nfront = min(16 * w, nq);
+        for (unsigned round = 1; round < 64; ++round) {
+            unsigned m = 1u;
+#pragma unroll 8
+            for (int j4 = 0; j4 < nfront; ++j4) {                       // entries of the waves in front of this one: every lane is behind them
+                const i32x4 v = l4[j4];
+                m = min(min(m, (unsigned)(v.x ^ mine)), min((unsigned)(v.y ^ mine), min((unsigned)(v.z ^ mine), (unsigned)(v.w ^ mine))));
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {                           // this wave's own entries: entry 64 w + c counts for the lanes > c
+                if (16 * w + c4 < nq) {
+                    const i32x4 v = l4[16 * w + c4];
+                    m = min(m, (unsigned)(v.x ^ mine) | (unsigned)(4 * c4 >= l));
+                    m = min(m, (unsigned)(v.y ^ mine) | (unsigned)(4 * c4 + 1 >= l));
+                    m = min(m, (unsigned)(v.z ^ mine) | (unsigned)(4 * c4 + 2 >= l));
+                    m = min(m, (unsigned)(v.w ^ mine) | (unsigned)(4 * c4 + 3 >= l));
+                }
+            }
+            const bool dup = m == 0u && tid < batch;
+            if (dup) fl[round & 1] = 1;
+            lds_barrier();                                              // everybody has compared against the old values and raised the flag
+            if (!fl[round & 1]) break;
+            if (tid == 0) fl[(round + 1) & 1] = 0;
+            if (dup) {
+                mine = (int)uniform_index(philox4x32_10(counter, stream + round * 0x10000u, (unsigned)tid, key), (unsigned)size);
+                lidx[tid] = mine;
+            }
+            lds_barrier();
+        }
+        if (tid < batch) idx[tid] = mine;
+        __syncthreads();              // (as the general path: callers count on it to have drained the workgroup's earlier global stores too)
+        return;
+    }
     for (int i = threadIdx.x; i < batch; i += kWG)
         lidx[i] = (int)uniform_index(philox4x32_10(counter, stream, (unsigned)i, key), (unsigned)size);
     __syncthreads();
     // does an earlier slot hold the same row?  four slots per LDS read (as a dependent chain of single reads this
     // check was most of the 33 us the kernel took)
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
     auto dup_before = [&](int i) {
         const int mine = lidx[i];
         bool d = false;

@@ -263,68 +263,6 @@ struct SoloNet {
     }
 };
 
-// ---- draw_indices (net.hpp) for a batch of <= 256 rows on 256 threads: `batch` distinct rows of [0, size) — the later of two equal
-// entries is redrawn, round by round, exactly as there (same Philox streams: the same indices).  The duplicate check is the cost (a
-// batch of 256 from a 5e4-row ring collides in two calls of three, so two rounds are the rule): wave w reads the entries of waves
-// 0 .. w (broadcast ds_read_b128) and keeps, per entry j, the wave's equality mask as a SCALAR — ballot(entry j == mine) AND the
-// constant mask of the lanes behind j — so a round is <= 256 v_cmp per lane and scalar ORs.  Measured inside this kernel's first
-// section (tools/solo_timing.py): net.hpp's scan of thread i's i predecessors (divergent trip count, a wait per four reads) 8.6 us; the
-// later entry of a pair flagged by the earlier one's thread (128 reads per thread, but the conditional LDS stores serialise them)
-// 16.8 us; all 256 compares as vector booleans (577 spilled SGPRs) 15.2 us.
-// lidx: 258 ints of LDS.  Returns with lidx[0 .. batch) final (and written to idx_out) behind a barrier.
-__device__ __forceinline__ void solo_draw_indices(g_i idx_out, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
-                                                  unsigned long long key
-#ifdef FRL_SOLO_TIMING
-                                                  , float* part, unsigned long long solo_t0_
-#endif
-                                                  ) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    FRL_LDS int* fl = lidx + 256;                                      // "somebody redraws" of round r in fl[r & 1]
-    int mine = tid < batch ? (int)uniform_index(philox4x32_10(counter, 0u, (unsigned)tid, key), (unsigned)size) : -1 - tid;
-    lidx[tid] = mine;
-    if (tid < 2) fl[tid] = 0;
-    SOLO_T(10);
-    lds_barrier();
-    SOLO_T(11);
-    const FRL_LDS i32x4* l4 = (const FRL_LDS i32x4*)lidx;
-    for (unsigned round = 1; round < 64; ++round) {
-        // m = min over the entries in front of this thread of (entry XOR mine): zero iff one of them equals it.  Vector ALU only — the
-        // first build kept the wave's equality masks as scalars (ballot, s_and / s_or): ~35 cycles per entry behind the
-        // VALU -> SGPR -> SALU hazards, 3.7 us per round for the last wave's 256 entries
-        unsigned m = 1u;
-#pragma unroll 8
-        for (int j4 = 0; j4 < 16 * w; ++j4) {                          // entries of the waves in front of this one: every lane is behind them
-            const i32x4 v = l4[j4];
-            m = min(min(m, (unsigned)(v.x ^ mine)), min((unsigned)(v.y ^ mine), min((unsigned)(v.z ^ mine), (unsigned)(v.w ^ mine))));
-        }
-#pragma unroll
-        for (int c4 = 0; c4 < 16; ++c4) {                              // this wave's own entries: entry 64 w + c counts for the lanes > c
-            const i32x4 v = l4[16 * w + c4];
-            m = min(m, (unsigned)(v.x ^ mine) | (unsigned)(4 * c4 >= l));
-            m = min(m, (unsigned)(v.y ^ mine) | (unsigned)(4 * c4 + 1 >= l));
-            m = min(m, (unsigned)(v.z ^ mine) | (unsigned)(4 * c4 + 2 >= l));
-            m = min(m, (unsigned)(v.w ^ mine) | (unsigned)(4 * c4 + 3 >= l));
-        }
-        const bool dup = m == 0u;
-        if (round == 1) SOLO_T(12);
-        // (__syncthreads_or took 5.6 us here — tools/solo_timing.py — against 0.1 us for a flag word between two LDS barriers)
-        if (dup) fl[round & 1] = 1;
-        lds_barrier();                                                 // everybody has compared against the old values and raised the flag
-        const int any = fl[round & 1];
-        if (round == 1) SOLO_T(13);
-        if (!any) break;
-        if (tid == 0) fl[(round + 1) & 1] = 0;
-        if (dup) {
-            mine = (int)uniform_index(philox4x32_10(counter, round * 0x10000u, (unsigned)tid, key), (unsigned)size);
-            lidx[tid] = mine;
-        }
-        lds_barrier();
-    }
-    SOLO_T(14);
-    if (tid < batch) idx_out[tid] = mine;
-}
-
 // ---- grid barrier of a learner's kSoloWG workgroups.  `bar` counts arrivals for ever; barrier number k (1, 2, ...) of a launch is
 // passed when it reaches base + k * kSoloWG.  Release / acquire at agent scope around it (__threadfence: L2 write-back and
 // invalidate, the workgroups of a learner sit on different XCDs).  A workgroup that waits ~2 s gives up and raises *err: the

@@ -76,10 +76,10 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
         if (a.device_rng) {
             // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
-            // rejection in its own LDS: ~1 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
+            // rejection in its own LDS: ~3 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
             // same values to D.idx (the actor stage and frl_last_indices read them)
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
-            solo_draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, key SOLO_TARGP);
+            draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key);
             ri = lidx[valid ? row : B - 1];
             SOLO_T(8);
         } else {

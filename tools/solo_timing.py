@@ -33,8 +33,6 @@ def stamps(do_actor):
     N.check(N.lib().frl_solo_debug_read(e._h, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size))
     if buf[:, 16:18].any():
         print("   (inside the first section, workgroup 0: indices drawn at %.2f us, row fields + noise issued at %.2f us)" % (buf[0, 16] * 0.01, buf[0, 17] * 0.01))
-    if buf[:, 18:23].any():
-        print("   (inside the draw, workgroup 0: first draw stored %.2f, barrier %.2f, round-1 compares %.2f, syncthreads_or %.2f, last round done %.2f us)" % tuple(buf[0, 18:23] * 0.01))
     return buf[:, 8:16] * 0.01          # us
 
 
