@@ -51,5 +51,4 @@ __device__ __forceinline__ float adam_elem(float th, float g, float& m, float& v
     return th - step * (m * __builtin_amdgcn_rcpf(denom));
 }
 
-
 }  // namespace frl

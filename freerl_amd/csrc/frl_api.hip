@@ -34,6 +34,7 @@
 #include "kernels_per.hip"
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
+#include "kernels_solo.hip"
 #endif
 
 using namespace frl;

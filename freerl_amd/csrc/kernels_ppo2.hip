@@ -495,6 +495,12 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             PPO_T(5);
             // -------------------------------------------------------------------- clip + Adam from the accumulators
             // (every wave finished its backward chain before the barriers above: the weights may change now)
+            // 13.5 k of a step's 73 k cycles (tools/ppo_timing.py), and that is its VALU cost: 88 elements per lane x (~12 fp32 ops + the
+            // quarter-rate v_sqrt / v_rcp + four accvgpr moves, m and v live in the AGPR half).  Round 5 tried three ways around the
+            // ds_read-behind-ds_write pattern of `W[dw] = adam_elem(W[dw], ...)` and measured them (profiles/README.md): a tile's theta
+            // read a tile ahead — 13.58 k, the same; a whole layer's slots read first, stepped, written — 21.3 ms per learn() at 256
+            // learners against 19.9 (more spills); theta += step through ds_add_f32, no read at all — ~780 cycles per LDS float atomic,
+            // 69 k cycles for the phase, 34.5 ms.
             auto upd = [&](lds_f W, int dw, float g, float& mm, float& vv) {
                 W[dw] = adam_elem(W[dw], g * coef, mm, vv, w1, w2, a.beta2, inv_bc2s, a.adam_eps, step);
             };
@@ -600,5 +606,12 @@ FRL_PPO2_KERNEL(ppo_update_v2_k1_relu, 1, ACT_RELU)
 FRL_PPO2_KERNEL(ppo_update_v2_k2_relu, 2, ACT_RELU)
 FRL_PPO2_KERNEL(ppo_update_v2_k1_tanh, 1, ACT_TANH)
 FRL_PPO2_KERNEL(ppo_update_v2_k2_tanh, 2, ACT_TANH)
+
+#if defined(FRL_PPO_TIMING) && !defined(FRL_UNITY)
+// (tools/build_ppo_timing.sh: this unit alone carries the stamps; the host unit fetches them through this kernel)
+__global__ void ppo2_clk_copy_kernel(long long* out) {
+    if (threadIdx.x < 16) out[threadIdx.x] = (&g_ppo_clk[0][0])[threadIdx.x];
+}
+#endif
 
 }  // namespace frl
