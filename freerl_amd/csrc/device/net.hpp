@@ -669,8 +669,10 @@ __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta
 // with __syncthreads_or (rounds 1-4, the general path below) 8.6 us — __syncthreads_or alone 5.6 us per call; the later entry of
 // a pair flagged by the earlier one's thread (128 reads per thread, but conditional LDS stores serialise them) 16.8 us; equality
 // masks kept as scalars (ballot, s_and / s_or: ~35 cycles per entry behind the VALU -> SGPR -> SALU hazards) 8 us.
+// drain = false (batch <= 256 only): return without the closing __syncthreads — lidx is final behind the last round's LDS barrier; the
+// caller does not need its earlier global stores (or the idx store) performed before it goes on (kernels_solo.hip: 1.7 us)
 __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
-                                             unsigned stream, unsigned long long key) {
+                                             unsigned stream, unsigned long long key, bool drain = true) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     if (batch <= kWG) {
         const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -711,7 +713,7 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
             lds_barrier();
         }
         if (tid < batch) idx[tid] = mine;
-        __syncthreads();              // (as the general path: callers count on it to have drained the workgroup's earlier global stores too)
+        if (drain) __syncthreads();   // (as the general path: callers count on it to have drained the workgroup's earlier global stores too)
         return;
     }
     for (int i = threadIdx.x; i < batch; i += kWG)

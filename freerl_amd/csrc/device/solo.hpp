@@ -16,7 +16,7 @@
 //     transposed through LDS, wave-local for the deltas), dH through the transposed reads of the W2 image;
 //   * the sixteen partial gradients go to per-workgroup slabs in image order; behind a GRID barrier (one atomic counter per
 //     learner, monotonic across launches) every workgroup sums ONE SIXTEENTH of the net over the slabs in workgroup order
-//     (bitwise deterministic), the partial squared norms meet behind a second grid barrier, and clip + Adam + soft update run on
+//     (bitwise deterministic), the partial squared norms meet through sixteen mailboxes, and clip + Adam + soft update run on
 //     the same sixteenth — torch's single-tensor Adam with exact sqrt / division, as the row-chunk family's adam_kernel.
 // Shape: chained_shape() (single agent, hidden 128 ReLU, obs + act <= 16 columns, act <= 4, batch <= 256), up to kSoloMaxP learners
 // (all their workgroups must be resident at once: the grid barrier spins).
@@ -32,7 +32,7 @@ namespace frl {
 
 // Developer instrument (tools/solo_timing.py; kernels_solo.hip compiled with -DFRL_SOLO_TIMING): thread 0 of every workgroup leaves
 // wall-clock stamps (100 MHz ticks since its start) in the tail of its `part` row
-constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::part: 0 loss / Q sum, 1 log-pi sum, 2 squared norm, 8.. stamps
+constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::part: 0 loss / Q sum, 1 log-pi sum, 2-3 the norm mailbox {partial, epoch}, 8.. stamps
 #ifdef FRL_SOLO_TIMING
 #define SOLO_T0() const unsigned long long solo_t0_ = wall_clock64()
 #define SOLO_T(slot) do { if (threadIdx.x == 0) part[(blockIdx.x % kSoloWG) * kSoloPart + 8 + (slot)] = (float)(wall_clock64() - solo_t0_); } while (0)
@@ -263,18 +263,20 @@ struct SoloNet {
     }
 };
 
-// ---- grid barrier of a learner's kSoloWG workgroups.  `bar` counts arrivals for ever; barrier number k (1, 2, ...) of a launch is
-// passed when it reaches base + k * kSoloWG.  Release / acquire at agent scope around it (__threadfence: L2 write-back and
-// invalidate, the workgroups of a learner sit on different XCDs).  A workgroup that waits ~2 s gives up and raises *err: the
-// launch then finishes with wrong numbers instead of hanging the queue.
-__device__ __forceinline__ void solo_grid_sync(unsigned* bar, unsigned target, int* err) {
-    __threadfence();
+// ---- "every workgroup of the learner has written its slab": sixteen FLAG words, not a counter.  Workgroup b, behind a workgroup
+// barrier (every thread's stores issued and counted), publishes flag[b] = epoch with ONE agent-scope release store (L2 write-back:
+// the readers sit on other XCDs); sixteen threads of every workgroup each poll one flag until it holds this launch's epoch, then the
+// workgroup takes an agent-scope acquire fence (invalidate) and reads the slabs.  Against the counter form (atomic add, then spin on
+// the count): one memory round trip less on the critical path — the add had to return before the spin could start.
+// epoch: unique per launch (SoloArgs::bar_base + kSoloWG, the host advances bar_base by kSoloWG per launch).  A thread that waits
+// 2 s gives up and raises *err: the launch then finishes with wrong numbers instead of hanging the queue.
+__device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kSoloWG) {
         const unsigned long long t0 = wall_clock64();                      // 100 MHz
-        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
         }
     }
@@ -344,13 +346,32 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
     if ((tid & 63) == 0) red[64 + (tid >> 6)] = ss;
     __syncthreads();
     float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
-    if (tid == 0) part[b * kSoloPart + 2] = ((red[64] + red[65]) + red[66]) + red[67];
+    // The sixteen partial norms meet through MAILBOXES, not a second grid barrier: workgroup b publishes {its partial, this launch's
+    // epoch} as ONE 64-bit agent-scope atomic store, sixteen threads of every workgroup each poll one mailbox until its epoch is
+    // this launch's.  Nothing but these words is exchanged here, so no release / acquire fence is needed (L2 write-back and
+    // invalidate: most of a grid barrier's 3.3 us — tools/solo_timing.py).  epoch = the barrier target this launch would have used.
+    typedef unsigned long long u64;
+    if (tid == 0) {
+        const float mine = ((red[64] + red[65]) + red[66]) + red[67];
+        __hip_atomic_store((u64*)(part + b * kSoloPart + 2), ((u64)bar2_target << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     SOLO_T(5);
-    solo_grid_sync(s.bar + p, bar2_target, s.err);
+    if (tid < kSoloWG) {
+        const u64* box = (const u64*)(part + tid * kSoloPart + 2);
+        const unsigned long long t0 = wall_clock64();
+        u64 v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((unsigned)(v >> 32) != bar2_target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull) { *s.err = 1; break; }
+            v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        red[80 + tid] = __uint_as_float((unsigned)v);
+    }
+    __syncthreads();
     SOLO_T(6);
     float tot = 0.f;
 #pragma unroll
-    for (int sb = 0; sb < kSoloWG; ++sb) tot += __hip_atomic_load(part + sb * kSoloPart + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sb = 0; sb < kSoloWG; ++sb) tot += red[80 + sb];
     const float total = sqrtf(tot);
     const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     const double bc1 = 1.0 - powi_d((double)a.beta1, u.t_new), bc2 = 1.0 - powi_d((double)a.beta2, u.t_new);

@@ -97,7 +97,7 @@ struct frl_engine {
     float* d_solo_part = nullptr;
     unsigned* d_solo_bar = nullptr;
     int* d_solo_err = nullptr;
-    unsigned solo_bar_base = 0;           // arrivals every counter has seen (2 barriers x kSoloWG per launch)
+    unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
     int solo_stride = 0;
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
@@ -522,9 +522,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
             CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
             float* z = nullptr;
-            CREATE_TRY(dalloc_zero(&z, P + 1, e->stream));
+            CREATE_TRY(dalloc_zero(&z, P * (size_t)kSoloWG + 1, e->stream));
             e->d_solo_bar = (unsigned*)z;
-            e->d_solo_err = (int*)(z + P);
+            e->d_solo_err = (int*)(z + P * (size_t)kSoloWG);
         }
         if (h.wide) {
             CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
@@ -1386,7 +1386,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         if (v2 && h.solo) {                               // kernels_solo.hip: sixteen workgroups per learner, reduce + Adam behind grid barriers
             prof_begin(e, PK_GRAD_CRITIC);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
-            e->solo_bar_base += 2 * kSoloWG;
+            e->solo_bar_base += kSoloWG;
             const size_t lb = (size_t)solo_lds_floats() * sizeof(float);
             if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
             else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
@@ -1424,7 +1424,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         if (v2 && h.solo) {
             prof_begin(e, PK_GRAD_ACTOR);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
-            e->solo_bar_base += 2 * kSoloWG;
+            e->solo_bar_base += kSoloWG;
             hipLaunchKernelGGL(solo_actor_kernel, dim3(pc * kSoloWG), blk, (size_t)solo_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;

@@ -202,9 +202,9 @@ __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs 
 struct SoloArgs {
     float* slab;            // [P][kSoloWG][slab_stride] partial gradients of the net being trained, fragment-image order
     float* part;            // [P][kSoloWG][8] per-workgroup partial sums: 0 loss / Q sum, 1 log-pi sum, 2 squared gradient norm
-    unsigned* bar;          // [P] grid-barrier arrival counters (monotonic; never reset)
+    unsigned* bar;          // [P][kSoloWG] "my slab is written" flags: the epoch of the last launch that wrote it
     int* err;               // [1] set to 1 by a barrier that timed out (a workgroup of the learner never arrived)
-    unsigned bar_base;      // value of bar[p] when this launch starts
+    unsigned bar_base;      // epoch of this launch = bar_base + kSoloWG (the host advances bar_base by kSoloWG per launch)
     int slab_stride;
 };
 __global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);

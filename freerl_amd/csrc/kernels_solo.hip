@@ -79,7 +79,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             // rejection in its own LDS: ~3 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
             // same values to D.idx (the actor stage and frl_last_indices read them)
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
-            draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key);
+            draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key, false);
             ri = lidx[valid ? row : B - 1];
             SOLO_T(8);
         } else {
@@ -170,13 +170,13 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         if (tid == 0) part[b * kSoloPart + 0] = lossp;
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
     u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
     u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG SOLO_TARG);
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float loss = 0.f;
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + p, s.bar_base + kSoloWG, s.err);
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + 2 * kSoloWG SOLO_TARG);
+    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;

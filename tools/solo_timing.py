@@ -37,9 +37,9 @@ def stamps(do_actor):
 
 
 names_c = ["first image staged (+ row fields)", "target actor forward", "target critic heads", "critic heads fwd + bwd -> slab", "grid barrier 1",
-           "slab sum + partial norm", "grid barrier 2", "clip + Adam + soft update"]
+           "slab sum + partial norm", "norm mailboxes", "clip + Adam + soft update"]
 names_a = ["first image staged (+ row fields)", "A: actor forward", "B: critic fwd + dX chain", "C: actor backward -> slab", "grid barrier 1",
-           "slab sum + partial norm", "grid barrier 2", "clip + Adam + soft update"]
+           "slab sum + partial norm", "norm mailboxes", "clip + Adam + soft update"]
 for title, names, do_actor in (("critic stage (last launch of a critic-only call)", names_c, False), ("actor stage", names_a, True)):
     if which != "td3" and not do_actor:
         continue
