@@ -382,15 +382,30 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
 #pragma unroll
         for (int x = 0; x < 2; ++x) { g.g1[x] = f32x4{0.f, 0.f, 0.f, 0.f}; g.g2[x] = g.g1[x]; g.gb1[x] = 0.f; }
         g.gb2 = 0.f;
-        for (int k = 0; k < nsp; ++k) {
-            g_cf sk = as_global(D.slab + ((size_t)p * D.S + k) * D.learner_stride + D.net_off[0]);
+        // every partial in flight at once (nsp <= 4: dqn_split_for), then added in workgroup order: a runtime loop with the adds inside
+        // was one dependent round trip to the memory side per partial — 16 k of this launch's 54 k cycles (tools/dqn2_timing.py 1)
+        {
+            f32x4 s1[4][2], s2[4][2];
+            float sb1[4][2], sb2[4], sl[4];
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                g.g1[x] += ld4(sk + o1[x]); g.g2[x] += ld4(sk + o2[x]);
-                g.gb1[x] += sk[ob1[x]];
+            for (int k = 0; k < 4; ++k) {
+                const int kc = k < nsp ? k : nsp - 1;
+                g_cf sk = as_global(D.slab + ((size_t)p * D.S + kc) * D.learner_stride + D.net_off[0]);
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { s1[k][x] = ld4(sk + o1[x]); s2[k][x] = ld4(sk + o2[x]); sb1[k][x] = sk[ob1[x]]; }
+                sb2[k] = sk[ob2];
+                sl[k] = D.part[((size_t)p * D.S + kc) * 4];
             }
-            g.gb2 += sk[ob2];
-            if (tid == 0) lsum += D.part[((size_t)p * D.S + k) * 4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < nsp) {
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) { g.g1[x] += s1[k][x]; g.g2[x] += s2[k][x]; g.gb1[x] += sb1[k][x]; }
+                    g.gb2 += sb2[k];
+                    if (tid == 0) lsum += sl[k];
+                }
+            }
         }
         if (l != 0) lsum = 0.f;
         if (w != 0) lsum = 0.f;

@@ -607,11 +607,5 @@ FRL_PPO2_KERNEL(ppo_update_v2_k2_relu, 2, ACT_RELU)
 FRL_PPO2_KERNEL(ppo_update_v2_k1_tanh, 1, ACT_TANH)
 FRL_PPO2_KERNEL(ppo_update_v2_k2_tanh, 2, ACT_TANH)
 
-#if defined(FRL_PPO_TIMING) && !defined(FRL_UNITY)
-// (tools/build_ppo_timing.sh: this unit alone carries the stamps; the host unit fetches them through this kernel)
-__global__ void ppo2_clk_copy_kernel(long long* out) {
-    if (threadIdx.x < 16) out[threadIdx.x] = (&g_ppo_clk[0][0])[threadIdx.x];
-}
-#endif
 
 }  // namespace frl
