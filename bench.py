@@ -398,20 +398,41 @@ def main():
         chained, lds, rc = e.learn_path(BATCH)
     e.close()
     if rank == 0:
-        # single-learner latency (P = 1): the reference-compatible drop-in case
-        single = None
+        # single-learner latency (P = 1): the reference's own case — one learn() per env step (TD3.py:403-450).  One learner of this
+        # shape runs kernels_solo.hip (sixteen workgroups per learner, slab sum + Adam behind a grid barrier)
+        single, single_detail = None, None
         if not args.headline_only:
-            e1 = make_engine(N, Engine, 1, local_rank, seed=7)
-            for k in range(10):
-                e1.learn(BATCH, **td3_kwargs(k))
-            e1.sync()
-            t1 = time.perf_counter()
-            n1 = 200
-            for k in range(n1):
-                e1.learn(BATCH, **td3_kwargs(k))
-            e1.sync()
-            single = n1 / (time.perf_counter() - t1)
-            e1.close()
+            single_detail = {"unit": "us per learn(), one learner, asynchronous calls", "batch": BATCH}
+            for name, algo, twin, kw in (("td3", N.ALGO_TD3, True, None), ("ddpg", N.ALGO_DDPG, False, {}),
+                                         ("sac", N.ALGO_SAC, True, dict(alpha_lr=1e-4, target_entropy=-float(ACT)))):
+                if name == "td3":
+                    e1 = make_engine(N, Engine, 1, local_rank, seed=7)
+                else:
+                    e1 = Engine(algo, OBS, ACT, 100_000, n_learners=1, twin_critic=twin, batch_max=BATCH, hidden=HIDDEN, device_id=local_rank, seed=7)
+                    g1 = np.random.default_rng(7)
+                    for net in range(2):
+                        flat = (g1.standard_normal(e1.num_params(net)) * 0.05).astype(np.float32)
+                        e1.set_params(net, flat, N.PARAM_ONLINE); e1.set_params(net, flat, N.PARAM_TARGET)
+                    if algo == N.ALGO_SAC:
+                        e1.set_alpha_state([np.log(0.01), 0, 0, 0.01])
+                    e1.fill_synthetic(100_000, seed=5)
+                call = (lambda k: e1.learn(BATCH, **td3_kwargs(k))) if name == "td3" else \
+                    (lambda k: e1.learn(BATCH, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, **kw))
+                for k in range(20):
+                    call(k)
+                e1.sync()
+                t1 = time.perf_counter()
+                n1 = 1000
+                for k in range(n1):
+                    call(k)
+                e1.sync()
+                dt1 = (time.perf_counter() - t1) / n1
+                path = e1.learn_path(BATCH)
+                single_detail[name] = dt1 * 1e6
+                single_detail["kernel_family"] = "solo: 16 workgroups per learner (kernels_solo.hip)" if path[2] == 16 and path[0] else ("chained" if path[0] else "row-chunk")
+                if name == "td3":
+                    single = 1.0 / dt1
+                e1.close()
         traffic, traffic_stale = traffic_figure()
         line = {
             "metric": "learner_updates_per_sec", "value": total_updates / dt_max, "unit": "updates/s",
@@ -431,7 +452,7 @@ def main():
                                   % (max(200, args.steps), ro_rates[0], ro_rates[len(ro_rates) // 2], ro_rates[-1]),
                         "loop": "act kernel with device-side exploration -> D2H actions -> host env pool step -> staged add "
                                 "(one H2D) -> learn"},
-            "single_learner_updates_per_sec": single,
+            "single_learner_updates_per_sec": single, "single_learner": single_detail,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
                          "kernel": dominant, "avg_launch_ms": launch_s * 1e3,

@@ -1,7 +1,11 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh'
 # kernel trace + stats first, then one --pmc pass per counter group (never combined with other traces).
+# The section-stamp tools need developer variants of the library under tools/_bin/ (not shipped with the product snapshot: build them
+# right before this call and delete them after it):
+#   for v in ppot:-DFRL_PPO_TIMING widet:-DFRL_WIDE_TIMING phase:-DFRL_PHASE_TIMING; do FRL_HIP_VARIANT=${v%%:*} FRL_HIPCC_FLAGS=${v#*:} \
+#       python -c "from freerl_amd import _native as N; N.build(force=True)"; done;  bash tools/build_solo_timing.sh
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
@@ -17,10 +21,16 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   python $R/tools/pmc_summary.py $O/pmc$i $O/pmc$i.json
 done
 python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_kernel
-timeout 300 python $R/tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
-timeout 300 python $R/tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
-timeout 300 python $R/tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
-timeout 300 python $R/tools/ppo_timing.py 256 > $O/ppo_timing.txt 2>&1 < /dev/null
+# the single-learner kernels (kernels_solo.hip): trace + section stamps + the loops
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_solo -- python $R/tools/single_bench.py 1000 > $O/single_bench.txt 2>&1
+cp $(ls $O/stats_solo/*/*kernel_stats.csv | head -1) $O/kernel_stats_single.csv
+cd $R
+for a in td3 ddpg sac; do FRL_HIP_VARIANT=solot timeout 120 python tools/solo_timing.py $a; done > $O/solo_timing.txt 2>&1 < /dev/null
+timeout 300 python tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
+timeout 300 python tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
+timeout 300 python tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
+timeout 300 python tools/ppo_timing.py 256 > $O/ppo_timing.txt 2>&1 < /dev/null
+timeout 300 python tools/dqn2_timing.py 512 > $O/dqn2_timing.txt 2>&1 < /dev/null
 timeout 300 $R/tools/_bin/chain_bench > $O/chain_bench.txt 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ppo -- python $R/tools/ppo_bench.py 256 > $O/stats_ppo.log 2>&1
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
@@ -30,19 +40,14 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $(ls $O/stats_cfg/*/*kernel_stats.csv | head -1) $O/kernel_stats_configs.csv
 cd $R && timeout 300 python tools/config_bench.py 1 512 > $O/config_bench.txt 2>&1
 FRL_CRITIC_V2=0 timeout 300 python tools/config_bench.py C4 C5 h256 512 > $O/config_bench_rowchunk.txt 2>&1
-# the K-sliced chained families' sections (library variant `widet`: -DFRL_WIDE_TIMING, built beforehand so that it travels)
+# the K-sliced chained families' sections (library variant `widet`: -DFRL_WIDE_TIMING)
 for c in sac_c4 maddpg_c5 td3_h256; do timeout 300 python tools/wide_timing.py $c 256 > $O/wide_timing_$c.txt 2>&1 < /dev/null; done
-timeout 300 python tools/wide_timing.py td3_h256 1 > $O/wide_timing_td3_h256_p1.txt 2>&1 < /dev/null
-for c in sac_c4 maddpg_c5 matd3_c5 td3_h256 sac_h256; do timeout 200 python tools/wide_ab.py $c 2; done > $O/wide_ab.txt 2>&1
-timeout 60 tools/_bin/icache > $O/icache_micro.txt 2>&1
 timeout 300 python tools/dqn_bench.py 1 512 2048 4096 > $O/dqn_bench.txt 2>&1
 timeout 300 python tools/ppo_bench.py 1 64 256 > $O/ppo_bench.txt 2>&1
 timeout 600 python tools/rollout_bench.py 1 512 > $O/rollout_bench.txt 2>&1
 timeout 300 python tools/config4_rollout.py 1 8 32 > $O/config4_rollout.txt 2>&1
-timeout 300 python tools/single_bench.py 2000 > $O/single_bench.txt 2>&1 < /dev/null
-FRL_HIP_VARIANT=phase FRL_HIPCC_FLAGS=-DFRL_PHASE_TIMING timeout 200 python tools/phase_timing.py 1 > $O/phase_critic_p1.txt 2>&1 < /dev/null
-timeout 120 tools/_bin/clock_probe > $O/clock_probe.txt 2>&1
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+FRL_CRITIC_V2=0 FRL_HIP_VARIANT=phase FRL_HIPCC_FLAGS=-DFRL_PHASE_TIMING timeout 200 python tools/phase_timing.py 1 > $O/phase_critic_p1.txt 2>&1 < /dev/null
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --spawn --headline-only --steps 10 --warmup 2 > $O/bench_spawn1.json 2> $O/bench_spawn1.err
-rm -rf $O/stats $O/stats_ppo $O/stats_dqn $O/stats_cfg $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
+rm -rf $O/stats $O/stats_solo $O/stats_ppo $O/stats_dqn $O/stats_cfg $O/pmc[0-9]     # keep the summaries only (gpurun_out is size-capped)
 ls -la $O
