@@ -683,8 +683,11 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
         if (tid < 2) fl[tid] = 0;
         lds_barrier();
         const FRL_LDS i32x4* l4 = (const FRL_LDS i32x4*)lidx;
-        const int nfront = min(16 * w, nq);
-        for (unsigned round = 1; round < 64; ++round) {
+        // one round's check.  FULL: batch == 256, every trip count a constant of the wave (the runtime-nq form costs 1.7 us more
+        // per draw in kernels_solo.hip: tools/solo_timing.py)
+        auto is_dup = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const int nfront = FULL ? 16 * w : min(16 * w, nq);
             unsigned m = 1u;
 #pragma unroll 8
             for (int j4 = 0; j4 < nfront; ++j4) {                       // entries of the waves in front of this one: every lane is behind them
@@ -693,7 +696,7 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
             }
 #pragma unroll
             for (int c4 = 0; c4 < 16; ++c4) {                           // this wave's own entries: entry 64 w + c counts for the lanes > c
-                if (16 * w + c4 < nq) {
+                if (FULL || 16 * w + c4 < nq) {
                     const i32x4 v = l4[16 * w + c4];
                     m = min(m, (unsigned)(v.x ^ mine) | (unsigned)(4 * c4 >= l));
                     m = min(m, (unsigned)(v.y ^ mine) | (unsigned)(4 * c4 + 1 >= l));
@@ -701,7 +704,10 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
                     m = min(m, (unsigned)(v.w ^ mine) | (unsigned)(4 * c4 + 3 >= l));
                 }
             }
-            const bool dup = m == 0u && tid < batch;
+            return m == 0u && tid < batch;
+        };
+        for (unsigned round = 1; round < 64; ++round) {
+            const bool dup = batch == kWG ? is_dup(std::true_type{}) : is_dup(std::false_type{});
             if (dup) fl[round & 1] = 1;
             lds_barrier();                                              // everybody has compared against the old values and raised the flag
             if (!fl[round & 1]) break;

@@ -147,6 +147,106 @@ struct SoloNet {
         }
     }
 
+    // ---- forward-ONLY passes (the target nets): the wave's A fragments straight from the net's block in HBM / L2 (fragment-image
+    // order: a lane's 16-byte slot of tile (ot, kb) is one global_load_dwordx4) into registers — no LDS image, no staging barriers —
+    // and NHD heads (the twin target critics) in ONE pass sharing its two layer barriers.  Same MFMA / fma order per accumulator as
+    // forward(): bit-identical outputs.  HN = head outputs the fragments provide for (1: a critic head; 4: an actor, o < hn loaded).
+    template <int HN>
+    struct Frag { f32x4 w1[2], b1[2], b2[2], w2[2][kHT], w3[HN][kHT]; float b3[HN], ls[HN]; };
+    template <int HN>
+    __device__ __forceinline__ Frag<HN> frag_fetch(g_cf th, int hn, int extra_n) const {
+        Frag<HN> F;
+        const int w = C.w, q = C.q, fslot = C.fslot;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int ot = 2 * w + x;
+            F.w1[x] = ld4(th + kL1w + ot * 256 + fslot);
+            F.b1[x] = ld4(th + kL1b + ot * 16 + 4 * q);
+            F.b2[x] = ld4(th + kL2b + ot * 16 + 4 * q);
+#pragma unroll
+            for (int kb = 0; kb < kHT; ++kb) F.w2[x][kb] = ld4(th + kL2w + (ot * kHT + kb) * 256 + fslot);
+        }
+#pragma unroll
+        for (int o = 0; o < HN; ++o) {
+            F.b3[o] = 0.f; F.ls[o] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < kHT; ++kb) F.w3[o][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < hn) {
+#pragma unroll
+                for (int kb = 0; kb < kHT; ++kb) F.w3[o][kb] = ld4(th + kL3w + kb * 256 + ((q * 16 + (o ^ q)) << 2));
+                F.b3[o] = th[kL3b + o];
+                if (o < extra_n) F.ls[o] = th[kHeadFloats + o];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // the loads stay here: a pass ahead of their use
+        return F;
+    }
+    // xb[hd]: the heads' input columns; z[hd][o]: their outputs on every lane of the row.  Exchange buffers: head 0 ea / eb, head 1
+    // th1 / td (free outside a training pass).
+    template <int NHD, int HN>
+    __device__ __forceinline__ void forward_g(const Frag<HN> (&F)[NHD], const f32x4 (&xb)[NHD], f32x4 (&z)[NHD], int hn) const {
+        const int w = C.w, q = C.q;
+        lds_f EA[2] = {ea, th1}, EB[2] = {eb, td};
+#pragma unroll
+        for (int hd = 0; hd < NHD; ++hd)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const f32x4 acc = mfma4(F[hd].b1[x], F[hd].w1[x], xb[hd]);
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[r], 0.f);
+                put_d(EA[hd], 2 * w + x, h);
+            }
+        lds_barrier();
+        f32x4 h1f[NHD][kHT], acc[NHD][2];
+#pragma unroll
+        for (int hd = 0; hd < NHD; ++hd) {
+#pragma unroll
+            for (int kb = 0; kb < kHT; ++kb) h1f[hd][kb] = get_d(EA[hd], kb);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) acc[hd][x] = F[hd].b2[x];
+        }
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int hd = 0; hd < NHD; ++hd)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+                        acc[hd][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(F[hd].w2[x][kb][e], h1f[hd][kb][e], acc[hd][x], 0, 0, 0);
+#pragma unroll
+        for (int hd = 0; hd < NHD; ++hd)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[hd][x][r], 0.f);
+                put_d(EB[hd], 2 * w + x, h);
+            }
+        lds_barrier();
+#pragma unroll
+        for (int hd = 0; hd < NHD; ++hd) {
+            f32x4 h2f[kHT];
+#pragma unroll
+            for (int kb = 0; kb < kHT; ++kb) h2f[kb] = get_d(EB[hd], kb);
+            z[hd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < HN; ++o) {
+                if (o < hn) {
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < kHT; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc1 = fmaf(F[hd].w3[o][kb][r], h2f[kb][r], acc1);
+                    acc1 += __shfl_xor(acc1, 16, 64);
+                    acc1 += __shfl_xor(acc1, 32, 64);
+                    z[hd][o] = acc1 + F[hd].b3[o];
+                }
+            }
+        }
+    }
+
     // sum over the 16 rows of the tile (lanes of one q group): every lane of the group gets it
     __device__ __forceinline__ static float rows_sum(float v) {
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);

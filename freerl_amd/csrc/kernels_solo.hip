@@ -108,7 +108,11 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         SOLO_T(9);
         C.stage_commit(pend);
         SOLO_T(0);
-        pend = C.stage_fetch((g_cf)tgC, 0);
+        // the target critics are forward-only: their fragments go straight from the block into registers (SoloNet::forward_g), both
+        // heads in one pass — in flight under the target actor's pass
+        SoloNet::Frag<1> FC[NH];
+#pragma unroll
+        for (int hd = 0; hd < NH; ++hd) FC[hd] = N.frag_fetch<1>((g_cf)tgC + hd * kHeadFloats, 1, 0);
         // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
         f32x4 h1o[2], h2o[2], h2f[kHT], z, an = {0.f, 0.f, 0.f, 0.f};
         float lp = 0.f;
@@ -134,14 +138,17 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             }
         }
         SOLO_T(1);
-        // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi)
-        float qmin = 0.f;
+        // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi): the twin heads in one pass; the online critic's
+        // first image travels under it
+        pend = C.stage_fetch((g_cf)thC, 0);
+        float qmin;
+        {
+            f32x4 xc[NH], zc[NH];
 #pragma unroll
-        for (int hd = 0; hd < NH; ++hd) {
-            C.stage_commit(pend);
-            pend = hd + 1 < NH ? C.stage_fetch((g_cf)tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
-            N.forward<false>(critic_input(N, sn, an, O, A), h1o, h2o, h2f, z, 1);
-            qmin = hd == 0 ? z[0] : fminf(qmin, z[0]);
+            for (int hd = 0; hd < NH; ++hd) xc[hd] = critic_input(N, sn, an, O, A);
+            N.forward_g<NH, 1>(FC, xc, zc, 1);
+            qmin = zc[0][0];
+            if constexpr (NH == 2) qmin = fminf(qmin, zc[1][0]);
         }
         SOLO_T(2);
         const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);

@@ -22,9 +22,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
 done
 python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_kernel
 # the single-learner kernels (kernels_solo.hip): trace + section stamps + the loops
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_solo -- python $R/tools/single_bench.py 1000 > $O/single_bench.txt 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_solo -- python $R/tools/single_bench.py 1000 > $O/stats_solo.log 2>&1
 cp $(ls $O/stats_solo/*/*kernel_stats.csv | head -1) $O/kernel_stats_single.csv
 cd $R
+timeout 300 python tools/single_bench.py 2000 > $O/single_bench.txt 2>&1 < /dev/null        # (the numbers: without the profiler attached)
 for a in td3 ddpg sac; do FRL_HIP_VARIANT=solot timeout 120 python tools/solo_timing.py $a; done > $O/solo_timing.txt 2>&1 < /dev/null
 timeout 300 python tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
 timeout 300 python tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
