@@ -522,9 +522,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
             CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
             float* z = nullptr;
-            CREATE_TRY(dalloc_zero(&z, P * (size_t)kSoloWG + 1, e->stream));
-            e->d_solo_bar = (unsigned*)z;
-            e->d_solo_err = (int*)(z + P * (size_t)kSoloWG);
+            CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
+            e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
+            e->d_solo_err = (int*)(z + 2 * P * (size_t)kSoloWG);           // the error word, the rollout tail's learner ticket
         }
         if (h.wide) {
             CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
@@ -567,7 +567,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
                        ac_actor_wide_a1_kernel, ac_actor_wide_a2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solo) {
-        const int lb = solo_lds_floats() * (int)sizeof(float);
+        const int lb = std::max(solo_lds_floats(), critic2_lds_floats()) * (int)sizeof(float);      // (critic2: the rollout tail's act_frag_body)
         for (auto k : {solo_critic_twin_kernel, solo_critic_single_kernel, solo_actor_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, critic2_lds_floats() * (int)sizeof(float)));
@@ -991,8 +991,11 @@ struct ActExplore {
     bool device_eps = false;
 };
 
+// build_only: fill *build_only with the launch's arguments and return without launching or consuming a Philox counter (the caller
+// sets rng_counter: frl_rollout's folded step, whose act rides on the learn launches)
 static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_target, int n_rows, int in_dim,
-                      const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev, const ActExplore* ex = nullptr) {
+                      const float* in_dev, const float* eps_dev, float* out_dev, float* logp_dev, const ActExplore* ex = nullptr,
+                      ActArgs* build_only = nullptr) {
     int mode = mode_flags & ~FRL_ACT_NO_OBSNORM;
     if (!e->has_nets) return fail(FRL_ERR_STATE, "replay-only engine has no networks");
     if (net < 0 || net >= e->h.n_nets) return fail(FRL_ERR_INVALID, "net %d out of range", net);
@@ -1019,12 +1022,13 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
         a.epsilon = x.epsilon; a.sigma = x.sigma; a.scale0 = x.scale; a.max_action = x.max_action != 0.f ? x.max_action : 1.f;
         a.ou_theta = x.ou_theta; a.ou_sigma = x.ou_sigma; a.ou_dt = x.ou_dt;
         a.scale = ex->scale_dev; a.ou_state = ex->ou_state_dev; a.flags = ex->flags_dev; a.env_out = ex->env_out_dev;
-        a.rng_counter = e->rng_counter++;
+        if (!build_only) a.rng_counter = e->rng_counter++;
     }
     a.net = net; a.use_target = use_target; a.mode = mode; a.n_rows = n_rows; a.head = head; a.in_dim = in_dim;
     const int agent = e->h.n_agents > 1 ? net / 2 : 0;            // MADDPG: only the actors (even nets) take a single agent's obs
     a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
+    if (build_only) { *build_only = a; return FRL_OK; }
     if (N.frag && e->h.wide) {
         // fragment-image parameters of a shape act_frag_kernel does not take: the net is re-laid out to Wk in a scratch copy (one
         // small launch: the actor of config 4 is 67 k floats per learner) and act_kernel reads that
@@ -1340,7 +1344,7 @@ static bool dqn_fused_path(const EngineDesc& h, int batch, bool per_weights) {
 }
 
 static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int stage, int p0, int pc, bool dev_rng, bool needs_noise,
-                               const DqnStepArgs* step = nullptr) {
+                               const DqnStepArgs* step = nullptr, const SoloStepArgs* sstep = nullptr) {
     const EngineDesc& h = e->h;
     a.p0 = p0; a.p_count = pc;
     const int ns = ((a.batch + h.rc - 1) / h.rc + h.cps - 1) / h.cps;      // workgroups (= slabs) per unit
@@ -1387,9 +1391,12 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_begin(e, PK_GRAD_CRITIC);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
             e->solo_bar_base += kSoloWG;
-            const size_t lb = (size_t)solo_lds_floats() * sizeof(float);
-            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
-            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa);
+            SoloStepArgs ss;
+            memset(&ss, 0, sizeof ss);
+            if (sstep) ss = *sstep;
+            const size_t lb = (size_t)std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float);
+            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa, ss);
+            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa, ss);
             prof_end(e);
             return;
         }
@@ -1425,7 +1432,10 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_begin(e, PK_GRAD_ACTOR);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
             e->solo_bar_base += kSoloWG;
-            hipLaunchKernelGGL(solo_actor_kernel, dim3(pc * kSoloWG), blk, (size_t)solo_lds_floats() * sizeof(float), st, e->d, a, sa);
+            SoloStepArgs ss;
+            memset(&ss, 0, sizeof ss);
+            if (sstep) ss = *sstep;
+            hipLaunchKernelGGL(solo_actor_kernel, dim3(pc * kSoloWG), blk, (size_t)std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float), st, e->d, a, sa, ss);
             prof_end(e);
             return;
         }
@@ -1450,7 +1460,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
 }
 
 // `step` (frl_rollout only, DQN engines on the fused path): the vector step's add() and the next select_action in the same launch
-static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step) {
+static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step, const SoloStepArgs* sstep = nullptr) {
     ENG(e);
     if (!args) return fail(FRL_ERR_INVALID, "args is NULL");
     const EngineDesc& h = e->h;
@@ -1509,6 +1519,18 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         const int first = a.double_dqn ? 0 : 1;
         if (args->noisy_eps) { rc = noisy_upload(e, args->noisy_eps, first, 3 - first); if (rc) return rc; }
         else hipLaunchKernelGGL(noisy_draw_kernel, dim3(h.P, 3), dim3(256), 0, e->stream, e->d, 0, 3, e->rng_counter++);
+    }
+    if (sstep) {
+        // frl_rollout on a solo engine: the step's add() rides at the head of the critic launch, its tail (obs advance + the next
+        // select_action + hand-over) at the end of the step's LAST launch
+        if (!(h.solo && chained_path(h, a.batch, h.P)) || !dev_rng) return fail(FRL_ERR_STATE, "step fusion needs a solo engine with device draws");
+        SoloStepArgs s0 = *sstep, s1 = *sstep;
+        s0.head = 1; s0.tail = actor_stage ? 0 : 1;
+        s1.head = 0; s1.tail = 1;
+        launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise, nullptr, &s0);
+        if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise, nullptr, &s1);
+        HIP_TRY(hipGetLastError());
+        return FRL_OK;
     }
     launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise, step);
     if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise);

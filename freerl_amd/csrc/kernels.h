@@ -207,9 +207,23 @@ struct SoloArgs {
     unsigned bar_base;      // epoch of this launch = bar_base + kSoloWG (the host advances bar_base by kSoloWG per launch)
     int slab_stride;
 };
-__global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
-__global__ void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
-__global__ void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+// The rollout loop's step folded into these launches (frl_rollout; what dqn_fused_kernel does for DQN): `head` — Buffer.add of the
+// vector step's transitions at the start of the critic launch (every workgroup of the learner writes the same ring rows: it
+// samples from them next) — and `tail` — at the end of the step's LAST launch: the device copy of the current observations moves
+// on to obs_next, select_action + the exploration rule run on it (kernels_act.hip's own act_frag_body: the same draws, bit for
+// bit, as the separate act launch), the env actions land in host memory and a host-visible word is flagged.
+struct SoloStepArgs {
+    int head, tail, act;          // act: the tail also selects the next actions (0 on a rollout call's last step)
+    CommitArgs c;                 // c.obs_cur / store_act / row / next_obs / obs_next / reward / flags, n = P * E
+    ActArgs act_args;             // as launch_act would have built them for the separate launch (in = c.obs_cur)
+    int* ticket;                  // [1] learners that have finished their tail (zero between launches)
+    int* done_flag;               // host-visible word (or nullptr): set to done_value once every learner's env actions are out
+    int done_value;
+    unsigned* bar2;               // [P][kSoloWG] "my slice of the actor is stepped" flags (the tail reads the whole actor)
+};
+__global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
+__global__ void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
+__global__ void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }

@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "device/solo.hpp"
 #include "device/rng.hpp"
+#include "device/act_common.hpp"
 
 namespace frl {
 
@@ -35,10 +36,55 @@ __device__ __forceinline__ f32x4 critic_input(const SoloNet& N, const f32x4& ob,
     return x;
 }
 
+// Buffer.add of the vector step (replay_commit_kernel's ring writes, without its obs_cur update: that is the tail's): a 16-lane group
+// per env of learner p.  Ends with a draining barrier: the gathers behind the draw may read these rows.
+__device__ __forceinline__ void solo_step_head(const EngineDesc& D, const SoloStepArgs& st, int p) {
+    const CommitArgs& c = st.c;
+    const RecordDesc& R = D.rec;
+    const int lane = threadIdx.x & 15;
+    for (int j = threadIdx.x >> 4; j < c.E; j += kWG / 16) {
+        const size_t i = (size_t)p * c.E + j;
+        g_f r = as_global(D.replay + ((size_t)p * D.capacity + c.row[i]) * R.stride);
+        const unsigned char fl = c.flags[i];
+        for (int k = lane; k < c.O; k += 16) {
+            r[R.obs_off[0] + k] = c.obs_cur[i * c.O + k];
+            r[R.nobs_off[0] + k] = c.next_obs[i * c.O + k];
+        }
+        for (int k = lane; k < c.aout; k += 16) r[R.act_off[0] + k] = c.store_act[i * c.aout + k];
+        if (lane == 0) { r[R.rew_off] = c.reward[i]; r[R.done_off] = (fl & 1) ? 1.f : 0.f; }
+    }
+    __syncthreads();
+}
+
+// The step's tail, workgroup 0 of learner p, behind whatever made the actor's parameters final: obs_cur <- obs_next, then
+// select_action + exploration on it (act_frag_body re-carves the workgroup's LDS: everything else of this launch is done), then
+// the hand-over to the host once every learner of the launch is through.
+__device__ __forceinline__ void solo_step_tail(const EngineDesc& D, const LearnArgs& a, const SoloStepArgs& st, float* smem, int p) {
+    const CommitArgs& c = st.c;
+    __syncthreads();
+    for (int e = threadIdx.x; e < c.E * c.O; e += kWG) c.obs_cur[(size_t)p * c.E * c.O + e] = c.obs_next[(size_t)p * c.E * c.O + e];
+    __syncthreads();
+    if (!st.act) return;
+    for (int r0 = 0; r0 < c.E; r0 += 64) {
+        act_frag_body(D, st.act_args, smem, p, r0);
+        __syncthreads();
+    }
+    if (st.done_flag) {
+        __threadfence_system();                                        // this learner's actions are out; the last learner to get here flags the host
+        if (threadIdx.x == 0) {
+            if (atomicAdd(st.ticket, 1) == a.p_count - 1) {
+                *st.ticket = 0;
+                __threadfence_system();
+                __hip_atomic_store(st.done_flag, st.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 template <bool TWIN>
-__device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
+__device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, const SoloStepArgs& st, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
     const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
     const RecordDesc& R = D.rec;
@@ -62,6 +108,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
     SOLO_T0();
+    if (st.head) solo_step_head(D, st, p);             // (every workgroup, also the ones without rows: they all pass the same barriers)
 
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
@@ -189,23 +236,26 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         float loss = 0.f;
         for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         steps[1] = t_new;
-        float* st = D.stats + (size_t)p * ST_COUNT;
-        st[ST_CRITIC_LOSS] = loss * invB;
-        st[ST_CRITIC_GNORM] = total;
+        float* sts = D.stats + (size_t)p * ST_COUNT;
+        sts[ST_CRITIC_LOSS] = loss * invB;
+        sts[ST_CRITIC_GNORM] = total;
     }
+    // the rollout step's tail when no actor stage follows (the actor is unchanged: nothing to wait for; every workgroup's reads of
+    // obs_cur / store_act in the head lie in front of the slab hand-over above)
+    if (st.tail && b == 0) solo_step_tail(D, a, st, smem, p);
 }
 
-__global__ __launch_bounds__(256) void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+__global__ __launch_bounds__(256) void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    solo_critic_body<true>(*Dp, a, s, smem);
+    solo_critic_body<true>(*Dp, a, s, st, smem);
 }
-__global__ __launch_bounds__(256) void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+__global__ __launch_bounds__(256) void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    solo_critic_body<false>(*Dp, a, s, smem);
+    solo_critic_body<false>(*Dp, a, s, st, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------- actor stage
-__global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {
+__global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const EngineDesc& D = *Dp;
     const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
@@ -357,9 +407,9 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
             lptot += __hip_atomic_load(part + k * kSoloPart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         steps[0] = t_new;
-        float* st = D.stats + (size_t)p * ST_COUNT;
-        st[ST_ACTOR_LOSS] = sac ? (-(qtot * 0.5f) + alpha * lptot) * invB : -qtot * invB;   // SAC.py:251: (alpha log pi - Q).mean()
-        st[ST_ACTOR_GNORM] = total;
+        float* sts = D.stats + (size_t)p * ST_COUNT;
+        sts[ST_ACTOR_LOSS] = sac ? (-(qtot * 0.5f) + alpha * lptot) * invB : -qtot * invB;   // SAC.py:251: (alpha log pi - Q).mean()
+        sts[ST_ACTOR_GNORM] = total;
         if (sac) {                                                         // alpha step on the batch's entropy (SAC.py:154-169,257-260)
             float* al = D.alpha + p * 4;
             const float ent_mean = -lptot * invB;
@@ -376,10 +426,16 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
             al[2] = vi;
             al[3] = expf(al[0]);
             steps[kMaxNets] = ta;
-            st[ST_ALPHA_LOSS] = alpha * mean_term;
-            st[ST_ALPHA] = al[3];
-            st[ST_ENTROPY] = ent_mean;
+            sts[ST_ALPHA_LOSS] = alpha * mean_term;
+            sts[ST_ALPHA] = al[3];
+            sts[ST_ENTROPY] = ent_mean;
         }
+    }
+    // the rollout step's tail: the next select_action reads the WHOLE stepped actor, sixteen workgroups' slices of it — a second
+    // flag hand-over (its own flag words; same epoch) in front of workgroup 0's act
+    if (st.tail) {
+        solo_grid_sync(st.bar2 + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
+        if (b == 0) solo_step_tail(D, a, st, smem, p);
     }
 }
 

@@ -279,3 +279,45 @@ def test_dqn_rollout_one_launch_per_step_matches_the_separate_launches(N, monkey
         np.testing.assert_array_equal(a[4][p], b[4][p])
         assert a[5][p] == b[5][p]
     assert a[0]["return_sum"] == b[0]["return_sum"] and a[1]["episodes"] == b[1]["episodes"]
+
+
+@pytest.mark.parametrize("algo,P,Ev,every,freq,handover", [
+    ("td3", 1, 1, 1, 2, "flag"), ("td3", 3, 2, 1, 2, "flag"), ("td3", 2, 5, 1, 1, "sync"), ("ddpg", 1, 70, 1, 1, "flag"), ("sac", 2, 3, 1, 1, "flag"),
+    ("td3", 2, 2, 3, 2, "flag"), ("sac", 1, 4, 2, 1, "memcpy"), ("td3", 8, 1, 1, 2, "flag")])
+def test_solo_rollout_folded_step_matches_the_separate_launches(N, monkeypatch, algo, P, Ev, every, freq, handover):
+    """frl_rollout on a single-learner engine (kernels_solo.hip) folds add() into the head of the critic launch and the next
+    select_action + exploration into the tail of the step's last launch (the actor launch on policy steps, behind a second flag
+    hand-over; the critic launch otherwise).  FRL_SOLO_STEP_FUSE=0 runs the separate commit / learn / act launches on the same Philox
+    counters; the tail IS act_frag_kernel's body, so rings, parameters, targets and returns must agree bit for bit."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    if handover == "sync":
+        monkeypatch.setenv("FRL_ROLLOUT_POLL", "0")
+    if handover == "memcpy":
+        monkeypatch.setenv("FRL_ROLLOUT_ZEROCOPY", "0")
+    aid = dict(td3=N.ALGO_TD3, ddpg=N.ALGO_DDPG, sac=N.ALGO_SAC)[algo]
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("FRL_SOLO_STEP_FUSE", fuse)
+        e = Engine(aid, 8, 2, 16384, twin_critic=algo != "ddpg", batch_max=32, n_learners=P, seed=11)
+        assert e.learn_path(32) == (True, 117376, 16)
+        _rand_params(e, N, 0.3, seed=12)
+        if algo == "sac":
+            for p in range(P):
+                e.set_alpha_state([np.log(0.05), 0, 0, 0.05], learner=p)
+        pool = EnvPool("SynLinear-v0", P * Ev, n_threads=1, seed=5)
+        kw = dict(envs_per_learner=Ev, start_steps=64, learn_every=every, batch=32, actor_lr=1e-3, critic_lr=1e-3, tau=0.05, policy_freq=freq)     # (learn from 65 rows on)
+        o1 = rollout(e, pool, 90, **kw)
+        o2 = rollout(e, pool, 35, **kw)                     # a second call: starts with a separate act launch again
+        rows = [e.read_rows(p, 0, min(16384, 125 * Ev)) for p in range(P)]
+        par = [np.concatenate([e.get_params(net, kind, learner=p) for net in (0, 1) for kind in (N.PARAM_ONLINE, N.PARAM_TARGET, N.PARAM_ADAM_M)]) for p in range(P)]
+        res.append((o1, o2, rows, par, [(e.opt_step(0, learner=p), e.opt_step(1, learner=p)) for p in range(P)]))
+        pool.close(); e.close()
+    a, b = res
+    assert a[0]["updates"] == b[0]["updates"] > 0 and a[1]["updates"] == b[1]["updates"] == (35 // every) * P
+    for p in range(P):
+        np.testing.assert_array_equal(a[2][p], b[2][p])
+        np.testing.assert_array_equal(a[3][p], b[3][p])
+        assert a[4][p] == b[4][p]
+    assert a[0]["return_sum"] == b[0]["return_sum"] and a[1]["episodes"] == b[1]["episodes"]
