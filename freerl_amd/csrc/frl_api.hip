@@ -1460,7 +1460,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
 }
 
 // `step` (frl_rollout only, DQN engines on the fused path): the vector step's add() and the next select_action in the same launch
-static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step, const SoloStepArgs* sstep = nullptr) {
+// size_override >= 0: the rings' common size WHEN THE LAUNCH RUNS (a pre-armed launch of frl_rollout is enqueued before the step's rows
+// are counted in e->size)
+static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step, const SoloStepArgs* sstep = nullptr, int size_override = -1) {
     ENG(e);
     if (!args) return fail(FRL_ERR_INVALID, "args is NULL");
     const EngineDesc& h = e->h;
@@ -1469,6 +1471,7 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
     if (args->batch < 1 || args->batch > h.batch_max) return fail(FRL_ERR_INVALID, "batch %d outside [1,%d]", args->batch, h.batch_max);
     int min_size = h.capacity;
     for (int p = 0; p < h.P; ++p) min_size = std::min(min_size, e->size[p]);
+    if (size_override >= 0) min_size = size_override;
     if (min_size < args->batch) return fail(FRL_ERR_STATE, "a ring holds %d rows < batch %d", min_size, args->batch);
     if (args->per && (h.algo != ALGO_DQN || !e->per_on)) return fail(FRL_ERR_STATE, "per = 1 needs a DQN engine with frl_per_enable");
     if (args->per && args->idx) return fail(FRL_ERR_INVALID, "per = 1 uses the rows of the last frl_per_sample; idx must be NULL");

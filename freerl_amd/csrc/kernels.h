@@ -245,6 +245,11 @@ struct DqnStepArgs {
     unsigned long long act_counter;   // Philox counter of the act draw (act_kernel's stream 0x9000)
     int* done_flag;               // host-visible word (or nullptr): set to done_value once env_out is written, so that the
     int done_value;               // host can pick the actions up without waiting for the launch to retire
+    // PRE-ARMED launch (frl_rollout, small populations): the launch is enqueued a vector step AHEAD, stages both nets and then spins on
+    // this host-visible word until the host — env stepped, block filled — sets it to go_value: the launch latency and the weight
+    // staging run under the host's turn.  -1 in the word: the host gave the step up, the launch returns without touching anything.
+    const int* go_flag;
+    int go_value;
 };
 __global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s);
 

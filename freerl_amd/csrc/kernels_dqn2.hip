@@ -153,6 +153,25 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     // the select_action at the end.
     PPO_T0();
     const Dqn2::StageRegs so = C.stage_load(th, L1, L2), stg = C.stage_load(tg, L1, L2);
+    if (s.go_flag) {
+        // pre-armed: the images go to LDS now, the step's block is not there yet — wait for the host's doorbell (2 s, then give up)
+        C.stage_store(0, so);
+        C.stage_store(1, stg);
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int v = __hip_atomic_load(s.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            while (v != s.go_value && v != -1) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
+                v = __hip_atomic_load(s.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            S.lidx[0] = v;
+        }
+        __syncthreads();
+        const int go = S.lidx[0];
+        __syncthreads();
+        if (go != s.go_value) return;
+    }
     if (s.commit) {
         g_f wring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         const int lane = tid & 15;
@@ -169,8 +188,10 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             if (j < 64) S.onx[j * 16 + lane] = on;
         }
     }
-    C.stage_store(0, so);
-    C.stage_store(1, stg);
+    if (!s.go_flag) {
+        C.stage_store(0, so);
+        C.stage_store(1, stg);
+    }
     PPO_T(1);
     // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones).  The barriers inside wait
     // for the stores above: the gathers below may read the rows just added.
