@@ -220,6 +220,8 @@ struct SoloStepArgs {
     int* done_flag;               // host-visible word (or nullptr): set to done_value once every learner's env actions are out
     int done_value;
     unsigned* bar2;               // [P][kSoloWG] "my slice of the actor is stepped" flags (the tail reads the whole actor)
+    const int* go_flag;           // pre-armed launch (DqnStepArgs::go_flag): the critic launch stages its first image, then spins on this
+    int go_value;                 // host-visible word until it holds go_value (-1: the host gave the step up, nothing is touched)
 };
 __global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
 __global__ void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);

@@ -108,6 +108,25 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
     SOLO_T0();
+    bool staged_early = false;
+    if (st.go_flag) {
+        // pre-armed (frl_rollout): enqueued a vector step ahead.  The first image is staged now; the step's block is not there yet —
+        // every workgroup waits for the host's doorbell (2 s, then gives up: a launch that returns here has touched nothing; the
+        // actor launch queued behind it sees the same word)
+        if (b < nb) { C.stage_commit(C.stage_fetch(tgA, 0, NA.extra_n)); staged_early = true; }
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int v = __hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            while (v != st.go_value && v != -1) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
+                v = __hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            N.red[100] = __int_as_float(v);
+        }
+        __syncthreads();
+        if (__float_as_int(N.red[100]) != st.go_value) return;
+    }
     if (st.head) solo_step_head(D, st, p);             // (every workgroup, also the ones without rows: they all pass the same barriers)
 
     if (b < nb) {
@@ -118,7 +137,8 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         const int row = 16 * b + i16;
         const bool valid = row < B;
         // the first image travels while the indices are drawn and the row's fields fetched
-        ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        ChainNet::StageRegs pend;
+        if (!staged_early) pend = C.stage_fetch(tgA, 0, NA.extra_n);
         int ri;
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
         if (a.device_rng) {
@@ -153,7 +173,8 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         }
         const float rew = rec[R.rew_off], done = rec[R.done_off];
         SOLO_T(9);
-        C.stage_commit(pend);
+        if (!staged_early) C.stage_commit(pend);
+        else lds_barrier();                                            // (ea held the drawn indices: every wave has read its rows')
         SOLO_T(0);
         // the target critics are forward-only: their fragments go straight from the block into registers (SoloNet::forward_g), both
         // heads in one pass — in flight under the target actor's pass
@@ -282,6 +303,11 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
     SOLO_T0();
+    if (st.go_flag) {                                                      // (pre-armed step: the critic launch in front of this one waited for the doorbell; -1 = given up)
+        if (tid == 0) N.red[100] = __int_as_float(__hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        __syncthreads();
+        if (__float_as_int(N.red[100]) != st.go_value) return;
+    }
 
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
