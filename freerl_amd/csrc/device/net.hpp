@@ -659,7 +659,7 @@ __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta
 // Draw `batch` distinct row indices in [0,size) into idx (global, this learner's slice) using
 // `lidx` (LDS) for the duplicate check: rejection keeps the draw uniform over subsets, like
 // np.random.choice(size, batch, replace=False) (DQN.py:97): the LATER of two equal entries is redrawn, round by round.
-// lidx: 2 * round_up(batch, 4) ints of LDS.  Returns with lidx[0 .. batch) final behind a barrier.
+// lidx: 2 * round_up(batch, 4) ints of LDS.  Returns with lidx[0 .. batch) final behind a barrier.  idx == nullptr: LDS only.
 //
 // batch <= 256 (one entry per thread; every config but MADDPG's 1024): the duplicate check is the cost — a batch of 256 from a
 // 5e4-row ring collides in two calls of three, so two rounds are the rule.  Wave w reads the entries of waves 0 .. w (broadcast
@@ -718,7 +718,7 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
             }
             lds_barrier();
         }
-        if (tid < batch) idx[tid] = mine;
+        if (idx && tid < batch) idx[tid] = mine;
         if (drain) __syncthreads();   // (as the general path: callers count on it to have drained the workgroup's earlier global stores too)
         return;
     }
@@ -758,7 +758,7 @@ __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int bat
                                              (unsigned)size);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < batch; i += kWG) idx[i] = lidx[i];
+    if (idx) for (int i = threadIdx.x; i < batch; i += kWG) idx[i] = lidx[i];
     __syncthreads();
 }
 

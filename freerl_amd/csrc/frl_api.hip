@@ -1462,7 +1462,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
 // `step` (frl_rollout only, DQN engines on the fused path): the vector step's add() and the next select_action in the same launch
 // size_override >= 0: the rings' common size WHEN THE LAUNCH RUNS (a pre-armed launch of frl_rollout is enqueued before the step's rows
 // are counted in e->size)
-static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step, const SoloStepArgs* sstep = nullptr, int size_override = -1) {
+static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepArgs* step, const SoloStepArgs* sstep = nullptr, int size_override = -1,
+                      hipStream_t stream_override = nullptr) {
     ENG(e);
     if (!args) return fail(FRL_ERR_INVALID, "args is NULL");
     const EngineDesc& h = e->h;
@@ -1523,6 +1524,7 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         if (args->noisy_eps) { rc = noisy_upload(e, args->noisy_eps, first, 3 - first); if (rc) return rc; }
         else hipLaunchKernelGGL(noisy_draw_kernel, dim3(h.P, 3), dim3(256), 0, e->stream, e->d, 0, 3, e->rng_counter++);
     }
+    hipStream_t lst = stream_override ? stream_override : e->stream;      // (frl_rollout's pre-armed launches: the pool's second stream)
     if (sstep) {
         // frl_rollout on a solo engine: the step's add() rides at the head of the critic launch, its tail (obs advance + the next
         // select_action + hand-over) at the end of the step's LAST launch
@@ -1530,14 +1532,14 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         SoloStepArgs s0 = *sstep, s1 = *sstep;
         s0.head = 1; s0.tail = actor_stage ? 0 : 1;
         s1.head = 0; s1.tail = 1;
-        launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise, nullptr, &s0);
-        if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise, nullptr, &s1);
+        launch_learn_stage(e, lst, a, 0, 0, h.P, dev_rng, needs_noise, nullptr, &s0);
+        if (actor_stage) launch_learn_stage(e, lst, a, 1, 0, h.P, dev_rng, needs_noise, nullptr, &s1);
         HIP_TRY(hipGetLastError());
         return FRL_OK;
     }
-    launch_learn_stage(e, e->stream, a, 0, 0, h.P, dev_rng, needs_noise, step);
-    if (actor_stage) launch_learn_stage(e, e->stream, a, 1, 0, h.P, dev_rng, needs_noise);
-    if (soft_stage) launch_learn_stage(e, e->stream, a, 2, 0, h.P, dev_rng, needs_noise);
+    launch_learn_stage(e, lst, a, 0, 0, h.P, dev_rng, needs_noise, step);
+    if (actor_stage) launch_learn_stage(e, lst, a, 1, 0, h.P, dev_rng, needs_noise);
+    if (soft_stage) launch_learn_stage(e, lst, a, 2, 0, h.P, dev_rng, needs_noise);
     HIP_TRY(hipGetLastError());
     if (args->stats_out) return frl_stats_get(e, args->stats_out);
     return FRL_OK;

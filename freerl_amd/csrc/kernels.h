@@ -220,8 +220,10 @@ struct SoloStepArgs {
     int* done_flag;               // host-visible word (or nullptr): set to done_value once every learner's env actions are out
     int done_value;
     unsigned* bar2;               // [P][kSoloWG] "my slice of the actor is stepped" flags (the tail reads the whole actor)
-    const int* go_flag;           // pre-armed launch (DqnStepArgs::go_flag): the critic launch stages its first image, then spins on this
-    int go_value;                 // host-visible word until it holds go_value (-1: the host gave the step up, nothing is touched)
+    const int* go_flag;           // pre-armed launch (DqnStepArgs::go_flag; on the pool's second stream): the critic launch draws its rows, waits
+    int go_value;                 // until dev_cnt has reached dev_wait (every workgroup of the step in front has left), stages its first image, then
+    int* dev_cnt;                 // spins on this host-visible word until it holds go_value (-1: the host gave the step up, nothing is touched).
+    int dev_wait;                 // dev_cnt: device word (or nullptr) every workgroup of a folded step's launches adds one to on its way out
 };
 __global__ void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
 __global__ void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
@@ -247,11 +249,16 @@ struct DqnStepArgs {
     unsigned long long act_counter;   // Philox counter of the act draw (act_kernel's stream 0x9000)
     int* done_flag;               // host-visible word (or nullptr): set to done_value once env_out is written, so that the
     int done_value;               // host can pick the actions up without waiting for the launch to retire
-    // PRE-ARMED launch (frl_rollout, small populations): the launch is enqueued a vector step AHEAD, stages both nets and then spins on
-    // this host-visible word until the host — env stepped, block filled — sets it to go_value: the launch latency and the weight
-    // staging run under the host's turn.  -1 in the word: the host gave the step up, the launch returns without touching anything.
+    // PRE-ARMED launch (frl_rollout, small populations): the launch is enqueued a vector step AHEAD on the pool's second stream, so it
+    // starts while the previous step's launch is still running: it draws the batch's rows (launch arguments only), waits on the DEVICE
+    // word dev_done for the previous launch's done_value (that launch's parameters are final), stages both nets, then spins on the
+    // host-visible word go_flag until the host — env stepped, block filled — sets it to go_value: launch latency, the gap between two
+    // launches of a stream, the draw and the weight staging all run under the previous launch and the host's turn.  -1 in go_flag: the
+    // host gave the step up, the launch returns without having touched anything.
     const int* go_flag;
     int go_value;
+    int* dev_done;                // device word (or nullptr): set to done_value together with done_flag
+    int dev_wait;                 // pre-armed: the done_value of the launch in front
 };
 __global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s);
 

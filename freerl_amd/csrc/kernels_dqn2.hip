@@ -152,25 +152,44 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     // writes the same rows (it samples from them next, and its own stores are the ones it sees); obs_next is kept in LDS for
     // the select_action at the end.
     PPO_T0();
-    const Dqn2::StageRegs so = C.stage_load(th, L1, L2), stg = C.stage_load(tg, L1, L2);
+    Dqn2::StageRegs so, stg;
     if (s.go_flag) {
-        // pre-armed: the images go to LDS now, the step's block is not there yet — wait for the host's doorbell (2 s, then give up)
+        // pre-armed, on its own stream behind nothing: the previous step's launch may still be running.  The batch's rows depend on the
+        // launch's arguments only (ring size after this step's add, Philox counter): drawn now, into LDS.  Then the previous launch's
+        // device word (its parameters are final: release there, acquire here), the images, and the host's doorbell (2 s each, then give up)
+        if (a.device_rng) draw_indices((g_i) nullptr, S.lidx, B, a.size, a.rng_counter, 0u, key);
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int v = __hip_atomic_load(s.dev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (v - s.dev_wait < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ull) break;
+                v = __hip_atomic_load(s.dev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            S.red[21] = __int_as_float(v - s.dev_wait < 0 ? 0 : 1);
+        }
+        __syncthreads();
+        if (__float_as_int(S.red[21]) == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // (the polls are relaxed: one invalidate here, not one per poll)
+        so = C.stage_load(th, L1, L2); stg = C.stage_load(tg, L1, L2);
         C.stage_store(0, so);
         C.stage_store(1, stg);
         if (tid == 0) {
             const unsigned long long t0 = wall_clock64();
-            int v = __hip_atomic_load(s.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            int v = __hip_atomic_load(s.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             while (v != s.go_value && v != -1) {
                 __builtin_amdgcn_s_sleep(4);
                 if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
-                v = __hip_atomic_load(s.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = __hip_atomic_load(s.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            S.lidx[0] = v;
+            S.red[20] = __int_as_float(v);
         }
         __syncthreads();
-        const int go = S.lidx[0];
-        __syncthreads();
-        if (go != s.go_value) return;
+        if (__float_as_int(S.red[20]) != s.go_value) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (a.device_rng && tid < B) idx[tid] = S.lidx[tid];            // (frl_last_indices; B <= 256 on this kernel)
+    } else {
+        so = C.stage_load(th, L1, L2); stg = C.stage_load(tg, L1, L2);
     }
     if (s.commit) {
         g_f wring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
@@ -195,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     PPO_T(1);
     // ---- sample(): the batch's row indices (every workgroup of the learner draws the same ones).  The barriers inside wait
     // for the stores above: the gathers below may read the rows just added.
-    if (a.device_rng) {
+    if (a.device_rng && s.go_flag) {
+        __syncthreads();                                               // (drawn in front of the doorbell; the rows just added are stored)
+    } else if (a.device_rng) {
         draw_indices(idx, S.lidx, B, a.size, a.rng_counter, 0u, key);
     } else {
         for (int i = tid; i < B; i += kWG) S.lidx[i] = idx[i];
@@ -527,10 +548,11 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         __syncthreads();                                               // every wave's env_out stores have been issued and counted down
         if (tid == 0) {
             __threadfence_system();                                    // this learner's actions are out; the last learner to get here flags the host
-            if (atomicAdd(D.ticket + D.P, 1) == a.p_count - 1) {
-                D.ticket[D.P] = 0;
-                __threadfence_system();
-                __hip_atomic_store(s.done_flag, s.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (one learner: it is the last one — no ticket round trip)
+            if (a.p_count == 1 || atomicAdd(D.ticket + D.P, 1) == a.p_count - 1) {
+                if (a.p_count > 1) { D.ticket[D.P] = 0; __threadfence_system(); }
+                __hip_atomic_store(s.done_flag, s.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // (the host first: it is the one waited for)
+                if (s.dev_done) __hip_atomic_store(s.dev_done, s.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

@@ -72,12 +72,22 @@ __device__ __forceinline__ void solo_step_tail(const EngineDesc& D, const LearnA
     if (st.done_flag) {
         __threadfence_system();                                        // this learner's actions are out; the last learner to get here flags the host
         if (threadIdx.x == 0) {
-            if (atomicAdd(st.ticket, 1) == a.p_count - 1) {
-                *st.ticket = 0;
-                __threadfence_system();
+            if (a.p_count == 1 || atomicAdd(st.ticket, 1) == a.p_count - 1) {     // (one learner: no ticket round trip)
+                if (a.p_count > 1) { *st.ticket = 0; __threadfence_system(); }
                 __hip_atomic_store(st.done_flag, st.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
+}
+
+// a folded step's workgroup on its way out: its parameter slices, flags and mailboxes are written — the next step's pre-armed critic
+// launch (other stream) counts the workgroups of this step before it reads any of them
+__device__ __forceinline__ void solo_leave(const SoloStepArgs& st) {
+    if (!st.dev_cnt) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(st.dev_cnt, 1);
     }
 }
 
@@ -104,29 +114,48 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     g_f mC = as_global(D.m + lbase + D.net_off[1]);
     g_f vC = as_global(D.v + lbase + D.net_off[1]);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
     float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
     SOLO_T0();
-    bool staged_early = false;
+    bool drawn_early = false;
+    int ri_early = 0;
     if (st.go_flag) {
-        // pre-armed (frl_rollout): enqueued a vector step ahead.  The first image is staged now; the step's block is not there yet —
-        // every workgroup waits for the host's doorbell (2 s, then gives up: a launch that returns here has touched nothing; the
-        // actor launch queued behind it sees the same word)
-        if (b < nb) { C.stage_commit(C.stage_fetch(tgA, 0, NA.extra_n)); staged_early = true; }
+        // pre-armed (frl_rollout): enqueued a vector step ahead on the pool's second stream — the previous step's launches may still be
+        // running.  The batch's rows depend on the launch's arguments only: drawn now (LDS only: the actor launch in front may still be
+        // reading D.idx).  Then: every workgroup of the previous step has left (dev_cnt: the nets are final), and the host's doorbell —
+        // the step's block is there (2 s each, then give up: a launch that returns here has touched nothing; the actor launch queued
+        // behind it sees the same word)
+        if (b < nb && a.device_rng) {
+            FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
+            draw_indices((g_i) nullptr, lidx, B, a.size, a.rng_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (p + 1), false);
+            ri_early = lidx[16 * b + i16 < B ? 16 * b + i16 : B - 1];
+            drawn_early = true;
+        }
         if (tid == 0) {
             const unsigned long long t0 = wall_clock64();
-            int v = __hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-            while (v != st.go_value && v != -1) {
-                __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
-                v = __hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            int c = __hip_atomic_load(st.dev_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (c - st.dev_wait < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ull) break;
+                c = __hip_atomic_load(st.dev_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int v = -1;
+            if (c - st.dev_wait >= 0) {
+                v = __hip_atomic_load(st.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                while (v != st.go_value && v != -1) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > 400000000ull) { v = -1; break; }
+                    v = __hip_atomic_load(st.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             N.red[100] = __int_as_float(v);
         }
-        __syncthreads();
+        __syncthreads();                               // (also: every wave has read its row out of ea)
         if (__float_as_int(N.red[100]) != st.go_value) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                  // (the polls are relaxed: one invalidate here, not one per poll)
+        if (drawn_early && q == 0 && 16 * b + i16 < B && w == 0) D.idx[(size_t)p * D.batch_max + 16 * b + i16] = ri_early;
     }
+    const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
     if (st.head) solo_step_head(D, st, p);             // (every workgroup, also the ones without rows: they all pass the same barriers)
 
     if (b < nb) {
@@ -138,10 +167,12 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         const bool valid = row < B;
         // the first image travels while the indices are drawn and the row's fields fetched
         ChainNet::StageRegs pend;
-        if (!staged_early) pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        pend = C.stage_fetch(tgA, 0, NA.extra_n);
         int ri;
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
-        if (a.device_rng) {
+        if (drawn_early) {
+            ri = ri_early;
+        } else if (a.device_rng) {
             // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
             // rejection in its own LDS: ~3 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
             // same values to D.idx (the actor stage and frl_last_indices read them)
@@ -173,8 +204,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         }
         const float rew = rec[R.rew_off], done = rec[R.done_off];
         SOLO_T(9);
-        if (!staged_early) C.stage_commit(pend);
-        else lds_barrier();                                            // (ea held the drawn indices: every wave has read its rows')
+        C.stage_commit(pend);
         SOLO_T(0);
         // the target critics are forward-only: their fragments go straight from the block into registers (SoloNet::forward_g), both
         // heads in one pass — in flight under the target actor's pass
@@ -264,6 +294,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     // the rollout step's tail when no actor stage follows (the actor is unchanged: nothing to wait for; every workgroup's reads of
     // obs_cur / store_act in the head lie in front of the slab hand-over above)
     if (st.tail && b == 0) solo_step_tail(D, a, st, smem, p);
+    solo_leave(st);
 }
 
 __global__ __launch_bounds__(256) void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
     const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
     SOLO_T0();
     if (st.go_flag) {                                                      // (pre-armed step: the critic launch in front of this one waited for the doorbell; -1 = given up)
-        if (tid == 0) N.red[100] = __int_as_float(__hip_atomic_load(st.go_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (tid == 0) N.red[100] = __int_as_float(__hip_atomic_load(st.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         __syncthreads();
         if (__float_as_int(N.red[100]) != st.go_value) return;
     }
@@ -463,6 +494,7 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         solo_grid_sync(st.bar2 + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
         if (b == 0) solo_step_tail(D, a, st, smem, p);
     }
+    solo_leave(st);
 }
 
 }  // namespace frl
