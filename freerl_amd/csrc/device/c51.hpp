@@ -60,7 +60,7 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[R]) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] += __shfl_xor(v[k], off, 64);
+        for (int k = 0; k < R; ++k) v[k] += lane_xor(v[k], off);
 }
 template <int R>
 __device__ __forceinline__ void c51_softmax_wave_n(lds_cf (&lg)[R], int atoms, float vmin, float dz, float (&p)[R], float (&q)[R]) {
@@ -71,7 +71,7 @@ __device__ __forceinline__ void c51_softmax_wave_n(lds_cf (&lg)[R], int atoms, f
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int k = 0; k < R; ++k) mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+        for (int k = 0; k < R; ++k) mx[k] = fmaxf(mx[k], lane_xor(mx[k], off));
 #pragma unroll
     for (int k = 0; k < R; ++k) { e[k] = l < atoms ? expf(x[k] - mx[k]) : 0.f; p[k] = e[k]; }
     wave_sum_n<R>(p);                                 // p = sum of e

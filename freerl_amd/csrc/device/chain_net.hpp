@@ -243,8 +243,8 @@ struct ChainNet {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     float a = acc[t];
-                    a += __shfl_xor(a, 16, 64);
-                    a += __shfl_xor(a, 32, 64);
+                    a += lane_xor<16>(a);
+                    a += lane_xor<32>(a);
                     z[t][o] = a + bo;
                 }
             }
@@ -400,10 +400,10 @@ struct ChainNet {
     __device__ __forceinline__ void grad_finish(HeadGrad& g) const {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            g.gb1[x] += __shfl_xor(g.gb1[x], 16, 64); g.gb1[x] += __shfl_xor(g.gb1[x], 32, 64);
-            g.gb2[x] += __shfl_xor(g.gb2[x], 16, 64); g.gb2[x] += __shfl_xor(g.gb2[x], 32, 64);
+            g.gb1[x] += lane_xor<16>(g.gb1[x]); g.gb1[x] += lane_xor<32>(g.gb1[x]);
+            g.gb2[x] += lane_xor<16>(g.gb2[x]); g.gb2[x] += lane_xor<32>(g.gb2[x]);
         }
-        g.gb3 += __shfl_xor(g.gb3, 16, 64); g.gb3 += __shfl_xor(g.gb3, 32, 64);
+        g.gb3 += lane_xor<16>(g.gb3); g.gb3 += lane_xor<32>(g.gb3);
     }
     // this lane's share of the squared gradient norm (bias entries counted once: lanes q == 0 / wave 0)
     __device__ __forceinline__ float grad_sumsq(const HeadGrad& g) const {

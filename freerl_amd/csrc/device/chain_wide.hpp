@@ -439,11 +439,11 @@ struct WideNet {
     __device__ __forceinline__ void grad_finish(WideGrad<NT3>& g) const {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            g.gb1[x] += __shfl_xor(g.gb1[x], 16, 64); g.gb1[x] += __shfl_xor(g.gb1[x], 32, 64);
-            g.gb2[x] += __shfl_xor(g.gb2[x], 16, 64); g.gb2[x] += __shfl_xor(g.gb2[x], 32, 64);
+            g.gb1[x] += lane_xor<16>(g.gb1[x]); g.gb1[x] += lane_xor<32>(g.gb1[x]);
+            g.gb2[x] += lane_xor<16>(g.gb2[x]); g.gb2[x] += lane_xor<32>(g.gb2[x]);
         }
 #pragma unroll
-        for (int o3 = 0; o3 < NT3; ++o3) { g.gb3[o3] += __shfl_xor(g.gb3[o3], 16, 64); g.gb3[o3] += __shfl_xor(g.gb3[o3], 32, 64); }
+        for (int o3 = 0; o3 < NT3; ++o3) { g.gb3[o3] += lane_xor<16>(g.gb3[o3]); g.gb3[o3] += lane_xor<32>(g.gb3[o3]); }
     }
 
     // ---- dW1^T of one head over the whole batch, then its tiles -> grad; returns this lane's share of the squared norm.

@@ -560,8 +560,8 @@ struct SweepNet {
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             float v = bsum[y];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v += lane_xor<16>(v);
+            v += lane_xor<32>(v);
             if ((w >> 1) == 0 && q == 0) {
                 Gb[(ot0 + y) * 16 + i16] = v;
                 ss += v * v;
@@ -671,8 +671,8 @@ struct SweepNet {
 #pragma unroll
         for (int y = 0; y < NY; ++y) {
             float v = bsum[y];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v += lane_xor<16>(v);
+            v += lane_xor<32>(v);
             if (Gb != nullptr && q == 0) {                             // (the caller names one owner wave per out tile)
                 Gb[(ot0 + y) * 16 + i16] = v;
                 ss += v * v;
@@ -765,8 +765,8 @@ struct SweepNet {
         }
 #pragma unroll
         for (int y = 0; y < NY; ++y) {
-            bsum[y] += __shfl_xor(bsum[y], 16, 64);
-            bsum[y] += __shfl_xor(bsum[y], 32, 64);
+            bsum[y] += lane_xor<16>(bsum[y]);
+            bsum[y] += lane_xor<32>(bsum[y]);
         }
         lds_f bsl = b1;                                                // two slots of 256 floats (b1, b2 are adjacent)
         auto put = [&](lds_f area, lds_f bslot) {

@@ -312,8 +312,8 @@ __device__ __forceinline__ void linear_fwd_head_t(const LayerDesc& L, const Laye
         for (int x = 0; x < BM; ++x) {
 #pragma unroll
             for (int c = 0; c < (ONE ? 1 : 4); ++c) {
-                part[x][c] += __shfl_xor(part[x][c], 16, 64);
-                part[x][c] += __shfl_xor(part[x][c], 32, 64);
+                part[x][c] += lane_xor<16>(part[x][c]);
+                part[x][c] += lane_xor<32>(part[x][c]);
             }
             if (q == 0) st4(outb + (mt0 * 16 + x * 16 + row) * op + 4 * g, part[x]);
         }
@@ -368,7 +368,7 @@ __device__ __forceinline__ void head_bwd(const LayerDesc& LH, g_cf theta, g_f G,
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gw[c] += __shfl_xor(gw[c], 32, 64);
+        for (int c = 0; c < 4; ++c) gw[c] += lane_xor<32>(gw[c]);
         if (G && half == 0) {
             g_f g = G + LH.w_off + k * 16;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};

@@ -140,8 +140,8 @@ struct SoloNet {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc1 = fmaf(wv[r], h2f[kb][r], acc1);
                 }
-                acc1 += __shfl_xor(acc1, 16, 64);
-                acc1 += __shfl_xor(acc1, 32, 64);
+                acc1 += lane_xor<16>(acc1);
+                acc1 += lane_xor<32>(acc1);
                 z[o] = acc1 + S.b3[o];
             }
         }
@@ -239,8 +239,8 @@ struct SoloNet {
                     for (int kb = 0; kb < kHT; ++kb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc1 = fmaf(F[hd].w3[o][kb][r], h2f[kb][r], acc1);
-                    acc1 += __shfl_xor(acc1, 16, 64);
-                    acc1 += __shfl_xor(acc1, 32, 64);
+                    acc1 += lane_xor<16>(acc1);
+                    acc1 += lane_xor<32>(acc1);
                     z[hd][o] = acc1 + F[hd].b3[o];
                 }
             }
@@ -249,7 +249,7 @@ struct SoloNet {
 
     // sum over the 16 rows of the tile (lanes of one q group): every lane of the group gets it
     __device__ __forceinline__ static float rows_sum(float v) {
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
         return v;
     }
 
@@ -310,7 +310,7 @@ struct SoloNet {
                 const int ot = 2 * w + x;
                 const f32x4 af = get_t(td, ot);
                 float gb = (af[0] + af[1]) + (af[2] + af[3]);
-                gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+                gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
                 if (q == 0) hs[kL2b + ot * 16 + i16] = gb;
 #pragma unroll
                 for (int kt = 0; kt < kHT; ++kt) {
@@ -343,7 +343,7 @@ struct SoloNet {
                 put_t(td, ot, d1o[x]);                                            // (this wave's own tiles: its reads of d2 above are done, in order)
                 const f32x4 af = get_t(td, ot);
                 float gb = (af[0] + af[1]) + (af[2] + af[3]);
-                gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+                gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
                 if (q == 0) hs[kL1b + ot * 16 + i16] = gb;
                 st4_slab(hs + kL1w + ot * 256 + fslot, mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af));
             }

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "lane.hpp"
+
 namespace frl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -304,7 +306,7 @@ __device__ __forceinline__ void for_il_blocks(int tm, int groups, Body body) {
 // ---- block-wide sum (all threads get the result); `red` = 8 floats of LDS scratch -----------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v += lane_xor(v, off);
     return v;
 }
 __device__ __forceinline__ float block_sum(float v, lds_f red) {

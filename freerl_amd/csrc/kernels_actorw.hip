@@ -257,7 +257,7 @@ __device__ __forceinline__ void ac_actor_wide_body(const EngineDesc& D, const Le
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = gls[o3][r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
             gls[o3][r] = v;
         }
     lds_f lsred = W.u;                                                 // [4 waves][32 components]

@@ -152,8 +152,8 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 float qv = zp[t];
-                qv += __shfl_xor(qv, 16, 64);
-                qv += __shfl_xor(qv, 32, 64);
+                qv += lane_xor<16>(qv);
+                qv += lane_xor<32>(qv);
                 qv += N.b3[0];
                 dzv[t] = row < B ? dqv : 0.f;                          // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
                 if (q == 0 && row < B) qsum += qv;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void ac_actor_x_body(const EngineDesc& D, const Learn
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = gls[o3][r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
             gls[o3][r] = v;
         }
     lds_f lsred = W.u;                                                 // [4 waves][32 components]

@@ -58,15 +58,15 @@ __global__ __launch_bounds__(256, FRL_GRAD_WGS) void c51_grad_kernel(const Engin
             const int i0 = hf * half, i1 = hf ? atoms : half;
             float mx = lg[i0];
             for (int i = i0 + 1; i < i1; ++i) mx = fmaxf(mx, lg[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, lane_xor<1>(mx));
             float sum = 0.f, zsum = 0.f;
             for (int i = i0; i < i1; ++i) {
                 const float ex = __expf(lg[i] - mx);
                 sum += ex;
                 zsum += ex * (vmin + dz * (float)i);
             }
-            sum += __shfl_xor(sum, 1, 64);
-            zsum += __shfl_xor(zsum, 1, 64);
+            sum += lane_xor<1>(sum);
+            zsum += lane_xor<1>(zsum);
             if (e < 2 * npair && hf == 0) qb[r * ap + act] = zsum / sum;
         }
         FRL_PHASE(S);

@@ -114,8 +114,8 @@ __device__ __forceinline__ void ac_critic_wide_body(const EngineDesc& D, const L
                             }
                         }
                     }
-                    lp += __shfl_xor(lp, 16, 64);
-                    lp += __shfl_xor(lp, 32, 64);
+                    lp += lane_xor<16>(lp);
+                    lp += lane_xor<32>(lp);
                     if (valid) {
                         // agent j's columns of the joint target action (the agents' blocks need not be 16-byte aligned: scalar stores)
 #pragma unroll

@@ -112,8 +112,8 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
                             X.xrow[(size_t)row * X.xp + OT + aoff + c] = av;
                         }
                     }
-                lp += __shfl_xor(lp, 16, 64);
-                lp += __shfl_xor(lp, 32, 64);
+                lp += lane_xor<16>(lp);
+                lp += lane_xor<32>(lp);
                 if (valid && q == 0) X.lpn[row] = lp;
             }
             WIDE_T(3);
@@ -148,8 +148,8 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 float qv = zp[t];
-                qv += __shfl_xor(qv, 16, 64);
-                qv += __shfl_xor(qv, 32, 64);
+                qv += lane_xor<16>(qv);
+                qv += lane_xor<32>(qv);
                 qv += N.b3[0];
                 if (q == 0 && row < B) {
                     if (hd == 1) qv = fminf(X.q1[row], qv);
@@ -197,8 +197,8 @@ __device__ __forceinline__ void ac_critic_x_body(const EngineDesc& D, const Lear
             for (int t = 0; t < 4; ++t) {
                 const int row = row_of(sc, t);
                 float qv = zp[t];
-                qv += __shfl_xor(qv, 16, 64);
-                qv += __shfl_xor(qv, 32, 64);
+                qv += lane_xor<16>(qv);
+                qv += lane_xor<32>(qv);
                 qv += N.b3[0];
                 dzv[t] = 0.f;                                          // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
                 if (row < B) {

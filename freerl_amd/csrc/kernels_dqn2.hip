@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
                 if (o >= 1 && o <= nA) sa += z[r];
                 if (o == 0) v = z[r];
             }
-            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            sa += lane_xor<16>(sa); sa += lane_xor<32>(sa);
+            v += lane_xor<16>(v); v += lane_xor<32>(v);
             const float mean = sa / (float)nA;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = (v + z[r]) - mean;
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         }
 #pragma unroll
         for (int s = 16; s < 64; s <<= 1) {
-            const float om = __shfl_xor(mx, s, 64);
-            const int ob = __shfl_xor(best, s, 64);
+            const float om = lane_xor(mx, s);
+            const int ob = lane_xor(best, s);
             if (om > mx || (om == mx && ob < best)) { mx = om; best = ob; }
         }
     };
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r == o0 + j) v = z[r];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        v += lane_xor<16>(v);
+        v += lane_xor<32>(v);
         return v;
     };
 
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     }
     // bias partials of the four lane groups (rows 4q .. 4q + 3 of every 16-row block) added up
 #pragma unroll
-    for (int x = 0; x < 2; ++x) { g.gb1[x] += __shfl_xor(g.gb1[x], 16, 64); g.gb1[x] += __shfl_xor(g.gb1[x], 32, 64); }
-    g.gb2 += __shfl_xor(g.gb2, 16, 64); g.gb2 += __shfl_xor(g.gb2, 32, 64);
+    for (int x = 0; x < 2; ++x) { g.gb1[x] += lane_xor<16>(g.gb1[x]); g.gb1[x] += lane_xor<32>(g.gb1[x]); }
+    g.gb2 += lane_xor<16>(g.gb2); g.gb2 += lane_xor<32>(g.gb2);
     float lsum = wave_sum(lossp);
 
     // ---- several workgroups per learner: partials to the slab; the last to arrive adds them in workgroup order

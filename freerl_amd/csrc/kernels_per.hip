@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const EngineDesc* __res
         wmax = fmaxf(wmax, w);
     }
     // block max through LDS
-    for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+    for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, lane_xor(wmax, off));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));

@@ -287,7 +287,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (4 * q + r < A) mx = fmaxf(mx, z[r]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    mx = fmaxf(mx, lane_xor<16>(mx)); mx = fmaxf(mx, lane_xor<32>(mx));
                     f32x4 ex = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (4 * q + r < A) ex[r] = expf(z[r] - mx);
@@ -322,7 +322,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     float lp_now = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (4 * q + r == ar) lp_now = lg[r];
-                    lp_now += __shfl_xor(lp_now, 16, 64); lp_now += __shfl_xor(lp_now, 32, 64);      // one group holds it, the others 0
+                    lp_now += lane_xor<16>(lp_now); lp_now += lane_xor<32>(lp_now);      // one group holds it, the others 0
                     if (valid) {
                         const float ratio = expf(lp_now - cur.lpo[0]), Ar = cur.tgt;
                         const float s1 = ratio * Ar, s2 = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip) * Ar;
@@ -439,17 +439,17 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             // bias partials: lane (i16, q) summed rows 4q..4q+3 of every 16-row block: add the four lane groups
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                gb1[x] += __shfl_xor(gb1[x], 16, 64); gb1[x] += __shfl_xor(gb1[x], 32, 64);
-                gb2[x] += __shfl_xor(gb2[x], 16, 64); gb2[x] += __shfl_xor(gb2[x], 32, 64);
+                gb1[x] += lane_xor<16>(gb1[x]); gb1[x] += lane_xor<32>(gb1[x]);
+                gb2[x] += lane_xor<16>(gb2[x]); gb2[x] += lane_xor<32>(gb2[x]);
             }
-            gb3 += __shfl_xor(gb3, 16, 64); gb3 += __shfl_xor(gb3, 32, 64);
+            gb3 += lane_xor<16>(gb3); gb3 += lane_xor<32>(gb3);
             // log_std: sum over the rows = over the 16 columns of every wave, then over the waves
             const bool gauss = !critic && !discrete;
             if (gauss) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) gls4[r] += __shfl_xor(gls4[r], o, 64);
+                    for (int o = 1; o < 16; o <<= 1) gls4[r] += lane_xor(gls4[r], o);
                 }
                 if (i16 == 0) st4(S.red + 32 + w * 16 + 4 * q, gls4);
             }
