@@ -321,3 +321,48 @@ def test_solo_rollout_folded_step_matches_the_separate_launches(N, monkeypatch, 
         np.testing.assert_array_equal(a[3][p], b[3][p])
         assert a[4][p] == b[4][p]
     assert a[0]["return_sum"] == b[0]["return_sum"] and a[1]["episodes"] == b[1]["episodes"]
+
+
+@pytest.mark.parametrize("kind,P,Ev,every", [("dqn", 5, 2, 1), ("dqn", 1, 1, 2), ("td3", 3, 2, 1), ("sac", 1, 1, 3)])
+def test_prearmed_launches_on_and_off_agree(N, monkeypatch, kind, P, Ev, every):
+    """The folded rollout step with the next step's launch enqueued a step ahead on the pool's second stream (doorbell + device word,
+    frl_api_rollout.inc) against the same loop launching each step when its block is filled: FRL_ROLLOUT_PREARM=1 forces the first
+    (also past the population sizes it is the default for), =0 the second.  Same Philox counters, same predicted ring sizes: rings,
+    parameters, targets, Adam moments and step counts bit for bit — with learn_every > 1 armed and unarmed steps alternate."""
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import EnvPool, rollout
+    monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
+    res = []
+    for arm in ("0", "1"):
+        monkeypatch.setenv("FRL_ROLLOUT_PREARM", arm)
+        if kind == "dqn":
+            e = Engine(N.ALGO_DQN, 8, 4, 400, discrete=True, batch_max=64, n_learners=P, seed=11)           # (the ring wraps inside the run)
+            pool = EnvPool("SynLinearDiscrete-v0", P * Ev, n_threads=1, seed=5)
+            kw = dict(envs_per_learner=Ev, start_steps=128 // Ev, learn_every=every, epsilon=0.2, batch=64, critic_lr=1e-3, tau=0.05)
+            nets = (0,)
+        else:
+            aid = dict(td3=N.ALGO_TD3, sac=N.ALGO_SAC)[kind]
+            e = Engine(aid, 8, 2, 400, twin_critic=True, batch_max=32, n_learners=P, seed=11)
+            assert e.learn_path(32) == (True, 117376, 16)
+            if kind == "sac":
+                for p in range(P):
+                    e.set_alpha_state([np.log(0.05), 0, 0, 0.05], learner=p)
+            pool = EnvPool("SynLinear-v0", P * Ev, n_threads=1, seed=5)
+            kw = dict(envs_per_learner=Ev, start_steps=64, learn_every=every, batch=32, actor_lr=1e-3, critic_lr=1e-3, tau=0.05, policy_freq=2)
+            nets = (0, 1)
+        _rand_params(e, N, 0.3, seed=12)
+        outs = [rollout(e, pool, n, **kw) for n in (150, 1, 60)]                 # (a one-step call in the middle: nothing to arm)
+        rows = [e.read_rows(p, 0, 400) for p in range(P)]
+        par = [np.concatenate([e.get_params(net, k, learner=p) for net in nets for k in (N.PARAM_ONLINE, N.PARAM_TARGET, N.PARAM_ADAM_M, N.PARAM_ADAM_V)])
+               for p in range(P)]
+        res.append((outs, rows, par, [[e.opt_step(net, learner=p) for net in nets] for p in range(P)], e.last_indices(kw["batch"]) if hasattr(e, "last_indices") else None))
+        pool.close(); e.close()
+    a, b = res
+    assert [o["updates"] for o in a[0]] == [o["updates"] for o in b[0]] and a[0][0]["updates"] > 0
+    assert [o["return_sum"] for o in a[0]] == [o["return_sum"] for o in b[0]]
+    for p in range(P):
+        np.testing.assert_array_equal(a[1][p], b[1][p])
+        np.testing.assert_array_equal(a[2][p], b[2][p])
+        assert a[3][p] == b[3][p]
+    if a[4] is not None:
+        np.testing.assert_array_equal(a[4], b[4])

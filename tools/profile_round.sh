@@ -33,6 +33,7 @@ timeout 300 python tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
 timeout 300 python tools/ppo_timing.py 256 > $O/ppo_timing.txt 2>&1 < /dev/null
 timeout 300 python tools/dqn2_timing.py 512 > $O/dqn2_timing.txt 2>&1 < /dev/null
 timeout 300 $R/tools/_bin/chain_bench > $O/chain_bench.txt 2>&1
+timeout 60 $R/tools/_bin/lane_xor_test > $O/lane_xor_test.txt 2>&1        # hipcc --offload-arch=gfx950 -O3 -I freerl_amd/csrc tools/lane_xor_test.hip -o tools/_bin/lane_xor_test
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ppo -- python $R/tools/ppo_bench.py 256 > $O/stats_ppo.log 2>&1
 cp $(ls $O/stats_ppo/*/*kernel_stats.csv | head -1) $O/kernel_stats_ppo.csv
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dqn -- python $R/tools/dqn_bench.py 512 > $O/stats_dqn.log 2>&1
