@@ -46,7 +46,8 @@ constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w +
 // One learner on sixteen workgroups (device/solo.hpp, kernels_solo.hip): the single-learner latency path
 constexpr int kSoloWG = 16;              // workgroups per learner = 16-row tiles of a 256-row batch
 constexpr int kSoloPartHost = 32;        // floats per workgroup of SoloArgs::part (device/solo.hpp: kSoloPart)
-constexpr int kSoloMaxP = 8;             // learners per engine on this path: every workgroup of a launch must be resident (grid barrier)
+constexpr int kSoloMaxP = 16;            // learners per engine on this path: every workgroup of a launch must be resident (flag hand-overs): 16 x 16 = 256 CUs.
+                                         // Measured (tools/small_pop_bench.py, TD3): 9 / 12 / 16 learners 82 / 90 / 101 us per learn() against 144 / 150 / 150 on the row-chunk kernels
 constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 128 + 16 + 16 + 4 * 8 * 256 + 256 + 128; }
 
 // The K-sliced chained family (device/chain_wide.hpp)

@@ -20,6 +20,7 @@ CASES = {
     "td3_h256": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True, hidden=256),
     "sac_h256": dict(algo=N.ALGO_SAC, obs=40, act=17, B=200, twin=True, hidden=256),
     "ddpg_h256": dict(algo=N.ALGO_DDPG, obs=11, act=3, B=96, twin=False, hidden=256),
+    "td3_syn": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True),                 # the bench shape
     "td3_narrow_b100": dict(algo=N.ALGO_TD3, obs=8, act=2, B=100, twin=True),        # the narrow register-chained kernels, ragged batches
     "sac_narrow_b200": dict(algo=N.ALGO_SAC, obs=11, act=3, B=200, twin=True),
     "ddpg_narrow_b37": dict(algo=N.ALGO_DDPG, obs=3, act=1, B=37, twin=False),
@@ -37,13 +38,16 @@ CASES = {
 def run(name, family, calls, P=2):
     c = CASES[name]
     old = os.environ.get("FRL_CRITIC_V2")
-    os.environ["FRL_CRITIC_V2"] = str(family)
+    if family is None:                         # nothing forced: up to sixteen learners of the narrow shape take kernels_solo.hip
+        os.environ.pop("FRL_CRITIC_V2", None)
+    else:
+        os.environ["FRL_CRITIC_V2"] = str(family)
     try:
         e = Engine(c["algo"], c["obs"], c["act"], 4096, n_learners=P, twin_critic=c["twin"], batch_max=c["B"],
                    hidden=c.get("hidden", 128), seed=3)
     finally:
         if old is None:
-            del os.environ["FRL_CRITIC_V2"]
+            os.environ.pop("FRL_CRITIC_V2", None)
         else:
             os.environ["FRL_CRITIC_V2"] = old
     g = np.random.default_rng(0)
@@ -73,7 +77,7 @@ def run(name, family, calls, P=2):
         st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx if na > 1 else idx[:, 0],
                      noise=noise if need_noise else None, want_stats=True, **kw)
         stats.append(st.copy())
-    out = dict(stats=np.stack(stats), family=e.learn_path(c["B"])[0])
+    out = dict(stats=np.stack(stats), family=e.learn_path(c["B"])[0], path=e.learn_path(c["B"]))
     for net in range(e.n_nets):
         for kind, nm in ((N.PARAM_ONLINE, "theta"), (N.PARAM_TARGET, "target"), (N.PARAM_ADAM_M, "m"), (N.PARAM_ADAM_V, "v")):
             out["%s%d" % (nm, net)] = np.stack([e.get_params(net, kind, learner=p) for p in range(P)])
@@ -94,7 +98,7 @@ def diff(a, b):
     are large in BOTH families against the oracle and say nothing (the oracle tests hold each family to it)."""
     out = {}
     for key in sorted(a):
-        if key in ("stats", "family", "layers"):
+        if key in ("stats", "family", "layers", "path"):
             continue
         x, y = a[key], b[key]
         rel = np.abs(x - y) / (np.abs(x).max() + 1e-30)

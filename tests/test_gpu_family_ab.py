@@ -61,6 +61,27 @@ def test_chained_vs_rowchunk_20_calls(N, case):
         assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
 
 
+@pytest.mark.parametrize("case,P", [("td3_syn", 16), ("sac_narrow_b200", 16), ("ddpg_narrow_b37", 13), ("td3_narrow_b100", 5)])
+def test_sixteen_workgroups_per_learner_vs_rowchunk_at_population_size(N, case, P):
+    """kernels_solo.hip with every learner of a FULL population of its family (sixteen learners = all 256 CUs; per-learner slabs, flag
+    words and mailboxes) against the row-chunk kernels on the same injected indices and noise, own parameters per learner, 20 calls,
+    every array of every learner — the other solo tests run one learner, or compare two solo runs with each other."""
+    from tests import family_ab as AB
+    calls = 20 if AB.CASES[case]["B"] >= 64 else 5
+    a, b = AB.run(case, 0, calls, P), AB.run(case, None, calls, P)
+    assert not a["family"] and b["path"] == (True, 117376, 16), (a["path"], b["path"])
+    d = AB.diff(a, b)
+    st = d.pop("stats")
+    REPORT["solo/" + case] = dict(calls=calls, P=P, arrays={k: v[0] for k, v in d.items()}, arrays_q99={k: v[3] for k, v in d.items()},
+                                  loss_rel_first5=float(st[:5, :, :, :2].max()), loss_rel_all=float(st[:, :, :, :2].max()))
+    assert st[:5, :, :, :2].max() <= 1e-4, (case, st[:5, :, :, :2].max())
+    assert st[:, :, :, :2].max() <= 5e-3, (case, st[:, :, :, :2].max())
+    for key, (w, at, mx, q99) in d.items():
+        tol = TOL_THETA if key.startswith(("theta", "target", "act")) else TOL_MOMENT
+        assert q99 <= tol, "%s %s: 99th percentile of |diff| / max |x| = %.3e (max %.3e at flat index %d, |x| max %.3g)" % (case, key, q99, w, at, mx)
+        assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
+
+
 @pytest.mark.parametrize("case", ["sac_c4", "maddpg_c5", "td3_h256", "td3_narrow_b100"])
 def test_padding_stays_zero_and_unsampled_nonfinite_rows_are_inert(N, monkeypatch, case):
     """(1) frl_params_pad_max == 0 for theta / target / m / v of every net after 12 updates on the chained families; (2) the same run with
