@@ -372,7 +372,13 @@ struct SoloNet {
 // 2 s gives up and raises *err: the launch then finishes with wrong numbers instead of hanging the queue.
 __device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        // (every wave's stores are acknowledged: __syncthreads waits for them)  release fence, an explicit wait — hipcc may drop the
+        // fence's own when it believes the wave has nothing outstanding, and the flag would overtake the write-back — then the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (threadIdx.x < kSoloWG) {
         const unsigned long long t0 = wall_clock64();                      // 100 MHz
         while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
@@ -381,7 +387,10 @@ __device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned 
         }
     }
     __syncthreads();
-    __threadfence();
+    // ONE lane's acquire serves the CU (buffer_inv sc1 drops the CU's L1; MI355X_MICROARCH.md, inter-workgroup visibility): 256 threads
+    // running __threadfence() here each wrote the L2 back again and invalidated again
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
 }
 
 // What the update of one net needs besides the slabs

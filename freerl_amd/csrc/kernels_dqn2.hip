@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
                 if (wall_clock64() - t0 > 200000000ull) break;
                 v = __hip_atomic_load(s.dev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (relaxed polls, then ONE lane's invalidate for the CU, in front of the barrier)
             S.red[21] = __int_as_float(v - s.dev_wait < 0 ? 0 : 1);
         }
         __syncthreads();
         if (__float_as_int(S.red[21]) == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // (the polls are relaxed: one invalidate here, not one per poll)
         so = C.stage_load(th, L1, L2); stg = C.stage_load(tg, L1, L2);
         C.stage_store(0, so);
         C.stage_store(1, stg);
@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
                 if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
                 v = __hip_atomic_load(s.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             S.red[20] = __int_as_float(v);
         }
         __syncthreads();
         if (__float_as_int(S.red[20]) != s.go_value) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (a.device_rng && tid < B) idx[tid] = S.lidx[tid];            // (frl_last_indices; B <= 256 on this kernel)
     } else {
         so = C.stage_load(th, L1, L2); stg = C.stage_load(tg, L1, L2);
@@ -413,12 +413,18 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         if (l == 0) S.red[w] = lsum;
         lds_barrier();
         if (tid == 0) D.part[((size_t)p * D.S + sp) * 4] = ((S.red[0] + S.red[1]) + S.red[2]) + S.red[3];
-        __threadfence();
+        // publish: every wave's stores acknowledged (__syncthreads), then ONE lane's agent-scope release, an explicit wait (hipcc may
+        // drop the fence's own) and the ticket; the last arriver: one lane's acquire for the CU.  (All 256 threads running
+        // __threadfence() on both sides wrote the L2 back and invalidated it once per thread.)
         __syncthreads();
-        if (tid == 0) S.lidx[0] = atomicAdd(D.ticket + p, 1);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S.lidx[0] = __hip_atomic_fetch_add(D.ticket + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (S.lidx[0] == nsp - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
         if (S.lidx[0] != nsp - 1) return;
-        __threadfence();
         if (tid == 0) D.ticket[p] = 0;                                 // ready for the next launch
         lsum = 0.f;
 #pragma unroll
@@ -547,11 +553,13 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
     if (s.act && s.done_flag) {
         __syncthreads();                                               // every wave's env_out stores have been issued and counted down
         if (tid == 0) {
-            __threadfence_system();                                    // this learner's actions are out; the last learner to get here flags the host
+            // this learner's actions are out; the last learner to get here flags the host: system-scope release + an explicit wait
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // (one learner: it is the last one — no ticket round trip)
             if (a.p_count == 1 || atomicAdd(D.ticket + D.P, 1) == a.p_count - 1) {
-                if (a.p_count > 1) { D.ticket[D.P] = 0; __threadfence_system(); }
-                __hip_atomic_store(s.done_flag, s.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // (the host first: it is the one waited for)
+                if (a.p_count > 1) { D.ticket[D.P] = 0; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                __hip_atomic_store(s.done_flag, s.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (the host first: it is the one waited for)
                 if (s.dev_done) __hip_atomic_store(s.dev_done, s.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

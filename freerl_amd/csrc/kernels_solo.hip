@@ -70,11 +70,14 @@ __device__ __forceinline__ void solo_step_tail(const EngineDesc& D, const LearnA
         __syncthreads();
     }
     if (st.done_flag) {
-        __threadfence_system();                                        // this learner's actions are out; the last learner to get here flags the host
+        // this learner's actions are out (the __syncthreads above: every wave's stores acknowledged); the last learner to get here flags
+        // the host — lane 0's system-scope release + an explicit wait in front of the flag
         if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (a.p_count == 1 || atomicAdd(st.ticket, 1) == a.p_count - 1) {     // (one learner: no ticket round trip)
-                if (a.p_count > 1) { *st.ticket = 0; __threadfence_system(); }
-                __hip_atomic_store(st.done_flag, st.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.p_count > 1) { *st.ticket = 0; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                __hip_atomic_store(st.done_flag, st.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -86,8 +89,9 @@ __device__ __forceinline__ void solo_leave(const SoloStepArgs& st) {
     if (!st.dev_cnt) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(st.dev_cnt, 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(st.dev_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -148,11 +152,11 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
                     v = __hip_atomic_load(st.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // (relaxed polls, then ONE lane's invalidate for the CU, in front of the barrier)
             N.red[100] = __int_as_float(v);
         }
         __syncthreads();                               // (also: every wave has read its row out of ea)
         if (__float_as_int(N.red[100]) != st.go_value) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                  // (the polls are relaxed: one invalidate here, not one per poll)
         if (drawn_early && q == 0 && 16 * b + i16 < B && w == 0) D.idx[(size_t)p * D.batch_max + 16 * b + i16] = ri_early;
     }
     const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
