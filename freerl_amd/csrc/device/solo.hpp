@@ -46,7 +46,9 @@ constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::pa
 #endif
 
 // (slab stores are plain stores.  Measured: write-through ones — global_store_dwordx4 ... sc0 sc1, so that the barrier's release fence
-// finds nothing dirty in this XCD's L2 — take 1.4 us off grid barrier 1 and put 1.1 us on the backward that issues them.)
+// finds nothing dirty in this XCD's L2 — take 1.4 us off grid barrier 1 and put 1.1 us on the backward that issues them; `sc1` alone,
+// with the one-lane fences: nothing for one learner, -3 % / -6 % at 8 / 16 — and wrong numbers at sixteen learners: inline-asm stores
+// are outside hipcc's wait-count bookkeeping, the fragile kind of fast.)
 __device__ __forceinline__ void st4_slab(g_f p, const f32x4& v) { st4(p, v); }
 
 struct SoloNet {
