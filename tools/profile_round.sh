@@ -26,6 +26,7 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $(ls $O/stats_solo/*/*kernel_stats.csv | head -1) $O/kernel_stats_single.csv
 cd $R
 timeout 300 python tools/single_bench.py 2000 > $O/single_bench.txt 2>&1 < /dev/null        # (the numbers: without the profiler attached)
+timeout 300 python tools/small_pop_bench.py 1 2 4 8 12 16 17 32 64 128 129 256 512 > $O/small_pop_bench.txt 2>&1 < /dev/null
 for a in td3 ddpg sac; do FRL_HIP_VARIANT=solot timeout 120 python tools/solo_timing.py $a; done > $O/solo_timing.txt 2>&1 < /dev/null
 timeout 300 python tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
 timeout 300 python tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
