@@ -333,8 +333,14 @@ def test_prearmed_launches_on_and_off_agree(N, monkeypatch, kind, P, Ev, every):
     from freerl_amd.envpool import EnvPool, rollout
     monkeypatch.delenv("FRL_CRITIC_V2", raising=False)
     res = []
-    for arm in ("0", "1"):
-        monkeypatch.setenv("FRL_ROLLOUT_PREARM", arm)
+    for arm in ("0", "1", "cancel"):
+        # "cancel": armed, and the host's patience with an armed launch set to zero — every one of them is cancelled (what a 1 s env step
+        # does: the launch's own 2 s bound must not cost the update) and the step replayed the plain way with the counters put back
+        monkeypatch.setenv("FRL_ROLLOUT_PREARM", "0" if arm == "0" else "1")
+        if arm == "cancel":
+            monkeypatch.setenv("FRL_ROLLOUT_ARM_PATIENCE_MS", "0")
+        else:
+            monkeypatch.delenv("FRL_ROLLOUT_ARM_PATIENCE_MS", raising=False)
         if kind == "dqn":
             e = Engine(N.ALGO_DQN, 8, 4, 400, discrete=True, batch_max=64, n_learners=P, seed=11)           # (the ring wraps inside the run)
             pool = EnvPool("SynLinearDiscrete-v0", P * Ev, n_threads=1, seed=5)
@@ -357,12 +363,56 @@ def test_prearmed_launches_on_and_off_agree(N, monkeypatch, kind, P, Ev, every):
                for p in range(P)]
         res.append((outs, rows, par, [[e.opt_step(net, learner=p) for net in nets] for p in range(P)], e.last_indices(kw["batch"]) if hasattr(e, "last_indices") else None))
         pool.close(); e.close()
+    a = res[0]
+    for b in res[1:]:
+        assert [o["updates"] for o in a[0]] == [o["updates"] for o in b[0]] and a[0][0]["updates"] > 0
+        assert [o["return_sum"] for o in a[0]] == [o["return_sum"] for o in b[0]]
+        for p in range(P):
+            np.testing.assert_array_equal(a[1][p], b[1][p])
+            np.testing.assert_array_equal(a[2][p], b[2][p])
+            assert a[3][p] == b[3][p]
+        if a[4] is not None:
+            np.testing.assert_array_equal(a[4], b[4])
+
+
+class _SlowOnce:
+    """An in-repo env whose k-th step takes `seconds` — longer than the host's patience with a pre-armed launch (1 s) and, with the
+    default launch bound, most of the way to the launch's own 2 s."""
+
+    def __init__(self, env, k, seconds):
+        self.env, self.k, self.seconds, self.n = env, k, seconds, 0
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+
+    def reset(self, seed=None):
+        return self.env.reset(seed=seed)
+
+    def step(self, a):
+        self.n += 1
+        if self.n == self.k:
+            import time
+            time.sleep(self.seconds)
+        return self.env.step(a)
+
+
+@pytest.mark.parametrize("seconds", [0.0, 1.3])
+def test_a_slow_env_step_does_not_cost_the_prearmed_update(N, monkeypatch, seconds):
+    """One env.step of 1.3 s in the middle of a DQN run over Python CartPole: the launch that was armed for that step is cancelled and
+    the step replayed the plain way — same ring, same net and optimiser state as the run that never arms."""
+    from freerl_amd import envs as E
+    from freerl_amd.engine import Engine
+    from freerl_amd.envpool import CallbackEnvPool, rollout
+    monkeypatch.delenv("FRL_ROLLOUT_ARM_PATIENCE_MS", raising=False)
+    res = []
+    for arm in ("0", "1"):
+        monkeypatch.setenv("FRL_ROLLOUT_PREARM", arm)
+        pool = CallbackEnvPool([_SlowOnce(E.make("CartPole-v1", prefer_gymnasium=False), 90, seconds)], seed=7)        # (seeded resets: the two runs see the same env)
+        e = Engine(N.ALGO_DQN, 4, 2, 1000, discrete=True, batch_max=32, n_learners=1, seed=4)
+        _rand_params(e, N, 0.2, seed=5)
+        out = rollout(e, pool, 120, envs_per_learner=1, start_steps=64, learn_every=1, epsilon=0.3, batch=32, critic_lr=1e-3, tau=0.05)
+        res.append((out["updates"], out["return_sum"], e.read_rows(0, 0, 120), e.get_params(0), e.get_params(0, N.PARAM_TARGET),
+                    e.get_params(0, N.PARAM_ADAM_V), e.opt_step(0)))
+        pool.close(); e.close()
     a, b = res
-    assert [o["updates"] for o in a[0]] == [o["updates"] for o in b[0]] and a[0][0]["updates"] > 0
-    assert [o["return_sum"] for o in a[0]] == [o["return_sum"] for o in b[0]]
-    for p in range(P):
-        np.testing.assert_array_equal(a[1][p], b[1][p])
-        np.testing.assert_array_equal(a[2][p], b[2][p])
-        assert a[3][p] == b[3][p]
-    if a[4] is not None:
-        np.testing.assert_array_equal(a[4], b[4])
+    assert a[0] == b[0] > 40 and a[1] == b[1] and a[6] == b[6]
+    for k in (2, 3, 4, 5):
+        np.testing.assert_array_equal(a[k], b[k])
