@@ -181,6 +181,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             // rejection in its own LDS: ~3 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
             // same values to D.idx (the actor stage and frl_last_indices read them)
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
+            SOLO_T(10);
             draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key, false);
             ri = lidx[valid ? row : B - 1];
             SOLO_T(8);

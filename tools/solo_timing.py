@@ -32,7 +32,8 @@ def stamps(do_actor):
     buf = np.zeros((16, 32), np.float32)
     N.check(N.lib().frl_solo_debug_read(e._h, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size))
     if buf[:, 16:18].any():
-        print("   (inside the first section, workgroup 0: indices drawn at %.2f us, row fields + noise issued at %.2f us)" % (buf[0, 16] * 0.01, buf[0, 17] * 0.01))
+        print("   (inside the first section, workgroup 0: the index draw starts at %.2f us, indices drawn at %.2f us, row fields + noise issued at %.2f us)"
+              % (buf[0, 18] * 0.01, buf[0, 16] * 0.01, buf[0, 17] * 0.01))
     return buf[:, 8:16] * 0.01          # us
 
 
