@@ -9,7 +9,10 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KINDS = {"dqn1": ("dqn", 1, 1), "dqn4": ("dqn", 4, 3), "td3": ("td3", 1, 1), "sac": ("sac", 1, 2), "ddpg2": ("ddpg", 2, 1)}
+KINDS = {"dqn1": ("dqn", 1, 1), "dqn4": ("dqn", 4, 3), "td3": ("td3", 1, 1), "sac": ("sac", 1, 2), "ddpg2": ("ddpg", 2, 1),
+         # full-chip populations of the sixteen-workgroup kernels (every CU busy: the flag hand-overs under load); no launch is armed at
+         # these sizes, so the two runs are the same program twice — a stale read or a race shows as a run-to-run difference
+         "td3x16": ("td3", 16, 1), "sacx12": ("sac", 12, 2)}
 
 
 def worker(kind, steps):
@@ -56,10 +59,12 @@ if __name__ == "__main__":
         sys.exit(0)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
     bad = 0
-    for kind in (sys.argv[2:] or list(KINDS)):
+    for kind in (sys.argv[2:] or [k for k in KINDS if "x" not in k]):
         res = []
         for arm in ("1", "0"):
             env = dict(os.environ, FRL_ROLLOUT_PREARM=arm)
+            if "x" in kind:                    # (the default: nothing armed at these sizes)
+                env.pop("FRL_ROLLOUT_PREARM")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", kind, str(steps)], env=env, capture_output=True, text=True)
             res.append(r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED: " + r.stderr[-300:])
         same = res[0].split()[:3] == res[1].split()[:3] and not res[0].startswith("FAILED")
