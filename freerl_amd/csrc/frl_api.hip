@@ -96,7 +96,9 @@ struct frl_engine {
     float* d_solo_slab = nullptr;
     float* d_solo_part = nullptr;
     unsigned* d_solo_bar = nullptr;
-    int* d_solo_err = nullptr;
+    int* d_solo_err = nullptr;            // device address of h_solo_err
+    int* h_solo_err = nullptr;            // pinned: a solo workgroup that waited 2 s for its learner's others sets it (checked after syncs: solo_err_check)
+    int* d_solo_ticket = nullptr;         // the rollout tail's learner ticket
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
     int solo_stride = 0;
     float* d_act_in = nullptr;
@@ -261,6 +263,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_solo_slab) hipFree(e->d_solo_slab);
     if (e->d_solo_part) hipFree(e->d_solo_part);
     if (e->d_solo_bar) hipFree(e->d_solo_bar);
+    if (e->h_solo_err) hipHostFree(e->h_solo_err);
     float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo, e->d_act_wk, e->h.wide_scr};
     for (float* p : dev) if (p) hipFree(p);
@@ -524,7 +527,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             float* z = nullptr;
             CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
             e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
-            e->d_solo_err = (int*)(z + 2 * P * (size_t)kSoloWG);           // the error word, the rollout tail's learner ticket
+            e->d_solo_ticket = (int*)(z + 2 * P * (size_t)kSoloWG);        // ... and the rollout tail's learner ticket
+            CREATE_TRY(hipHostMalloc((void**)&e->h_solo_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
+            *e->h_solo_err = 0;
+            CREATE_TRY(hipHostGetDevicePointer((void**)&e->d_solo_err, e->h_solo_err, 0));
         }
         if (h.wide) {
             CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
@@ -610,10 +616,20 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     if (!(e)) return fail(FRL_ERR_INVALID, "engine is NULL");   \
     HIP_TRY(hipSetDevice((e)->cfg.device_id))
 
+// kernels_solo.hip's hand-overs spin on flags of the learner's other workgroups, which therefore must all be resident; a workgroup that
+// has waited 2 s gives up, sets the pinned word and the launch's numbers are not valid.  That takes something else holding this GPU's CUs
+// for seconds (another process' long kernel): reported at the next synchronising call instead of passing silently.
+static int solo_err_check(frl_engine* e) {
+    if (!e->h_solo_err || *(volatile int*)e->h_solo_err == 0) return FRL_OK;
+    *(volatile int*)e->h_solo_err = 0;
+    return fail(FRL_ERR_STATE, "kernels_solo.hip: a workgroup waited 2 s for the other workgroups of its learner (is something else holding this GPU's "
+                               "CUs?); the updates since the last synchronising call are not valid");
+}
+
 extern "C" int frl_sync(frl_engine* e) {
     ENG(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return FRL_OK;
+    return solo_err_check(e);
 }
 
 extern "C" int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* rc_out) {
@@ -888,7 +904,11 @@ static int params_xfer(frl_engine* e, int learner, int net, int kind, float* hos
     // Wk[k_pad][n_pad], or the fragment-image order of the register-chained engines (frl_desc.h: weight_index)
     std::vector<float> blk(N.size, 0.f);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (!to_device) HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
+    if (!to_device) {
+        const int rs = solo_err_check(e);
+        if (rs) return rs;
+        HIP_TRY(hipMemcpy(blk.data(), dev, (size_t)N.size * sizeof(float), hipMemcpyDeviceToHost));
+    }
     size_t o = 0;
     for (int i = 0; i < N.n_layers + N.n_shadow; ++i) {       // shadow layers (a noisy head's sigma) follow the forward ones
         const LayerDesc& L = N.L[i];
@@ -1191,7 +1211,7 @@ extern "C" int frl_stats_get(frl_engine* e, float* out_host) {
     if (!e->has_nets || !out_host) return fail(FRL_ERR_INVALID, "bad argument");
     HIP_TRY(hipMemcpyAsync(out_host, e->h.stats, (size_t)e->h.P * e->h.n_agents * ST_COUNT * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return FRL_OK;
+    return solo_err_check(e);
 }
 
 extern "C" int frl_last_indices(frl_engine* e, int batch, int64_t* out_host) {
