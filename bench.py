@@ -433,6 +433,23 @@ def main():
                 if name == "td3":
                     single = 1.0 / dt1
                 e1.close()
+            # ... and sixteen learners: the largest population of the same kernels (16 x 16 workgroups = every CU of the chip)
+            try:
+                e16 = make_engine(N, Engine, 16, local_rank, seed=7)
+                for k in range(20):
+                    e16.learn(BATCH, **td3_kwargs(k))
+                e16.sync()
+                t1 = time.perf_counter()
+                for k in range(400):
+                    e16.learn(BATCH, **td3_kwargs(k))
+                e16.sync()
+                dt16 = (time.perf_counter() - t1) / 400
+                p16 = e16.learn_path(BATCH)
+                single_detail["td3_16_learners"] = {"us_per_learn": dt16 * 1e6, "updates_per_sec": 16 / dt16,
+                                                    "kernel_family": "solo" if p16[2] == 16 and p16[0] else ("chained" if p16[0] else "row-chunk")}
+                e16.close()
+            except Exception as ex:                       # a detail of the report, never the reason a bench line is missing
+                single_detail["td3_16_learners"] = {"error": str(ex)[:200]}
         traffic, traffic_stale = traffic_figure()
         line = {
             "metric": "learner_updates_per_sec", "value": total_updates / dt_max, "unit": "updates/s",
