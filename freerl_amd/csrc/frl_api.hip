@@ -1271,7 +1271,7 @@ extern "C" int frl_noisy_resample(frl_engine* e, const float* eps_host) {
     if (!e->h.noisy) return fail(FRL_ERR_STATE, "engine has no NoisyLinear head");
     if (eps_host) { int rc = noisy_upload(e, eps_host, 0, 1); if (rc) return rc; }
     else hipLaunchKernelGGL(noisy_draw_kernel, dim3(e->h.P, 1), dim3(256), 0, e->stream, e->d, 0, 1, e->rng_counter++);
-    hipLaunchKernelGGL(noisy_materialise_kernel, dim3(e->h.P, 1), dim3(256), 0, e->stream, e->d, 0, 1, 0);
+    hipLaunchKernelGGL(noisy_materialise_kernel, dim3(e->h.P), dim3(256), 0, e->stream, e->d, 0, 1, 0);
     HIP_TRY(hipGetLastError());
     return FRL_OK;
 }
@@ -1395,7 +1395,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         if (h.obs_norm_on && h.algo != ALGO_DQN)                         // sample(): norm(obs) updates the statistics first
             hipLaunchKernelGGL(obsnorm_kernel, dim3(pc), blk, 0, st, e->d, a.batch, 0, p0);
         if (h.noisy)      // sets: 0 online on s' (Double only), 1 target on s', 2 online on s
-            hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P, 3), blk, 0, st, e->d, 0, 3, 0x2);
+            hipLaunchKernelGGL(noisy_materialise_kernel, dim3(h.P), blk, 0, st, e->d, 0, 3, 0x2);
         if (v2 && h.wide) {                               // kernels_criticw.hip: one workgroup per (learner, agent)
             prof_begin(e, PK_GRAD_CRITIC);
             const bool x = h.wide == 2;
