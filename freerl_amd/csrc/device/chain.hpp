@@ -20,6 +20,16 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
 }
 
+// v[c] for a runtime c without a dynamically indexed register array (which hipcc would put in scratch memory): a chain of
+// selects over compile-time indices
+template <int I, int N, class T>
+__device__ __forceinline__ T pick_from(const T (&v)[N], int c, T r) {
+    if constexpr (I < N) return pick_from<I + 1, N, T>(v, c, c == I ? v[I] : r);
+    else return r;
+}
+template <int N, class T>
+__device__ __forceinline__ T pick(const T (&v)[N], int c) { return pick_from<1, N, T>(v, c, v[0]); }
+
 // dword offset of element (f16, k16) of 16x16 fragment tile `tile` in a fragment-ordered LDS image: the 16-byte slot of
 // (q = k16 >> 2, f16) sits at q*16 + (f16 ^ q)
 __device__ __forceinline__ int frag_dw(int tile, int f16, int k16) {

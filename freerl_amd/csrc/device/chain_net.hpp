@@ -26,17 +26,24 @@ constexpr int kChainBatch = 256;          // rows of per-row staging (actions, t
 // (the constants themselves: frl_desc.h, kL1w .. kHeadFloats)
 
 struct ChainLds {
-    lds_f w1, w2, w3, b1, b2, b3, ls, ea, eb, ab, yb, q1, lpn, red;
+    lds_f w1, w2, w3, b1, b2, b3, ls, ea, eb, ab, yb, q1, lpn, red, ex;
 };
 constexpr int chain_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + kChainBatch * 4 + 3 * kChainBatch + 64; }
+// the eight-wave workgroups (ChainNetT<8>) carry one more kilofloat: `ex`, the narrow tile (dz / x) of each of the eight waves in
+// the exchanges that put all 128 rows at once, is `ab` (dead during a backward) plus these 4 KB behind it
+constexpr int chain8_lds_floats() { return chain_lds_floats() + 1024; }
 
 // the weight-gradient accumulators one lane owns for one 3-layer head, TRANSPOSED (MFMA D layout of dW^T: in = 16*kt + 4q + r,
 // out = 16*ot + i16 — the lane's four registers are the 16-byte slot (q, f = i16) of image tile (ot, kt)):
 // layer 2: ot in {2w, 2w+1} x kt 0..7; layer 1 (one 16-wide input block): ot in {2w, 2w+1}; head: kt in {2w, 2w+1}
-struct HeadGrad {
-    f32x4 g2[2][kHT], g1[2], g3[2];
-    float gb1[2], gb2[2], gb3;
+// NW = waves of the workgroup (4 or 8): a wave owns OT = 8 / NW tile rows of layers 1 / 2 and as many k-tiles of the head
+template <int NW>
+struct HeadGradT {
+    static constexpr int OT = kHT / NW;
+    f32x4 g2[OT][kHT], g1[OT], g3[OT];
+    float gb1[OT], gb2[OT], gb3;
 };
+using HeadGrad = HeadGradT<4>;
 
 // (no flags in here: the update runs inside MFMA chains, where a branch would cut the scheduling region — the soft target update is
 // a template argument of the functions below, weight decay is applied unconditionally: g + 0 * theta = g)
@@ -85,7 +92,17 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int 
 
 
 
-struct ChainNet {
+// NW = waves per workgroup.  4 (256 threads): a wave carries its 16 (or T x 16) rows through the whole MLP at ONE wave per SIMD
+// and owns two tile rows of every weight-gradient.  8 (512 threads, round 6): the same chains on twice as many waves, each
+// owning ONE tile row — half the accumulators, every wave inside 256 registers, TWO waves per SIMD: one wave's exchange writes,
+// row fetches, epilogues and its Adam stream overlap the MFMAs of the wave it shares the SIMD with.  The images are one learner's
+// either way; the exchange buffers hold 64 rows (NW = 4: a chunk; NW = 8: half a chunk — the layer-2 exchange runs in two
+// halves, the two narrow ones put all 128 rows at once: 8 x 8 wide tiles fill ea + eb, the ninth tile of a wave goes to `ex`).
+template <int NW>
+struct ChainNetT {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static constexpr int OT = kHT / NW, kThreads = 64 * NW, kRows = 16 * NW;
+    using Grad = HeadGradT<NW>;
     ChainLds S;
     int tid, l, w, i16, q, fslot, tslot;
     int lane2, lane1;      // byte offsets of this lane's slot inside its first owned tile of the 128 x 128 layer / of the two narrow layers
@@ -101,11 +118,21 @@ struct ChainNet {
         S.b2 = p; p += kHid;
         S.b3 = p; p += 16;
         S.ls = p; p += 16;
-        S.ab = p; p += kChainBatch * 4;
-        S.yb = p; p += kChainBatch;
-        S.q1 = p; p += kChainBatch;
-        S.lpn = p; p += kChainBatch;
-        S.red = p; p += 64;
+        if constexpr (NW == 4) {
+            S.ab = p; p += kChainBatch * 4;
+            S.yb = p; p += kChainBatch;
+            S.q1 = p; p += kChainBatch;
+            S.lpn = p; p += kChainBatch;
+            S.red = p; p += 64;
+            S.ex = S.ab;                                               // (unused)
+        } else {
+            S.yb = p; p += kChainBatch;
+            S.q1 = p; p += kChainBatch;
+            S.lpn = p; p += kChainBatch;
+            S.red = p; p += 64;
+            S.ab = p; p += kChainBatch * 4;                            // ex = ab + the kilofloat behind it (chain8_lds_floats)
+            S.ex = S.ab;
+        }
         init_lanes();
     }
     // the lane constants alone (device/chain_wide.hpp carves its own LDS and borrows the tile helpers below)
@@ -113,23 +140,23 @@ struct ChainNet {
         tid = threadIdx.x; l = tid & 63; w = __builtin_amdgcn_readfirstlane(tid >> 6); i16 = l & 15; q = l >> 4;
         fslot = (q * 16 + (i16 ^ q)) << 2;                             // forward / exchange fragment read (16 B)
         tslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);                  // transposed read / owner write: + ((f ^ (i16 >> 2)) << 2)
-        lane2 = 4 * (w * 2 * kHT * 256 + fslot);
-        lane1 = 4 * (w * 2 * 256 + fslot);
+        lane2 = 4 * (w * OT * kHT * 256 + fslot);
+        lane1 = 4 * (w * OT * 256 + fslot);
     }
 
-    // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy, in two
-    // halves.  stage_fetch issues every load of the net (84 registers per lane) and can sit IN FRONT of the previous net's last
-    // pass: all 256 workgroups stage at the same moment, 21 MB in one burst that HBM serves in ~9-12 k cycles — under a pass's
-    // MFMAs that costs nothing.  stage_commit waits for the other waves to be done with the old images and stores.
+    // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy.
+    // stage_fetch issues every load of the net (84 registers per lane at four waves, 44 at eight) and can sit IN FRONT of the
+    // previous net's last pass: all 256 workgroups stage at the same moment, 21 MB in one burst that HBM serves in ~9-12 k cycles —
+    // under a pass's MFMAs that costs nothing.  stage_commit waits for the other waves to be done with the old images and stores.
     // th = the net's block, head = which head of it; extra_n > 0: a single-head net's log_std entries behind its block
-    struct StageRegs { f32x4 t2[16], t1[2], t3[2]; float bb1, bb2, bb3, lsv; };
+    struct StageRegs { f32x4 t2[64 / NW], t1[8 / NW], t3[8 / NW]; float bb1, bb2, bb3, lsv; };
     __device__ __forceinline__ StageRegs stage_fetch(g_cf th, int head, int extra_n = 0) const {
         th += head * kHeadFloats;
         StageRegs R;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) R.t2[j] = ld4_stage(th + kL2w + 4 * (tid + 256 * j));
+        for (int j = 0; j < 64 / NW; ++j) R.t2[j] = ld4_stage(th + kL2w + 4 * (tid + kThreads * j));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { R.t1[j] = ld4_stage(th + kL1w + 4 * (tid + 256 * j)); R.t3[j] = ld4_stage(th + kL3w + 4 * (tid + 256 * j)); }
+        for (int j = 0; j < 8 / NW; ++j) { R.t1[j] = ld4_stage(th + kL1w + 4 * (tid + kThreads * j)); R.t3[j] = ld4_stage(th + kL3w + 4 * (tid + kThreads * j)); }
         R.bb1 = R.bb2 = R.bb3 = R.lsv = 0.f;
         if (tid < kHid) { R.bb1 = th[kL1b + tid]; R.bb2 = th[kL2b + tid]; }
         if (tid < 16) { R.bb3 = th[kL3b + tid]; R.lsv = tid < extra_n ? th[kHeadFloats + tid] : 0.f; }
@@ -139,9 +166,9 @@ struct ChainNet {
     __device__ __forceinline__ void stage_commit(const StageRegs& R) const {
         lds_barrier();                                                 // every wave is done with the previous images
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st4(S.w2 + 4 * (tid + 256 * j), R.t2[j]);
+        for (int j = 0; j < 64 / NW; ++j) st4(S.w2 + 4 * (tid + kThreads * j), R.t2[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { st4(S.w1 + 4 * (tid + 256 * j), R.t1[j]); st4(S.w3 + 4 * (tid + 256 * j), R.t3[j]); }
+        for (int j = 0; j < 8 / NW; ++j) { st4(S.w1 + 4 * (tid + kThreads * j), R.t1[j]); st4(S.w3 + 4 * (tid + kThreads * j), R.t3[j]); }
         if (tid < kHid) { S.b1[tid] = R.bb1; S.b2[tid] = R.bb2; }
         if (tid < 16) { S.b3[tid] = R.bb3; S.ls[tid] = R.lsv; }
         lds_barrier();
@@ -323,15 +350,22 @@ struct ChainNet {
         return dx;
     }
 
+    // exchange tiles: E[(feature tile ft) * 4 + (wave slot)][256] in image order, 64 rows = four wave slots per buffer
     __device__ __forceinline__ void put_tile(lds_f E, int ft, const f32x4& t) const {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) E[(ft * 4 + w) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
+        for (int r = 0; r < 4; ++r) E[(ft * 4 + (w & 3)) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
     }
     __device__ __forceinline__ f32x4 get_frag(lds_cf E, int ft, int bb) const { return ld4(E + (ft * 4 + bb) * 256 + fslot); }
-
-    __device__ __forceinline__ void grad_zero(HeadGrad& g) const {
+    // ... and the all-rows form of the eight-wave workgroups: ea + eb as ONE buffer of [ft][8 wave slots]; a wave's narrow tile in ex
+    __device__ __forceinline__ void put_tile8(lds_f E, int ft, const f32x4& t) const {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int r = 0; r < 4; ++r) E[(ft * 8 + w) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
+    }
+    __device__ __forceinline__ f32x4 get_frag8(lds_cf E, int ft, int bb) const { return ld4(E + (ft * 8 + bb) * 256 + fslot); }
+
+    __device__ __forceinline__ void grad_zero(Grad& g) const {
+#pragma unroll
+        for (int x = 0; x < OT; ++x) {
 #pragma unroll
             for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             g.g1[x] = f32x4{0.f, 0.f, 0.f, 0.f}; g.g3[x] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -340,10 +374,11 @@ struct ChainNet {
         g.gb3 = 0.f;
     }
 
-    // ---- backward of one 64-row chunk (16 rows per wave) into the owners' accumulators: three exchanges through ea / eb
-    // (H2 + dz -> head gradient; H1 + dz2 -> layer 2; X + dz1 -> layer 1), the dH chains in between
+    // ---- backward of one chunk (16 rows per wave: 64 rows at four waves, 128 at eight) into the owners' accumulators: three
+    // exchanges through ea / eb (H2 + dz -> head gradient; H1 + dz2 -> layer 2; X + dz1 -> layer 1), the dH chains in between
     // hn > 0: the head has hn <= 4 outputs and its dH runs as dot products (delta2_valu)
-    __device__ __forceinline__ void backward(HeadGrad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn = 0) const {
+    __device__ __forceinline__ void backward(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn = 0) const {
+        if constexpr (NW == 8) { backward8(g, xb, h1, h2, dz, hn); return; }
         lds_barrier();                                                 // the previous chunk's readers of ea / eb are done
 #pragma unroll
         for (int ft = 0; ft < kHT; ++ft) put_tile(S.ea, ft, h2[ft]);
@@ -354,7 +389,7 @@ struct ChainNet {
             const f32x4 af = get_frag(S.eb, 0, bb);
             if (w == 0) g.gb3 += (af[0] + af[1]) + (af[2] + af[3]);
 #pragma unroll
-            for (int x = 0; x < 2; ++x) g.g3[x] = mfma4(g.g3[x], get_frag(S.ea, 2 * w + x, bb), af);
+            for (int x = 0; x < OT; ++x) g.g3[x] = mfma4(g.g3[x], get_frag(S.ea, OT * w + x, bb), af);
         }
         f32x4 d2[kHT];
         if (hn > 0) delta2_valu(dz, h2, d2, hn); else delta2(dz, h2, d2);
@@ -362,21 +397,7 @@ struct ChainNet {
 #pragma unroll
         for (int ft = 0; ft < kHT; ++ft) { put_tile(S.ea, ft, h1[ft]); put_tile(S.eb, ft, d2[ft]); }
         lds_barrier();
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            f32x4 af[2], bf[kHT];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                af[x] = get_frag(S.eb, 2 * w + x, bb);
-                g.gb2[x] += (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
-            }
-#pragma unroll
-            for (int kt = 0; kt < kHT; ++kt) bf[kt] = get_frag(S.ea, kt, bb);
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], bf[kt], af[x]);
-        }
+        layer2_consume(g);
         f32x4 d1[kHT];
         delta1(d2, h1, d1);
         lds_barrier();
@@ -388,28 +409,92 @@ struct ChainNet {
         for (int bb = 0; bb < 4; ++bb) {
             const f32x4 bf = get_frag(S.ea, 0, bb);
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const f32x4 af = get_frag(S.eb, 2 * w + x, bb);
+            for (int x = 0; x < OT; ++x) {
+                const f32x4 af = get_frag(S.eb, OT * w + x, bb);
                 g.gb1[x] += (af[0] + af[1]) + (af[2] + af[3]);
                 g.g1[x] = mfma4(g.g1[x], bf, af);
             }
         }
     }
+    // the layer-2 contraction over the 64 rows that lie in ea (h1) / eb (d2): this wave's OT tile rows x 8 k-tiles
+    __device__ __forceinline__ void layer2_consume(Grad& g) const {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            f32x4 af[OT], bf[kHT];
+#pragma unroll
+            for (int x = 0; x < OT; ++x) {
+                af[x] = get_frag(S.eb, OT * w + x, bb);
+                g.gb2[x] += (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < kHT; ++kt) bf[kt] = get_frag(S.ea, kt, bb);
+#pragma unroll
+            for (int x = 0; x < OT; ++x)
+#pragma unroll
+                for (int kt = 0; kt < kHT; ++kt) g.g2[x][kt] = mfma4(g.g2[x][kt], bf[kt], af[x]);
+        }
+    }
+    // Eight waves, 128 rows.  The two narrow exchanges (head: H2 + dz; first layer: dz1 + X) put ALL rows at once — the wide
+    // operand's 8 x 8 tiles are exactly ea + eb, the narrow one's eight tiles lie in ex — two barriers each.  The layer-2 exchange
+    // needs H1 and dz2 of every row, 128 KB: it runs in two 64-row halves (the waves of the other half wait out the ~500 cycles of
+    // a half's writes: 2 % of a chunk; running their dH1 chain there instead was built — it holds d1 through the contraction, 32
+    // registers the kernel does not have).
+    __device__ __forceinline__ void backward8(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn) const {
+        const lds_f E = S.ea;
+        const int hv = w >> 2;                                         // which 64-row half this wave's rows belong to
+        lds_barrier();                                                 // the previous chunk's readers of ea / eb / ex are done
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) put_tile8(E, ft, h2[ft]);
+        put_tile8(S.ex, 0, dz);
+        f32x4 d2[kHT];
+        if (hn > 0) delta2_valu(dz, h2, d2, hn); else delta2(dz, h2, d2);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const f32x4 af = get_frag8(S.ex, 0, bb);
+            if (w == 0) g.gb3 += (af[0] + af[1]) + (af[2] + af[3]);
+            g.g3[0] = mfma4(g.g3[0], get_frag8(E, w, bb), af);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            lds_barrier();
+            if (hv == half) {
+#pragma unroll
+                for (int ft = 0; ft < kHT; ++ft) { put_tile(S.ea, ft, h1[ft]); put_tile(S.eb, ft, d2[ft]); }
+            }
+            lds_barrier();
+            layer2_consume(g);
+        }
+        f32x4 d1[kHT];
+        delta1(d2, h1, d1);
+        lds_barrier();
+        put_tile8(S.ex, 0, xb);
+#pragma unroll
+        for (int ft = 0; ft < kHT; ++ft) put_tile8(E, ft, d1[ft]);
+        lds_barrier();
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const f32x4 bf = get_frag8(S.ex, 0, bb);
+            const f32x4 af = get_frag8(E, w, bb);
+            g.gb1[0] += (af[0] + af[1]) + (af[2] + af[3]);
+            g.g1[0] = mfma4(g.g1[0], bf, af);
+        }
+    }
 
     // after the last chunk: the bias partials of the four lane groups (rows 4q..4q+3 of every 16-row block) added up
-    __device__ __forceinline__ void grad_finish(HeadGrad& g) const {
+    __device__ __forceinline__ void grad_finish(Grad& g) const {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < OT; ++x) {
             g.gb1[x] += lane_xor<16>(g.gb1[x]); g.gb1[x] += lane_xor<32>(g.gb1[x]);
             g.gb2[x] += lane_xor<16>(g.gb2[x]); g.gb2[x] += lane_xor<32>(g.gb2[x]);
         }
         g.gb3 += lane_xor<16>(g.gb3); g.gb3 += lane_xor<32>(g.gb3);
     }
     // this lane's share of the squared gradient norm (bias entries counted once: lanes q == 0 / wave 0)
-    __device__ __forceinline__ float grad_sumsq(const HeadGrad& g) const {
+    __device__ __forceinline__ float grad_sumsq(const Grad& g) const {
         float ss = 0.f;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < OT; ++x) {
 #pragma unroll
             for (int kt = 0; kt < kHT; ++kt)
                 ss += (g.g2[x][kt][0] * g.g2[x][kt][0] + g.g2[x][kt][1] * g.g2[x][kt][1]) + (g.g2[x][kt][2] * g.g2[x][kt][2] + g.g2[x][kt][3] * g.g2[x][kt][3]);
@@ -426,16 +511,17 @@ struct ChainNet {
     // lane and one whole contiguous 1 KB tile per wave-instruction.  Loads of a batch of tiles before its stores (the compiler
     // cannot prove the four arrays distinct and would wait for every store before the next load).  No LDS, no barriers.
     struct AdamIn { f32x4 th, mm, vv, tg; };
-    // accumulator unit J of a head block: J < 16 the 128 x 128 layer's tile (ot = 2w + J / 8, kt = J % 8), 16 / 17 the first layer's
-    // tiles ot = 2w + (J & 1), 18 / 19 the head layer's tiles kb = 2w + (J & 1).  Its 16-byte slot sits at lane offset
+    // accumulator unit J of a head block: J < 8 OT the 128 x 128 layer's tile (ot = OT w + J / 8, kt = J % 8), then the first layer's
+    // OT tiles ot = OT w + x, then the head layer's OT tiles kb = OT w + x.  Its 16-byte slot sits at lane offset
     // unit_voff<J>() + the compile-time unit_soff<J>() bytes inside the head's block.
-    template <int J> __device__ __forceinline__ int unit_voff() const { return J < 16 ? lane2 : lane1; }
-    template <int J> static constexpr int unit_soff() { return 4 * (J < 16 ? kL2w + J * 256 : (J < 18 ? kL1w + (J & 1) * 256 : kL3w + (J & 1) * 256)); }
+    static constexpr int kUnits = 10 * OT;
+    template <int J> __device__ __forceinline__ int unit_voff() const { return J < 8 * OT ? lane2 : lane1; }
+    template <int J> static constexpr int unit_soff() { return 4 * (J < 8 * OT ? kL2w + J * 256 : (J < 9 * OT ? kL1w + (J - 8 * OT) * 256 : kL3w + (J - 9 * OT) * 256)); }
     template <int J>
-    __device__ __forceinline__ static const f32x4& unit_grad(const HeadGrad& g) {
-        if constexpr (J < 16) return g.g2[J / 8][J % 8];
-        else if constexpr (J < 18) return g.g1[J - 16];
-        else return g.g3[J - 18];
+    __device__ __forceinline__ static const f32x4& unit_grad(const Grad& g) {
+        if constexpr (J < 8 * OT) return g.g2[J / 8][J % 8];
+        else if constexpr (J < 9 * OT) return g.g1[J - 8 * OT];
+        else return g.g3[J - 9 * OT];
     }
     // HB = byte offset of the head's block inside the net (head * kHeadFloats * 4).  THL: theta from the head's image in LDS — the
     // last head staged is still there, in the same slot order — instead of a second trip to HBM (the update phase is the one
@@ -445,7 +531,7 @@ struct ChainNet {
         AdamIn X;
         constexpr int so = HB + unit_soff<J>();
         const int vo = unit_voff<J>();
-        if constexpr (THL) X.th = ld4((lds_cf)((J < 16 ? S.w2 + (w * 2 * kHT + J) * 256 : (J < 18 ? S.w1 : S.w3) + (w * 2 + (J & 1)) * 256) + fslot));
+        if constexpr (THL) X.th = ld4((lds_cf)((J < 8 * OT ? S.w2 + (w * OT * kHT + J) * 256 : (J < 9 * OT ? S.w1 + (w * OT + J - 8 * OT) * 256 : S.w3 + (w * OT + J - 9 * OT) * 256)) + fslot));
         else X.th = buf_ld4(B.th, vo, so);
         X.mm = buf_ld4(B.mm, vo, so); X.vv = buf_ld4(B.vv, vo, so);
         if constexpr (SOFT) X.tg = buf_ld4(B.tg, vo, so); else X.tg = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -484,26 +570,27 @@ struct ChainNet {
     }
     // biases (every lane group holds the full sums after grad_finish: group q == 0 writes) [, log_std behind a single head]
     template <bool SOFT>
-    __device__ __forceinline__ void adam_biases(const HeadGrad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra, int extra_n) const {
+    __device__ __forceinline__ void adam_biases(const Grad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra, int extra_n) const {
         if (q == 0) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                adam_scalar<SOFT>(th, mA, vA, tg, c, kL1b + (2 * w + x) * 16 + i16, g.gb1[x]);
-                adam_scalar<SOFT>(th, mA, vA, tg, c, kL2b + (2 * w + x) * 16 + i16, g.gb2[x]);
+            for (int x = 0; x < OT; ++x) {
+                adam_scalar<SOFT>(th, mA, vA, tg, c, kL1b + (OT * w + x) * 16 + i16, g.gb1[x]);
+                adam_scalar<SOFT>(th, mA, vA, tg, c, kL2b + (OT * w + x) * 16 + i16, g.gb2[x]);
             }
             if (w == 0) adam_scalar<SOFT>(th, mA, vA, tg, c, kL3b + i16, g.gb3);
             if (w == 1 && i16 < extra_n) adam_scalar<SOFT>(th, mA, vA, tg, c, kHeadFloats + i16, g_extra);
         }
     }
-    // the whole update of head HD of a net, in the open: the 128 x 128 layer's 16 tiles in two batches of 8 (loads of a batch before
-    // its stores), then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
+    // the whole update of head HD of a net, in the open: the units in batches of up to 8 (loads of a batch before its stores),
+    // the 128 x 128 layer's tiles first, then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
     template <bool SOFT, int HD, bool THL = false>
-    __device__ __forceinline__ void adam_head(const HeadGrad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
+    __device__ __forceinline__ void adam_head(const Grad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
                                               int extra_n = 0) const {
         const AdamBuf B = adam_buf(th, mA, vA, tg);
         constexpr int HB = HD * kHeadFloats * 4;
-        static_for<0, 3>([&](auto bc) {
-            constexpr int b0 = decltype(bc)::value * 8, nb = decltype(bc)::value < 2 ? 8 : 4;
+        constexpr int kBatch = NW == 4 ? 8 : 5;                        // (NW = 8: ten units in two batches of five — 80 registers of state)
+        static_for<0, (kUnits + kBatch - 1) / kBatch>([&](auto bc) {
+            constexpr int b0 = decltype(bc)::value * kBatch, nb = b0 + kBatch <= kUnits ? kBatch : kUnits - b0;
             AdamIn in[nb];
             static_for<0, nb>([&](auto j) { in[decltype(j)::value] = adam_load<SOFT, b0 + decltype(j)::value, HB, THL>(B); });
             // Every load of the batch has landed before its first store is issued: gfx9 counts loads and stores in one counter,
@@ -519,5 +606,6 @@ struct ChainNet {
         adam_biases<SOFT>(g, th + HD * kHeadFloats, mA + HD * kHeadFloats, vA + HD * kHeadFloats, tg + HD * kHeadFloats, c, g_extra, extra_n);
     }
 };
+using ChainNet = ChainNetT<4>;
 
 }  // namespace frl

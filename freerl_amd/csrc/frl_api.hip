@@ -127,6 +127,7 @@ struct frl_engine {
     std::vector<int> size_flushed;        // rows valid per learner as of the last flush (PER_Buffer.add's `len(self.buffer) == 0`)
     int* d_size = nullptr;                // [2][P]: size before the flush being applied / current size
     int n_cus = 256;                      // compute units of the device (grid of the persistent kernels)
+    int chain_waves = 8;                  // waves per workgroup of the register-chained actor-critic kernels (FRL_CHAIN_WAVES=4: round 5's)
     int* stage_bucket = nullptr;          // PER, pinned: [off[P + 1] | size_before[P] | leaf[stage_cap]] of the flush being applied
     int* d_stage_bucket = nullptr;
     float* d_per_prio = nullptr;          // [P][batch_max] float32 priorities of the last sample
@@ -561,6 +562,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     e->index.assign(P, 0);
     e->size.assign(P, 0);
     e->staged_per_learner.assign(P, 0);
+    { const char* cw = getenv("FRL_CHAIN_WAVES"); e->chain_waves = (cw && atoi(cw) == 4) ? 4 : 8; }
     if (h.algo == ALGO_DQN)
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
     if (h.wide == 2) {
@@ -578,10 +580,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, critic2_lds_floats() * (int)sizeof(float)));
     } else if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
-        const int lb = critic2_lds_floats() * (int)sizeof(float);
-        CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        const int lb = critic2_lds_floats() * (int)sizeof(float), lb8 = critic8_lds_floats() * (int)sizeof(float);
+        for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_actor_v2_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb8));
+        for (auto k : {ac_critic_v2w4_twin_kernel, ac_critic_v2w4_single_kernel, ac_actor_v2w4_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, c.device_id));
@@ -594,10 +597,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(hipFuncSetAttribute((const void*)act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         if (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) {
-            const int lb = critic2_lds_floats() * (int)sizeof(float);
-            CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_twin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            CREATE_TRY(hipFuncSetAttribute((const void*)ac_critic_v2_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            CREATE_TRY(hipFuncSetAttribute((const void*)ac_actor_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            const int lb = critic2_lds_floats() * (int)sizeof(float), lb8 = critic8_lds_floats() * (int)sizeof(float);
+            for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_actor_v2_kernel})
+                CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb8));
+            for (auto k : {ac_critic_v2w4_twin_kernel, ac_critic_v2w4_single_kernel, ac_actor_v2w4_kernel})
+                CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         }
         if (h.algo == ALGO_PPO) {
             const int lb = ppo2_lds_floats(2) * (int)sizeof(float);
@@ -668,7 +672,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
         return FRL_OK;
     }
     if (chained_out) *chained_out = v2 ? 1 : 0;
-    if (bytes_out) *bytes_out = v2 ? (e->h.wide == 2 ? wide16_lds_floats_host() : (e->h.wide ? wide_lds_floats() : critic2_lds_floats())) * (int)sizeof(float) : e->lds_bytes;
+    if (bytes_out) *bytes_out = v2 ? (e->h.wide == 2 ? wide16_lds_floats_host() : (e->h.wide ? wide_lds_floats() : (e->chain_waves == 8 && !e->h.solo ? critic8_lds_floats() : critic2_lds_floats()))) * (int)sizeof(float) : e->lds_bytes;
     if (rows_out) *rows_out = v2 ? batch : e->h.rc;
     return FRL_OK;
 }
@@ -1423,9 +1427,10 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         if (v2) {
             { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
             prof_begin(e, PK_GRAD_CRITIC);
-            const size_t lb = (size_t)critic2_lds_floats() * sizeof(float);
-            if (h.net[1].heads == 2) hipLaunchKernelGGL(ac_critic_v2_twin_kernel, dim3(pc), blk, lb, st, e->d, a);
-            else hipLaunchKernelGGL(ac_critic_v2_single_kernel, dim3(pc), blk, lb, st, e->d, a);
+            const bool w8 = e->chain_waves == 8, twin = h.net[1].heads == 2;
+            const size_t lb = (size_t)(w8 ? critic8_lds_floats() : critic2_lds_floats()) * sizeof(float);
+            auto k = w8 ? (twin ? ac_critic_v2_twin_kernel : ac_critic_v2_single_kernel) : (twin ? ac_critic_v2w4_twin_kernel : ac_critic_v2w4_single_kernel);
+            hipLaunchKernelGGL(k, dim3(pc), dim3(w8 ? 512 : 256), lb, st, e->d, a);
             prof_end(e);
             return;
         }
@@ -1461,7 +1466,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2) {        // kernels_actor2.hip: the whole actor stage of DDPG / TD3 / SAC in one launch
             prof_begin(e, PK_GRAD_ACTOR);
-            hipLaunchKernelGGL(ac_actor_v2_kernel, dim3(pc), blk, (size_t)critic2_lds_floats() * sizeof(float), st, e->d, a);
+            const bool w8 = e->chain_waves == 8;
+            hipLaunchKernelGGL(w8 ? ac_actor_v2_kernel : ac_actor_v2w4_kernel, dim3(pc), dim3(w8 ? 512 : 256),
+                               (size_t)(w8 ? critic8_lds_floats() : critic2_lds_floats()) * sizeof(float), st, e->d, a);
             prof_end(e);
             return;
         }

@@ -176,7 +176,11 @@ __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau,
 // kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)
 __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+// (round 2-5's four-wave form of the same stage, one wave per SIMD: FRL_CHAIN_WAVES=4, same-box A/B runs)
+__global__ void ac_critic_v2w4_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v2w4_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 constexpr int critic2_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 2 * 8192 + 128 + 128 + 16 + 16 + 256 * 4 + 3 * 256 + 64; }
+constexpr int critic8_lds_floats() { return critic2_lds_floats() + 1024; }      // the eight-wave workgroups' carve (device/chain_net.hpp: chain8_lds_floats)
 
 // kernels_criticw.hip / kernels_actorw.hip: the same two stages on the K-sliced chained design (device/chain_wide.hpp) for wide
 // first layers / heads and multi-agent critics; h<critic heads>a<actor head tiles>
@@ -197,6 +201,7 @@ __global__ void ac_actor_x_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArg
 
 // kernels_actor2.hip: the actor stage of DDPG / TD3 likewise
 __global__ void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_actor_v2w4_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 
 // ---- kernels_solo.hip: a single learner's DDPG / TD3 / SAC update on kSoloWG workgroups (device/solo.hpp)
 struct SoloArgs {

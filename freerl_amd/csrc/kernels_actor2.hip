@@ -20,14 +20,19 @@
 
 namespace frl {
 
-__global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const EngineDesc& D = *Dp;
+// NW = waves per workgroup (device/chain_net.hpp; 8 since round 6, 4 = round 2-5's kernel for A/B runs), TA = 16-row tiles per wave
+// in passes A and B (nothing is accumulated there)
+template <int NW, int TA>
+__device__ __forceinline__ void ac_actor_v2_body(const EngineDesc& D, const LearnArgs& a, float* smem) {
+    constexpr int kRC = 16 * NW, kRowsT = kRC * TA;                    // rows per chunk of pass C / of passes A and B
+    constexpr int kNC = kChainBatch / kRC, kNCT = kChainBatch / kRowsT;
+    static_assert(kNCT >= 1, "a chunk of passes A / B is at most the whole batch");
     const int p = a.p0 + blockIdx.x;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
-    ChainNet C;
+    using Net = ChainNetT<NW>;
+    Net C;
     C.init(smem);
     const ChainLds& S = C.S;
     const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
@@ -47,25 +52,27 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     g_cf noise1 = as_global(D.noise + ((size_t)p * D.noise_sets + 1) * D.batch_max * am);     // the actor stage's eps (set 1)
     const int nq = sac ? NC.heads : 1;                                 // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
     const float dqv = sac ? -0.5f * invB : -invB;
-    const int nchunks = (B + 63) / 64, nch2 = (B + 127) / 128;
+    const int nchunks = (B + kRC - 1) / kRC, nch2 = (B + kRowsT - 1) / kRowsT;
     lds_f dab = S.eb;                                                  // dQ/da[row][4] at the start of eb: pass B has no exchanges
 
-    // observation columns of this lane's rows: pass A / B in the two-tile mapping (128 c2 + 32 w + 16 t + i16), pass C in the
-    // 64-row mapping (64 c + 16 w + i16); ring addresses once, fields one chunk ahead of their use
-    int ridxT[4], ridx[4];
+    // observation columns of this lane's rows: pass A / B in the TA-tile mapping (kRowsT c2 + 16 TA w + 16 t + i16), pass C in the
+    // one-tile mapping (kRC c + 16 w + i16); ring addresses once, fields one chunk ahead of their use
+    int ridxT[kNC], ridx[kNC];
 #pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-        const int rowT = (j4 >> 1) * 128 + 32 * w + (j4 & 1) * 16 + i16, row = j4 * 64 + 16 * w + i16;
+    for (int j4 = 0; j4 < kNC; ++j4) {
+        const int rowT = (j4 / TA) * kRowsT + 16 * TA * w + (j4 % TA) * 16 + i16, row = j4 * kRC + 16 * w + i16;
         ridxT[j4] = rowT < B ? idx[rowT] : -1;
         ridx[j4] = row < B ? idx[row] : -1;
     }
-    struct RowIn2 { f32x4 x[2]; };
+    struct RowIn2 { f32x4 x[TA]; };
     auto load_obs2 = [&](int c2) {
         RowIn2 X;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TA; ++t) {
             X.x[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int ri = c2 == 0 ? ridxT[t] : ridxT[2 + t];
+            int ri = ridxT[t];
+#pragma unroll
+            for (int cc = 1; cc < kNCT; ++cc) ri = c2 == cc ? ridxT[TA * cc + t] : ri;
             if (ri >= 0) {
                 g_cf rec = ring + (size_t)ri * R.stride;
 #pragma unroll
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     };
     auto load_obs = [&](int c) {
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        const int ri = c == 0 ? ridx[0] : (c == 1 ? ridx[1] : (c == 2 ? ridx[2] : ridx[3]));
+        const int ri = pick(ridx, c);
         if (ri >= 0) {
             g_cf rec = ring + (size_t)ri * R.stride;
 #pragma unroll
@@ -93,18 +100,18 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     RowIn2 nxt2 = load_obs2(0);
     // every net's image is fetched (global -> registers) in front of the last pass over the previous net: only the first staging
     // waits for HBM in the open
-    ChainNet::StageRegs pend = C.stage_fetch((g_cf)thA, 0, NA.extra_n);
+    typename Net::StageRegs pend = C.stage_fetch((g_cf)thA, 0, NA.extra_n);
     C.stage_commit(pend);
     PPO_T(0);
     for (int c2 = 0; c2 < nch2; ++c2) {
         const RowIn2 cur = nxt2;
         nxt2 = load_obs2(c2 + 1 < nch2 ? c2 + 1 : 0);                  // (after the last chunk: chunk 0 again, for pass B)
         if (c2 + 1 == nch2) pend = C.stage_fetch(thC, 0);
-        f32x4 z[2], h1[2][kHT], h2[2][kHT];
-        C.forward_vh<2>(cur.x, h1, h2, z, A);
+        f32x4 z[TA], h1[TA][kHT], h2[TA][kHT];
+        C.template forward_vh<TA>(cur.x, h1, h2, z, A);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = c2 * 128 + 32 * w + 16 * t + i16;
+        for (int t = 0; t < TA; ++t) {
+            const int row = c2 * kRowsT + 16 * TA * w + 16 * t + i16;
             if (q == 0 && row < kChainBatch) {
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -137,10 +144,10 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
             if (c2 + 1 < nch2) nxt2 = load_obs2(c2 + 1);
             else if (hd + 1 < nq) nxt2 = load_obs2(0);                 // the next head starts over
             else nxt = load_obs(0);                                    // first chunk of pass C
-            f32x4 xb[2], z[2], h1[2][kHT], h2[2][kHT];
+            f32x4 xb[TA], z[TA], h1[TA][kHT], h2[TA][kHT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            for (int t = 0; t < TA; ++t) {
+                const int row = c2 * kRowsT + 16 * TA * w + 16 * t + i16;
                 xb[t] = cur.x[t];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -148,10 +155,10 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
                     if (row < B && f >= O && f < O + A) xb[t][e] = S.ab[row * 4 + f - O];
                 }
             }
-            C.forward_vh<2>(xb, h1, h2, z, 1);
+            C.template forward_vh<TA>(xb, h1, h2, z, 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = c2 * 128 + 32 * w + 16 * t + i16;
+            for (int t = 0; t < TA; ++t) {
+                const int row = c2 * kRowsT + 16 * TA * w + 16 * t + i16;
                 const bool valid = row < B;
                 f32x4 dz = {0.f, 0.f, 0.f, 0.f};
                 if (q == 0 && valid) { qsum += z[t][0]; dz[0] = dqv; } // actor_loss = -Q(s, actor(s)).mean() [+ alpha log pi]
@@ -167,22 +174,24 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
             }
         }
         // the next image is fetched AFTER this pass, in the open: held across the two-tile forward + dX chain its 84 registers
-        // put the kernel at 512 VGPRs with 54 spilled (fetch-ahead here: 0.355 ms per launch; this way 470 VGPRs, no scratch, 0.347)
+        // put the four-wave kernel at 512 VGPRs with 54 spilled (fetch-ahead here: 0.355 ms per launch; this way 470 VGPRs, no scratch, 0.347)
         pend = hd + 1 < nq ? C.stage_fetch(thC, hd + 1) : C.stage_fetch((g_cf)thA, 0, NA.extra_n);
         PPO_T(2);
     }
     // =========================================================== C: actor forward again, delta through tanh, backward into the accumulators
-    HeadGrad g;
+    typename Net::Grad g;
     PPO_T(2);
     C.grad_zero(g);
     C.stage_commit(pend);                                              // (its leading barrier also publishes dab)
     PPO_T(0);
-    // dab lives in eb, which the backward's exchanges overwrite: this lane's four values per chunk into registers first
-    f32x4 dqa[4], epsa[4];                                             // (SAC: the rows' eps as well, ahead of the loop)
+    // dab lives in eb, which the backward's exchanges overwrite (and at eight waves a[row] in ab as well: ex): this lane's four
+    // values per chunk into registers first
+    f32x4 dqa[kNC], epsa[kNC], ava[NW == 8 ? kNC : 1];                 // (SAC: the rows' eps as well, ahead of the loop)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int row = c * 64 + 16 * w + i16;
+    for (int c = 0; c < kNC; ++c) {
+        const int row = c * kRC + 16 * w + i16;
         dqa[c] = (q == 0 && row < B) ? ld4((lds_cf)(dab + row * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NW == 8) ava[c] = (q == 0 && row < B) ? ld4((lds_cf)(S.ab + row * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
         epsa[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (sac && q == 0 && row < B) {
 #pragma unroll
@@ -192,18 +201,19 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     }
     float gls[4] = {0.f, 0.f, 0.f, 0.f};                               // d loss / d log_std, this lane's rows
     for (int c = 0; c < nchunks; ++c) {
-        const int row = c * 64 + 16 * w + i16;
+        const int row = c * kRC + 16 * w + i16;
         f32x4 xb[1] = {nxt}, z[1], h1[1][kHT], h2[1][kHT];
         nxt = load_obs(c + 1 < nchunks ? c + 1 : 0);
         PPO_T(5);
-        C.forward_vh<1>(xb, h1, h2, z, A);
+        C.template forward_vh<1>(xb, h1, h2, z, A);
         PPO_T(3);
-        const f32x4 dq = c == 0 ? dqa[0] : (c == 1 ? dqa[1] : (c == 2 ? dqa[2] : dqa[3]));
+        const f32x4 dq = pick(dqa, c);
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
         if (q == 0 && row < B) {
             if (sac) {                                                 // through a = tanh(u), u = mean + exp(log_std) eps, and alpha log pi
-                const f32x4 ep = c == 0 ? epsa[0] : (c == 1 ? epsa[1] : (c == 2 ? epsa[2] : epsa[3]));
-                const f32x4 av4 = ld4((lds_cf)(S.ab + row * 4));
+                const f32x4 ep = pick(epsa, c);
+                f32x4 av4;
+                if constexpr (NW == 8) av4 = pick(ava, c); else av4 = ld4((lds_cf)(S.ab + row * 4));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (r < A) {
@@ -230,14 +240,20 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) gls[r] = wave_sum(gls[r]);
     lds_barrier();
-    if (l == 0) {
-        S.red[w] = ss; S.red[8 + w] = qs; S.red[12 + w] = lps;
+    if (l == 0) {                                                      // red: [0, 8) norm, [8, 16) Q, [16, 24) log pi, [24 + 8 r, ...) log_std gradients, 56 the step count
+        S.red[w] = ss; S.red[8 + w] = qs; S.red[16 + w] = lps;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S.red[16 + 4 * r + w] = gls[r];
+        for (int r = 0; r < 4; ++r) S.red[24 + 8 * r + w] = gls[r];
     }
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    if (tid == 0) S.red[32] = __int_as_float(steps[0]);                // (thread 0 rewrites steps[0] after the update: the count travels with the partials)
+    if (tid == 0) S.red[56] = __int_as_float(steps[0]);                // (thread 0 rewrites steps[0] after the update: the count travels with the partials)
     lds_barrier();
+    auto red_sum = [&](int base) {
+        float v = S.red[base];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v += S.red[base + i];
+        return v;
+    };
     // log_std gradient of component i16 (lanes i16 < A); outside the clamp [-20, 2] the gradient is zero (SAC.py:77)
     float g_extra = 0.f, ss_extra = 0.f;
     if (sac) {
@@ -245,16 +261,16 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
         for (int r = 0; r < 4; ++r) {
             if (r < A) {
                 const float raw = S.ls[r];
-                const float gr = (raw >= -20.f && raw <= 2.f) ? ((S.red[16 + 4 * r] + S.red[17 + 4 * r]) + S.red[18 + 4 * r]) + S.red[19 + 4 * r] : 0.f;
+                const float gr = (raw >= -20.f && raw <= 2.f) ? red_sum(24 + 8 * r) : 0.f;
                 ss_extra += gr * gr;
                 if (i16 == r) g_extra = gr;
             }
         }
     }
-    const float total = sqrtf((((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]) + ss_extra);
-    const float qtot = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
-    const float lptot = ((S.red[12] + S.red[13]) + S.red[14]) + S.red[15];
-    const int t = __float_as_int(S.red[32]) + 1;
+    const float total = sqrtf(red_sum(0) + ss_extra);
+    const float qtot = red_sum(8);
+    const float lptot = red_sum(16);
+    const int t = __float_as_int(S.red[56]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     AdamCoef co;
     co.coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = 0.f;
     co.tk = 1.f - a.tau; co.tau = a.tau;
     PPO_T(5);
-    C.adam_head<true, 0, true>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);      // (theta from the actor's image, still staged from pass C)
+    C.template adam_head<true, 0, true>(g, thA, mA, vA, tgA, co, g_extra, sac ? NA.extra_n : 0);      // (theta from the actor's image, still staged from pass C)
     PPO_T(6);
     PPO_TDUMP();
     if (tid == 0) {
@@ -291,6 +307,18 @@ __global__ __launch_bounds__(256) void ac_actor_v2_kernel(const EngineDesc* __re
             st[ST_ENTROPY] = ent_mean;
         }
     }
+}
+
+#ifndef FRL_ACTOR8_TA
+#define FRL_ACTOR8_TA 1
+#endif
+__global__ __launch_bounds__(512) void ac_actor_v2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ac_actor_v2_body<8, FRL_ACTOR8_TA>(*Dp, a, smem);
+}
+__global__ __launch_bounds__(256) void ac_actor_v2w4_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ac_actor_v2_body<4, 2>(*Dp, a, smem);
 }
 
 }  // namespace frl

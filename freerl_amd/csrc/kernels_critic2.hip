@@ -32,15 +32,23 @@ namespace frl {
 #ifndef FRL_CRITIC2_AHEAD
 #define FRL_CRITIC2_AHEAD 1     // the next net's image fetched in front of a target pass's last forward (1) or behind it (0)
 #endif
-template <bool TWIN, int TT>
+// NW = waves per workgroup (device/chain_net.hpp): 8 since round 6 — 512 threads, every wave inside 256 registers, two waves
+// per SIMD; a chunk is 16 NW rows (the target passes: TT times that).  NW = 4 is round 2-5's kernel (one wave per SIMD at
+// 458-472 registers), kept as ac_critic_v2w4_* for same-box A/B runs (FRL_CHAIN_WAVES=4).
+template <bool TWIN, int TT, int NW>
 __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const LearnArgs& a, float* smem) {
-    constexpr int kRowsT = 64 * TT;                                    // rows per target-pass chunk
+    constexpr int kRC = 16 * NW;                                       // rows per chunk of the training pass
+    constexpr int kRowsT = kRC * TT;                                   // rows per target-pass chunk
+    constexpr int kNC = kChainBatch / kRC;                             // chunks of the largest batch = 16-row tiles per wave
+    constexpr int kNCT = kChainBatch / kRowsT;
+    static_assert(kNCT >= 1, "a target-pass chunk is at most the whole batch");
     constexpr int NH = TWIN ? 2 : 1;
     const int p = a.p0 + blockIdx.x;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
-    ChainNet C;
+    using Net = ChainNetT<NW>;
+    Net C;
     C.init(smem);
     const ChainLds& S = C.S;
     const int tid = C.tid, l = C.l, w = C.w, i16 = C.i16, q = C.q;
@@ -58,18 +66,18 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     g_cf noise0 = as_global(D.noise + (size_t)p * D.noise_sets * D.batch_max * am);
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const float invB = 1.f / (float)B;
-    const int nchunks = (B + 63) / 64;
+    const int nchunks = (B + kRC - 1) / kRC;
 
-    // ---- this lane's rows (one per 64-row chunk) are the same in every pass: their ring addresses once, up front; a chunk's
-    // record fields are loaded one chunk ahead of their use (one workgroup per CU: nobody else hides that latency)
+    // ---- this lane's rows (one per chunk) are the same in every pass: their ring addresses once, up front; a chunk's
+    // record fields are loaded one chunk ahead of their use (nobody else hides that latency)
     // Every load below is UNCONDITIONAL — rows past the batch read the batch's last row, columns past the input read its last
     // column — because hipcc's s_waitcnt counts only loads that are always issued: one load under an `if` turns every wait of
     // the loop into vmcnt(0), i.e. into a wait for the chunk that was just prefetched (4.6 k cycles per target chunk pass).
     // What the clamped lanes loaded is dropped where it is USED, a chunk later (zero_pad), not where it is loaded.
-    int ridx[4];
+    int ridx[kNC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int row = c * 64 + 16 * w + i16;
+    for (int c = 0; c < kNC; ++c) {
+        const int row = c * kRC + 16 * w + i16;
         ridx[c] = idx[row < B ? row : B - 1];
     }
     int colx[4];                                                       // this lane's four columns of [s | a] in the record
@@ -81,8 +89,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     struct RowIn { f32x4 x; };
     auto load_row = [&](int c) {                                       // [s | a] of this lane's row of chunk c
         RowIn X;
-        const int ri = c == 0 ? ridx[0] : (c == 1 ? ridx[1] : (c == 2 ? ridx[2] : ridx[3]));
-        g_cf rec = ring + (size_t)ri * R.stride;
+        g_cf rec = ring + (size_t)pick(ridx, c) * R.stride;
 #pragma unroll
         for (int e = 0; e < 4; ++e) X.x[e] = rec[colx[e]];
         return X;
@@ -93,12 +100,12 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         for (int e = 0; e < 4; ++e) r[e] = 4 * q + e < width ? x[e] : 0.f;
         return r;
     };
-    // ---- The target passes carry TT 16-row tiles per wave (64 TT rows per chunk): nothing is differentiated through them, so the
-    // registers the gradient accumulators need later hold more tiles now, and every weight fragment read from LDS feeds
-    // 4 TT MFMAs.  Row of (chunk c2, tile t) on this lane: 64 TT c2 + 16 TT w + 16 t + i16; j4 = TT c2 + t.
-    int ridxT[4];
+    // ---- The target passes carry TT 16-row tiles per wave (16 NW TT rows per chunk): nothing is differentiated through them, so
+    // the registers the gradient accumulators need later hold more tiles now, and every weight fragment read from LDS feeds
+    // 4 TT MFMAs.  Row of (chunk c2, tile t) on this lane: kRowsT c2 + 16 TT w + 16 t + i16; j4 = TT c2 + t.
+    int ridxT[kNC];
 #pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
+    for (int j4 = 0; j4 < kNC; ++j4) {
         const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
         ridxT[j4] = idx[row < B ? row : B - 1];
     }
@@ -106,12 +113,17 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
     for (int e = 0; e < 4; ++e) colo[e] = R.nobs_off[0] + (4 * q + e < O ? 4 * q + e : O - 1);
     struct RowIn2 { f32x4 x[TT]; float rew[TT], done[TT]; };
+    auto tile_of = [&](const int (&v)[kNC], int c2, int t) {           // entry TT c2 + t (t is a constant of an unrolled loop)
+        int r = v[t];
+#pragma unroll
+        for (int cc = 1; cc < kNCT; ++cc) r = c2 == cc ? v[TT * cc + t] : r;
+        return r;
+    };
     auto load_row2 = [&](bool want_rd, int c2) {                       // s' (obs columns) [+ reward / done] of the chunk's tiles
         RowIn2 X;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int ri = (TT == 4 || c2 == 0) ? ridxT[t] : ridxT[(TT == 4 ? 0 : 2) + t];
-            g_cf rec = ring + (size_t)ri * R.stride;
+            g_cf rec = ring + (size_t)tile_of(ridxT, c2, t) * R.stride;
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.x[t][e] = rec[colo[e]];
             X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off];
@@ -120,10 +132,10 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     };
     const int nch2 = (B + kRowsT - 1) / kRowsT;
 
-    // Developer knob (FRL_STAGGER): every workgroup runs the same ~670 k cycles and ends in the one phase that streams HBM
+    // Developer knob (FRL_STAGGER): every workgroup runs the same ~600 k cycles and ends in the one phase that streams HBM
     // (theta / m / v / target, ~1 MB per learner), so the 256 CUs reach it together and share the chip's bandwidth (111 k
     // cycles per learner against 61 k for a CU on its own).  Four start phases spread the bursts (72 k) but the delayed
-    // groups finish later by as much: no net gain at two learners per CU (profiles/README.md), so the default is 0.
+    // groups finish later by as much: no net gain (profiles/README.md), so the default is 0.
     if (a.stagger > 0) {
         const int group = (blockIdx.x >> 3) & 3;
         for (int i = 0; i < group * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
@@ -133,9 +145,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     RowIn2 nxt2 = load_row2(false, 0);
     // the target actor's noise of this lane's rows (lane group 0 finalises the rows), loaded ahead of the pass: inside the epilogue
     // every load was an exposed HBM round trip (~2 k cycles, four per 128-row chunk)
-    f32x4 nzr[4];
+    f32x4 nzr[kNC];
 #pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
+    for (int j4 = 0; j4 < kNC; ++j4) {
         nzr[j4] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
         if (q == 0 && row < B && (sac || a.use_policy_noise)) {
@@ -146,7 +158,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     }
     // every net's image is FETCHED (global -> registers) in front of the last pass over the previous net and committed to LDS
     // when that pass is done: of the five stagings of a critic update only the first waits for HBM in the open
-    ChainNet::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
+    typename Net::StageRegs pend = C.stage_fetch(tgA, 0, NA.extra_n);
     C.stage_commit(pend);
     PPO_T(0);
     PPO_U0();
@@ -159,7 +171,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         if constexpr (last && FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
         PPO_U(0);
         f32x4 z[TT], h1[TT][kHT], h2[TT][kHT];
-        C.forward_vh<TT>(cur.x, h1, h2, z, A);                          // (the actor head's act_dim <= 4 outputs as dot products)
+        C.template forward_vh<TT>(cur.x, h1, h2, z, A);                 // (the actor head's act_dim <= 4 outputs as dot products)
         PPO_U(1);
         if constexpr (last && !FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
 #pragma unroll
@@ -169,7 +181,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             if (q == 0 && row < kChainBatch) {                         // act_dim <= 4: the head's outputs sit on lane group 0
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
                 float lp = 0.f;
-                const f32x4 nr = (TT == 4 || c2 == 0) ? nzr[t] : nzr[(TT == 4 ? 0 : 2) + t];
+                f32x4 nr = nzr[t];
+#pragma unroll
+                for (int cc = 1; cc < kNCT; ++cc) nr = c2 == cc ? nzr[TT * cc + t] : nr;
                 if (valid) {
                     if (sac) {                                         // SAC.py:70-97 on actor_target (SAC.py:227)
 #pragma unroll
@@ -218,7 +232,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             const RowIn2 cur = nxt2;
             if constexpr (!last) nxt2 = load_row2(true, c2 + 1);
             else if (hd + 1 < NH) nxt2 = load_row2(true, 0);           // (hd is a constant of the unrolled head loop)
-            else nxt = load_row(0);                                    // first chunk of the critic pass: [s | a], 64-row mapping
+            else nxt = load_row(0);                                    // first chunk of the critic pass: [s | a], training-pass mapping
             if constexpr (last && FRL_CRITIC2_AHEAD) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
             f32x4 xb[TT], z[TT], h1[TT][kHT], h2[TT][kHT];
 #pragma unroll
@@ -232,7 +246,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                 }
             }
             PPO_U(4);
-            C.forward_vh<TT>(xb, h1, h2, z, 1);
+            C.template forward_vh<TT>(xb, h1, h2, z, 1);
             PPO_U(5);
             if constexpr (last && !FRL_CRITIC2_AHEAD) pend = hd + 1 < NH ? C.stage_fetch(tgC, hd + 1) : C.stage_fetch((g_cf)thC, 0);
 #pragma unroll
@@ -257,18 +271,18 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     PPO_UDUMP();
     PPO_T(2);
     // =========================================================== critic heads: forward, TD delta, backward into the owners' accumulators
-    HeadGrad G[NH];
+    typename Net::Grad G[NH];
     float lossp = 0.f;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
-        HeadGrad& g = G[hd];
+        typename Net::Grad& g = G[hd];
         C.grad_zero(g);
         PPO_T(3);
         C.stage_commit(pend);
         PPO_T(0);
         auto critic_chunk = [&](int c, auto last_c) {
             constexpr bool last = decltype(last_c)::value;
-            const int row = c * 64 + 16 * w + i16;
+            const int row = c * kRC + 16 * w + i16;
             const bool valid = row < B;
             const RowIn cur = nxt;
             nxt = load_row(last ? 0 : c + 1);                          // (after the last chunk: the second head re-reads chunk 0)
@@ -277,7 +291,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             }
             f32x4 xb[1] = {zero_pad(cur.x, O + A)}, z[1], h1[1][kHT], h2[1][kHT];
             PPO_T(4);
-            C.forward_vh<1>(xb, h1, h2, z, 1);
+            C.template forward_vh<1>(xb, h1, h2, z, 1);
             PPO_T(5);
             f32x4 dz = {0.f, 0.f, 0.f, 0.f};
             if (q == 0 && valid) {                                     // loss(Q_h(s, a), y): F.mse_loss, or the Huber option
@@ -308,8 +322,10 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // barrier in between, so a wave must not read it from global memory on its own schedule
     if (tid == 0) S.red[16] = __int_as_float(steps[1]);
     lds_barrier();
-    const float total = sqrtf(((S.red[0] + S.red[1]) + S.red[2]) + S.red[3]);
-    const float loss = ((S.red[8] + S.red[9]) + S.red[10]) + S.red[11];
+    float tot2 = S.red[0], loss = S.red[8];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) { tot2 += S.red[i]; loss += S.red[8 + i]; }
+    const float total = sqrtf(tot2);
     const int t = __float_as_int(S.red[16]) + 1;
     const double bc1 = 1.0 - powi_d((double)a.beta1, t), bc2 = 1.0 - powi_d((double)a.beta2, t);
     AdamCoef co;
@@ -332,13 +348,24 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     }
 }
 
-__global__ __launch_bounds__(256) void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+#ifndef FRL_CRITIC8_TT
+#define FRL_CRITIC8_TT 1        // 16-row tiles per wave in the eight-wave kernels' target passes (2 holds 128 activation registers next to the fetched image: spills)
+#endif
+__global__ __launch_bounds__(512) void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<true, FRL_CRITIC2_TT>(*Dp, a, smem);
+    ac_critic_v2_body<true, FRL_CRITIC8_TT, 8>(*Dp, a, smem);
 }
-__global__ __launch_bounds__(256) void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+__global__ __launch_bounds__(512) void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<false, FRL_CRITIC2_TT>(*Dp, a, smem);
+    ac_critic_v2_body<false, FRL_CRITIC8_TT, 8>(*Dp, a, smem);
+}
+__global__ __launch_bounds__(256) void ac_critic_v2w4_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ac_critic_v2_body<true, FRL_CRITIC2_TT, 4>(*Dp, a, smem);
+}
+__global__ __launch_bounds__(256) void ac_critic_v2w4_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ac_critic_v2_body<false, FRL_CRITIC2_TT, 4>(*Dp, a, smem);
 }
 
 }  // namespace frl
