@@ -12,6 +12,12 @@ namespace frl {
 
 constexpr int kHid = 128, kHT = kHid / 16;
 
+// Developer ablations (timing only — the results are WRONG): bit 0 no clip + Adam + soft update, bit 1 no exchange writes / barriers
+// in the eight-wave backward, bit 2 no barriers in stage_commit, bit 3 no exchange writes (barriers kept)
+#ifndef FRL_ABL
+#define FRL_ABL 0
+#endif
+
 // compile-time loop: f(integral_constant<int, I>) for I in [I0, N) — for bodies that index register arrays and template
 // parameters with the loop variable
 template <int I> using IC = std::integral_constant<int, I>;

@@ -15,6 +15,13 @@
 #pragma once
 #include "chain.hpp"
 
+#ifndef FRL_BW_MASK
+#define FRL_BW_MASK 0
+#endif
+#ifndef FRL_FW_HALF
+#define FRL_FW_HALF 0
+#endif
+
 namespace frl {
 
 constexpr int kChainBatch = 256;          // rows of per-row staging (actions, targets, ...) the carve provides
@@ -144,6 +151,22 @@ struct ChainNetT {
         lane1 = 4 * (w * OT * 256 + fslot);
     }
 
+    // The lane constants as short-lived LOCALS.  The members above are loop invariants of the whole kernel: hipcc hoists every
+    // LDS address built on them (a VGPR per 64 KB window, per transposed-access register r, per wave-dependent tile offset: ~30) to
+    // the kernel's top and, at 256 registers, spills them — and a spill RELOAD is a scratch load behind `s_waitcnt vmcnt(0)`, i.e. a
+    // wait for every row / image prefetch in flight.  The eight-wave kernels re-derive them from the lane number behind an opaque
+    // asm at the top of each phase (five VALU instructions) so that an address lives exactly as long as the phase that uses it.
+    struct LaneK { int i16, q, fslot, tslot; };
+    __device__ __forceinline__ LaneK lanes() const {
+        int L = l;
+        if constexpr (NW == 8) asm volatile("" : "+v"(L));
+        LaneK K;
+        K.i16 = L & 15; K.q = L >> 4;
+        K.fslot = (K.q * 16 + (K.i16 ^ K.q)) << 2;
+        K.tslot = (((K.i16 >> 2) * 16) << 2) + (K.i16 & 3);
+        return K;
+    }
+
     // ---- one net's three layers -> LDS images: the HBM block is already in image order (NetDesc::frag), a linear copy.
     // stage_fetch issues every load of the net (84 registers per lane at four waves, 44 at eight) and can sit IN FRONT of the
     // previous net's last pass: all 256 workgroups stage at the same moment, 21 MB in one burst that HBM serves in ~9-12 k cycles —
@@ -164,14 +187,14 @@ struct ChainNetT {
         return R;
     }
     __device__ __forceinline__ void stage_commit(const StageRegs& R) const {
-        lds_barrier();                                                 // every wave is done with the previous images
+        if constexpr (!(FRL_ABL & 4)) lds_barrier();                   // every wave is done with the previous images
 #pragma unroll
         for (int j = 0; j < 64 / NW; ++j) st4(S.w2 + 4 * (tid + kThreads * j), R.t2[j]);
 #pragma unroll
         for (int j = 0; j < 8 / NW; ++j) { st4(S.w1 + 4 * (tid + kThreads * j), R.t1[j]); st4(S.w3 + 4 * (tid + kThreads * j), R.t3[j]); }
         if (tid < kHid) { S.b1[tid] = R.bb1; S.b2[tid] = R.bb2; }
         if (tid < 16) { S.b3[tid] = R.bb3; S.ls[tid] = R.lsv; }
-        lds_barrier();
+        if constexpr (!(FRL_ABL & 4)) lds_barrier();
     }
     __device__ __forceinline__ void stage(g_cf th, int head, int extra_n = 0) const { stage_commit(stage_fetch(th, head, extra_n)); }
 
@@ -189,13 +212,14 @@ struct ChainNetT {
     }
     template <int T, bool VH>
     __device__ __forceinline__ void forward(const f32x4 (&xb)[T], f32x4 (&h1)[T][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn = 0) const {
+        const LaneK K = lanes();
         // first layer: all eight fragments and biases in flight before the first MFMA.  (All four k-steps are needed whatever the
         // input width: k-step e of the fragment layout holds columns e, 4 + e, 8 + e, 12 + e, so the zero padding is spread
         // over every step — a build that skipped "unused" steps dropped real columns and failed parity by 1 %.)
         {
             f32x4 w1f[kHT], b1f[kHT];
 #pragma unroll
-            for (int ot = 0; ot < kHT; ++ot) { w1f[ot] = ld4((lds_cf)(S.w1 + ot * 256 + fslot)); b1f[ot] = ld4((lds_cf)(S.b1 + ot * 16 + 4 * q)); }
+            for (int ot = 0; ot < kHT; ++ot) { w1f[ot] = ld4((lds_cf)(S.w1 + ot * 256 + K.fslot)); b1f[ot] = ld4((lds_cf)(S.b1 + ot * 16 + 4 * K.q)); }
 #pragma unroll
             for (int ot = 0; ot < kHT; ++ot)
 #pragma unroll
@@ -207,15 +231,31 @@ struct ChainNetT {
         }
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
-            const f32x4 bb = ld4((lds_cf)(S.b2 + ot * 16 + 4 * q));
+            const f32x4 bb = ld4((lds_cf)(S.b2 + ot * 16 + 4 * K.q));
 #pragma unroll
             for (int t = 0; t < T; ++t) h2[t][ot] = bb;
         }
+#if FRL_FW_HALF
+        if constexpr (NW == 8) {                                       // fragments of four output tiles at a time: 16 registers in flight, not 32
+            static_for<0, 2 * kHT>([&](auto kc) {
+                constexpr int kb = decltype(kc)::value >> 1, o0 = (decltype(kc)::value & 1) * 4;
+                f32x4 wf[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) wf[o] = ld4((lds_cf)(S.w2 + ((o0 + o) * kHT + kb) * 256 + K.fslot));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) h2[t][o0 + o] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[o][e], h1[t][kb][e], h2[t][o0 + o], 0, 0, 0);
+            });
+        } else
+#endif
         static_for<0, kHT>([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
             f32x4 wf[kHT];
 #pragma unroll
-            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + fslot));
+            for (int ot = 0; ot < kHT; ++ot) wf[ot] = ld4((lds_cf)(S.w2 + (ot * kHT + kb) * 256 + K.fslot));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -234,12 +274,13 @@ struct ChainNetT {
     // head layer as MFMA tiles: z[t][r] = output 4q + r of this lane's row (16 outputs)
     template <int T>
     __device__ __forceinline__ void head_mfma(const f32x4 (&h2)[T][kHT], f32x4 (&z)[T]) const {
-        const f32x4 b3 = ld4((lds_cf)(S.b3 + 4 * q));
+        const LaneK K = lanes();
+        const f32x4 b3 = ld4((lds_cf)(S.b3 + 4 * K.q));
 #pragma unroll
         for (int t = 0; t < T; ++t) z[t] = b3;
 #pragma unroll
         for (int kb = 0; kb < kHT; ++kb) {
-            const f32x4 wf = ld4((lds_cf)(S.w3 + kb * 256 + fslot));
+            const f32x4 wf = ld4((lds_cf)(S.w3 + kb * 256 + K.fslot));
 #pragma unroll
             for (int t = 0; t < T; ++t) z[t] = mfma4(z[t], wf, h2[t][kb]);
         }
@@ -250,6 +291,7 @@ struct ChainNetT {
     // group (the callers read it on group 0); entries o >= hn are zero.
     template <int T>
     __device__ __forceinline__ void head_valu(const f32x4 (&h2)[T][kHT], f32x4 (&z)[T], int hn) const {
+        const LaneK K = lanes();
 #pragma unroll
         for (int t = 0; t < T; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -260,7 +302,7 @@ struct ChainNetT {
                 for (int t = 0; t < T; ++t) acc[t] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < kHT; ++kb) {
-                    const f32x4 wv = ld4((lds_cf)(S.w3 + kb * 256 + ((q * 16 + (o ^ q)) << 2)));
+                    const f32x4 wv = ld4((lds_cf)(S.w3 + kb * 256 + ((K.q * 16 + (o ^ K.q)) << 2)));
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -280,9 +322,10 @@ struct ChainNetT {
     // dH2 = W3^T dz through the ReLU of h2 for such a head: dz[o] of the row sits on lane group 0 and is broadcast to the row's
     // other groups; the fragments are the forward's
     __device__ __forceinline__ void delta2_valu(const f32x4& dz, const f32x4 (&h2)[kHT], f32x4 (&d2)[kHT], int hn) const {
+        const LaneK K = lanes();
         f32x4 dzb;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) dzb[o] = __shfl(dz[o], i16, 64);
+        for (int o = 0; o < 4; ++o) dzb[o] = __shfl(dz[o], K.i16, 64);
 #pragma unroll
         for (int it = 0; it < kHT; ++it) d2[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -290,7 +333,7 @@ struct ChainNetT {
             if (o < hn) {
 #pragma unroll
                 for (int it = 0; it < kHT; ++it) {
-                    const f32x4 wv = ld4((lds_cf)(S.w3 + it * 256 + ((q * 16 + (o ^ q)) << 2)));
+                    const f32x4 wv = ld4((lds_cf)(S.w3 + it * 256 + ((K.q * 16 + (o ^ K.q)) << 2)));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d2[it][r] = fmaf(wv[r], dzb[o], d2[it][r]);
                 }
@@ -304,11 +347,12 @@ struct ChainNetT {
 
     // dH2 = W3^T dz through the ReLU of h2 (A = W3^T: transposed fragment reads)
     __device__ __forceinline__ void delta2(const f32x4& dz, const f32x4 (&h2)[kHT], f32x4 (&d2)[kHT]) const {
+        const LaneK K = lanes();
 #pragma unroll
         for (int it = 0; it < kHT; ++it) {
             f32x4 wa;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) wa[e] = S.w3[it * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+            for (int e = 0; e < 4; ++e) wa[e] = S.w3[it * 256 + K.tslot + (((4 * K.q + e) ^ (K.i16 >> 2)) << 2)];
             const f32x4 acc = mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, wa, dz);
 #pragma unroll
             for (int r = 0; r < 4; ++r) d2[it][r] = h2[it][r] > 0.f ? acc[r] : 0.f;
@@ -318,12 +362,13 @@ struct ChainNetT {
     // reads, eight per k-step: the reads of step s + 1 are issued in front of the MFMAs of step s (double-buffered in the source —
     // hipcc waited for every step's reads right in front of its MFMAs: ~130 exposed cycles x 32 steps per call)
     __device__ __forceinline__ void delta1(const f32x4 (&d2)[kHT], const f32x4 (&h1)[kHT], f32x4 (&d1)[kHT]) const {
+        const LaneK K = lanes();
 #pragma unroll
         for (int it = 0; it < kHT; ++it) d1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         float wa[2][kHT];
         auto fetch = [&](int ob, int e, float (&dst)[kHT]) {
 #pragma unroll
-            for (int it = 0; it < kHT; ++it) dst[it] = S.w2[(ob * kHT + it) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+            for (int it = 0; it < kHT; ++it) dst[it] = S.w2[(ob * kHT + it) * 256 + K.tslot + (((4 * K.q + e) ^ (K.i16 >> 2)) << 2)];
         };
         fetch(0, 0, wa[0]);
         static_for<0, 4 * kHT>([&](auto sc) {
@@ -337,14 +382,46 @@ struct ChainNetT {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? d1[it][r] : 0.f;
     }
+    // ... with relu'(h1) as one bit per element (bit 4 it + r of `mask`): the eight-wave backward drops h1's 32 registers once its
+    // tiles are in the exchange buffer
+    __device__ __forceinline__ unsigned relu_mask(const f32x4 (&h1)[kHT]) const {
+        unsigned m = 0;
+#pragma unroll
+        for (int it = 0; it < kHT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m |= h1[it][r] > 0.f ? 1u << (4 * it + r) : 0u;
+        return m;
+    }
+    __device__ __forceinline__ void delta1_m(const f32x4 (&d2)[kHT], unsigned mask, f32x4 (&d1)[kHT]) const {
+        const LaneK K = lanes();
+#pragma unroll
+        for (int it = 0; it < kHT; ++it) d1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float wa[2][kHT];
+        auto fetch = [&](int ob, int e, float (&dst)[kHT]) {
+#pragma unroll
+            for (int it = 0; it < kHT; ++it) dst[it] = S.w2[(ob * kHT + it) * 256 + K.tslot + (((4 * K.q + e) ^ (K.i16 >> 2)) << 2)];
+        };
+        fetch(0, 0, wa[0]);
+        static_for<0, 4 * kHT>([&](auto sc) {
+            constexpr int s_ = decltype(sc)::value, ob = s_ >> 2, e = s_ & 3;
+            if constexpr (s_ + 1 < 4 * kHT) fetch((s_ + 1) >> 2, (s_ + 1) & 3, wa[(s_ + 1) & 1]);
+#pragma unroll
+            for (int it = 0; it < kHT; ++it) d1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_ & 1][it], d2[ob][e], d1[it], 0, 0, 0);
+        });
+#pragma unroll
+        for (int it = 0; it < kHT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[it][r] = (mask >> (4 * it + r)) & 1u ? d1[it][r] : 0.f;
+    }
     // dX = W1^T dz1: d loss / d input column 4q + r of this lane's row (no activation in front of the input)
     __device__ __forceinline__ f32x4 delta0(const f32x4 (&d1)[kHT]) const {
+        const LaneK K = lanes();
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ob = 0; ob < kHT; ++ob) {
             f32x4 wa;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) wa[e] = S.w1[ob * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+            for (int e = 0; e < 4; ++e) wa[e] = S.w1[ob * 256 + K.tslot + (((4 * K.q + e) ^ (K.i16 >> 2)) << 2)];
             dx = mfma4(dx, wa, d1[ob]);
         }
         return dx;
@@ -356,12 +433,17 @@ struct ChainNetT {
         for (int r = 0; r < 4; ++r) E[(ft * 4 + (w & 3)) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
     }
     __device__ __forceinline__ f32x4 get_frag(lds_cf E, int ft, int bb) const { return ld4(E + (ft * 4 + bb) * 256 + fslot); }
-    // ... and the all-rows form of the eight-wave workgroups: ea + eb as ONE buffer of [ft][8 wave slots]; a wave's narrow tile in ex
-    __device__ __forceinline__ void put_tile8(lds_f E, int ft, const f32x4& t) const {
+    __device__ __forceinline__ void put_tile(const LaneK& K, lds_f E, int ft, const f32x4& t) const {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) E[(ft * 8 + w) * 256 + tslot + (((4 * q + r) ^ (i16 >> 2)) << 2)] = t[r];
+        for (int r = 0; r < 4; ++r) E[(ft * 4 + (w & 3)) * 256 + K.tslot + (((4 * K.q + r) ^ (K.i16 >> 2)) << 2)] = t[r];
     }
-    __device__ __forceinline__ f32x4 get_frag8(lds_cf E, int ft, int bb) const { return ld4(E + (ft * 8 + bb) * 256 + fslot); }
+    __device__ __forceinline__ f32x4 get_frag(const LaneK& K, lds_cf E, int ft, int bb) const { return ld4(E + (ft * 4 + bb) * 256 + K.fslot); }
+    // ... and the all-rows form of the eight-wave workgroups: ea + eb as ONE buffer of [ft][8 wave slots]; a wave's narrow tile in ex
+    __device__ __forceinline__ void put_tile8(const LaneK& K, lds_f E, int ft, const f32x4& t) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[(ft * 8 + w) * 256 + K.tslot + (((4 * K.q + r) ^ (K.i16 >> 2)) << 2)] = t[r];
+    }
+    __device__ __forceinline__ f32x4 get_frag8(const LaneK& K, lds_cf E, int ft, int bb) const { return ld4(E + (ft * 8 + bb) * 256 + K.fslot); }
 
     __device__ __forceinline__ void grad_zero(Grad& g) const {
 #pragma unroll
@@ -377,8 +459,15 @@ struct ChainNetT {
     // ---- backward of one chunk (16 rows per wave: 64 rows at four waves, 128 at eight) into the owners' accumulators: three
     // exchanges through ea / eb (H2 + dz -> head gradient; H1 + dz2 -> layer 2; X + dz1 -> layer 1), the dH chains in between
     // hn > 0: the head has hn <= 4 outputs and its dH runs as dot products (delta2_valu)
-    __device__ __forceinline__ void backward(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn = 0) const {
-        if constexpr (NW == 8) { backward8(g, xb, h1, h2, dz, hn); return; }
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
+    // late(): called once where the fewest registers are live (behind the dH1 chain: only d1 and x are left) — the callers issue
+    // the NEXT image's fetch there: its 44 registers riding through the whole forward + backward were spilled by hipcc right
+    // behind the loads (i.e. with a wait for HBM in the open), and so they were when issued behind the head exchange
+    template <class Late = NoHook>
+    __device__ __forceinline__ void backward(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn = 0,
+                                             Late&& late = NoHook{}) const {
+        if constexpr (NW == 8) { backward8(g, xb, h1, h2, dz, hn, late); return; }
+        late();
         lds_barrier();                                                 // the previous chunk's readers of ea / eb are done
 #pragma unroll
         for (int ft = 0; ft < kHT; ++ft) put_tile(S.ea, ft, h2[ft]);
@@ -418,16 +507,17 @@ struct ChainNetT {
     }
     // the layer-2 contraction over the 64 rows that lie in ea (h1) / eb (d2): this wave's OT tile rows x 8 k-tiles
     __device__ __forceinline__ void layer2_consume(Grad& g) const {
+        const LaneK K = lanes();
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             f32x4 af[OT], bf[kHT];
 #pragma unroll
             for (int x = 0; x < OT; ++x) {
-                af[x] = get_frag(S.eb, OT * w + x, bb);
+                af[x] = get_frag(K, S.eb, OT * w + x, bb);
                 g.gb2[x] += (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
             }
 #pragma unroll
-            for (int kt = 0; kt < kHT; ++kt) bf[kt] = get_frag(S.ea, kt, bb);
+            for (int kt = 0; kt < kHT; ++kt) bf[kt] = get_frag(K, S.ea, kt, bb);
 #pragma unroll
             for (int x = 0; x < OT; ++x)
 #pragma unroll
@@ -439,45 +529,70 @@ struct ChainNetT {
     // needs H1 and dz2 of every row, 128 KB: it runs in two 64-row halves (the waves of the other half wait out the ~500 cycles of
     // a half's writes: 2 % of a chunk; running their dH1 chain there instead was built — it holds d1 through the contraction, 32
     // registers the kernel does not have).
-    __device__ __forceinline__ void backward8(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn) const {
+    __device__ __forceinline__ void xbar() const { if constexpr (!(FRL_ABL & 2)) lds_barrier(); }
+    __device__ __forceinline__ void xput8(const LaneK& K, lds_f E, int ft, const f32x4& t) const { if constexpr (!(FRL_ABL & 10)) put_tile8(K, E, ft, t); else asm volatile("" :: "v"(t)); }
+    __device__ __forceinline__ void xput(const LaneK& K, lds_f E, int ft, const f32x4& t) const { if constexpr (!(FRL_ABL & 10)) put_tile(K, E, ft, t); else asm volatile("" :: "v"(t)); }
+    template <class Late>
+    __device__ __forceinline__ void backward8(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn, Late&& late) const {
         const lds_f E = S.ea;
         const int hv = w >> 2;                                         // which 64-row half this wave's rows belong to
-        lds_barrier();                                                 // the previous chunk's readers of ea / eb / ex are done
+        xbar();                                                        // the previous chunk's readers of ea / eb / ex are done
+        {
+            const LaneK K = lanes();
 #pragma unroll
-        for (int ft = 0; ft < kHT; ++ft) put_tile8(E, ft, h2[ft]);
-        put_tile8(S.ex, 0, dz);
+            for (int ft = 0; ft < kHT; ++ft) xput8(K, E, ft, h2[ft]);
+            xput8(K, S.ex, 0, dz);
+        }
         f32x4 d2[kHT];
         if (hn > 0) delta2_valu(dz, h2, d2, hn); else delta2(dz, h2, d2);
-        lds_barrier();
+        xbar();
+        {
+            const LaneK K = lanes();
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const f32x4 af = get_frag8(S.ex, 0, bb);
-            if (w == 0) g.gb3 += (af[0] + af[1]) + (af[2] + af[3]);
-            g.g3[0] = mfma4(g.g3[0], get_frag8(E, w, bb), af);
+            for (int bb = 0; bb < 8; ++bb) {
+                const f32x4 af = get_frag8(K, S.ex, 0, bb);
+                if (w == 0) g.gb3 += (af[0] + af[1]) + (af[2] + af[3]);
+                g.g3[0] = mfma4(g.g3[0], get_frag8(K, E, w, bb), af);
+            }
         }
+#if FRL_BW_MASK
+        const unsigned m1 = relu_mask(h1);
+#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            lds_barrier();
+            xbar();
             if (hv == half) {
+                const LaneK K = lanes();
 #pragma unroll
-                for (int ft = 0; ft < kHT; ++ft) { put_tile(S.ea, ft, h1[ft]); put_tile(S.eb, ft, d2[ft]); }
+                for (int ft = 0; ft < kHT; ++ft) { xput(K, S.ea, ft, h1[ft]); xput(K, S.eb, ft, d2[ft]); }
             }
-            lds_barrier();
+            xbar();
             layer2_consume(g);
         }
         f32x4 d1[kHT];
+#if FRL_BW_MASK
+        delta1_m(d2, m1, d1);
+#else
         delta1(d2, h1, d1);
-        lds_barrier();
-        put_tile8(S.ex, 0, xb);
+#endif
+        late();
+        xbar();
+        {
+            const LaneK K = lanes();
+            xput8(K, S.ex, 0, xb);
 #pragma unroll
-        for (int ft = 0; ft < kHT; ++ft) put_tile8(E, ft, d1[ft]);
-        lds_barrier();
+            for (int ft = 0; ft < kHT; ++ft) xput8(K, E, ft, d1[ft]);
+        }
+        xbar();
+        {
+            const LaneK K = lanes();
 #pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const f32x4 bf = get_frag8(S.ex, 0, bb);
-            const f32x4 af = get_frag8(E, w, bb);
-            g.gb1[0] += (af[0] + af[1]) + (af[2] + af[3]);
-            g.g1[0] = mfma4(g.g1[0], bf, af);
+            for (int bb = 0; bb < 8; ++bb) {
+                const f32x4 bf = get_frag8(K, S.ex, 0, bb);
+                const f32x4 af = get_frag8(K, E, w, bb);
+                g.gb1[0] += (af[0] + af[1]) + (af[2] + af[3]);
+                g.g1[0] = mfma4(g.g1[0], bf, af);
+            }
         }
     }
 
@@ -515,7 +630,10 @@ struct ChainNetT {
     // OT tiles ot = OT w + x, then the head layer's OT tiles kb = OT w + x.  Its 16-byte slot sits at lane offset
     // unit_voff<J>() + the compile-time unit_soff<J>() bytes inside the head's block.
     static constexpr int kUnits = 10 * OT;
-    template <int J> __device__ __forceinline__ int unit_voff() const { return J < 8 * OT ? lane2 : lane1; }
+    template <int J> __device__ __forceinline__ int unit_voff() const {
+        if constexpr (NW == 8) { const int fs = lanes().fslot; return 4 * (w * OT * (J < 8 * OT ? kHT : 1) * 256 + fs); }
+        else return J < 8 * OT ? lane2 : lane1;
+    }
     template <int J> static constexpr int unit_soff() { return 4 * (J < 8 * OT ? kL2w + J * 256 : (J < 9 * OT ? kL1w + (J - 8 * OT) * 256 : kL3w + (J - 9 * OT) * 256)); }
     template <int J>
     __device__ __forceinline__ static const f32x4& unit_grad(const Grad& g) {
@@ -531,7 +649,7 @@ struct ChainNetT {
         AdamIn X;
         constexpr int so = HB + unit_soff<J>();
         const int vo = unit_voff<J>();
-        if constexpr (THL) X.th = ld4((lds_cf)((J < 8 * OT ? S.w2 + (w * OT * kHT + J) * 256 : (J < 9 * OT ? S.w1 + (w * OT + J - 8 * OT) * 256 : S.w3 + (w * OT + J - 9 * OT) * 256)) + fslot));
+        if constexpr (THL) X.th = ld4((lds_cf)((J < 8 * OT ? S.w2 + (w * OT * kHT + J) * 256 : (J < 9 * OT ? S.w1 + (w * OT + J - 8 * OT) * 256 : S.w3 + (w * OT + J - 9 * OT) * 256)) + (NW == 8 ? lanes().fslot : fslot)));
         else X.th = buf_ld4(B.th, vo, so);
         X.mm = buf_ld4(B.mm, vo, so); X.vv = buf_ld4(B.vv, vo, so);
         if constexpr (SOFT) X.tg = buf_ld4(B.tg, vo, so); else X.tg = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -558,6 +676,17 @@ struct ChainNetT {
         buf_st4(B.th, vo, so, R.th); buf_st4(B.mm, vo, so, R.mm); buf_st4(B.vv, vo, so, R.vv);
         if constexpr (SOFT) buf_st4(B.tg, vo, so, R.tg);
     }
+    // ---- a head's weight-gradient tiles parked in HBM (the learner's `grad` block, image order) while another head's pass needs
+    // the registers; adam_head<..., PARKED> reads them back next to theta / m / v.  The bias sums stay in registers.
+    template <int HD>
+    __device__ __forceinline__ void grad_park(g_f gr, const Grad& g) const {
+        const __amdgpu_buffer_rsrc_t Rg = __builtin_amdgcn_make_buffer_rsrc((float*)gr, 0, 0x7fffffff, 0x00020000);
+        constexpr int HB = HD * kHeadFloats * 4;
+        static_for<0, kUnits>([&](auto j) {
+            constexpr int J = decltype(j)::value;
+            buf_st4(Rg, unit_voff<J>(), HB + unit_soff<J>(), unit_grad<J>(g));
+        });
+    }
     template <bool SOFT>
     __device__ __forceinline__ float adam_scalar(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, float gr) const {
         float t1 = th[o], m1 = mA[o], v1 = vA[o];
@@ -583,11 +712,32 @@ struct ChainNetT {
     }
     // the whole update of head HD of a net, in the open: the units in batches of up to 8 (loads of a batch before its stores),
     // the 128 x 128 layer's tiles first, then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
-    template <bool SOFT, int HD, bool THL = false>
+    template <bool SOFT, int HD, bool THL = false, bool PARKED = false>
     __device__ __forceinline__ void adam_head(const Grad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
-                                              int extra_n = 0) const {
+                                              int extra_n = 0, g_f parked = nullptr) const {
         const AdamBuf B = adam_buf(th, mA, vA, tg);
         constexpr int HB = HD * kHeadFloats * 4;
+        if constexpr (PARKED) {
+            const __amdgpu_buffer_rsrc_t Rg = __builtin_amdgcn_make_buffer_rsrc((float*)parked, 0, 0x7fffffff, 0x00020000);
+            constexpr int kB = 4;
+            static_for<0, (kUnits + kB - 1) / kB>([&](auto bc) {
+                constexpr int b0 = decltype(bc)::value * kB, nb = b0 + kB <= kUnits ? kB : kUnits - b0;
+                AdamIn in[nb];
+                f32x4 gr[nb];
+                static_for<0, nb>([&](auto j) {
+                    constexpr int J = b0 + decltype(j)::value;
+                    in[decltype(j)::value] = adam_load<SOFT, J, HB, THL>(B);
+                    gr[decltype(j)::value] = buf_ld4(Rg, unit_voff<J>(), HB + unit_soff<J>());
+                });
+                __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+                static_for<0, nb>([&](auto j) {
+                    constexpr int J = b0 + decltype(j)::value;
+                    adam_store<SOFT, J, HB>(B, adam_compute<SOFT>(c, gr[decltype(j)::value], in[decltype(j)::value]));
+                });
+            });
+            adam_biases<SOFT>(g, th + HD * kHeadFloats, mA + HD * kHeadFloats, vA + HD * kHeadFloats, tg + HD * kHeadFloats, c, g_extra, extra_n);
+            return;
+        }
         constexpr int kBatch = NW == 4 ? 8 : 5;                        // (NW = 8: ten units in two batches of five — 80 registers of state)
         static_for<0, (kUnits + kBatch - 1) / kBatch>([&](auto bc) {
             constexpr int b0 = decltype(bc)::value * kBatch, nb = b0 + kBatch <= kUnits ? kBatch : kUnits - b0;

@@ -581,7 +581,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, critic2_lds_floats() * (int)sizeof(float)));
     } else if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
         const int lb = critic2_lds_floats() * (int)sizeof(float), lb8 = critic8_lds_floats() * (int)sizeof(float);
-        for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_actor_v2_kernel})
+        for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_critic_v2_twin_nv_kernel, ac_critic_v2_single_nv_kernel, ac_actor_v2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb8));
         for (auto k : {ac_critic_v2w4_twin_kernel, ac_critic_v2w4_single_kernel, ac_actor_v2w4_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -598,7 +598,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(hipFuncSetAttribute((const void*)ppo_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
         if (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) {
             const int lb = critic2_lds_floats() * (int)sizeof(float), lb8 = critic8_lds_floats() * (int)sizeof(float);
-            for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_actor_v2_kernel})
+            for (auto k : {ac_critic_v2_twin_kernel, ac_critic_v2_single_kernel, ac_critic_v2_twin_nv_kernel, ac_critic_v2_single_nv_kernel, ac_actor_v2_kernel})
                 CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb8));
             for (auto k : {ac_critic_v2w4_twin_kernel, ac_critic_v2w4_single_kernel, ac_actor_v2w4_kernel})
                 CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -1319,6 +1319,8 @@ static bool chained_shape(const EngineDesc& h) {
         return N.extra_n == 0 || (N.heads == 1 && N.extra_off == kHeadFloats);
     };
     if (NA0.n_layers != 3 || NC0.n_layers != 3 * NC0.heads || h.hidden != 128 || !packed(NA0) || !packed(NC0)) return false;
+    // ([s | a] as one aligned slice of the record: the chained kernels read a lane's four columns of it as one dwordx4)
+    if (h.rec.obs_off[0] % 4 != 0 || h.rec.act_off[0] != h.rec.obs_off[0] + h.rec.obs_dim[0] || h.rec.obs_off[0] + 16 > h.rec.stride) return false;
     return (h.algo == ALGO_DDPG || h.algo == ALGO_TD3 || h.algo == ALGO_SAC) && h.n_agents == 1 && h.hidden == 128 &&
            NA0.L[0].k_pad == 16 && NC0.L[0].k_pad == 16 && h.rec.act_dim[0] <= 4 && NA0.L[2].n_pad == 16 &&
            h.batch_max <= 256 && NA0.hidden_act == ACT_RELU && NC0.hidden_act == ACT_RELU &&
@@ -1425,11 +1427,16 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             return;
         }
         if (v2) {
-            { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0; }      // measured: spreading the Adam bursts gains what the delayed groups' tail loses
+            { const char* sg = getenv("FRL_STAGGER"); a.stagger = sg ? atoi(sg) : 0;         // developer knob: spread the Adam bursts of the first round
+              const char* gg = getenv("FRL_STAGGER_GROUPS"); a.stagger_groups = gg ? atoi(gg) : 4; a.stagger_wgs = e->n_cus; }
             prof_begin(e, PK_GRAD_CRITIC);
             const bool w8 = e->chain_waves == 8, twin = h.net[1].heads == 2;
             const size_t lb = (size_t)(w8 ? critic8_lds_floats() : critic2_lds_floats()) * sizeof(float);
-            auto k = w8 ? (twin ? ac_critic_v2_twin_kernel : ac_critic_v2_single_kernel) : (twin ? ac_critic_v2w4_twin_kernel : ac_critic_v2w4_single_kernel);
+            // (_nv: next_obs 16-byte aligned with its 16 columns inside the row, (reward, done) an aligned pair)
+            const RecordDesc& R = h.rec;
+            const bool nv = R.nobs_off[0] % 4 == 0 && R.nobs_off[0] + 16 <= R.stride && R.rew_off % 2 == 0 && R.done_off == R.rew_off + 1 && !getenv("FRL_CRITIC2_NOVEC");
+            auto k = w8 ? (nv ? (twin ? ac_critic_v2_twin_nv_kernel : ac_critic_v2_single_nv_kernel) : (twin ? ac_critic_v2_twin_kernel : ac_critic_v2_single_kernel))
+                        : (twin ? ac_critic_v2w4_twin_kernel : ac_critic_v2w4_single_kernel);
             hipLaunchKernelGGL(k, dim3(pc), dim3(w8 ? 512 : 256), lb, st, e->d, a);
             prof_end(e);
             return;

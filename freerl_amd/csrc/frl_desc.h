@@ -188,7 +188,9 @@ struct LearnArgs {
     int double_dqn;       // DQN trick['Double']: a* = argmax_a Q(s',a), y uses Q_target(s', a*) (DQN_with_tricks.py:263-265)
     int use_isw;          // DQN trick['PER']: loss = mean(w * td^2) with the weights in desc.isw (:276-278)
     int dqn_split;        // dqn_fused_kernel: workgroups per learner (its 64-row chunks dealt round-robin)
-    int stagger;          // kernels_critic2 / _actor2: s_sleep(127) units between the four start phases of the workgroups (0: none)
+    int stagger;          // kernels_critic2: s_sleep(32) units (2 k cycles) between the start phases of the first round's workgroups (0: none)
+    int stagger_groups;   // ... how many start phases (a power of two), and how many workgroups make the first round (the device's CUs)
+    int stagger_wgs;
     int huber;            // TD loss: 0 F.mse_loss (every hot-path loss of the reference), 1 Huber with `huber_delta`
     float huber_delta;    // (the reference's huber_loss, MAPPO_file/MAPPO.py:273-276: e^2/2 if |e| <= d else d(|e| - d/2), mean)
 };

@@ -176,6 +176,8 @@ __global__ void soft_update_kernel(const EngineDesc* __restrict__ Dp, float tau,
 // kernels_critic2.hip: the critic stage of DDPG / TD3 / SAC for one learner per workgroup (register-chained, Adam fused)
 __global__ void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
+__global__ void ac_critic_v2_twin_nv_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);      // (_nv: aligned next_obs / (reward, done) loads)
+__global__ void ac_critic_v2_single_nv_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 // (round 2-5's four-wave form of the same stage, one wave per SIMD: FRL_CHAIN_WAVES=4, same-box A/B runs)
 __global__ void ac_critic_v2w4_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);
 __global__ void ac_critic_v2w4_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a);

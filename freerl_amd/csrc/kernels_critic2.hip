@@ -29,13 +29,16 @@ namespace frl {
 #ifndef FRL_CRITIC2_TT
 #define FRL_CRITIC2_TT 2
 #endif
+#ifndef FRL_CRITIC2_PARK
+#define FRL_CRITIC2_PARK 0      // the first head's weight-gradient tiles parked in HBM during the second head's pass (eight-wave twin kernel)
+#endif
 #ifndef FRL_CRITIC2_AHEAD
 #define FRL_CRITIC2_AHEAD 1     // the next net's image fetched in front of a target pass's last forward (1) or behind it (0)
 #endif
 // NW = waves per workgroup (device/chain_net.hpp): 8 since round 6 — 512 threads, every wave inside 256 registers, two waves
 // per SIMD; a chunk is 16 NW rows (the target passes: TT times that).  NW = 4 is round 2-5's kernel (one wave per SIMD at
 // 458-472 registers), kept as ac_critic_v2w4_* for same-box A/B runs (FRL_CHAIN_WAVES=4).
-template <bool TWIN, int TT, int NW>
+template <bool TWIN, int TT, int NW, bool NVEC>
 __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const LearnArgs& a, float* smem) {
     constexpr int kRC = 16 * NW;                                       // rows per chunk of the training pass
     constexpr int kRowsT = kRC * TT;                                   // rows per target-pass chunk
@@ -80,18 +83,14 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         const int row = c * kRC + 16 * w + i16;
         ridx[c] = idx[row < B ? row : B - 1];
     }
-    int colx[4];                                                       // this lane's four columns of [s | a] in the record
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int f = 4 * q + e < O + A ? 4 * q + e : O + A - 1;
-        colx[e] = f < O ? R.obs_off[0] + f : R.act_off[0] + f - O;
-    }
+    // [s | a] is one contiguous, 16-byte aligned slice of the record (chained_shape checks it): this lane's four columns
+    // 4q .. 4q + 3 of it are ONE dwordx4 — a wave-load of 16 rows x 64 B instead of four dword gathers at ~65 cycles of the
+    // CU's texture path each.  Columns past the input hold whatever follows in the record: zero_pad drops them by select.
+    const int xoff = R.obs_off[0] + 4 * q;
     struct RowIn { f32x4 x; };
     auto load_row = [&](int c) {                                       // [s | a] of this lane's row of chunk c
         RowIn X;
-        g_cf rec = ring + (size_t)pick(ridx, c) * R.stride;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) X.x[e] = rec[colx[e]];
+        X.x = ld4(ring + (size_t)pick(ridx, c) * R.stride + xoff);
         return X;
     };
     auto zero_pad = [&](const f32x4& x, int width) {                   // columns >= width of a loaded slice are padding: exact zeros
@@ -109,9 +108,12 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         const int row = (j4 / TT) * kRowsT + 16 * TT * w + (j4 % TT) * 16 + i16;
         ridxT[j4] = idx[row < B ? row : B - 1];
     }
-    int colo[4];                                                       // ... of s' (the columns past obs_dim meet zero weight rows)
+    // ... of s' (the columns past obs_dim: clamped to the last one in the dword form, dropped by zero_pad in both).  NVEC: the
+    // record layout has next_obs 16-byte aligned and (reward, done) as one aligned pair — one dwordx4 + one dwordx2 per tile
+    // instead of six dword gathers
+    int colo[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) colo[e] = R.nobs_off[0] + (4 * q + e < O ? 4 * q + e : O - 1);
+    for (int e = 0; e < 4; ++e) colo[e] = R.nobs_off[0] + (NVEC ? 4 * q : (4 * q + e < O ? 4 * q + e : O - 1));
     struct RowIn2 { f32x4 x[TT]; float rew[TT], done[TT]; };
     auto tile_of = [&](const int (&v)[kNC], int c2, int t) {           // entry TT c2 + t (t is a constant of an unrolled loop)
         int r = v[t];
@@ -124,9 +126,16 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             g_cf rec = ring + (size_t)tile_of(ridxT, c2, t) * R.stride;
+            if constexpr (NVEC) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                X.x[t] = ld4(rec + colo[0]);
+                const f32x2 rd = *reinterpret_cast<const FRL_GLB f32x2*>(rec + R.rew_off);
+                X.rew[t] = rd[0]; X.done[t] = rd[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) X.x[t][e] = rec[colo[e]];
-            X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off];
+                for (int e = 0; e < 4; ++e) X.x[t][e] = rec[colo[e]];
+                X.rew[t] = rec[R.rew_off]; X.done[t] = rec[R.done_off];
+            }
         }
         return X;
     };
@@ -136,9 +145,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // (theta / m / v / target, ~1 MB per learner), so the 256 CUs reach it together and share the chip's bandwidth (111 k
     // cycles per learner against 61 k for a CU on its own).  Four start phases spread the bursts (72 k) but the delayed
     // groups finish later by as much: no net gain (profiles/README.md), so the default is 0.
-    if (a.stagger > 0) {
-        const int group = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < group * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
+    if (a.stagger > 0 && (int)blockIdx.x < a.stagger_wgs) {            // (the first round's workgroups only: later ones inherit the spread)
+        const int group = (blockIdx.x >> 3) & (a.stagger_groups - 1);
+        for (int i = 0; i < group * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);       // 32 x 64 cycles each
     }
     // =========================================================== a' = actor_target(s') for the whole batch -> S.ab (SAC: + log pi)
     PPO_T0();
@@ -170,8 +179,10 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         nxt2 = load_row2(true, last ? 0 : c2 + 1);                     // (after the last chunk: chunk 0 of the target-critic pass)
         if constexpr (last && FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
         PPO_U(0);
-        f32x4 z[TT], h1[TT][kHT], h2[TT][kHT];
-        C.template forward_vh<TT>(cur.x, h1, h2, z, A);                 // (the actor head's act_dim <= 4 outputs as dot products)
+        f32x4 xo[TT], z[TT], h1[TT][kHT], h2[TT][kHT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) xo[t] = zero_pad(cur.x[t], O);
+        C.template forward_vh<TT>(xo, h1, h2, z, A);                    // (the actor head's act_dim <= 4 outputs as dot products)
         PPO_U(1);
         if constexpr (last && !FRL_CRITIC2_AHEAD) pend = C.stage_fetch(tgC, 0);
 #pragma unroll
@@ -273,6 +284,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // =========================================================== critic heads: forward, TD delta, backward into the owners' accumulators
     typename Net::Grad G[NH];
     float lossp = 0.f;
+#if FRL_CRITIC2_PARK
+    float ss_parked = 0.f;
+#endif
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         typename Net::Grad& g = G[hd];
@@ -286,7 +300,7 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
             const bool valid = row < B;
             const RowIn cur = nxt;
             nxt = load_row(last ? 0 : c + 1);                          // (after the last chunk: the second head re-reads chunk 0)
-            if constexpr (last) {
+            if constexpr (last && NW == 4) {
                 if (hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
             }
             f32x4 xb[1] = {zero_pad(cur.x, O + A)}, z[1], h1[1][kHT], h2[1][kHT];
@@ -300,19 +314,37 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
                 dz[0] = grow * invB;
                 lossp += lrow;
             }
-            C.backward(g, xb[0], h1[0], h2[0], dz, 1);
+            C.backward(g, xb[0], h1[0], h2[0], dz, 1, [&]() {         // (eight waves: the next head's image fetched where few registers are live)
+                if constexpr (last && NW == 8) {
+                    if (hd + 1 < NH) pend = C.stage_fetch((g_cf)thC, hd + 1);
+                }
+            });
             PPO_T(6);
         };
         for (int c = 0; c + 1 < nchunks; ++c) critic_chunk(c, IC<0>{});
         critic_chunk(nchunks - 1, IC<1>{});
         C.grad_finish(g);
+#if FRL_CRITIC2_PARK
+        if (NW == 8 && hd + 1 < NH) {                                  // the first head's tiles wait in HBM: the second head's pass has its registers
+            ss_parked += C.grad_sumsq(g);
+            C.template grad_park<0>(as_global(D.grad + lbase + D.net_off[1]), g);
+        }
+#endif
     }
 
     PPO_T(3);
     // =========================================================== clip_grad_norm_ over the whole critic net, Adam, soft update
+#if FRL_CRITIC2_PARK
+    constexpr bool kPark = NW == 8 && NH == 2;
+    float ss = ss_parked;
+#pragma unroll
+    for (int hd = kPark ? 1 : 0; hd < NH; ++hd) ss += C.grad_sumsq(G[hd]);
+#else
+    constexpr bool kPark = false;
     float ss = 0.f;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) ss += C.grad_sumsq(G[hd]);
+#endif
     ss = wave_sum(ss);
     const float lsum = wave_sum(lossp);
     lds_barrier();
@@ -333,11 +365,15 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     co.step = (float)((double)a.critic_lr / bc1); co.inv_bc2s = 1.f / (float)sqrt(bc2);
     co.w1 = 1.f - a.beta1; co.w2 = 1.f - a.beta2; co.beta2 = a.beta2; co.eps = a.adam_eps; co.wd = a.critic_wd;
     co.tk = 1.f - a.tau; co.tau = a.tau;
+#if !(FRL_ABL & 1)
     if (a.do_actor != 0) {                                             // TD3: targets move with the delayed policy step (TD3.py:224-233)
-        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value, decltype(hd)::value == NH - 1, kPark && decltype(hd)::value == 0>(G[decltype(hd)::value], thC, mC, vC, tgCw, co, 0.f, 0, as_global(D.grad + lbase + D.net_off[1])); });
     } else {
-        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value, decltype(hd)::value == NH - 1, kPark && decltype(hd)::value == 0>(G[decltype(hd)::value], thC, mC, vC, tgCw, co, 0.f, 0, as_global(D.grad + lbase + D.net_off[1])); });
     }
+#else
+    if (co.coef == 123.f) static_for<0, NH>([&](auto hd) { S.red[40 + decltype(hd)::value] = C.grad_sumsq(G[decltype(hd)::value]) * co.step; });
+#endif
     PPO_T(7);
     PPO_TDUMP();
     if (tid == 0) {
@@ -351,21 +387,17 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
 #ifndef FRL_CRITIC8_TT
 #define FRL_CRITIC8_TT 1        // 16-row tiles per wave in the eight-wave kernels' target passes (2 holds 128 activation registers next to the fetched image: spills)
 #endif
-__global__ __launch_bounds__(512) void ac_critic_v2_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<true, FRL_CRITIC8_TT, 8>(*Dp, a, smem);
-}
-__global__ __launch_bounds__(512) void ac_critic_v2_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<false, FRL_CRITIC8_TT, 8>(*Dp, a, smem);
-}
-__global__ __launch_bounds__(256) void ac_critic_v2w4_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<true, FRL_CRITIC2_TT, 4>(*Dp, a, smem);
-}
-__global__ __launch_bounds__(256) void ac_critic_v2w4_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    ac_critic_v2_body<false, FRL_CRITIC2_TT, 4>(*Dp, a, smem);
-}
+// _nv: records whose next_obs slice is 16-byte aligned and whose (reward, done) pair 8-byte (critic2_nvec() in frl_api.hip)
+#define FRL_CRITIC2_KERNEL(name, threads, twin, tt, nw, nvec)                                              \
+    __global__ __launch_bounds__(threads) void name(const EngineDesc* __restrict__ Dp, LearnArgs a) {       \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                       \
+        ac_critic_v2_body<twin, tt, nw, nvec>(*Dp, a, smem);                                               \
+    }
+FRL_CRITIC2_KERNEL(ac_critic_v2_twin_kernel, 512, true, FRL_CRITIC8_TT, 8, false)
+FRL_CRITIC2_KERNEL(ac_critic_v2_single_kernel, 512, false, FRL_CRITIC8_TT, 8, false)
+FRL_CRITIC2_KERNEL(ac_critic_v2_twin_nv_kernel, 512, true, FRL_CRITIC8_TT, 8, true)
+FRL_CRITIC2_KERNEL(ac_critic_v2_single_nv_kernel, 512, false, FRL_CRITIC8_TT, 8, true)
+FRL_CRITIC2_KERNEL(ac_critic_v2w4_twin_kernel, 256, true, FRL_CRITIC2_TT, 4, false)
+FRL_CRITIC2_KERNEL(ac_critic_v2w4_single_kernel, 256, false, FRL_CRITIC2_TT, 4, false)
 
 }  // namespace frl
