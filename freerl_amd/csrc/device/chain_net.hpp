@@ -14,7 +14,20 @@
 // update to the workgroup's other waves (round 2: 17 % of the critic stage, every CU in it at the same time).
 #pragma once
 #include "chain.hpp"
+#include "ppo_timing.hpp"
 
+// Developer instrument (-DFRL_PPO_TIMING -DFRL_BWD_TIMING, one unit: tools/build_unit_timing.sh): thread 0 of workgroup 0 adds the
+// shader clock of every section of the eight-wave backward to row 1 of g_ppo_clk (summed over chunks, heads AND launches)
+#if defined(FRL_PPO_TIMING) && defined(FRL_BWD_TIMING)
+#define BWD_T0() long long b_prev_ = clock64()
+#define BWD_T(i) do { const long long n_ = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd((unsigned long long*)&g_ppo_clk[1][i], (unsigned long long)(n_ - b_prev_)); b_prev_ = n_; } while (0)
+#else
+#define BWD_T0() do {} while (0)
+#define BWD_T(i) do {} while (0)
+#endif
+#ifndef FRL_LANES_OPAQUE4
+#define FRL_LANES_OPAQUE4 1     // the four-wave kernels' lanes() opaque as well (see ChainNetT::lanes)
+#endif
 #ifndef FRL_BW_MASK
 #define FRL_BW_MASK 0
 #endif
@@ -159,7 +172,7 @@ struct ChainNetT {
     struct LaneK { int i16, q, fslot, tslot; };
     __device__ __forceinline__ LaneK lanes() const {
         int L = l;
-        if constexpr (NW == 8) asm volatile("" : "+v"(L));
+        if constexpr (NW == 8 || FRL_LANES_OPAQUE4) asm volatile("" : "+v"(L));
         LaneK K;
         K.i16 = L & 15; K.q = L >> 4;
         K.fslot = (K.q * 16 + (K.i16 ^ K.q)) << 2;
@@ -536,16 +549,21 @@ struct ChainNetT {
     __device__ __forceinline__ void backward8(Grad& g, const f32x4& xb, const f32x4 (&h1)[kHT], const f32x4 (&h2)[kHT], const f32x4& dz, int hn, Late&& late) const {
         const lds_f E = S.ea;
         const int hv = w >> 2;                                         // which 64-row half this wave's rows belong to
-        xbar();                                                        // the previous chunk's readers of ea / eb / ex are done
+        BWD_T0();
+        xbar();
+        BWD_T(0);                                                        // the previous chunk's readers of ea / eb / ex are done
         {
             const LaneK K = lanes();
 #pragma unroll
             for (int ft = 0; ft < kHT; ++ft) xput8(K, E, ft, h2[ft]);
             xput8(K, S.ex, 0, dz);
         }
+        BWD_T(1);
         f32x4 d2[kHT];
         if (hn > 0) delta2_valu(dz, h2, d2, hn); else delta2(dz, h2, d2);
+        BWD_T(2);
         xbar();
+        BWD_T(0);
         {
             const LaneK K = lanes();
 #pragma unroll
@@ -555,19 +573,24 @@ struct ChainNetT {
                 g.g3[0] = mfma4(g.g3[0], get_frag8(K, E, w, bb), af);
             }
         }
+        BWD_T(3);
 #if FRL_BW_MASK
         const unsigned m1 = relu_mask(h1);
 #endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             xbar();
+            BWD_T(0);
             if (hv == half) {
                 const LaneK K = lanes();
 #pragma unroll
                 for (int ft = 0; ft < kHT; ++ft) { xput(K, S.ea, ft, h1[ft]); xput(K, S.eb, ft, d2[ft]); }
             }
+            BWD_T(1);
             xbar();
+            BWD_T(0);
             layer2_consume(g);
+            BWD_T(4);
         }
         f32x4 d1[kHT];
 #if FRL_BW_MASK
@@ -575,15 +598,19 @@ struct ChainNetT {
 #else
         delta1(d2, h1, d1);
 #endif
+        BWD_T(5);
         late();
         xbar();
+        BWD_T(0);
         {
             const LaneK K = lanes();
             xput8(K, S.ex, 0, xb);
 #pragma unroll
             for (int ft = 0; ft < kHT; ++ft) xput8(K, E, ft, d1[ft]);
         }
+        BWD_T(1);
         xbar();
+        BWD_T(0);
         {
             const LaneK K = lanes();
 #pragma unroll
@@ -594,6 +621,7 @@ struct ChainNetT {
                 g.g1[0] = mfma4(g.g1[0], bf, af);
             }
         }
+        BWD_T(6);
     }
 
     // after the last chunk: the bias partials of the four lane groups (rows 4q..4q+3 of every 16-row block) added up

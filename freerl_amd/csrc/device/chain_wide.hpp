@@ -174,7 +174,8 @@ struct WideNet {
     // only the MFMAs of the partial tail slice are guarded.
     template <int T>
     __device__ __forceinline__ void l1_sweep(f32x4 (&h1)[T][kHT], const g_cf (&rp)[T], g_cf w1, int KB1) const {
-        const int l = C.l, w = C.w, q = C.q, fslot = C.fslot;
+        const auto K_ = C.lanes();
+        const int l = C.l, w = C.w, q = K_.q, fslot = K_.fslot;
         const int nfull = KB1 / kWideSliceKB, tail = KB1 - nfull * kWideSliceKB, last = KB1 - 1;
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
@@ -255,7 +256,8 @@ struct WideNet {
     // (h1 may be a window [T0, T0 + T) of a sweep's TT tiles)
     template <int T, int NT3, bool VH, int TT = T, int T0 = 0>
     __device__ __forceinline__ void l23(const f32x4 (&h1)[TT][kHT], f32x4 (&h2)[T][kHT], f32x4 (&z)[T][NT3], int hn) const {
-        const int q = C.q, fslot = C.fslot;
+        const auto K_ = C.lanes();
+        const int q = K_.q, fslot = K_.fslot;
 #pragma unroll
         for (int ot = 0; ot < kHT; ++ot) {
             const f32x4 bb = ld4((lds_cf)(C.S.b2 + ot * 16 + 4 * q));
@@ -310,7 +312,8 @@ struct WideNet {
     // dH2 = W3^T dz through the ReLU of h2 for a head of NT3 tiles (transposed fragment reads, as ChainNet::delta2)
     template <int NT3>
     __device__ __forceinline__ void delta2_tiles(const f32x4 (&dz)[NT3], const f32x4 (&h2)[kHT], f32x4 (&d2)[kHT]) const {
-        const int q = C.q, i16 = C.i16, tslot = C.tslot;
+        const auto K_ = C.lanes();
+        const int q = K_.q, i16 = K_.i16, tslot = K_.tslot;
 #pragma unroll
         for (int it = 0; it < kHT; ++it) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -330,7 +333,8 @@ struct WideNet {
     // h1 may be a window [T0, T0 + T) of TT tiles)
     template <int T, int TT, int T0>
     __device__ __forceinline__ void delta1_t(const f32x4 (&d2)[T][kHT], const f32x4 (&h1)[TT][kHT], f32x4 (&d1)[T][kHT]) const {
-        const int q = C.q, i16 = C.i16, tslot = C.tslot;
+        const auto K_ = C.lanes();
+        const int q = K_.q, i16 = K_.i16, tslot = K_.tslot;
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -459,7 +463,8 @@ struct WideNet {
     template <int NKT> struct Dw1Ops { f32x4 a[NKT], b[4]; };
     template <int NKT, class RowF>
     __device__ __forceinline__ float dw1_grad(g_f G, const LayerDesc* L, g_cf dz1, int nchunks, int B, int KB1, int XT, RowF rowptr) const {
-        const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
+        const auto K_ = C.lanes();
+        const int w = C.w, q = K_.q, i16 = K_.i16, fslot = K_.fslot;
         const int oh = w & 1, kt0 = w >> 1, nkt = (KB1 - kt0 + 1) >> 1;
         f32x4 acc[NKT][4];
 #pragma unroll
@@ -549,7 +554,8 @@ struct WideNet {
     // head's LayerDescs), BEFORE the dW1 pass (its accumulators want the registers); returns this lane's share of the squared norm
     template <int NT3>
     __device__ __forceinline__ float grad_store_23(g_f G, const LayerDesc* L, const WideGrad<NT3>& g) const {
-        const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot;
+        const auto K_ = C.lanes();
+        const int w = C.w, q = K_.q, i16 = K_.i16, fslot = K_.fslot;
         float ss = 0.f;
         auto sq = [](const f32x4& v) { return (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); };
 #pragma unroll

@@ -91,7 +91,8 @@ struct SweepNet {
     // chain_wide.hpp: l1_sweep (same pipelining rules: loads pinned in front of the slice's MFMAs, none of them conditional)
     template <int T, bool RELU>
     __device__ __forceinline__ void sweep_f(f32x4 (&acc)[T][8], const g_cf (&p)[T], int kstride, g_cf wimg, int KB, lds_cf bias) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, fslot = W.C.fslot;
+        const auto K_ = W.C.lanes();
+        const int l = W.C.l, w = W.C.w, q = K_.q, fslot = K_.fslot;
         const int nfull = KB / 4, tail = KB - nfull * 4, last = KB - 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -176,7 +177,8 @@ struct SweepNet {
 
     // first layer into XR: images of <= 32 tiles (KB1 <= 2) are staged whole, wider ones take the two K-outer half-sweeps
     __device__ __forceinline__ void l1_x(f32x4 (&X)[2][4][8], const g_cf (&p)[4], g_cf w1, int KB1) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, fslot = W.C.fslot;
+        const auto K_ = W.C.lanes();
+        const int l = W.C.l, w = W.C.w, q = K_.q, fslot = K_.fslot;
 #ifdef FRL_WIDE_TIMING
         long long lc_[5] = {clock64(), 0, 0, 0, 0};
 #endif
@@ -291,7 +293,8 @@ struct SweepNet {
     }
     template <bool TR, class Epi>
     __device__ __forceinline__ void sweep_x(const f32x4 (&X)[2][4][8], g_cf w2, lds_cf bias, Epi&& epi, const Slice0& f0) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot, tslot = W.C.tslot;
+        const auto K_ = W.C.lanes();
+        const int l = W.C.l, w = W.C.w, q = K_.q, i16 = K_.i16, fslot = K_.fslot, tslot = K_.tslot;
         f32x4 R[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) R[j] = f0.R[j];
@@ -396,7 +399,8 @@ struct SweepNet {
 
     // layer-2 deltas into XR from the head's deltas and h2's ReLU masks: one-output dot-product head (dzv[t] = the row's delta)
     __device__ __forceinline__ void delta2_x_valu(f32x4 (&X)[2][4][8], const unsigned (&m2)[8], const float (&dzv)[4]) const {
-        const int q = W.C.q;
+        const auto K_ = W.C.lanes();
+        const int q = K_.q;
 #pragma unroll
         for (int it = 0; it < kHT2; ++it) {
             const f32x4 wv = ld4((lds_cf)(w3 + it * 256 + ((q * 16 + q) << 2)));          // slot (q, f = 0): W3[0][16 it + 4 q ..]
@@ -409,7 +413,8 @@ struct SweepNet {
     // ... NT3 head tiles: W3^T dz through transposed fragments of the head image
     template <int NT3>
     __device__ __forceinline__ void delta2_x_tiles(f32x4 (&X)[2][4][8], const unsigned (&m2)[8], const f32x4 (&dz)[4][NT3]) const {
-        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
+        const auto K_ = W.C.lanes();
+        const int q = K_.q, i16 = K_.i16, tslot = K_.tslot;
 #pragma unroll
         for (int it = 0; it < kHT2; ++it) {
             f32x4 wa[NT3];
@@ -429,7 +434,8 @@ struct SweepNet {
     }
     // head partials of one finished pair of h2 tiles (sweep_x epilogue): dot-product head / NT3 MFMA tiles
     __device__ __forceinline__ void head_valu_pair(const f32x4 (&h)[2][4], int s, float (&zp)[4]) const {
-        const int q = W.C.q;
+        const auto K_ = W.C.lanes();
+        const int q = K_.q;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const f32x4 wv = ld4((lds_cf)(w3 + (2 * s + o) * 256 + ((q * 16 + q) << 2)));
@@ -496,7 +502,8 @@ struct SweepNet {
 
     // a tile written at the fragment slot, read back transposed: lane (i16, q) gets element (row 4 q + e, column i16)
     __device__ __forceinline__ f32x4 tr_read(lds_cf tb) const {
-        const int q = W.C.q, i16 = W.C.i16, tslot = W.C.tslot;
+        const auto K_ = W.C.lanes();
+        const int q = K_.q, i16 = K_.i16, tslot = K_.tslot;
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = tb[tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
@@ -508,7 +515,8 @@ struct SweepNet {
     // buffered through the union at the fragment slot, and every wave reads its operands back transposed: wave w owns k-tiles
     // 8 (w >> 1) + j x out tiles 8 (w & 1) + y — 64 accumulator tiles, 256 MFMAs per block and barrier.
     __device__ __forceinline__ float dw2_coop(g_f Gw, g_f Gb, g_cf h1t, g_cf d2t, int nchunks) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
+        const auto K_ = W.C.lanes();
+        const int l = W.C.l, w = W.C.w, q = K_.q, i16 = K_.i16, fslot = K_.fslot;
         const int nit = nchunks * 4, kt0 = 8 * (w >> 1), ot0 = 8 * (w & 1);
         g_cf src = (w < 2 ? h1t + w * 8 * 256 : d2t + (w - 2) * 8 * 256) + 4 * l;
         f32x4 acc[8][8];
@@ -580,7 +588,8 @@ struct SweepNet {
     template <int NKT, int NY, bool AROWS, class RowF>
     __device__ __forceinline__ float dw_pass(g_f Gw, g_f Gb, int KBimg, int XT, int kt0, int kstep, int nkt, int ot0, RowF arow, g_cf atl, int NTA, g_cf btl,
                                              int NTB, int nchunks, int B) const {
-        const int q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
+        const auto K_ = W.C.lanes();
+        const int q = K_.q, i16 = K_.i16, fslot = K_.fslot;
         const int nit = nchunks * 4;
         const int lane_t = (((i16 >> 2) * 16 + 4 * q) << 2) + (i16 & 3);      // + 4 e: element (row 4 q + e, column i16) of a tile-lane tile
         int kcl[NKT], fcol[NKT];
@@ -686,7 +695,8 @@ struct SweepNet {
     // bias partials through the b1 / b2 slots, free between a head's main pass and the next stage3).  Wave 0 stores.
     template <int NKT, int NY, bool AROWS, class RowF>
     __device__ __forceinline__ float dw_rows(g_f Gw, g_f Gb, int KBimg, int XT, int nkt, RowF arow, g_cf atl, int NTA, g_cf btl, int NTB, int nchunks, int B) const {
-        const int l = W.C.l, w = W.C.w, q = W.C.q, i16 = W.C.i16, fslot = W.C.fslot;
+        const auto K_ = W.C.lanes();
+        const int l = W.C.l, w = W.C.w, q = K_.q, i16 = K_.i16, fslot = K_.fslot;
         int kcl[NKT], fcol[NKT];
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {

@@ -16,6 +16,8 @@ __device__ long long g_ppo_clk[2][8];
 // a helper function that stamps sections too takes / is handed the caller's clock state
 #define PPO_TPARAMS , long long& t_prev_, long long (&t_acc_)[8]
 #define PPO_TARGS , t_prev_, t_acc_
+#define PPO_UPARAMS , long long& u_prev_, long long (&u_acc_)[8]
+#define PPO_UARGS , u_prev_, u_acc_
 // the quick form of the developer build (tools/build_unit_timing.sh <unit>): ONE kernels_*.hip compiled with -DFRL_PPO_TIMING
 // -DFRL_CLK_COPY=1 carries the stamps and this kernel, which the host unit (compiled with -DFRL_PPO_TIMING_SPLIT) launches to fetch them
 #if defined(FRL_CLK_COPY) && !defined(FRL_UNITY)
@@ -26,6 +28,8 @@ __global__ void frl_clk_copy_kernel(long long* out) {
 #else
 #define PPO_TPARAMS
 #define PPO_TARGS
+#define PPO_UPARAMS
+#define PPO_UARGS
 #define PPO_T0() do {} while (0)
 #define PPO_T(slot) do {} while (0)
 #define PPO_TDUMP() do {} while (0)

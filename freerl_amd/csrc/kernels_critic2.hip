@@ -19,6 +19,11 @@
 #include "device/update_common.hpp"
 #include "device/ppo_timing.hpp"
 
+#if defined(FRL_BWD_TIMING)
+#undef PPO_UDUMP
+#define PPO_UDUMP() do {} while (0)      // (row 1 of the clock array belongs to the backward's stamps in this build)
+#endif
+
 namespace frl {
 
 // TT = 16-row tiles per wave in the target passes (4: one 256-row chunk, every weight fragment read from LDS feeds 16 MFMAs;

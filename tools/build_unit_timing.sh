@@ -8,7 +8,7 @@ set -e
 U=${1:-kernels_ppo2}
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/freerl_amd/_lib/obj; mkdir -p $R/tools/_bin
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed"
-hipcc $F -DFRL_PPO_TIMING -DFRL_CLK_COPY=1 -c $R/freerl_amd/csrc/$U.hip -o /tmp/${U}_t.o &
+hipcc $F -DFRL_PPO_TIMING -DFRL_CLK_COPY=1 $FRL_UNIT_FLAGS -c $R/freerl_amd/csrc/$U.hip -o /tmp/${U}_t.o &
 hipcc $F -DFRL_PPO_TIMING_SPLIT -c $R/freerl_amd/csrc/frl_api.hip -o /tmp/frl_api_t.o &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_bin/libfreerl_hip_ppot.so $(ls $O/*.o | grep -v -e $U.o -e frl_api.o) /tmp/${U}_t.o /tmp/frl_api_t.o
