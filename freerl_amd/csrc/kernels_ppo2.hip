@@ -26,6 +26,10 @@
 #include "device/chain.hpp"
 #include "device/ppo_timing.hpp"
 
+#ifndef FRL_PPO2_REFRESH
+#define FRL_PPO2_REFRESH 1
+#endif
+
 namespace frl {
 
 namespace {
@@ -61,7 +65,16 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
     const NetDesc& N = D.net[critic ? 1 : 0];
     const RecordDesc& R = D.rec;
     const Ppo2Lds S = ppo2_carve<K0B>(smem);
-    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = l & 15, q = l >> 4;
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // i16 / q are re-declared "changed" at every phase boundary below (an empty asm the compiler cannot see through): every LDS
+    // address built on them then lives exactly as long as its phase.  Left as loop invariants, hipcc hoists ~30 address registers
+    // to the top of the kernel and spills them around the MFMA chains (round 6: device/chain_net.hpp, ChainNetT::lanes).
+    int i16 = l & 15, q = l >> 4;
+#if FRL_PPO2_REFRESH
+#define PPO2_REFRESH() asm volatile("" : "+v"(i16), "+v"(q))
+#else
+#define PPO2_REFRESH() do {} while (0)
+#endif
     const size_t off = (size_t)p * D.learner_stride + D.net_off[critic ? 1 : 0];
     g_f th_g = as_global(D.theta + off);
     g_f m_g = as_global(D.m + off);
@@ -197,6 +210,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             }
             for (int r0 = 0; r0 < m; r0 += 64) {
                 // ---------------------------------------------------------------- this wave's 16 rows, in registers
+                PPO2_REFRESH();
                 const Rows cur = (r0 == 0) ? nxt : load_rows(k, s, r0, m);
                 const bool valid = cur.valid != 0;
                 f32x4 xb[K0B];                                     // B operand of layer 1: X[in = 16 kb + 4q + e][row]
@@ -230,6 +244,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     z = mfma4(z, ld4((lds_cf)(S.w3 + kb * 256 + ((q * 16 + (i16 ^ q)) << 2))), h2[kb]);
 
                 PPO_T(0);
+                PPO2_REFRESH();
                 // ---------------------------------------------------------------- per-row loss and head delta dz[out][row]
                 f32x4 dz = {0.f, 0.f, 0.f, 0.f};
                 if (critic) {                                      // mse(v_target[idx], V(obs[idx])) (:349-351)
@@ -336,6 +351,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                 }
 
                 PPO_T(1);
+                PPO2_REFRESH();
                 // ---------------------------------------------------------------- exchange 1: H2 and dz -> head gradient
                 lds_barrier();                                     // the previous chunk's / step's readers of ea / eb are done
                 const int wslot = (((i16 >> 2) * 16) << 2) + (i16 & 3);          // + ((f16 ^ (i16 >> 2)) << 2)
@@ -357,6 +373,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                     for (int x = 0; x < 2; ++x) g3[x] = mfma4(g3[x], af, get_frag(S.ea, 2 * w + x, bb));
                 }
                 // dH2 = W3^T dz, through the activation: dz2[in][row]   (A = W3^T: transposed fragment reads)
+                PPO2_REFRESH();
                 f32x4 d2[kHT];
 #pragma unroll
                 for (int it = 0; it < kHT; ++it) {
@@ -389,6 +406,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
                         for (int kt = 0; kt < kHT; ++kt) g2[x][kt] = mfma4(g2[x][kt], af[x], bf[kt]);
                 }
                 // dH1 = W2^T dz2 -> dz1[in][row]
+                PPO2_REFRESH();
                 f32x4 d1[kHT];
 #pragma unroll
                 for (int it = 0; it < kHT; ++it) {
@@ -430,6 +448,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             }
 
             PPO_T(4);
+            PPO2_REFRESH();
             {       // the next step's rows: in flight during the reductions and Adam
                 int k2 = k, s2 = s + mb;
                 if (s2 >= T) { s2 = 0; ++k2; }
@@ -493,6 +512,7 @@ __device__ __forceinline__ void ppo_update_v2_body(const EngineDesc& D, const Pp
             const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
 
             PPO_T(5);
+            PPO2_REFRESH();
             // -------------------------------------------------------------------- clip + Adam from the accumulators
             // (every wave finished its backward chain before the barriers above: the weights may change now)
             // 13.5 k of a step's 73 k cycles (tools/ppo_timing.py), and that is its VALU cost: 88 elements per lane x (~12 fp32 ops + the
