@@ -366,17 +366,17 @@ struct SoloNet {
 };
 
 // ---- "every workgroup of the learner has written its slab": sixteen FLAG words, not a counter.  Workgroup b, behind a workgroup
-// barrier (every thread's stores issued and counted), publishes flag[b] = epoch with ONE agent-scope release store (L2 write-back:
+// barrier (sync_stores: every thread's stores acknowledged), publishes flag[b] = epoch with ONE agent-scope release store (L2 write-back:
 // the readers sit on other XCDs); sixteen threads of every workgroup each poll one flag until it holds this launch's epoch, then the
 // workgroup takes an agent-scope acquire fence (invalidate) and reads the slabs.  Against the counter form (atomic add, then spin on
 // the count): one memory round trip less on the critical path — the add had to return before the spin could start.
 // epoch: unique per launch (SoloArgs::bar_base + kSoloWG, the host advances bar_base by kSoloWG per launch).  A thread that waits
 // 2 s gives up and raises *err: the launch then finishes with wrong numbers instead of hanging the queue.
 __device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
-    __syncthreads();
+    sync_stores();
     if (threadIdx.x == 0) {
-        // (every wave's stores are acknowledged: __syncthreads waits for them)  release fence, an explicit wait — hipcc may drop the
-        // fence's own when it believes the wave has nothing outstanding, and the flag would overtake the write-back — then the flag
+        // (every wave's stores are acknowledged: each drained its own vmcnt in front of the barrier)  release fence, an explicit wait —
+        // hipcc may drop the fence's own when it believes the wave has nothing outstanding, and the flag would overtake the write-back — then the flag
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -61,6 +61,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// The barrier in front of a ONE-LANE release (flag store / ticket add that tells another workgroup, the next launch or the host
+// "this workgroup's global stores are there").  On gfx90a+ outside threadgroup-split mode __syncthreads() is
+// `s_waitcnt lgkmcnt(0); s_barrier`: it does NOT wait for a wave's outstanding global stores, and lane 0's own vmcnt wait behind
+// its release fence covers wave 0 only — so every thread drains its own stores first (a per-wave wait, no cache operation).
+__device__ __forceinline__ void sync_stores() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 __device__ __forceinline__ void st4_stream(g_f p, f32x4 v) {      // write-once data: do not keep it in L2
     __builtin_nontemporal_store(v, reinterpret_cast<FRL_GLB f32x4*>(p));
 }

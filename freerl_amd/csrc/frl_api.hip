@@ -126,7 +126,8 @@ struct frl_engine {
     std::vector<int> bucket_cursor;
     std::vector<int> size_flushed;        // rows valid per learner as of the last flush (PER_Buffer.add's `len(self.buffer) == 0`)
     int* d_size = nullptr;                // [2][P]: size before the flush being applied / current size
-    int n_cus = 256;                      // compute units of the device (grid of the persistent kernels)
+    int n_cus = 256;                      // compute units of the device (how many one-per-CU workgroups are resident at once)
+    int lds_per_cu = 160 * 1024;          // LDS bytes of one compute unit
     int chain_waves = 8;                  // waves per workgroup of the register-chained actor-critic kernels (FRL_CHAIN_WAVES=4: round 5's)
     int* stage_bucket = nullptr;          // PER, pinned: [off[P + 1] | size_before[P] | leaf[stage_cap]] of the flush being applied
     int* d_stage_bucket = nullptr;
@@ -324,6 +325,15 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
 
     frl_engine* e = new frl_engine();
     e->cfg = c;
+    {   // what the device can hold resident at once: the solo kernels' flag hand-overs spin on every workgroup of a launch
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device_id) == hipSuccess) {
+            e->n_cus = std::max(1, prop.multiProcessorCount);
+            e->lds_per_cu = (int)std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlock);
+        }
+        const char* fc = getenv("FRL_ASSUME_CUS");                      // (tests: a smaller / partitioned device)
+        if (fc && atoi(fc) > 0) e->n_cus = atoi(fc);
+    }
     EngineDesc& h = e->h;
     memset(&h, 0, sizeof h);
     h.algo = c.algo;
@@ -394,7 +404,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         // up to kSoloMaxP learners: one learner on sixteen workgroups (kernels_solo.hip; FRL_SOLO=0/1 overrides, FRL_CRITIC_V2 set
         // means the caller asked for one of the other two families by name)
         const char* solo = getenv("FRL_SOLO");
-        h.solo = (solo ? atoi(solo) != 0 : (!force && h.P <= kSoloMaxP)) && (long long)h.P * kSoloWG <= 256 ? 1 : 0;
+        // (every one of its P x 16 workgroups — 156 KB of LDS each: one per CU — has to be RESIDENT: they wait for each other's flags.
+        //  On a device with fewer CUs, a CU-masked or partitioned one, the row-chunk kernels take the engine instead)
+        const bool solo_fits = (long long)h.P * kSoloWG <= e->n_cus && e->lds_per_cu >= (int)(std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float));
+        h.solo = (solo ? atoi(solo) != 0 : (!force && h.P <= kSoloMaxP)) && solo_fits ? 1 : 0;
         if (h.solo || (force ? atoi(force) != 0 : h.P > 128)) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
@@ -586,9 +599,6 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (auto k : {ac_critic_v2w4_twin_kernel, ac_critic_v2w4_single_kernel, ac_actor_v2w4_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        hipDeviceProp_t prop;
-        CREATE_TRY(hipGetDeviceProperties(&prop, c.device_id));
-        e->n_cus = std::max(1, prop.multiProcessorCount);
     }
     if (e->lds_bytes > 64 * 1024) {
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));

@@ -413,10 +413,10 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         if (l == 0) S.red[w] = lsum;
         lds_barrier();
         if (tid == 0) D.part[((size_t)p * D.S + sp) * 4] = ((S.red[0] + S.red[1]) + S.red[2]) + S.red[3];
-        // publish: every wave's stores acknowledged (__syncthreads), then ONE lane's agent-scope release, an explicit wait (hipcc may
+        // publish: every wave's stores acknowledged (sync_stores: each drains its own), then ONE lane's agent-scope release, an explicit wait (hipcc may
         // drop the fence's own) and the ticket; the last arriver: one lane's acquire for the CU.  (All 256 threads running
         // __threadfence() on both sides wrote the L2 back and invalidated it once per thread.)
-        __syncthreads();
+        sync_stores();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
         }
     }
     if (s.act && s.done_flag) {
-        __syncthreads();                                               // every wave's env_out stores have been issued and counted down
+        sync_stores();                                                 // every wave's env_out stores have been issued and acknowledged
         if (tid == 0) {
             // this learner's actions are out; the last learner to get here flags the host: system-scope release + an explicit wait
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -70,8 +70,9 @@ __device__ __forceinline__ void solo_step_tail(const EngineDesc& D, const LearnA
         __syncthreads();
     }
     if (st.done_flag) {
-        // this learner's actions are out (the __syncthreads above: every wave's stores acknowledged); the last learner to get here flags
+        // this learner's actions are out (sync_stores: every wave's stores acknowledged); the last learner to get here flags
         // the host — lane 0's system-scope release + an explicit wait in front of the flag
+        sync_stores();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -87,7 +88,7 @@ __device__ __forceinline__ void solo_step_tail(const EngineDesc& D, const LearnA
 // launch (other stream) counts the workgroups of this step before it reads any of them
 __device__ __forceinline__ void solo_leave(const SoloStepArgs& st) {
     if (!st.dev_cnt) return;
-    __syncthreads();
+    sync_stores();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -60,7 +60,26 @@ def _watch(P):
 # learners x 3 agents x 2 calls a flip SOMEWHERE is the expected case (seen: MATD3 learner 30, one critic's l2.weight moment off by
 # 6.6e-3 of its max on < 1 % of its elements).  So: >= 99 % of a net's elements within (rtol, atol), every element within 2 lr per
 # Adam step; Adam's first moment within 2e-3 of the array's largest on >= 99 % of its elements and within 5e-2 on all of them.
+# The check that would catch a wrong ROW is the moment's `max <= 5e-2 max|m|` (a row taken from another unit is O(1) off) together with
+# _no_structured_block below: the out-of-tolerance elements of a weight matrix may not cover a whole row, column or 16 x 16 tile.
 LR, CALLS = 1e-3, 2
+
+
+def _no_structured_block(bad, label):
+    """The escape of the 1 % rule made explicit: the elements outside (rtol, atol) must be SCATTERED — rounding noise and single
+    flipped ReLU units touch isolated elements of a weight matrix, whereas an addressing error (another unit's rows, a wrong tile
+    offset, a lane group reading its neighbour's slot) is wrong on a whole row, a whole column or a whole 16 x 16 MFMA tile.  One
+    full hidden unit of a 128 x 128 layer is 0.78 % of it and would pass the fraction test on its own."""
+    if bad.ndim != 2 or min(bad.shape) < 2:
+        return
+    # (a flipped unit legitimately moves MANY elements of its row a little; what never happens by rounding is ALL of them at once)
+    full_rows, full_cols = np.flatnonzero(bad.all(axis=1)), np.flatnonzero(bad.all(axis=0))
+    assert full_rows.size == 0, "%s: every element of row(s) %s is outside tolerance" % (label, full_rows[:8])
+    assert full_cols.size == 0 or bad.shape[0] < 4, "%s: every element of column(s) %s is outside tolerance" % (label, full_cols[:8])
+    r16, c16 = bad.shape[0] // 16, bad.shape[1] // 16
+    if r16 and c16:
+        tiles = bad[:r16 * 16, :c16 * 16].reshape(r16, 16, c16, 16).all(axis=(1, 3))
+        assert not tiles.any(), "%s: every element of 16 x 16 tile(s) %s is outside tolerance" % (label, np.argwhere(tiles)[:4].tolist())
 
 
 def _assert_net(got_flat, want, names, extra, rtol, atol, label):
@@ -70,6 +89,7 @@ def _assert_net(got_flat, want, names, extra, rtol, atol, label):
         bad = d > atol + rtol * np.abs(want[k])
         assert bad.mean() <= 0.01, "%s/%s: %d of %d elements outside rtol %g atol %g (max |diff| %.3g)" % (label, k, bad.sum(), bad.size, rtol, atol, d.max())
         assert d.max() <= 2 * LR * CALLS, "%s/%s: max |diff| %.3g is more than Adam can move an element in %d steps" % (label, k, d.max(), CALLS)
+        _no_structured_block(bad, "%s/%s" % (label, k))
 
 
 def _assert_adam_m(got_flat, opt_m, names, extra, label):
