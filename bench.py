@@ -234,6 +234,55 @@ def dqn_single_learner_loop(P=512):
                            "updates_per_sec": r["updates"] / r["seconds"]}}
 
 
+def dqn_roofline(device_id=0):
+    """The DQN update (north_star's own target algorithm: DQN_file/DQN.py:104-118) against BOTH rooflines.  One launch of
+    dqn_fused_kernel (kernels_dqn2.hip) is the whole learn() of every resident learner — index draw, target + online forward,
+    TD loss, backward, Adam, soft update: SURVEY 8(d)'s figures per learn() (frl_learn_work: 3.1 MFLOP, 72.8 KB at obs 8 / 4 actions /
+    batch 256) x the launch's learners / the launch's average duration from HIP events on the engine's stream.  What bounds it is
+    neither: the 128 -> 4 head and the 8 -> 128 input layer are padded to 16-wide MFMA tiles (the kernel ISSUES ~2.7x its useful
+    flops) and a learner's chain of dependent phases (draw -> gather -> forward -> TD -> backward -> exchange -> Adam) is latency:
+    `issued_frac` prices the padded tiles, `resident_learners` says how many chains a CU overlaps."""
+    from freerl_amd import _native as N
+    from freerl_amd.engine import Engine
+    out = {"kernel": "dqn_fused_kernel", "unit": "per launch = one learn() of every learner; HIP events on the engine's stream",
+           "shape": "obs 8, 4 actions, batch 256, hidden 128, replay 1e5 rows filled, device-drawn indices", "by_population": {}}
+    for P in (512, 4096):
+        e = Engine(N.ALGO_DQN, 8, 4, 100_000, discrete=True, batch_max=BATCH, n_learners=P, device_id=device_id, seed=1)
+        g = np.random.default_rng(0)
+        flat = (g.standard_normal(e.num_params(0)) * 0.05).astype(np.float32)
+        for p in range(P):
+            e.set_params(0, flat, N.PARAM_ONLINE, learner=p); e.set_params(0, flat, N.PARAM_TARGET, learner=p)
+        e.fill_synthetic(100_000, seed=5)
+        kw = dict(gamma=0.99, tau=0.01, critic_lr=1e-3, clip_norm=0.0)
+        for _ in range(5):
+            e.learn(BATCH, **kw)
+        e.sync()
+        t0 = time.perf_counter()
+        n = 40
+        for _ in range(n):
+            e.learn(BATCH, **kw)
+        e.sync()
+        wall = (time.perf_counter() - t0) / n
+        e.profile(True)
+        for _ in range(n):
+            e.learn(BATCH, **kw)
+        prof = e.profile_read()
+        e.profile(False)
+        launch_s = prof["grad_critic"][0] / prof["grad_critic"][1] * 1e-3
+        fl, by = e.learn_work(BATCH, False)                # whole launch: P learners
+        issued = 2.0 * BATCH * (16 * 128 + 128 * 16) * (2 + 2) * P      # padded tiles: two forwards, backward ~ two more
+        out["by_population"]["%d learners" % P] = {
+            "avg_launch_ms": launch_s * 1e3, "updates_per_sec": P / wall, "flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+            "mfma": {"achieved": fl / launch_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                     "issued_frac": issued / launch_s / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+            "hbm": {"achieved": by / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / launch_s / 1e9 / HBM_PEAK_GBS},
+            "lds_bytes": e.learn_path(BATCH)[1]}
+        e.close()
+    out["bound"] = ("latency of one learner's dependent phases x resident learners per CU (two 77 KB workgroups); of the MFMA issue, "
+                    "the padded head / input tiles are ~63 %: DESIGN.md 5")
+    return out
+
+
 def fifty_x_statement(gpu_by_rows, cpu_loops):
     """north_star: ">= 50x the reference CPU env-steps/s on DQN".  ONE statement from like-for-like points (same loop, same box,
     same full ring on both sides, one learner x one env against one core): the ratio per ring size and — interpolated
@@ -385,12 +434,13 @@ def main():
         n_act = sum(1 for k in range(args.steps) if k % 2 == 1)
         step_s = kernel_ms * 1e-3 / args.steps
         kern = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
-        # dominant kernel: the critic stage.  At this population it is ac_critic_v2_twin_kernel (kernels_critic2.hip): targets,
-        # twin-critic forward / backward, clip + Adam + soft update of one learner per workgroup in ONE launch ("adam_critic"
-        # absent from the per-kernel times); up to 128 learners ac_critic_kernel + adam_fused_kernel.  Its flops are the same
+        # dominant kernel: the critic stage.  At this population it is ac_critic_v2_twin_nv_kernel (kernels_critic2.hip; _nv = the
+        # record layout allows 16-byte row loads): targets, twin-critic forward / backward, clip + Adam + soft update of one learner per
+        # eight-wave workgroup in ONE launch ("adam_critic" absent from the per-kernel times); up to 128 learners ac_critic_kernel +
+        # adam_fused_kernel.  Its flops are the same
         # algorithmic figure either way (frl_learn_work): the Adam / soft-update phase adds HBM bytes, not flops.
         fused = "adam_critic" not in kern
-        dominant = "ac_critic_v2_twin_kernel" if fused else "ac_critic_kernel"
+        dominant = "ac_critic_v2_twin_nv_kernel" if fused else "ac_critic_kernel"
         launch_s = kern["grad_critic"]["avg_ms"] * 1e-3
         stage_s = launch_s + (0.0 if fused else kern["adam_critic"]["avg_ms"] * 1e-3)
         achieved = fl_c / launch_s / 1e12
@@ -458,7 +508,7 @@ def main():
             "config": {"workload": "TD3.learn() (BASELINE configs[1] algorithm; north_star synthetic shape): obs_dim 8, "
                                    "act_dim 2, batch 256, replay 1e6 rows filled, hidden 128, policy_freq 2, "
                                    "device-drawn indices/noise",
-                       "learners_per_gpu": P, "updates_per_step": P * world, "kernel_family": "chained (one workgroup per learner)" if chained else "row-chunk",
+                       "learners_per_gpu": P, "updates_per_step": P * world, "kernel_family": "chained (one eight-wave workgroup per learner, two waves per SIMD)" if chained else "row-chunk",
                        "rows_per_workgroup": rc, "lds_bytes": lds,
                        "parallelism": "seeds sharded over %d GPU(s), no data-path collective" % world,
                        "collective": "metric all-reduce: %s" % backend},
@@ -474,8 +524,9 @@ def main():
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
                          "kernel": dominant, "avg_launch_ms": launch_s * 1e3,
                          "critic_stage_ms": stage_s * 1e3, "critic_stage_tflops": fl_c / stage_s / 1e12,
-                         "note": "round 1's 0.51 was ac_critic_kernel alone (0.523 ms) with clip + Adam in a second launch (0.120 ms): "
-                                 "0.41 for the stage this kernel now covers on its own",
+                         "note": "round 6: eight-wave workgroups (two waves per SIMD, every wave inside 256 registers) - FRL_CHAIN_WAVES=4 runs "
+                                 "rounds 2-5's four-wave kernels on the same box; the clip + Adam phase (~17 % of the launch) streams "
+                                 "theta / m / v at the chip's HBM rate with every CU in it at once and is not overlapped with MFMA work",
                          "flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
                          "flops_convention": "achieved / frac: SURVEY 8(d)'s formula, 2 B sum(in x out) x (#fwd + 2 x #bwd) (frl_learn_work); "
                                              "*_executed: the flops autograd and these kernels execute - no first-layer dX of a trained net, "
@@ -488,6 +539,7 @@ def main():
                          "step_ms_avg": step_s * 1e3,
                          "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "kernels": kern},
+            "roofline_dqn": None if args.headline_only else dqn_roofline(local_rank),
             "dropin_classes": None if args.headline_only else dropin_classes(),
             "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(args.learners),
             "cpu_baseline": None if (args.no_cpu_baseline or args.headline_only) else cpu_baseline(),
