@@ -28,11 +28,8 @@
 #ifndef FRL_LANES_OPAQUE4
 #define FRL_LANES_OPAQUE4 1     // the four-wave kernels' lanes() opaque as well (see ChainNetT::lanes)
 #endif
-#ifndef FRL_BW_MASK
-#define FRL_BW_MASK 0
-#endif
 #ifndef FRL_FW_HALF
-#define FRL_FW_HALF 0
+#define FRL_FW_HALF 1      // the 128 x 128 layer's fragments four output tiles at a time in the eight-wave kernels: 16 registers in flight, not 32 (critic 0.4692 -> 0.4659 ms, actor 0.3120 -> 0.3109, same box)
 #endif
 
 namespace frl {
@@ -395,37 +392,6 @@ struct ChainNetT {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d1[it][r] = h1[it][r] > 0.f ? d1[it][r] : 0.f;
     }
-    // ... with relu'(h1) as one bit per element (bit 4 it + r of `mask`): the eight-wave backward drops h1's 32 registers once its
-    // tiles are in the exchange buffer
-    __device__ __forceinline__ unsigned relu_mask(const f32x4 (&h1)[kHT]) const {
-        unsigned m = 0;
-#pragma unroll
-        for (int it = 0; it < kHT; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m |= h1[it][r] > 0.f ? 1u << (4 * it + r) : 0u;
-        return m;
-    }
-    __device__ __forceinline__ void delta1_m(const f32x4 (&d2)[kHT], unsigned mask, f32x4 (&d1)[kHT]) const {
-        const LaneK K = lanes();
-#pragma unroll
-        for (int it = 0; it < kHT; ++it) d1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float wa[2][kHT];
-        auto fetch = [&](int ob, int e, float (&dst)[kHT]) {
-#pragma unroll
-            for (int it = 0; it < kHT; ++it) dst[it] = S.w2[(ob * kHT + it) * 256 + K.tslot + (((4 * K.q + e) ^ (K.i16 >> 2)) << 2)];
-        };
-        fetch(0, 0, wa[0]);
-        static_for<0, 4 * kHT>([&](auto sc) {
-            constexpr int s_ = decltype(sc)::value, ob = s_ >> 2, e = s_ & 3;
-            if constexpr (s_ + 1 < 4 * kHT) fetch((s_ + 1) >> 2, (s_ + 1) & 3, wa[(s_ + 1) & 1]);
-#pragma unroll
-            for (int it = 0; it < kHT; ++it) d1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s_ & 1][it], d2[ob][e], d1[it], 0, 0, 0);
-        });
-#pragma unroll
-        for (int it = 0; it < kHT; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d1[it][r] = (mask >> (4 * it + r)) & 1u ? d1[it][r] : 0.f;
-    }
     // dX = W1^T dz1: d loss / d input column 4q + r of this lane's row (no activation in front of the input)
     __device__ __forceinline__ f32x4 delta0(const f32x4 (&d1)[kHT]) const {
         const LaneK K = lanes();
@@ -574,9 +540,6 @@ struct ChainNetT {
             }
         }
         BWD_T(3);
-#if FRL_BW_MASK
-        const unsigned m1 = relu_mask(h1);
-#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             xbar();
@@ -593,11 +556,7 @@ struct ChainNetT {
             BWD_T(4);
         }
         f32x4 d1[kHT];
-#if FRL_BW_MASK
-        delta1_m(d2, m1, d1);
-#else
         delta1(d2, h1, d1);
-#endif
         BWD_T(5);
         late();
         xbar();
@@ -704,17 +663,6 @@ struct ChainNetT {
         buf_st4(B.th, vo, so, R.th); buf_st4(B.mm, vo, so, R.mm); buf_st4(B.vv, vo, so, R.vv);
         if constexpr (SOFT) buf_st4(B.tg, vo, so, R.tg);
     }
-    // ---- a head's weight-gradient tiles parked in HBM (the learner's `grad` block, image order) while another head's pass needs
-    // the registers; adam_head<..., PARKED> reads them back next to theta / m / v.  The bias sums stay in registers.
-    template <int HD>
-    __device__ __forceinline__ void grad_park(g_f gr, const Grad& g) const {
-        const __amdgpu_buffer_rsrc_t Rg = __builtin_amdgcn_make_buffer_rsrc((float*)gr, 0, 0x7fffffff, 0x00020000);
-        constexpr int HB = HD * kHeadFloats * 4;
-        static_for<0, kUnits>([&](auto j) {
-            constexpr int J = decltype(j)::value;
-            buf_st4(Rg, unit_voff<J>(), HB + unit_soff<J>(), unit_grad<J>(g));
-        });
-    }
     template <bool SOFT>
     __device__ __forceinline__ float adam_scalar(g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, int o, float gr) const {
         float t1 = th[o], m1 = mA[o], v1 = vA[o];
@@ -740,32 +688,11 @@ struct ChainNetT {
     }
     // the whole update of head HD of a net, in the open: the units in batches of up to 8 (loads of a batch before its stores),
     // the 128 x 128 layer's tiles first, then first layer + head layer, then the biases.  th / mA / vA / tg = the NET's blocks.
-    template <bool SOFT, int HD, bool THL = false, bool PARKED = false>
+    template <bool SOFT, int HD, bool THL = false>
     __device__ __forceinline__ void adam_head(const Grad& g, g_f th, g_f mA, g_f vA, g_f tg, const AdamCoef& c, float g_extra = 0.f,
-                                              int extra_n = 0, g_f parked = nullptr) const {
+                                              int extra_n = 0) const {
         const AdamBuf B = adam_buf(th, mA, vA, tg);
         constexpr int HB = HD * kHeadFloats * 4;
-        if constexpr (PARKED) {
-            const __amdgpu_buffer_rsrc_t Rg = __builtin_amdgcn_make_buffer_rsrc((float*)parked, 0, 0x7fffffff, 0x00020000);
-            constexpr int kB = 4;
-            static_for<0, (kUnits + kB - 1) / kB>([&](auto bc) {
-                constexpr int b0 = decltype(bc)::value * kB, nb = b0 + kB <= kUnits ? kB : kUnits - b0;
-                AdamIn in[nb];
-                f32x4 gr[nb];
-                static_for<0, nb>([&](auto j) {
-                    constexpr int J = b0 + decltype(j)::value;
-                    in[decltype(j)::value] = adam_load<SOFT, J, HB, THL>(B);
-                    gr[decltype(j)::value] = buf_ld4(Rg, unit_voff<J>(), HB + unit_soff<J>());
-                });
-                __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
-                static_for<0, nb>([&](auto j) {
-                    constexpr int J = b0 + decltype(j)::value;
-                    adam_store<SOFT, J, HB>(B, adam_compute<SOFT>(c, gr[decltype(j)::value], in[decltype(j)::value]));
-                });
-            });
-            adam_biases<SOFT>(g, th + HD * kHeadFloats, mA + HD * kHeadFloats, vA + HD * kHeadFloats, tg + HD * kHeadFloats, c, g_extra, extra_n);
-            return;
-        }
         constexpr int kBatch = NW == 4 ? 8 : 5;                        // (NW = 8: ten units in two batches of five — 80 registers of state)
         static_for<0, (kUnits + kBatch - 1) / kBatch>([&](auto bc) {
             constexpr int b0 = decltype(bc)::value * kBatch, nb = b0 + kBatch <= kUnits ? kBatch : kUnits - b0;

@@ -34,9 +34,6 @@ namespace frl {
 #ifndef FRL_CRITIC2_TT
 #define FRL_CRITIC2_TT 2
 #endif
-#ifndef FRL_CRITIC2_PARK
-#define FRL_CRITIC2_PARK 0      // the first head's weight-gradient tiles parked in HBM during the second head's pass (eight-wave twin kernel)
-#endif
 #ifndef FRL_CRITIC2_AHEAD
 #define FRL_CRITIC2_AHEAD 1     // the next net's image fetched in front of a target pass's last forward (1) or behind it (0)
 #endif
@@ -289,9 +286,6 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     // =========================================================== critic heads: forward, TD delta, backward into the owners' accumulators
     typename Net::Grad G[NH];
     float lossp = 0.f;
-#if FRL_CRITIC2_PARK
-    float ss_parked = 0.f;
-#endif
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) {
         typename Net::Grad& g = G[hd];
@@ -329,27 +323,13 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
         for (int c = 0; c + 1 < nchunks; ++c) critic_chunk(c, IC<0>{});
         critic_chunk(nchunks - 1, IC<1>{});
         C.grad_finish(g);
-#if FRL_CRITIC2_PARK
-        if (NW == 8 && hd + 1 < NH) {                                  // the first head's tiles wait in HBM: the second head's pass has its registers
-            ss_parked += C.grad_sumsq(g);
-            C.template grad_park<0>(as_global(D.grad + lbase + D.net_off[1]), g);
-        }
-#endif
     }
 
     PPO_T(3);
     // =========================================================== clip_grad_norm_ over the whole critic net, Adam, soft update
-#if FRL_CRITIC2_PARK
-    constexpr bool kPark = NW == 8 && NH == 2;
-    float ss = ss_parked;
-#pragma unroll
-    for (int hd = kPark ? 1 : 0; hd < NH; ++hd) ss += C.grad_sumsq(G[hd]);
-#else
-    constexpr bool kPark = false;
     float ss = 0.f;
 #pragma unroll
     for (int hd = 0; hd < NH; ++hd) ss += C.grad_sumsq(G[hd]);
-#endif
     ss = wave_sum(ss);
     const float lsum = wave_sum(lossp);
     lds_barrier();
@@ -372,9 +352,9 @@ __device__ __forceinline__ void ac_critic_v2_body(const EngineDesc& D, const Lea
     co.tk = 1.f - a.tau; co.tau = a.tau;
 #if !(FRL_ABL & 1)
     if (a.do_actor != 0) {                                             // TD3: targets move with the delayed policy step (TD3.py:224-233)
-        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value, decltype(hd)::value == NH - 1, kPark && decltype(hd)::value == 0>(G[decltype(hd)::value], thC, mC, vC, tgCw, co, 0.f, 0, as_global(D.grad + lbase + D.net_off[1])); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<true, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
     } else {
-        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value, decltype(hd)::value == NH - 1, kPark && decltype(hd)::value == 0>(G[decltype(hd)::value], thC, mC, vC, tgCw, co, 0.f, 0, as_global(D.grad + lbase + D.net_off[1])); });
+        static_for<0, NH>([&](auto hd) { C.template adam_head<false, decltype(hd)::value, decltype(hd)::value == NH - 1>(G[decltype(hd)::value], thC, mC, vC, tgCw, co); });
     }
 #else
     if (co.coef == 123.f) static_for<0, NH>([&](auto hd) { S.red[40 + decltype(hd)::value] = C.grad_sumsq(G[decltype(hd)::value]) * co.step; });
