@@ -97,6 +97,8 @@ struct frl_engine {
     float* d_solo_part = nullptr;
     unsigned* d_solo_bar = nullptr;
     int* d_solo_err = nullptr;            // device address of h_solo_err
+    int* d_solo_pre = nullptr;            // [2][P][kSoloPre]: the next call's rows, drawn a launch ahead (SoloArgs::pre_read / pre_write)
+    unsigned solo_pre_seq = 0;            // critic-stage launches so far: which of the two slots is read / written
     int* h_solo_err = nullptr;            // pinned: a solo workgroup that waited 2 s for its learner's others sets it (checked after syncs: solo_err_check)
     int* d_solo_ticket = nullptr;         // the rollout tail's learner ticket
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
@@ -264,6 +266,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->h_noisy) hipHostFree(e->h_noisy);
     if (e->d_solo_slab) hipFree(e->d_solo_slab);
     if (e->d_solo_part) hipFree(e->d_solo_part);
+    if (e->d_solo_pre) hipFree(e->d_solo_pre);
     if (e->d_solo_bar) hipFree(e->d_solo_bar);
     if (e->h_solo_err) hipHostFree(e->h_solo_err);
     float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
@@ -538,6 +541,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             e->solo_stride = std::max(h.net[0].size, h.net[1].size);
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
             CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
+            { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloPre, e->stream)); e->d_solo_pre = (int*)z; }
             float* z = nullptr;
             CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
             e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
@@ -1425,14 +1429,28 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solo) {                               // kernels_solo.hip: sixteen workgroups per learner, reduce + Adam behind grid barriers
             prof_begin(e, PK_GRAD_CRITIC);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
             e->solo_bar_base += kSoloWG;
             SoloStepArgs ss;
             memset(&ss, 0, sizeof ss);
             if (sstep) ss = *sstep;
             const size_t lb = (size_t)std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float);
-            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa, ss);
-            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG), blk, lb, st, e->d, a, sa, ss);
+            // the next call's rows drawn by pc spare workgroups of this launch (plain frl_learn calls with device draws; the spare ones
+            // need a CU of their own — 117 KB of LDS — next to the learners' pc x 16: FRL_SOLO_PREDRAW=0/1 overrides)
+            const char* pdf = getenv("FRL_SOLO_PREDRAW");
+            const bool predraw = dev_rng && !sstep && e->d_solo_pre && pc == h.P && pc * (kSoloWG + 1) <= e->n_cus && !(pdf && atoi(pdf) == 0);
+            int extra = 0;
+            if (dev_rng && !sstep && e->d_solo_pre && pc == h.P) {
+                sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * kSoloPre;      // (stale or foreign tags fail the kernel's check)
+                if (predraw) {
+                    sa.pre_write = e->d_solo_pre + (size_t)((e->solo_pre_seq + 1) & 1) * h.P * kSoloPre;
+                    sa.pre_counter = e->rng_counter;              // what the next frl_learn takes, unless something else draws first
+                    extra = pc;
+                }
+                ++e->solo_pre_seq;
+            }
+            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG + extra), blk, lb, st, e->d, a, sa, ss);
+            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG + extra), blk, lb, st, e->d, a, sa, ss);
             prof_end(e);
             return;
         }
@@ -1472,7 +1490,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solo) {
             prof_begin(e, PK_GRAD_ACTOR);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
             e->solo_bar_base += kSoloWG;
             SoloStepArgs ss;
             memset(&ss, 0, sizeof ss);

@@ -213,7 +213,15 @@ struct SoloArgs {
     int* err;               // [1] set to 1 by a barrier that timed out (a workgroup of the learner never arrived)
     unsigned bar_base;      // epoch of this launch = bar_base + kSoloWG (the host advances bar_base by kSoloWG per launch)
     int slab_stride;
+    // The NEXT call's batch rows, drawn by a spare workgroup of THIS launch on a CU the learner's sixteen leave idle (round 6: the
+    // draw was 6.5 us at the head of every critic launch's critical path).  Two slots per learner of kSoloPre ints, alternating by
+    // launch: [0..1] the Philox counter the rows were drawn for, [2] the ring size, [3] the batch, [8 ..) the rows.  A launch uses
+    // pre_read only if all three match its own arguments — same draw_indices(), same bits — and draws for itself otherwise.
+    const int* pre_read;    // [P][kSoloPre] or NULL
+    int* pre_write;         // [P][kSoloPre] or NULL: the grid carries p_count extra workgroups behind the learners'
+    unsigned long long pre_counter;   // the counter the next frl_learn call will take if nothing else draws in between
 };
+constexpr int kSoloPre = 8 + 256;
 // The rollout loop's step folded into these launches (frl_rollout; what dqn_fused_kernel does for DQN): `head` — Buffer.add of the
 // vector step's transitions at the start of the critic launch (every workgroup of the learner writes the same ring rows: it
 // samples from them next) — and `tail` — at the end of the step's LAST launch: the device copy of the current observations moves

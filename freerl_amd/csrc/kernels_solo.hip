@@ -101,6 +101,16 @@ __device__ __forceinline__ void solo_leave(const SoloStepArgs& st) {
 template <bool TWIN>
 __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, const SoloStepArgs& st, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
+    if ((int)blockIdx.x >= a.p_count * kSoloWG) {
+        // a spare workgroup (one per learner, behind the learners' own in the grid: it lands on a CU they leave idle and is gone
+        // long before they are): the rows of the NEXT call, where nobody waits for them
+        const int pp = a.p0 + (int)blockIdx.x - a.p_count * kSoloWG;
+        int* out = s.pre_write + (size_t)(pp - a.p0) * kSoloPre;
+        FRL_LDS int* lidx = (FRL_LDS int*)smem;
+        draw_indices((g_i)(out + 8), lidx, a.batch, a.size, s.pre_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (pp + 1), true);
+        if (threadIdx.x == 0) { out[0] = (int)(unsigned)s.pre_counter; out[1] = (int)(unsigned)(s.pre_counter >> 32); out[2] = a.size; out[3] = a.batch; }
+        return;
+    }
     const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
@@ -175,8 +185,19 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         pend = C.stage_fetch(tgA, 0, NA.extra_n);
         int ri;
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
+        // (the row is fetched next to the tag, not behind it: one round trip)
+        const int* pre = s.pre_read ? s.pre_read + (size_t)(p - a.p0) * kSoloPre : nullptr;
+        const int ri_pre = pre ? pre[8 + (valid ? row : B - 1)] : 0;
+        const bool pre_ok = pre && a.device_rng && !drawn_early && pre[0] == (int)(unsigned)a.rng_counter && pre[1] == (int)(unsigned)(a.rng_counter >> 32) &&
+                            pre[2] == a.size && pre[3] == B;
         if (drawn_early) {
             ri = ri_early;
+        } else if (pre_ok) {
+            // the previous launch's spare workgroup drew this call's rows (same counter, ring size and batch: the same bits as the
+            // draw below); this tile's sixteen go to D.idx for the actor stage and frl_last_indices
+            ri = ri_pre;
+            if (w == 0 && q == 0 && valid) D.idx[(size_t)p * D.batch_max + row] = ri;
+            SOLO_T(8);
         } else if (a.device_rng) {
             // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
             // rejection in its own LDS: ~3 us, against a 10 us launch in front of this one) and keeps its tile's; they all write the
