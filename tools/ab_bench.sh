@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of library variants on the headline bench (run on the GPU box):  bash tools/ab_bench.sh "" tt2 "" tt2
+# Same-box A/B of library variants on the headline bench (run on the GPU box):  bash tools/ab_bench.sh "" w8half "" w8half
 # ("" = the product library; anything else = FRL_HIP_VARIANT).  Prints updates/s, ms per step, the critic stage's fraction, per-kernel ms.
 R=$(cd "$(dirname "$0")/.." && pwd)
 for v in "$@"; do

@@ -20,7 +20,17 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- $BENCH > $O/pmc$i.log 2>&1
   python $R/tools/pmc_summary.py $O/pmc$i $O/pmc$i.json
 done
-python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_kernel
+python $R/tools/pmc_summary.py --traffic $O/traffic.json $O/pmc1.json $O/pmc2.json ac_critic_v2_twin_nv_kernel
+# ... and for the other families' dominant kernels: FETCH / WRITE / MFMA counters of the config shapes, the DQN launch and the Categorical update
+for w in "cfg:python $R/tools/config_bench.py C4 C5 h256 512" "dqn:python $R/tools/dqn_bench.py 512"; do
+  tag=${w%%:*}; cmd=${w#*:}; j=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES"; do
+    j=$((j+1))
+    cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${tag}$j -- $cmd > $O/pmc_${tag}$j.log 2>&1
+    python $R/tools/pmc_summary.py $O/pmc_${tag}$j $O/pmc_${tag}$j.json
+  done
+done
+rm -rf $O/pmc_cfg[0-9] $O/pmc_dqn[0-9]
 # the single-learner kernels (kernels_solo.hip): trace + section stamps + the loops
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_solo -- python $R/tools/single_bench.py 1000 > $O/stats_solo.log 2>&1
 cp $(ls $O/stats_solo/*/*kernel_stats.csv | head -1) $O/kernel_stats_single.csv
@@ -29,6 +39,11 @@ timeout 300 python tools/single_bench.py 2000 > $O/single_bench.txt 2>&1 < /dev/
 timeout 300 python tools/small_pop_bench.py 1 2 4 8 12 16 17 32 64 128 129 256 512 > $O/small_pop_bench.txt 2>&1 < /dev/null
 for a in td3 ddpg sac; do FRL_HIP_VARIANT=solot timeout 120 python tools/solo_timing.py $a; done > $O/solo_timing.txt 2>&1 < /dev/null
 timeout 300 python tools/critic2_timing.py 512 > $O/critic2_timing.txt 2>&1
+FRL_CHAIN_WAVES=4 timeout 300 python tools/critic2_timing.py 512 > $O/critic2_timing_w4.txt 2>&1        # (round 5's four-wave kernel, same box)
+FRL_HIP_VARIANT=bwdt timeout 300 python tools/bwd_timing.py 512 > $O/bwd_timing.txt 2>&1 < /dev/null   # FRL_UNIT_OUT=bwdt FRL_UNIT_FLAGS=-DFRL_BWD_TIMING bash tools/build_unit_timing.sh kernels_critic2
+FRL_CHAIN_WAVES=4 timeout 300 python bench.py --headline-only --steps 60 --warmup 3 > $O/bench_headline_w4.json 2>/dev/null   # the A/B of the round: four-wave kernels ...
+timeout 300 python bench.py --headline-only --steps 60 --warmup 3 > $O/bench_headline_w8.json 2>/dev/null                      # ... against the eight-wave ones
+timeout 120 $R/tools/_bin/lds_put > $O/lds_put.txt 2>&1
 timeout 300 python tools/actor2_timing.py 512 td3 > $O/actor2_timing.txt 2>&1
 timeout 300 python tools/actor2_timing.py 512 sac >> $O/actor2_timing.txt 2>&1
 timeout 300 python tools/ppo_timing.py 256 > $O/ppo_timing.txt 2>&1 < /dev/null
