@@ -4,8 +4,15 @@
 // (l ^ OFF)'s v through DPP (offsets 1 .. 8: quad_perm / row shifts / row_ror inside a row of 16 lanes) or gfx950's
 // v_permlane16_swap / v_permlane32_swap (offsets 16 / 32): VALU instructions, a few cycles each, the SAME values exchanged — every
 // reduction built on it is bit-identical to its __shfl_xor form (tools/lane_xor_test.hip checks the six offsets against __shfl_xor).
+// The lane-16 / lane-32 halves are told apart by bits 4 / 5 of threadIdx.x: every kernel of this library is launched with a 1-D block
+// whose size is a multiple of 64, where those ARE the lane number's bits (and threadIdx.x is a register every kernel has anyway; the
+// v_mbcnt pair of __lane_id() would be one more live VGPR in kernels that sit at their register limit).  gfx950 only: the offsets 16 / 32
+// use its v_permlane16_swap / v_permlane32_swap.
 #pragma once
 #include <hip/hip_runtime.h>
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "device/lane.hpp is written for gfx950 (v_permlane16_swap / v_permlane32_swap)"
+#endif
 
 namespace frl {
 

@@ -546,6 +546,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
             e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
             e->d_solo_ticket = (int*)(z + 2 * P * (size_t)kSoloWG);        // ... and the rollout tail's learner ticket
+        }
+        if (h.solo || h.algo == ALGO_DQN) {                                // the pinned give-up word of the spinning launches (solo hand-overs, pre-armed DQN steps)
             CREATE_TRY(hipHostMalloc((void**)&e->h_solo_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
             *e->h_solo_err = 0;
             CREATE_TRY(hipHostGetDevicePointer((void**)&e->d_solo_err, e->h_solo_err, 0));
@@ -639,7 +641,11 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
 // for seconds (another process' long kernel): reported at the next synchronising call instead of passing silently.
 static int solo_err_check(frl_engine* e) {
     if (!e->h_solo_err || *(volatile int*)e->h_solo_err == 0) return FRL_OK;
+    const int what = *(volatile int*)e->h_solo_err;
     *(volatile int*)e->h_solo_err = 0;
+    if (what == 2)
+        return fail(FRL_ERR_STATE, "dqn_fused_kernel: a pre-armed rollout launch waited 2 s for the previous launch or for the host's doorbell and gave up; "
+                                   "its update and the actions it was to select were dropped");
     return fail(FRL_ERR_STATE, "kernels_solo.hip: a workgroup waited 2 s for the other workgroups of its learner (is something else holding this GPU's "
                                "CUs?); the updates since the last synchronising call are not valid");
 }

@@ -274,7 +274,8 @@ struct DqnStepArgs {
     int go_value;
     int* dev_done;                // device word (or nullptr): set to done_value together with done_flag
     int dev_wait;                 // pre-armed: the done_value of the launch in front
-};
+    int* err;                     // pinned word (or nullptr): set to 2 when a pre-armed launch gives up after 2 s of waiting (NOT when the host cancels it):
+};                                // its update and the next actions were dropped — frl_rollout / frl_sync report FRL_ERR_STATE instead of stepping the envs on stale actions
 __global__ void dqn_fused_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, DqnStepArgs s);
 
 // kernels_ppo2.hip: the on-chip variant of ppo_update_kernel, <first-layer k-blocks, hidden activation>

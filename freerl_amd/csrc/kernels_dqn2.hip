@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             int v = __hip_atomic_load(s.dev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (v - s.dev_wait < 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 200000000ull) break;
+                if (wall_clock64() - t0 > 200000000ull) { if (s.err) __hip_atomic_store(s.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 v = __hip_atomic_load(s.dev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (relaxed polls, then ONE lane's invalidate for the CU, in front of the barrier)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void dqn_fused_kernel(const EngineDesc* __r
             int v = __hip_atomic_load(s.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             while (v != s.go_value && v != -1) {
                 __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > 200000000ull) { v = -1; break; }
+                if (wall_clock64() - t0 > 200000000ull) { v = -1; if (s.err) __hip_atomic_store(s.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 v = __hip_atomic_load(s.go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
