@@ -35,7 +35,7 @@ namespace frl {
 constexpr int kSoloPart = 32;            // floats per workgroup in SoloArgs::part: 0 loss / Q sum, 1 log-pi sum, 2-3 the norm mailbox {partial, epoch}, 8.. stamps
 #ifdef FRL_SOLO_TIMING
 #define SOLO_T0() const unsigned long long solo_t0_ = wall_clock64()
-#define SOLO_T(slot) do { if (threadIdx.x == 0) part[(blockIdx.x % kSoloWG) * kSoloPart + 8 + (slot)] = (float)(wall_clock64() - solo_t0_); } while (0)
+#define SOLO_T(slot) do { if (threadIdx.x == 0) part[b * kSoloPart + 8 + (slot)] = (float)(wall_clock64() - solo_t0_); } while (0)
 #define SOLO_TARG , solo_t0_
 #define SOLO_TARGP , part, solo_t0_
 #else
@@ -372,7 +372,7 @@ struct SoloNet {
 // the count): one memory round trip less on the critical path — the add had to return before the spin could start.
 // epoch: unique per launch (SoloArgs::bar_base + kSoloWG, the host advances bar_base by kSoloWG per launch).  A thread that waits
 // 2 s gives up and raises *err: the launch then finishes with wrong numbers instead of hanging the queue.
-__device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
+__device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned epoch, int* err, int nw = kSoloWG) {
     sync_stores();
     if (threadIdx.x == 0) {
         // (every wave's stores are acknowledged: each drained its own vmcnt in front of the barrier)  release fence, an explicit wait —
@@ -381,7 +381,7 @@ __device__ __forceinline__ void solo_grid_sync(unsigned* flags, int b, unsigned 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x < kSoloWG) {
+    if ((int)threadIdx.x < nw) {
         const unsigned long long t0 = wall_clock64();                      // 100 MHz
         while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(1);
@@ -406,6 +406,10 @@ struct SoloUpdate {
 
 // ---- behind grid barrier 1: this workgroup's sixteenth of the net — slab sum in workgroup order, partial squared norm ->
 // grid barrier 2 -> clip coefficient, Adam, soft update.  Returns the gradient norm.
+// W = workgroups of the learner (16: one row tile each; 8 / 4: two / four tiles each, every tile with a slab of its own): a workgroup's
+// share of the net is 1 / W of it, 48 / W float4 per thread, summed over the nb tiles' slabs in tile order, W slabs (48 loads per thread) in
+// flight at a time — the same sum in the same order whatever W is
+template <int W = kSoloWG>
 __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, int p, int b, int nb, lds_f red,
                                              unsigned bar2_target
 #ifdef FRL_SOLO_TIMING
@@ -413,8 +417,8 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
 #endif
                                              ) {
     const int tid = threadIdx.x;
-    const int n4 = u.size >> 2, per = (n4 + kSoloWG - 1) / kSoloWG, i0 = b * per, i1 = min(n4, i0 + per);
-    constexpr int KM = 3;                                                  // float4 per thread: nets of up to 16 x 3 x 256 x 4 = 49 k floats
+    const int n4 = u.size >> 2, per = (n4 + W - 1) / W, i0 = b * per, i1 = min(n4, i0 + per);
+    constexpr int KM = 3 * kSoloWG / W;                                    // float4 per thread: nets of up to 16 x 3 x 256 x 4 = 49 k floats
     g_cf slab = as_global(s.slab + (size_t)p * kSoloWG * s.slab_stride);
     f32x4 g[KM], th[KM], mi[KM], vi[KM], tg[KM];
 #pragma unroll
@@ -426,11 +430,12 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
     // every slab's share in flight at once — 16 x KM independent 16-byte loads per thread, ONE round trip to the memory side (the slabs
     // were written by other XCDs: nothing of them is in this L2) — then summed in workgroup order.  A runtime loop over the slabs with
     // the sum inside was four dependent round trips: 14 us of the 48 us launch (tools/solo_timing.py).
-    {
-        f32x4 sl[kSoloWG][KM];
 #pragma unroll
-        for (int sb = 0; sb < kSoloWG; ++sb) {
-            const int sc = sb < nb ? sb : nb - 1;                          // (slabs past the batch's tiles: a harmless re-read, dropped below)
+    for (int s0 = 0; s0 < kSoloWG; s0 += W) {
+        f32x4 sl[W][KM];
+#pragma unroll
+        for (int sb = 0; sb < W; ++sb) {
+            const int sc = s0 + sb < nb ? s0 + sb : nb - 1;                // (slabs past the batch's tiles: a harmless re-read, dropped below)
 #pragma unroll
             for (int k = 0; k < KM; ++k) {
                 const int i = i0 + tid + kWG * k, ic = i < i1 ? i : (i1 > i0 ? i1 - 1 : 0);
@@ -439,16 +444,16 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sb = 0; sb < kSoloWG; ++sb) {
-            if (sb < nb) {
+        for (int sb = 0; sb < W; ++sb) {
+            if (s0 + sb < nb) {
 #pragma unroll
                 for (int k = 0; k < KM; ++k) g[k] += sl[sb][k];
             }
         }
-#pragma unroll
-        for (int k = 0; k < KM; ++k)
-            if (i0 + tid + kWG * k >= i1) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+        if (i0 + tid + kWG * k >= i1) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < KM; ++k) ss += (g[k][0] * g[k][0] + g[k][1] * g[k][1]) + (g[k][2] * g[k][2] + g[k][3] * g[k][3]);
@@ -467,7 +472,7 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
         __hip_atomic_store((u64*)(part + b * kSoloPart + 2), ((u64)bar2_target << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SOLO_T(5);
-    if (tid < kSoloWG) {
+    if (tid < W) {
         const u64* box = (const u64*)(part + tid * kSoloPart + 2);
         const unsigned long long t0 = wall_clock64();
         u64 v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -482,7 +487,7 @@ __device__ __forceinline__ float solo_update(const SoloArgs& s, const LearnArgs&
     SOLO_T(6);
     float tot = 0.f;
 #pragma unroll
-    for (int sb = 0; sb < kSoloWG; ++sb) tot += red[80 + sb];
+    for (int sb = 0; sb < W; ++sb) tot += red[80 + sb];
     const float total = sqrtf(tot);
     const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     const double bc1 = 1.0 - powi_d((double)a.beta1, u.t_new), bc2 = 1.0 - powi_d((double)a.beta2, u.t_new);

@@ -409,8 +409,16 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         const char* solo = getenv("FRL_SOLO");
         // (every one of its P x 16 workgroups — 156 KB of LDS each: one per CU — has to be RESIDENT: they wait for each other's flags.
         //  On a device with fewer CUs, a CU-masked or partitioned one, the row-chunk kernels take the engine instead)
-        const bool solo_fits = (long long)h.P * kSoloWG <= e->n_cus && e->lds_per_cu >= (int)(std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float));
-        h.solo = (solo ? atoi(solo) != 0 : (!force && h.P <= kSoloMaxP)) && solo_fits ? 1 : 0;
+        // h.solo = workgroups per learner: 16 (one 16-row tile each) up to 16 learners; 8 (two tiles each, a slab per tile) up to 32
+        // learners — populations the row-chunk kernels used to take at 150-160 us per learn() (kernels_solo.hip has the numbers;
+        // FRL_SOLO_MAXP: the largest population on this family, default 32)
+        const char* smp = getenv("FRL_SOLO_MAXP");
+        const int solo_maxp = smp ? std::min(atoi(smp), 2 * kSoloMaxP) : 2 * kSoloMaxP;
+        int wgs = 0;
+        for (int cand : {16, 8})
+            if (wgs == 0 && (long long)h.P * cand <= e->n_cus && h.P * cand <= kSoloMaxP * kSoloWG) wgs = cand;
+        const bool solo_fits = wgs > 0 && h.P <= solo_maxp && e->lds_per_cu >= (int)(std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float));
+        h.solo = (solo ? atoi(solo) != 0 : !force) && solo_fits ? wgs : 0;
         if (h.solo || (force ? atoi(force) != 0 : h.P > 128)) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
@@ -595,7 +603,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solo) {
         const int lb = std::max(solo_lds_floats(), critic2_lds_floats()) * (int)sizeof(float);      // (critic2: the rollout tail's act_frag_body)
-        for (auto k : {solo_critic_twin_kernel, solo_critic_single_kernel, solo_actor_kernel})
+        for (auto k : {solo_critic_twin_kernel, solo_critic_single_kernel, solo_actor_kernel, solo_critic_twin_w8_kernel, solo_critic_single_w8_kernel, solo_actor_w8_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
         CREATE_TRY(hipFuncSetAttribute((const void*)act_frag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, critic2_lds_floats() * (int)sizeof(float)));
     } else if (h.net[0].frag) {        // the register-chained family: one workgroup per learner with the nets as LDS images (156 KB)
@@ -685,10 +693,10 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
         return FRL_OK;
     }
     const bool v2 = chained_path(e->h, batch, e->h.P);
-    if (v2 && e->h.solo) {                                  // kernels_solo.hip: a 16-row tile per workgroup
+    if (v2 && e->h.solo) {                                  // kernels_solo.hip: 16-row tiles, 16 / h.solo of them per workgroup
         if (chained_out) *chained_out = 1;
         if (bytes_out) *bytes_out = solo_lds_floats() * (int)sizeof(float);
-        if (rows_out) *rows_out = 16;
+        if (rows_out) *rows_out = 16 * (kSoloWG / e->h.solo);
         return FRL_OK;
     }
     if (chained_out) *chained_out = v2 ? 1 : 0;
@@ -1444,7 +1452,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             // the next call's rows drawn by pc spare workgroups of this launch (plain frl_learn calls with device draws; the spare ones
             // need a CU of their own — 117 KB of LDS — next to the learners' pc x 16: FRL_SOLO_PREDRAW=0/1 overrides)
             const char* pdf = getenv("FRL_SOLO_PREDRAW");
-            const bool predraw = dev_rng && !sstep && e->d_solo_pre && pc == h.P && pc * (kSoloWG + 1) <= e->n_cus && !(pdf && atoi(pdf) == 0);
+            const int W = h.solo;
+            const bool predraw = dev_rng && !sstep && e->d_solo_pre && pc == h.P && pc * (W + 1) <= e->n_cus && !(pdf && atoi(pdf) == 0);
             int extra = 0;
             if (dev_rng && !sstep && e->d_solo_pre && pc == h.P) {
                 sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * kSoloPre;      // (stale or foreign tags fail the kernel's check)
@@ -1455,8 +1464,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
                 }
                 ++e->solo_pre_seq;
             }
-            if (h.net[1].heads == 2) hipLaunchKernelGGL(solo_critic_twin_kernel, dim3(pc * kSoloWG + extra), blk, lb, st, e->d, a, sa, ss);
-            else hipLaunchKernelGGL(solo_critic_single_kernel, dim3(pc * kSoloWG + extra), blk, lb, st, e->d, a, sa, ss);
+            const bool twin = h.net[1].heads == 2;
+            auto k = W == 16 ? (twin ? solo_critic_twin_kernel : solo_critic_single_kernel) : (twin ? solo_critic_twin_w8_kernel : solo_critic_single_w8_kernel);
+            hipLaunchKernelGGL(k, dim3(pc * W + extra), blk, lb, st, e->d, a, sa, ss);
             prof_end(e);
             return;
         }
@@ -1501,7 +1511,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             SoloStepArgs ss;
             memset(&ss, 0, sizeof ss);
             if (sstep) ss = *sstep;
-            hipLaunchKernelGGL(solo_actor_kernel, dim3(pc * kSoloWG), blk, (size_t)std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float), st, e->d, a, sa, ss);
+            const int W = h.solo;
+            hipLaunchKernelGGL(W == 16 ? solo_actor_kernel : solo_actor_w8_kernel, dim3(pc * W), blk,
+                               (size_t)std::max(solo_lds_floats(), critic2_lds_floats()) * sizeof(float), st, e->d, a, sa, ss);
             prof_end(e);
             return;
         }

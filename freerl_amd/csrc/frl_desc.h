@@ -46,7 +46,7 @@ constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w +
 // One learner on sixteen workgroups (device/solo.hpp, kernels_solo.hip): the single-learner latency path
 constexpr int kSoloWG = 16;              // workgroups per learner = 16-row tiles of a 256-row batch
 constexpr int kSoloPartHost = 32;        // floats per workgroup of SoloArgs::part (device/solo.hpp: kSoloPart)
-constexpr int kSoloMaxP = 16;            // learners per engine on this path: every workgroup of a launch must be resident (flag hand-overs): 16 x 16 = 256 CUs.
+constexpr int kSoloMaxP = 16;            // learners per engine at sixteen workgroups each: every workgroup of a launch must be resident (flag hand-overs): 16 x 16 = 256 CUs (8 workgroups per learner, two tiles each: up to 32).
                                          // Measured (tools/small_pop_bench.py, TD3): 9 / 12 / 16 learners 82 / 90 / 101 us per learn() against 144 / 150 / 150 on the row-chunk kernels
 constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 128 + 16 + 16 + 4 * 8 * 256 + 256 + 128; }
 
@@ -165,7 +165,7 @@ struct EngineDesc {
     int wide_xp, wide_op; // row pitches of the scratch's critic-input rows / observation copies (the padded first-layer widths)
     int wide_unit;        // floats per (learner, agent): (wide_xp + n_agents * wide_op + kWideScratchPerRow) * wide_bm + 128, rounded up to 64
     float* wide_scr;
-    int solo;             // 1: DDPG / TD3 / SAC updates of this engine run on kernels_solo.hip (<= kSoloMaxP learners of the narrow standard
+    int solo;             // > 0 (the workgroups per learner: 16 / 8): DDPG / TD3 / SAC updates of this engine run on kernels_solo.hip (<= kSoloMaxP learners of the narrow standard
                           // shape, sixteen workgroups per learner); parameters in fragment-image order like the chained family's
 };
 

@@ -98,20 +98,25 @@ __device__ __forceinline__ void solo_leave(const SoloStepArgs& st) {
 
 }  // namespace
 
-template <bool TWIN>
+// W = workgroups per learner: 16 (one 16-row tile each: up to 16 learners) or 8 (two tiles each, walked one after the other, every tile's
+// gradient in a slab of its own: populations of 17 .. 32 learners, whose 8 P workgroups still are all resident).  Measured, TD3 us per learn():
+// 17 / 24 / 32 learners 113 / 124 / 140 against the row-chunk kernels' 151 / 155 / 160; W = 4 (33 .. 64 learners, four tiles each) was built
+// too: 255 / 275 / 319 us at 33 / 48 / 64 against 160-190 — every further tile costs ~37 us (five image stagings, the target critics'
+// fragment fetch and the row fetch in the open again), so it is not instantiated
+template <bool TWIN, int W>
 __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, const SoloStepArgs& st, float* smem) {
-    constexpr int NH = TWIN ? 2 : 1;
-    if ((int)blockIdx.x >= a.p_count * kSoloWG) {
+    constexpr int NH = TWIN ? 2 : 1, kT = kSoloWG / W;                 // kT: row tiles of a 256-row batch per workgroup
+    if ((int)blockIdx.x >= a.p_count * W) {
         // a spare workgroup (one per learner, behind the learners' own in the grid: it lands on a CU they leave idle and is gone
         // long before they are): the rows of the NEXT call, where nobody waits for them
-        const int pp = a.p0 + (int)blockIdx.x - a.p_count * kSoloWG;
+        const int pp = a.p0 + (int)blockIdx.x - a.p_count * W;
         int* out = s.pre_write + (size_t)(pp - a.p0) * kSoloPre;
         FRL_LDS int* lidx = (FRL_LDS int*)smem;
         draw_indices((g_i)(out + 8), lidx, a.batch, a.size, s.pre_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (pp + 1), true);
         if (threadIdx.x == 0) { out[0] = (int)(unsigned)s.pre_counter; out[1] = (int)(unsigned)(s.pre_counter >> 32); out[2] = a.size; out[3] = a.batch; }
         return;
     }
-    const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
+    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
@@ -133,7 +138,11 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     const float invB = 1.f / (float)B;
     SOLO_T0();
     bool drawn_early = false;
-    int ri_early = 0;
+    int ri_t[kT];                                      // the ring rows of this lane's row in each of the workgroup's tiles (tile b + W t)
+    auto tile_rows = [&](auto from) {                  // ri_t[t] = from(row of tile t), rows past the batch clamped to its last
+#pragma unroll
+        for (int t = 0; t < kT; ++t) { const int rr = 16 * (b + W * t) + i16; ri_t[t] = from(rr < B ? rr : B - 1); }
+    };
     if (st.go_flag) {
         // pre-armed (frl_rollout): enqueued a vector step ahead on the pool's second stream — the previous step's launches may still be
         // running.  The batch's rows depend on the launch's arguments only: drawn now (LDS only: the actor launch in front may still be
@@ -143,7 +152,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         if (b < nb && a.device_rng) {
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
             draw_indices((g_i) nullptr, lidx, B, a.size, a.rng_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (p + 1), false);
-            ri_early = lidx[16 * b + i16 < B ? 16 * b + i16 : B - 1];
+            tile_rows([&](int rr) { return lidx[rr]; });
             drawn_early = true;
         }
         if (tid == 0) {
@@ -168,35 +177,41 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         }
         __syncthreads();                               // (also: every wave has read its row out of ea)
         if (__float_as_int(N.red[100]) != st.go_value) return;
-        if (drawn_early && q == 0 && 16 * b + i16 < B && w == 0) D.idx[(size_t)p * D.batch_max + 16 * b + i16] = ri_early;
+        if (drawn_early && q == 0 && w == 0) {
+#pragma unroll
+            for (int t = 0; t < kT; ++t) { const int rr = 16 * (b + W * t) + i16; if (rr < B) D.idx[(size_t)p * D.batch_max + rr] = ri_t[t]; }
+        }
     }
     const int t_new = steps[1] + 1;                    // read by every workgroup before the first grid barrier; rewritten behind the second
     if (st.head) solo_step_head(D, st, p);             // (every workgroup, also the ones without rows: they all pass the same barriers)
 
+    float lossp = 0.f;
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
         g_cf noise0 = as_global(D.noise + (size_t)p * D.noise_sets * D.batch_max * am);
         const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
-        const int row = 16 * b + i16;
-        const bool valid = row < B;
         // the first image travels while the indices are drawn and the row's fields fetched
         ChainNet::StageRegs pend;
         pend = C.stage_fetch(tgA, 0, NA.extra_n);
-        int ri;
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
-        // (the row is fetched next to the tag, not behind it: one round trip)
+        // (the rows are fetched next to the tag, not behind it: one round trip)
         const int* pre = s.pre_read ? s.pre_read + (size_t)(p - a.p0) * kSoloPre : nullptr;
-        const int ri_pre = pre ? pre[8 + (valid ? row : B - 1)] : 0;
+        int ri_pre[kT];
+#pragma unroll
+        for (int t = 0; t < kT; ++t) { const int rr = 16 * (b + W * t) + i16; ri_pre[t] = pre ? pre[8 + (rr < B ? rr : B - 1)] : 0; }
         const bool pre_ok = pre && a.device_rng && !drawn_early && pre[0] == (int)(unsigned)a.rng_counter && pre[1] == (int)(unsigned)(a.rng_counter >> 32) &&
                             pre[2] == a.size && pre[3] == B;
         if (drawn_early) {
-            ri = ri_early;
         } else if (pre_ok) {
             // the previous launch's spare workgroup drew this call's rows (same counter, ring size and batch: the same bits as the
-            // draw below); this tile's sixteen go to D.idx for the actor stage and frl_last_indices
-            ri = ri_pre;
-            if (w == 0 && q == 0 && valid) D.idx[(size_t)p * D.batch_max + row] = ri;
+            // draw below); this workgroup's tiles go to D.idx for the actor stage and frl_last_indices
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                const int rr = 16 * (b + W * t) + i16;
+                ri_t[t] = ri_pre[t];
+                if (w == 0 && q == 0 && rr < B) D.idx[(size_t)p * D.batch_max + rr] = ri_t[t];
+            }
             SOLO_T(8);
         } else if (a.device_rng) {
             // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
@@ -205,11 +220,20 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
             SOLO_T(10);
             draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key, false);
-            ri = lidx[valid ? row : B - 1];
+            tile_rows([&](int rr) { return lidx[rr]; });
             SOLO_T(8);
         } else {
-            ri = idx[valid ? row : B - 1];
+            tile_rows([&](int rr) { return idx[rr]; });
         }
+#pragma unroll
+        for (int t = 0; t < kT; ++t) {                 // this workgroup's row tiles, one after the other (W = 16: one); a slab per TILE
+        const int bt = b + W * t;
+        if (bt >= nb) break;
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + bt) * s.slab_stride);
+        if (t > 0) pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        const int row = 16 * bt + i16;
+        const bool valid = row < B;
+        const int ri = ri_t[t];
         g_cf rec = ring + (size_t)ri * R.stride;
         f32x4 sn, so, ac = {0.f, 0.f, 0.f, 0.f}, nz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -278,9 +302,7 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         SOLO_T(2);
         const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);
         // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab
-        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
         const f32x4 xin = critic_input(N, so, ac, O, A);
-        float lossp = 0.f;
 #pragma unroll
         for (int hd = 0; hd < NH; ++hd) {
             C.stage_commit(pend);
@@ -298,21 +320,22 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             N.head_bwd<true>(hs, dz, h2o, d2o, 1);
             N.hidden_bwd<true>(hs, d2o, h1o, d1o);
         }
+        }   // tiles
         lossp = SoloNet::rows_sum(lossp);
         if (tid == 0) part[b * kSoloPart + 0] = lossp;
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
     u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
     u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solo_update<W>(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float loss = 0.f;
-        for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < min(nb, W); ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         steps[1] = t_new;
         float* sts = D.stats + (size_t)p * ST_COUNT;
         sts[ST_CRITIC_LOSS] = loss * invB;
@@ -324,20 +347,21 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
     solo_leave(st);
 }
 
-__global__ __launch_bounds__(256) void solo_critic_twin_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    solo_critic_body<true>(*Dp, a, s, st, smem);
-}
-__global__ __launch_bounds__(256) void solo_critic_single_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    solo_critic_body<false>(*Dp, a, s, st, smem);
-}
+#define FRL_SOLO_CRITIC(name, twin, wgs)                                                                                          \
+    __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {       \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
+        solo_critic_body<twin, wgs>(*Dp, a, s, st, smem);                                                                           \
+    }
+FRL_SOLO_CRITIC(solo_critic_twin_kernel, true, 16)
+FRL_SOLO_CRITIC(solo_critic_single_kernel, false, 16)
+FRL_SOLO_CRITIC(solo_critic_twin_w8_kernel, true, 8)
+FRL_SOLO_CRITIC(solo_critic_single_w8_kernel, false, 8)
 
 // ------------------------------------------------------------------------------------------------------------- actor stage
-__global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const EngineDesc& D = *Dp;
-    const int p = a.p0 + blockIdx.x / kSoloWG, b = blockIdx.x % kSoloWG;
+template <int W>
+__device__ __forceinline__ void solo_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, const SoloStepArgs& st, float* smem) {
+    constexpr int kT = kSoloWG / W;
+    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
@@ -367,11 +391,17 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         if (__float_as_int(N.red[100]) != st.go_value) return;
     }
 
+    float qrow = 0.f, lp = 0.f;
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
         g_cf noise1 = as_global(D.noise + ((size_t)p * D.noise_sets + 1) * D.batch_max * am);      // the actor stage's eps (set 1)
-        const int row = 16 * b + i16;
+#pragma unroll
+        for (int t = 0; t < kT; ++t) {                 // this workgroup's row tiles, one after the other (W = 16: one); a slab per TILE
+        const int bt = b + W * t;
+        if (bt >= nb) break;
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + bt) * s.slab_stride);
+        const int row = 16 * bt + i16;
         const bool valid = row < B;
         g_cf rec = ring + (size_t)idx[valid ? row : B - 1] * R.stride;
         ChainNet::StageRegs pend = C.stage_fetch((g_cf)thA, 0, NA.extra_n);
@@ -398,7 +428,7 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         pend = C.stage_fetch(thC, 0);
         // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
         f32x4 ah1[2], ah2[2], h2f[kHT], za, an = {0.f, 0.f, 0.f, 0.f}, lsv = {0.f, 0.f, 0.f, 0.f};
-        float lp = 0.f;
+        float lpr = 0.f;
         N.forward<true>(so, ah1, ah2, h2f, za, A);                         // (th1 / tx keep the actor's h1 and s for pass C: pass B leaves them alone)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -407,8 +437,8 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
                     lsv[r] = C.S.ls[r];
                     const float ls = fminf(fmaxf(lsv[r], -20.f), 2.f), sd = expf(ls);
                     const float u = za[r] + sd * ep[r], du = u - za[r];
-                    lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
-                    lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                    lpr += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                    lpr -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
                     an[r] = tanhf(u);
                 } else {
                     an[r] = tanhf(za[r]);
@@ -419,7 +449,6 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
         // ---- B: Q(s, a) and dQ/da through the frozen (already stepped) critic
         const f32x4 xin = critic_input(N, so, an, O, A);
         const float dqv = sac ? -0.5f * invB : -invB;
-        float qrow = 0.f;
         f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                   // d loss / d a[r] of this lane's row
         for (int hd = 0; hd < nq; ++hd) {
             C.stage_commit(pend);
@@ -460,7 +489,6 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
                 }
             }
         }
-        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
         f32x4 d2o[2], d1o[2];
         // head_bwd needs h2's own tiles and the head image: both the actor's again
         N.head_bwd<true>(slab, dz, ah2, d2o, A);
@@ -473,20 +501,22 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
             if (i16 == r) gl = (sac && r < A && lsv[r] >= -20.f && lsv[r] <= 2.f) ? sgl : 0.f;
         }
         if (w == 0 && q == 0) slab[kHeadFloats + i16] = gl;
+        lp += valid ? lpr : 0.f;
+        }   // tiles
         qrow = SoloNet::rows_sum(qrow);
-        lp = SoloNet::rows_sum(valid ? lp : 0.f);
+        lp = SoloNet::rows_sum(lp);
         if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solo_update(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solo_update<W>(s, a, u, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;
-        for (int k = 0; k < nb; ++k) {
+        for (int k = 0; k < min(nb, W); ++k) {
             qtot += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lptot += __hip_atomic_load(part + k * kSoloPart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -518,10 +548,18 @@ __global__ __launch_bounds__(256) void solo_actor_kernel(const EngineDesc* __res
     // the rollout step's tail: the next select_action reads the WHOLE stepped actor, sixteen workgroups' slices of it — a second
     // flag hand-over (its own flag words; same epoch) in front of workgroup 0's act
     if (st.tail) {
-        solo_grid_sync(st.bar2 + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
+        solo_grid_sync(st.bar2 + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
         if (b == 0) solo_step_tail(D, a, st, smem, p);
     }
     solo_leave(st);
 }
+
+#define FRL_SOLO_ACTOR(name, wgs)                                                                                                    \
+    __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st) {       \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
+        solo_actor_body<wgs>(*Dp, a, s, st, smem);                                                                                  \
+    }
+FRL_SOLO_ACTOR(solo_actor_kernel, 16)
+FRL_SOLO_ACTOR(solo_actor_w8_kernel, 8)
 
 }  // namespace frl

@@ -262,7 +262,7 @@ def test_per_tree_at_depth(N):
 
 
 def test_learn_path_reports_the_kernel_family(N, monkeypatch):
-    """frl_learn_path: at the narrow standard shape one to sixteen learners take the sixteen-workgroups-per-learner kernels, populations
+    """frl_learn_path: at the narrow standard shape one to sixteen learners take the sixteen-workgroups-per-learner kernels (17 .. 32: eight per learner), populations
     > 128 the one-workgroup-per-learner chained kernels (or when forced AT CREATION: the family fixes the parameter layout in HBM for
     the engine's life), the row-chunk kernels everything else; the reported LDS bytes fit the CU either way."""
     from freerl_amd.engine import Engine
@@ -274,7 +274,10 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
         solo = Engine(algo, 8, 2, 512, n_learners=16, twin_critic=twin, batch_max=256)       # ... up to 16 learners (256 resident workgroups)
         assert solo.learn_path(256) == (True, 117376, 16)
         solo.close()
-        more = Engine(algo, 8, 2, 512, n_learners=17, twin_critic=twin, batch_max=256)
+        more = Engine(algo, 8, 2, 512, n_learners=17, twin_critic=twin, batch_max=256)        # 17 .. 32 learners: eight workgroups per learner, two tiles each
+        assert more.learn_path(256) == (True, 117376, 32)
+        more.close()
+        more = Engine(algo, 8, 2, 512, n_learners=33, twin_critic=twin, batch_max=256)        # from 33 on: the row-chunk kernels (to 128)
         assert not more.learn_path(256)[0]
         more.close()
         monkeypatch.setenv("FRL_CRITIC_V2", "0")                              # the row-chunk family by name

@@ -3,6 +3,7 @@ frl_create on its own (no FRL_CRITIC_V2 / FRL_SOLO):
 
   * P = 512: the register-chained kernels bench.py's headline number comes from (kernels_critic2 / _actor2, eight-wave workgroups) —
     two rounds of workgroups on 256 CUs; learners 0, 255 (last of the first round), 256 (first of the second) and 511 are watched;
+  * P = 24 / 30: kernels_solo.hip with eight workgroups per learner, two 16-row tiles each (populations of 17 .. 32 learners, round 6);
   * P = 40 and P = 128: the row-chunk kernels (ac_critic_kernel / ac_actor_kernel + adam_fused_kernel), which serve populations of
     17 .. 128 learners and whose only oracle test at population size moved to the solo kernels when those took P <= 16.
 
@@ -33,13 +34,15 @@ def _watched(P):
 
 def _expect_family(e, P):
     chained, lds, rows = e.learn_path(B)
-    if P > 128:
+    if 16 < P <= 32:
+        assert chained and rows == 32, "P = %d is meant to run kernels_solo.hip with eight workgroups per learner: %r" % (P, (chained, lds, rows))
+    elif P > 128:
         assert chained and rows == B, "P = %d did not select the one-workgroup-per-learner chained kernels: %r" % (P, (chained, lds, rows))
     else:
         assert not chained, "P = %d is meant to run the row-chunk kernels: %r" % (P, (chained, lds, rows))
 
 
-@pytest.mark.parametrize("P", [40, 128, 512])
+@pytest.mark.parametrize("P", [24, 40, 128, 512])
 def test_td3_population_vs_oracles(N, monkeypatch, P):
     from freerl_amd.engine import Engine
     from oracle import algos
@@ -92,7 +95,7 @@ def test_td3_population_vs_oracles(N, monkeypatch, P):
     e.close()
 
 
-@pytest.mark.parametrize("P", [128, 512])
+@pytest.mark.parametrize("P", [30, 128, 512])
 def test_sac_population_vs_oracles(N, monkeypatch, P):
     """SAC at the same shape: the single-pass twin critic with the tanh-Gaussian target, the actor stage with both heads' dQ/da, the
     log_std and alpha steps — row-chunk kernels at 128 learners, the eight-wave chained ones at 512."""

@@ -29,7 +29,7 @@ def run(P, steps=400):
     e.sync()
     dt = (time.perf_counter() - t0) / steps
     path = e.learn_path(256)
-    fam = "solo" if path[2] == 16 else ("chained" if path[0] else "row-chunk")
+    fam = "solo" if path[2] == 16 else ("solo x8" if path[0] and path[2] == 32 else ("chained" if path[0] else "row-chunk"))
     print("P=%4d  %-9s %8.1f us per learn() -> %9.0f updates/s" % (P, fam, dt * 1e6, P / dt), flush=True)
     e.close()
 
