@@ -1,0 +1,483 @@
+// ONE learner's update on sixteen workgroups (device/solo.hpp) for the shapes whose FIRST LAYER does not fit an LDS image: up to
+// 416 input columns (SAC at Humanoid-v4's dims, config 4 of BASELINE.json: 376 + 17) and actor heads of up to 32 outputs, hidden
+// 128 — kernels_solow.hip.  What a single `SAC.learn()` per vector step is on one GPU (SAC_file/SAC.py:519-576); the row-chunk
+// chain took 330-390 us for it (eight 32-row workgroups, each phase behind an L2 round trip for its weight block, two more
+// launches for the reduce and Adam), the K-sliced population kernels (chain_wide.hpp) give the whole learner to ONE workgroup.
+//
+// Same decomposition as solo.hpp — a 256-row batch is sixteen 16-row tiles, one workgroup each; wave w owns output tiles 2w, 2w + 1
+// of every 128-wide layer; partial gradients to per-workgroup slabs in image order, summed in workgroup order behind a flag
+// hand-over — with these differences:
+//   * W1 (up to 26 k-tiles x 8 output tiles = 208 KB) never sits in LDS: a wave's A fragments of the first layer (its two output
+//     tiles x every k-tile) go from the net's block (fragment-image order: one global_load_dwordx4 per lane and tile, L2-resident
+//     after the first workgroup) straight into registers, four k-tiles at a time, the next four in flight under the MFMAs of
+//     these.  The row operand needs no LDS either: lane (row, q) reads columns 16 kb + 4 q .. + 3 of its row from the replay
+//     record (one dwordx4 where the field starts on a 16-byte boundary, four dwords otherwise) or, for a policy's actions, from
+//     a 2 KB table of the tile's action rows in LDS.
+//   * dW1 of the wave's two output tiles = (x^T of the row tile) x (delta tiles): x^T is left in LDS by the forward (26 KB,
+//     written by the wave that holds k-tile kb & 3), 2 x KB1 tiles of four MFMAs each, stored straight to the slab.
+//   * actor heads of up to 32 outputs run as MFMA tiles (every wave computes the head of the tile's 16 rows: 64 MFMAs), their
+//     backward (dW3 = h2^T dz, d2 = W3^T dz) on the wave's own tiles with wave-local transposes.
+//   * dQ/da for the policy step: only the k-tiles of W1 that hold action columns (<= 3) are walked backward, one per wave,
+//     transposed fragments as dword loads from the block.
+//   * the update: nets of up to 2 x 75 k floats do not fit a thread's registers — the slab sum goes through EngineDesc::grad
+//     (phase 1: sum + squared norm; mailboxes; phase 2: clip, Adam, soft update).
+#pragma once
+#include "solo.hpp"
+
+namespace frl {
+
+// (kSoloWMaxKB, solow_lds_floats(): frl_desc.h)
+
+// where the B operand of a first layer — this lane's row, input columns 16 kb + 4 q .. + 3 — comes from
+struct SoloWX {
+    g_cf base;              // columns [0, ng): base[c] (the row's record + a field offset)
+    int ng;
+    bool vec;               // base is 16-byte aligned: a fragment inside [0, ng) is one dwordx4
+    lds_cf act;             // columns [ng, ng + na): act[c - ng] (this row's 32 floats of the action table)
+    int na;
+};
+
+struct SoloWNet {
+    ChainNet C;             // lane constants; S.w2 / w3 / b1 / b2 / b3 / ls point into the carve below
+    lds_f ea, eb;           // activation / delta exchange, MFMA D layout: tile ft at ft * 256 + 4 * lane
+    lds_f th1;              // h1 of the row tile, transposed fragment image (all 8 feature tiles): operand of dW2
+    lds_f td;               // a delta's (or h2's) own tiles, transposed (wave-local)
+    lds_f tx;               // the input rows, transposed: k-tile kb at kb * 256 (operand of dW1)
+    lds_f tz;               // per wave: the head's dz tiles, transposed (operand of dW3)
+    lds_f ar;               // [16 rows][32] the tile's policy / target-policy actions
+    lds_f dxa;              // [16 rows][48] dQ/d(input columns of the action k-tiles)
+    lds_f red;
+
+    __device__ __forceinline__ void init(float* smem) {
+        lds_f p = (lds_f)smem;
+        C.S.w2 = p; p += kHT * kHT * 256;
+        C.S.w3 = p; p += 2 * kHT * 256;
+        C.S.b1 = p; p += kHid;
+        C.S.b2 = p; p += kHid;
+        C.S.b3 = p; p += 32;
+        C.S.ls = p; p += 32;
+        ea = p; p += kHT * 256;
+        eb = p; p += kHT * 256;
+        th1 = p; p += kHT * 256;
+        td = p; p += kHT * 256;
+        tx = p; p += kSoloWMaxKB * 256;
+        tz = p; p += 4 * 2 * 256;
+        ar = p; p += 16 * 32;
+        dxa = p; p += 16 * 48;
+        red = p; p += 128;
+        C.S.w1 = ea; C.S.ea = ea; C.S.eb = eb; C.S.ab = ea; C.S.yb = ea; C.S.q1 = ea; C.S.lpn = ea; C.S.red = red;
+        C.init_lanes();
+    }
+
+    __device__ __forceinline__ void put_t(lds_f E, int ft, const f32x4& t) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[ft * 256 + C.tslot + (((4 * C.q + r) ^ (C.i16 >> 2)) << 2)] = t[r];
+    }
+    __device__ __forceinline__ f32x4 get_t(lds_cf E, int ft) const { return ld4(E + ft * 256 + C.fslot); }
+    __device__ __forceinline__ void put_d(lds_f E, int ft, const f32x4& t) const { st4(E + ft * 256 + 4 * C.l, t); }
+    __device__ __forceinline__ f32x4 get_d(lds_cf E, int ft) const { return ld4(E + ft * 256 + 4 * C.l); }
+
+    __device__ __forceinline__ f32x4 xfrag(const SoloWX& X, int kb) const {
+        const int c0 = 16 * kb + 4 * C.q;
+        if (X.vec && c0 + 4 <= X.ng) return ld4(X.base + c0);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            v[e] = c < X.ng ? X.base[c] : (c - X.ng < X.na ? X.act[c - X.ng] : 0.f);
+        }
+        return v;
+    }
+
+    // ---- layers 2 and 3 of one head -> LDS images (linear copies of the block's image order), the three biases, log_std.
+    // fetch issues the loads (84 registers per lane) and can sit a pass ahead; commit waits for the other waves to be done
+    // with the old images.  L = the head's three LayerDescs, nt3 = head tiles
+    struct Stage { f32x4 t2[16], t3[4]; float bb, b3v, lsv; };
+    __device__ __forceinline__ Stage stage_fetch(g_cf th, const LayerDesc* L, int nt3, int extra_off, int extra_n) const {
+        Stage R;
+        const int tid = C.tid;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) R.t2[j] = ld4(th + L[1].w_off + 4 * (tid + kWG * j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R.t3[j] = j < 2 * nt3 ? ld4(th + L[2].w_off + 4 * (tid + kWG * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        R.bb = tid < kHid ? th[L[0].b_off + tid] : th[L[1].b_off + tid - kHid];
+        R.b3v = tid < 16 * nt3 ? th[L[2].b_off + tid] : 0.f;
+        R.lsv = tid < extra_n ? th[extra_off + tid] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);                             // the loads stay here: hipcc would sink them to the stores
+        return R;
+    }
+    __device__ __forceinline__ void stage_commit(const Stage& R) const {
+        const int tid = C.tid;
+        lds_barrier();                                                 // every wave is done with the previous images
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st4(C.S.w2 + 4 * (tid + kWG * j), R.t2[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st4(C.S.w3 + 4 * (tid + kWG * j), R.t3[j]);
+        if (tid < kHid) C.S.b1[tid] = R.bb; else C.S.b2[tid - kHid] = R.bb;
+        if (tid < 32) { C.S.b3[tid] = R.b3v; C.S.ls[tid] = R.lsv; }
+        lds_barrier();
+    }
+
+    // ---- first layer of the row tile: acc[x] (the bias on entry) += W1[tiles 2w + x] x, K = 16 KB1 columns, W1's fragments from
+    // the block.  KEEP: x is also left transposed in tx (k-tile kb by wave kb & 3)
+    template <bool KEEP>
+    __device__ __forceinline__ void l1(g_cf w1, int KB1, const SoloWX& X, f32x4 (&acc)[2]) const {
+        const int w = C.w, fslot = C.fslot;
+        constexpr int G = 4;
+        f32x4 wf[2][G], xf[G], wn[2][G], xn[G];
+        auto load = [&](int kb0, f32x4 (&W)[2][G], f32x4 (&Xf)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int kb = kb0 + g, kbc = kb < KB1 ? kb : KB1 - 1;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) W[x][g] = ld4(w1 + ((size_t)((2 * w + x) * KB1 + kbc) * 256 + fslot));
+                Xf[g] = xfrag(X, kbc);
+                if (kb >= KB1) Xf[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        load(0, wf, xf);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            xn[g] = xf[g];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) wn[x][g] = wf[x][g];
+        }
+        for (int kb0 = 0; kb0 < KB1; kb0 += G) {
+            if (kb0 + G < KB1) load(kb0 + G, wn, xn);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if constexpr (KEEP) { if (g == w && kb0 + g < KB1) put_t(tx, kb0 + g, xf[g]); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][g][e], xf[g][e], acc[x], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                xf[g] = xn[g];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) wf[x][g] = wn[x][g];
+            }
+        }
+    }
+
+    // ---- forward of the row tile through the staged head (W2 / W3 images in LDS, W1 from the block w1).  Out: the wave's own tiles
+    // of h1 / h2 (ReLU masks of a backward) and h2 of all tiles (D layout).  KEEP: h1 is also left transposed in th1 and x in tx.
+    template <bool KEEP>
+    __device__ __forceinline__ void forward(g_cf w1, int KB1, const SoloWX& X, f32x4 (&h1o)[2], f32x4 (&h2o)[2], f32x4 (&h2f)[kHT]) const {
+        const ChainLds& S = C.S;
+        const int w = C.w, q = C.q, fslot = C.fslot;
+        f32x4 acc[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) acc[x] = ld4((lds_cf)(S.b1 + (2 * w + x) * 16 + 4 * q));
+        l1<KEEP>(w1, KB1, X, acc);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1o[x][r] = fmaxf(acc[x][r], 0.f);
+            put_d(ea, 2 * w + x, h1o[x]);
+            if constexpr (KEEP) put_t(th1, 2 * w + x, h1o[x]);
+        }
+        lds_barrier();
+        f32x4 h1f[kHT];
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) h1f[kb] = get_d(ea, kb);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) acc[x] = ld4((lds_cf)(S.b2 + (2 * w + x) * 16 + 4 * q));
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) {
+            f32x4 wf[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) wf[x] = ld4((lds_cf)(S.w2 + ((2 * w + x) * kHT + kb) * 256 + fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][e], h1f[kb][e], acc[x], 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2o[x][r] = fmaxf(acc[x][r], 0.f);
+            put_d(eb, 2 * w + x, h2o[x]);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) h2f[kb] = get_d(eb, kb);
+    }
+
+    // a critic's single output as a dot product (solo.hpp: forward): on every lane of the row
+    __device__ __forceinline__ float head_q(const f32x4 (&h2f)[kHT]) const {
+        const ChainLds& S = C.S;
+        float acc1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < kHT; ++kb) {
+            const f32x4 wv = ld4((lds_cf)(S.w3 + kb * 256 + ((C.q * 16 + C.q) << 2)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1 = fmaf(wv[r], h2f[kb][r], acc1);
+        }
+        acc1 += lane_xor<16>(acc1);
+        acc1 += lane_xor<32>(acc1);
+        return acc1 + S.b3[0];
+    }
+    // an actor's NT3 head tiles: z[t][r] = output 16 t + 4 q + r of this lane's row (every wave computes all of them)
+    template <int NT3>
+    __device__ __forceinline__ void head_tiles(const f32x4 (&h2f)[kHT], f32x4 (&z)[NT3]) const {
+        const ChainLds& S = C.S;
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            f32x4 acc = ld4((lds_cf)(S.b3 + 16 * t + 4 * C.q));
+#pragma unroll
+            for (int kb = 0; kb < kHT; ++kb) acc = mfma4(acc, ld4((lds_cf)(S.w3 + (t * kHT + kb) * 256 + C.fslot)), h2f[kb]);
+            z[t] = acc;
+        }
+    }
+
+    // ---- a critic head's share of a backward: dz = d loss / d Q of this lane's row (on every lane of the row) -> the own tiles'
+    // deltas d2o through the ReLU of h2; WG: the head's gradient tiles / bias -> slab (hs = the net's slab, L = the head's layers)
+    template <bool WG>
+    __device__ __forceinline__ void head_bwd_q(g_f hs, const LayerDesc* L, float dz, const f32x4 (&h2o)[2], f32x4 (&d2o)[2]) const {
+        const ChainLds& S = C.S;
+        const int w = C.w, q = C.q, i16 = C.i16;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int ot = 2 * w + x;
+            const f32x4 wv = ld4((lds_cf)(S.w3 + ot * 256 + ((q * 16 + q) << 2)));                     // W3[0][16 ot + 4q .. + 3]
+            f32x4 g3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d2o[x][r] = h2o[x][r] > 0.f ? wv[r] * dz : 0.f;
+                if constexpr (WG) {
+                    const float s = SoloNet::rows_sum(h2o[x][r] * dz);
+                    if (i16 == 0) g3[r] = s;
+                }
+            }
+            if constexpr (WG) st4_slab(hs + L[2].w_off + ot * 256 + C.fslot, g3);
+        }
+        if constexpr (WG) {
+            const float s = SoloNet::rows_sum(dz);
+            if (w == 0 && q == 0) hs[L[2].b_off + i16] = i16 == 0 ? s : 0.f;
+        }
+    }
+
+    // ---- an actor head's share: dz[t][r] = d loss / d output 16 t + 4 q + r of this lane's row (the same on every wave)
+    template <int NT3>
+    __device__ __forceinline__ void head_bwd_a(g_f hs, const LayerDesc* L, const f32x4 (&dz)[NT3], const f32x4 (&h2o)[2], f32x4 (&d2o)[2]) const {
+        const ChainLds& S = C.S;
+        const int w = C.w, q = C.q, i16 = C.i16, tslot = C.tslot;
+        lds_f tzw = tz + w * 2 * 256;
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) put_t(tzw, t, dz[t]);                                            // (wave-local: read back below, in order)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) put_t(td, 2 * w + x, h2o[x]);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            const f32x4 zt = get_t(tzw, t);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int ot = 2 * w + x;
+                // dW3 tile (t, ot) = dz^T h2: accumulator layout of chain_net.hpp (in = 16 ot + 4q + r, out = 16 t + i16)
+                st4_slab(hs + L[2].w_off + (t * kHT + ot) * 256 + C.fslot, mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, get_t(td, ot), zt));
+                f32x4 wa;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wa[e] = S.w3[(t * kHT + ot) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];      // W3[16 t + 4q + e][16 ot + i16]
+                acc[x] = mfma4(acc[x], wa, dz[t]);
+            }
+            float gb = (zt[0] + zt[1]) + (zt[2] + zt[3]);                                              // db3[16 t + i16]: the tile's 16 rows
+            gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
+            if (w == 0 && q == 0) hs[L[2].b_off + 16 * t + i16] = gb;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2o[x][r] = h2o[x][r] > 0.f ? acc[x][r] : 0.f;
+    }
+
+    // ---- layers 2 and 1 of a backward from the own tiles' d2o.  WG: dW2 / db2 / dW1 / db1 of the wave's output tiles -> slab
+    // (needs forward<true>: th1, tx).  Returns d1o (own tiles, through the ReLU of h1).
+    template <bool WG>
+    __device__ __forceinline__ void hidden_bwd(g_f hs, const LayerDesc* L, int KB1, const f32x4 (&d2o)[2], const f32x4 (&h1o)[2], f32x4 (&d1o)[2]) const {
+        const ChainLds& S = C.S;
+        const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot, tslot = C.tslot;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            put_d(ea, 2 * w + x, d2o[x]);
+            if constexpr (WG) put_t(td, 2 * w + x, d2o[x]);
+        }
+        lds_barrier();
+        if constexpr (WG) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int ot = 2 * w + x;
+                const f32x4 af = get_t(td, ot);
+                float gb = (af[0] + af[1]) + (af[2] + af[3]);
+                gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
+                if (q == 0) hs[L[1].b_off + ot * 16 + i16] = gb;
+#pragma unroll
+                for (int kt = 0; kt < kHT; ++kt)
+                    st4_slab(hs + L[1].w_off + (ot * kHT + kt) * 256 + fslot, mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, get_t(th1, kt), af));
+            }
+        }
+        f32x4 d2f[kHT], acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ob = 0; ob < kHT; ++ob) d2f[ob] = get_d(ea, ob);
+#pragma unroll
+        for (int ob = 0; ob < kHT; ++ob)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const float wa = S.w2[(ob * kHT + 2 * w + x) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];      // W2[16 ob + 4q + e][16 (2w + x) + i16]
+                    acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, d2f[ob][e], acc[x], 0, 0, 0);
+                }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1o[x][r] = h1o[x][r] > 0.f ? acc[x][r] : 0.f;
+        if constexpr (WG) {
+            f32x4 af[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int ot = 2 * w + x;
+                put_t(td, ot, d1o[x]);                                            // (this wave's own tiles: its reads of d2 above are done, in order)
+                af[x] = get_t(td, ot);
+                float gb = (af[x][0] + af[x][1]) + (af[x][2] + af[x][3]);
+                gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
+                if (q == 0) hs[L[0].b_off + ot * 16 + i16] = gb;
+            }
+            for (int kt = 0; kt < KB1; ++kt) {
+                const f32x4 xt = get_t(tx, kt);
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+                    st4_slab(hs + L[0].w_off + ((size_t)((2 * w + x) * KB1 + kt) * 256 + fslot), mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af[x]));
+            }
+        }
+    }
+
+    // ---- dX of the k-tiles ka0 .. ka0 + nka - 1 (nka <= 3: the ones that hold action columns) = W1^T d1 of the row tile: the
+    // waves' d1 tiles meet through eb; wave j < nka walks k-tile ka0 + j (transposed fragments as dword loads from the block, issued
+    // by input_bwd_fetch a pass ahead) and leaves dxa[row][16 j + 4 q + r].  A workgroup barrier behind it makes dxa readable.
+    struct DxRegs { f32x4 wa[kHT]; };
+    __device__ __forceinline__ DxRegs input_bwd_fetch(g_cf w1, int KB1, int ka0, int nka) const {
+        DxRegs R;
+        const int kt = ka0 + (C.w < nka ? C.w : 0);
+#pragma unroll
+        for (int ob = 0; ob < kHT; ++ob)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) R.wa[ob][e] = w1[(size_t)(ob * KB1 + kt) * 256 + C.tslot + (((4 * C.q + e) ^ (C.i16 >> 2)) << 2)];
+        return R;
+    }
+    __device__ __forceinline__ void input_bwd(const DxRegs& R, int nka, const f32x4 (&d1o)[2]) const {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) put_d(eb, 2 * C.w + x, d1o[x]);
+        lds_barrier();
+        if (C.w < nka) {
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ob = 0; ob < kHT; ++ob) dx = mfma4(dx, R.wa[ob], get_d(eb, ob));
+            st4(dxa + C.i16 * 48 + 16 * C.w + 4 * C.q, dx);
+        }
+        lds_barrier();
+    }
+};
+
+// ---- behind the slab hand-over: this workgroup's sixteenth of a net of any size — phase 1: slab sum in workgroup order -> gsum
+// (EngineDesc::grad), partial squared norm; the sixteen partial norms meet through the mailboxes of solo_update; phase 2: clip
+// coefficient, Adam, soft update.  Returns the gradient norm.
+__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int p, int b, int nb, lds_f red,
+                                              unsigned bar2_target) {
+    constexpr int W = kSoloWG, KM = 3;
+    const int tid = threadIdx.x;
+    const int n4 = u.size >> 2, per = (n4 + W - 1) / W, i0 = b * per, i1 = min(n4, i0 + per);
+    g_cf slab = as_global(s.slab + (size_t)p * kSoloWG * s.slab_stride);
+    float ss = 0.f;
+    for (int c0 = i0; c0 < i1; c0 += kWG * KM) {
+        f32x4 sl[W][KM], g[KM];
+#pragma unroll
+        for (int sb = 0; sb < W; ++sb) {
+            const int sc = sb < nb ? sb : nb - 1;                          // (slabs past the batch's tiles: a harmless re-read, dropped below)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                const int i = c0 + tid + kWG * k, ic = i < i1 ? i : i1 - 1;
+                sl[sb][k] = ld4(slab + (size_t)sc * s.slab_stride + 4 * (size_t)ic);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < W; ++sb) {
+            if (sb < nb) {
+#pragma unroll
+                for (int k = 0; k < KM; ++k) g[k] += sl[sb][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int i = c0 + tid + kWG * k;
+            if (i < i1) {
+                st4(gsum + 4 * (size_t)i, g[k]);
+                ss += (g[k][0] * g[k][0] + g[k][1] * g[k][1]) + (g[k][2] * g[k][2] + g[k][3] * g[k][3]);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    sync_stores();                                                         // (phase 2 reads gsum back: the stores are acknowledged)
+    if ((tid & 63) == 0) red[64 + (tid >> 6)] = ss;
+    __syncthreads();
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    typedef unsigned long long u64;
+    if (tid == 0) {
+        const float mine = ((red[64] + red[65]) + red[66]) + red[67];
+        __hip_atomic_store((u64*)(part + b * kSoloPart + 2), ((u64)bar2_target << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < W) {
+        const u64* box = (const u64*)(part + tid * kSoloPart + 2);
+        const unsigned long long t0 = wall_clock64();
+        u64 v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((unsigned)(v >> 32) != bar2_target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull) { *s.err = 1; break; }
+            v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        red[80 + tid] = __uint_as_float((unsigned)v);
+    }
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int sb = 0; sb < W; ++sb) tot += red[80 + sb];
+    const float total = sqrtf(tot);
+    const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
+    const double bc1 = 1.0 - powi_d((double)a.beta1, u.t_new), bc2 = 1.0 - powi_d((double)a.beta2, u.t_new);
+    const float step = (float)((double)u.lr / bc1), bc2s = (float)sqrt(bc2);
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2, tk = 1.f - a.tau;
+    for (int c0 = i0; c0 < i1; c0 += kWG * KM) {
+        f32x4 g[KM], th[KM], mi[KM], vi[KM], tg[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int i = c0 + tid + kWG * k, ic = i < i1 ? i : i1 - 1;
+            g[k] = ld4((g_cf)(gsum + 4 * (size_t)ic));                  // (this thread's own stores of phase 1)
+            th[k] = ld4((g_cf)(u.th + 4 * (size_t)ic)); mi[k] = ld4((g_cf)(u.mm + 4 * (size_t)ic)); vi[k] = ld4((g_cf)(u.vv + 4 * (size_t)ic));
+            tg[k] = ld4((g_cf)(u.tg + 4 * (size_t)ic));
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int i = c0 + tid + kWG * k;
+            if (i < i1) {
+                f32x4 gi = g[k] * coef, t4 = th[k], m4 = mi[k], v4 = vi[k];
+                if (u.wd != 0.f) gi += u.wd * t4;
+                m4 = m4 + (gi - m4) * w1;
+                v4 = v4 * a.beta2 + (w2 * gi) * gi;
+                f32x4 den;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) den[r] = sqrtf(v4[r]) / bc2s + a.adam_eps;
+                t4 = t4 - step * (m4 / den);
+                st4(u.th + 4 * (size_t)i, t4); st4(u.mm + 4 * (size_t)i, m4); st4(u.vv + 4 * (size_t)i, v4);
+                if (u.soft) st4(u.tg + 4 * (size_t)i, tg[k] * tk + t4 * a.tau);
+            }
+        }
+    }
+    return total;
+}
+
+}  // namespace frl

@@ -35,6 +35,7 @@
 #include "kernels_noisy.hip"
 #include "kernels_c51.hip"
 #include "kernels_solo.hip"
+#include "kernels_solow.hip"
 #endif
 
 using namespace frl;
@@ -422,6 +423,18 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (h.solo || (force ? atoi(force) != 0 : h.P > 128)) h.net[0].frag = h.net[1].frag = 1;
     } else if (e->has_nets && wide_shape(h)) {   // the K-sliced chained family (kernels_criticw.hip / kernels_actorw.hip): one workgroup per (learner, agent)
         const char* force = getenv("FRL_CRITIC_V2");
+        // a handful of single-agent learners at hidden 128: sixteen workgroups per learner, W1 streamed from the block (kernels_solow.hip;
+        // FRL_SOLOW=0/1 overrides, FRL_CRITIC_V2 set means the caller asked for one of the other two families by name).  Every one of
+        // the P x 16 workgroups has to be resident, as for kernels_solo.hip.  [s | a] must be the record's first columns, 16-byte aligned
+        const char* sw = getenv("FRL_SOLOW");
+        const bool solow_shape = h.n_agents == 1 && h.algo != ALGO_MADDPG && h.hidden == 128 && h.batch_max <= 256 && h.rec.stride % 4 == 0 &&
+                                 h.rec.obs_off[0] % 4 == 0 && h.rec.act_off[0] == h.rec.obs_off[0] + h.rec.obs_dim[0] &&
+                                 h.net[0].L[0].k_pad <= 16 * kSoloWMaxKB && h.net[1].L[0].k_pad <= 16 * kSoloWMaxKB;
+        const bool solow_fits = h.P <= kSoloMaxP && (long long)h.P * kSoloWG <= e->n_cus && e->lds_per_cu >= (int)(solow_lds_floats() * sizeof(float));
+        if ((sw ? atoi(sw) != 0 : !force) && solow_shape && solow_fits) {
+            for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
+            h.solow = kSoloWG;
+        } else
         // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
         // kernels' 46.2, MADDPG simple_spread 77.2 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 71.1 / 56.9
         // (profiles/r04)
@@ -545,7 +558,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.steps, P * (kMaxNets + 1), e->stream));
         CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
-        if (h.solo) {
+        if (h.solo || h.solow) {
             e->solo_stride = std::max(h.net[0].size, h.net[1].size);
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
             CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
@@ -555,13 +568,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
             e->d_solo_ticket = (int*)(z + 2 * P * (size_t)kSoloWG);        // ... and the rollout tail's learner ticket
         }
-        if (h.solo || h.algo == ALGO_DQN) {                                // the pinned give-up word of the spinning launches (solo hand-overs, pre-armed DQN steps)
+        if (h.solo || h.solow || h.algo == ALGO_DQN) {                     // the pinned give-up word of the spinning launches (solo hand-overs, pre-armed DQN steps)
             CREATE_TRY(hipHostMalloc((void**)&e->h_solo_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
             *e->h_solo_err = 0;
             CREATE_TRY(hipHostGetDevicePointer((void**)&e->d_solo_err, e->h_solo_err, 0));
         }
-        if (h.wide) {
-            CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
+        if (h.wide) CREATE_TRY(dalloc_zero(&h.wide_scr, P * (size_t)h.n_agents * h.wide_unit, e->stream));
+        if (h.wide || h.solow) {                                           // select_action's Wk-layout copies of the nets (launch_act)
             int biggest = 0;
             for (int i = 0; i < h.n_nets; ++i) biggest = std::max(biggest, h.net[i].size);
             e->act_wk_slot = P * (size_t)biggest;
@@ -600,6 +613,10 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         const int lb = wide_lds_floats() * (int)sizeof(float);
         for (auto k : {ac_critic_wide_h1a1_kernel, ac_critic_wide_h1a2_kernel, ac_critic_wide_h2a1_kernel, ac_critic_wide_h2a2_kernel,
                        ac_actor_wide_a1_kernel, ac_actor_wide_a2_kernel})
+            CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    } else if (h.solow) {
+        const int lb = solow_lds_floats() * (int)sizeof(float);
+        for (auto k : {solow_critic_h1a1_kernel, solow_critic_h1a2_kernel, solow_critic_h2a1_kernel, solow_critic_h2a2_kernel, solow_actor_a1_kernel, solow_actor_a2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solo) {
         const int lb = std::max(solo_lds_floats(), critic2_lds_floats()) * (int)sizeof(float);      // (critic2: the rollout tail's act_frag_body)
@@ -697,6 +714,12 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
         if (chained_out) *chained_out = 1;
         if (bytes_out) *bytes_out = solo_lds_floats() * (int)sizeof(float);
         if (rows_out) *rows_out = 16 * (kSoloWG / e->h.solo);
+        return FRL_OK;
+    }
+    if (v2 && e->h.solow) {                                 // kernels_solow.hip: one 16-row tile per workgroup
+        if (chained_out) *chained_out = 1;
+        if (bytes_out) *bytes_out = solow_lds_floats() * (int)sizeof(float);
+        if (rows_out) *rows_out = 16;
         return FRL_OK;
     }
     if (chained_out) *chained_out = v2 ? 1 : 0;
@@ -1081,7 +1104,7 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
     a.normalize = (!no_norm && e->h.obs_norm_on && (e->h.n_agents == 1 || net % 2 == 0) && in_dim == e->h.rec.obs_dim[agent]) ? 1 : 0;
     a.in = in_dev; a.eps = eps_dev; a.out = out_dev; a.out_logp = logp_dev;
     if (build_only) { *build_only = a; return FRL_OK; }
-    if (N.frag && e->h.wide) {
+    if (N.frag && (e->h.wide || e->h.solow)) {
         // fragment-image parameters of a shape act_frag_kernel does not take: the net is re-laid out to Wk in a scratch copy (one
         // small launch: the actor of config 4 is 67 k floats per learner) and act_kernel reads that
         // (config 4 at 512 learners: 34 M floats per net — a collector that steps its envs many times between two learn() calls
@@ -1441,6 +1464,16 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_end(e);
             return;
         }
+        if (v2 && h.solow) {                              // kernels_solow.hip: sixteen workgroups per learner, W1 streamed from the block
+            prof_begin(e, PK_GRAD_CRITIC);
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
+            e->solo_bar_base += kSoloWG;
+            const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
+            auto k = twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel);
+            hipLaunchKernelGGL(k, dim3(pc * kSoloWG), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
+            prof_end(e);
+            return;
+        }
         if (v2 && h.solo) {                               // kernels_solo.hip: sixteen workgroups per learner, reduce + Adam behind grid barriers
             prof_begin(e, PK_GRAD_CRITIC);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
@@ -1501,6 +1534,15 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             const bool x = h.wide == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = x ? (a2 ? ac_actor_x_a2_kernel : ac_actor_x_a1_kernel) : (a2 ? ac_actor_wide_a2_kernel : ac_actor_wide_a1_kernel);
             hipLaunchKernelGGL(k, dim3(units), blk, (size_t)(x ? wide16_lds_floats_host() : wide_lds_floats()) * sizeof(float), st, e->d, a);
+            prof_end(e);
+            return;
+        }
+        if (v2 && h.solow) {
+            prof_begin(e, PK_GRAD_ACTOR);
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
+            e->solo_bar_base += kSoloWG;
+            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(pc * kSoloWG), blk,
+                               (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
         }
@@ -1755,6 +1797,7 @@ extern "C" int frl_obsnorm_enable(frl_engine* e, int on) {
         ++e->param_version;
         e->h.wide = 0;
         e->h.solo = 0;
+        e->h.solow = 0;
     }
     e->h.obs_norm_on = on ? 1 : 0;
     HIP_TRY(hipStreamSynchronize(e->stream));

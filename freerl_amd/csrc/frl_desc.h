@@ -50,6 +50,10 @@ constexpr int kSoloMaxP = 16;            // learners per engine at sixteen workg
                                          // Measured (tools/small_pop_bench.py, TD3): 9 / 12 / 16 learners 82 / 90 / 101 us per learn() against 144 / 150 / 150 on the row-chunk kernels
 constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 128 + 16 + 16 + 4 * 8 * 256 + 256 + 128; }
 
+// ... and its form for wide first layers / heads of up to 32 outputs (device/solo_wide.hpp, kernels_solow.hip): W1 stays in the block
+constexpr int kSoloWMaxKB = 26;          // first layer: <= 416 input columns
+constexpr int solow_lds_floats() { return 64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + kSoloWMaxKB * 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128; }
+
 // The K-sliced chained family (device/chain_wide.hpp)
 constexpr int kWideSliceKB = 4;          // k-blocks of W1 per streamed slice (4 x 8 tiles x 1 KB = 32 KB)
 constexpr int kWideSlice = kWideSliceKB * 8 * 256;
@@ -165,6 +169,8 @@ struct EngineDesc {
     int wide_xp, wide_op; // row pitches of the scratch's critic-input rows / observation copies (the padded first-layer widths)
     int wide_unit;        // floats per (learner, agent): (wide_xp + n_agents * wide_op + kWideScratchPerRow) * wide_bm + 128, rounded up to 64
     float* wide_scr;
+    int solow;            // > 0 (16): DDPG / TD3 / SAC updates of this engine run on kernels_solow.hip (single agent, hidden 128, first layers of up to 416
+                          // columns, heads of up to 32 outputs, batches of up to 256 rows, <= kSoloMaxP learners); every net in fragment-image order
     int solo;             // > 0 (the workgroups per learner: 16 / 8): DDPG / TD3 / SAC updates of this engine run on kernels_solo.hip (<= kSoloMaxP learners of the narrow standard
                           // shape, sixteen workgroups per learner); parameters in fragment-image order like the chained family's
 };

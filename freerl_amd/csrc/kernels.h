@@ -247,6 +247,14 @@ __global__ void solo_actor_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a
 __global__ void solo_critic_twin_w8_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
 __global__ void solo_critic_single_w8_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
 __global__ void solo_actor_w8_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s, SoloStepArgs st);
+// kernels_solow.hip: the same decomposition for wide first layers / heads of up to 32 outputs (device/solo_wide.hpp), behind draw_kernel;
+// h<critic heads>a<actor head tiles>
+__global__ void solow_critic_h1a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_h1a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_h2a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_actor_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_actor_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }

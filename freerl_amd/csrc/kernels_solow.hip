@@ -1,0 +1,377 @@
+// DDPG / TD3 / SAC update of a SINGLE learner (or a handful) with a WIDE first layer on sixteen workgroups per learner
+// (device/solo_wide.hpp): the shapes of BASELINE.json's config 4 (SAC at Humanoid-v4's dims, 376 + 17 input columns, 17 actions) and
+// of the MuJoCo-sized TD3 / DDPG runs, one `learn()` per env step as the reference drives them (SAC.py:519-576, TD3.py:403-450).
+// The critic stage — TD target with the target nets, critic forward / backward, clip, Adam, soft update: DDPG_simple.py:139-149,
+// TD3.py:193-213,235-244, SAC.py:226-238 — and the actor stage — a = actor(s), Q(s, a) through the updated critic, dQ/da, actor
+// backward, clip, Adam, soft update, SAC's alpha step: DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260 — one launch each,
+// behind draw_kernel (the batch's rows and noise sets in EngineDesc::idx / noise, as for the K-sliced family).  Same arithmetic per
+// row as kernels_criticw.hip / kernels_actorw.hip; the decomposition is kernels_solo.hip's.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "device/solo_wide.hpp"
+
+namespace frl {
+
+// NT3 = head tiles of the actor (act_dim <= 16 -> 1, <= 32 -> 2)
+template <bool TWIN, int NT3>
+__device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
+    constexpr int NH = TWIN ? 2 : 1, W = kSoloWG;
+    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    SoloWNet N;
+    N.init(smem);
+    const ChainNet& C = N.C;
+    const int tid = C.tid, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], A = R.act_dim[0], am = D.act_max;
+    const int nb = (B + 15) / 16;
+    const bool sac = (D.algo == ALGO_SAC);
+    const size_t lbase = (size_t)p * D.learner_stride;
+    g_cf tgA = as_global(D.target + lbase + D.net_off[0]);
+    g_f thC = as_global(D.theta + lbase + D.net_off[1]);
+    g_f tgC = as_global(D.target + lbase + D.net_off[1]);
+    g_f mC = as_global(D.m + lbase + D.net_off[1]);
+    g_f vC = as_global(D.v + lbase + D.net_off[1]);
+    g_f grC = as_global(D.grad + lbase + D.net_off[1]);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    const float invB = 1.f / (float)B;
+    const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
+    const int t_new = steps[1] + 1;                    // read by every workgroup before the hand-over; rewritten behind the mailboxes
+
+    float lossp = 0.f;
+    if (b < nb) {
+        g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+        g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
+        g_cf noise0 = as_global(D.noise + (size_t)p * D.noise_sets * D.batch_max * am);      // set 0: TD3 policy noise / SAC eps'
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
+        const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+        const int row = 16 * b + i16, rc = row < B ? row : B - 1;
+        const bool valid = row < B;
+        SoloWNet::Stage pend = N.stage_fetch(tgA, NA.L, NT3, NA.extra_off, NA.extra_n);
+        g_cf rec = ring + (size_t)idx[rc] * R.stride;
+        const float rew = rec[R.rew_off], done = rec[R.done_off];
+        f32x4 nz[NT3];
+#pragma unroll
+        for (int t = 0; t < NT3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * t + 4 * q + r;
+                nz[t][r] = (c < A && (sac || a.use_policy_noise)) ? noise0[(size_t)rc * am + c] : 0.f;
+            }
+        const bool vs = (R.stride & 3) == 0;
+        N.stage_commit(pend);
+        pend = N.stage_fetch((g_cf)tgC, NC.L, 1, -1, 0);
+        // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
+        f32x4 h1o[2], h2o[2], h2f[kHT];
+        float lp = 0.f;
+        {
+            const SoloWX Xn{rec + R.nobs_off[0], O, vs && (R.nobs_off[0] & 3) == 0, nullptr, 0};
+            N.forward<false>(tgA + NA.L[0].w_off, KB1a, Xn, h1o, h2o, h2f);
+            f32x4 z[NT3], an[NT3];
+            N.head_tiles<NT3>(h2f, z);
+#pragma unroll
+            for (int t = 0; t < NT3; ++t) {
+                an[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * t + 4 * q + r;
+                    if (c < A) {
+                        const float zr = z[t][r];
+                        if (sac) {
+                            const float ls = fminf(fmaxf(C.S.ls[c], -20.f), 2.f), sd = expf(ls);
+                            const float u = zr + sd * nz[t][r], du = u - zr;
+                            lp += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                            lp -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                            an[t][r] = tanhf(u);
+                        } else {
+                            float v = tanhf(zr);
+                            if (a.use_policy_noise) {
+                                float n1 = a.policy_noise_scale * (nz[t][r] * a.policy_noise);
+                                n1 = fminf(fmaxf(n1, -a.noise_clip), a.noise_clip);
+                                v = fminf(fmaxf(v * a.max_action + n1, -a.max_action), a.max_action) / a.max_action;
+                            }
+                            an[t][r] = v;
+                        }
+                    }
+                }
+            }
+            lp += lane_xor<16>(lp);
+            lp += lane_xor<32>(lp);
+            if (w == 0) {                                  // the tile's action rows (every wave holds the same values); read behind the next commit's barriers
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) st4(N.ar + i16 * 32 + 16 * t + 4 * q, an[t]);
+            }
+        }
+        // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi)
+        float qmin = 0.f;
+        {
+            const SoloWX Xc{rec + R.nobs_off[0], O, vs && (R.nobs_off[0] & 3) == 0, (lds_cf)(N.ar + i16 * 32), A};
+#pragma unroll
+            for (int hd = 0; hd < NH; ++hd) {
+                N.stage_commit(pend);
+                pend = hd + 1 < NH ? N.stage_fetch((g_cf)tgC, NC.L + 3 * (hd + 1), 1, -1, 0) : N.stage_fetch((g_cf)thC, NC.L, 1, -1, 0);
+                N.forward<false>((g_cf)tgC + NC.L[3 * hd].w_off, KB1c, Xc, h1o, h2o, h2f);
+                const float qv = N.head_q(h2f);
+                qmin = hd == 0 ? qv : fminf(qmin, qv);
+            }
+        }
+        const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);
+        // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab.  [s | a] are the record's first O + A columns
+        const SoloWX Xs{rec + R.obs_off[0], O + A, vs && (R.obs_off[0] & 3) == 0, nullptr, 0};
+#pragma unroll
+        for (int hd = 0; hd < NH; ++hd) {
+            const LayerDesc* L = NC.L + 3 * hd;
+            N.stage_commit(pend);
+            if (hd + 1 < NH) pend = N.stage_fetch((g_cf)thC, NC.L + 3 * (hd + 1), 1, -1, 0);
+            N.forward<true>((g_cf)thC + L[0].w_off, KB1c, Xs, h1o, h2o, h2f);
+            const float z = N.head_q(h2f);
+            float dz = 0.f;
+            if (valid) {
+                float lrow, grow;
+                td_loss_row(a, z - y, lrow, grow);
+                dz = grow * invB;
+                lossp += lrow;
+            }
+            f32x4 d2o[2], d1o[2];
+            N.head_bwd_q<true>(slab, L, dz, h2o, d2o);
+            N.hidden_bwd<true>(slab, L, KB1c, d2o, h1o, d1o);
+        }
+        lossp = SoloNet::rows_sum(lossp);
+        if (tid == 0) part[b * kSoloPart + 0] = lossp;
+    }
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    SoloUpdate u;
+    u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
+    u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
+    u.t_new = t_new;
+    const float total = solow_update(s, a, u, grC, p, b, nb, N.red, s.bar_base + kSoloWG);
+    if (b == 0 && tid == 0) {
+        float loss = 0.f;
+        for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        steps[1] = t_new;
+        float* sts = D.stats + (size_t)p * ST_COUNT;
+        sts[ST_CRITIC_LOSS] = loss * invB;
+        sts[ST_CRITIC_GNORM] = total;
+    }
+}
+
+#define FRL_SOLOW_CRITIC(name, twin, nt3)                                                                                          \
+    __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
+        solow_critic_body<twin, nt3>(*Dp, a, s, smem);                                                                              \
+    }
+FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1)
+FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2)
+FRL_SOLOW_CRITIC(solow_critic_h2a1_kernel, true, 1)
+FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2)
+
+// ------------------------------------------------------------------------------------------------------------- actor stage
+template <int NT3>
+__device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
+    constexpr int W = kSoloWG;
+    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
+    const RecordDesc& R = D.rec;
+    const NetDesc& NA = D.net[0];
+    const NetDesc& NC = D.net[1];
+    SoloWNet N;
+    N.init(smem);
+    const ChainNet& C = N.C;
+    const int tid = C.tid, w = C.w, i16 = C.i16, q = C.q;
+    const int B = a.batch, O = R.obs_dim[0], A = R.act_dim[0], am = D.act_max;
+    const int nb = (B + 15) / 16;
+    const bool sac = (D.algo == ALGO_SAC);
+    const size_t lbase = (size_t)p * D.learner_stride;
+    g_f thA = as_global(D.theta + lbase + D.net_off[0]);
+    g_f tgA = as_global(D.target + lbase + D.net_off[0]);
+    g_f mA = as_global(D.m + lbase + D.net_off[0]);
+    g_f vA = as_global(D.v + lbase + D.net_off[0]);
+    g_f grA = as_global(D.grad + lbase + D.net_off[0]);
+    g_cf thC = as_global(D.theta + lbase + D.net_off[1]);
+    int* steps = D.steps + (size_t)p * (kMaxNets + 1);
+    const int t_new = steps[0] + 1;
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    const float invB = 1.f / (float)B;
+    const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
+    const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
+    const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
+    const int ka0 = O >> 4, nka = ((O + A - 1) >> 4) - ka0 + 1;            // the k-tiles of the critic's first layer that hold action columns (<= 3)
+
+    float qrow = 0.f, lp = 0.f;
+    if (b < nb) {
+        g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
+        g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
+        g_cf noise1 = as_global(D.noise + ((size_t)p * D.noise_sets + 1) * D.batch_max * am);      // the actor stage's eps (set 1)
+        g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
+        const int row = 16 * b + i16, rc = row < B ? row : B - 1;
+        const bool valid = row < B;
+        SoloWNet::Stage pend = N.stage_fetch((g_cf)thA, NA.L, NT3, NA.extra_off, NA.extra_n);
+        g_cf rec = ring + (size_t)idx[rc] * R.stride;
+        f32x4 ep[NT3];
+#pragma unroll
+        for (int t = 0; t < NT3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * t + 4 * q + r;
+                ep[t][r] = (sac && c < A) ? noise1[(size_t)rc * am + c] : 0.f;
+            }
+        const bool vs = (R.stride & 3) == 0 && (R.obs_off[0] & 3) == 0;
+        N.stage_commit(pend);
+        pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
+        SoloWNet::DxRegs dxr = N.input_bwd_fetch(thC + NC.L[0].w_off, KB1c, ka0, nka);
+        // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
+        f32x4 ah1[2], ah2[2], h2f[kHT], an[NT3], lsv[NT3];
+        float lpr = 0.f;
+        {
+            const SoloWX Xo{rec + R.obs_off[0], O, vs, nullptr, 0};
+            N.forward<true>((g_cf)thA + NA.L[0].w_off, KB1a, Xo, ah1, ah2, h2f);   // (th1 / tx keep the actor's h1 and s for pass C: pass B leaves them alone)
+            f32x4 za[NT3];
+            N.head_tiles<NT3>(h2f, za);
+#pragma unroll
+            for (int t = 0; t < NT3; ++t) {
+                an[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lsv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * t + 4 * q + r;
+                    if (c < A) {
+                        if (sac) {
+                            lsv[t][r] = C.S.ls[c];
+                            const float ls = fminf(fmaxf(lsv[t][r], -20.f), 2.f), sd = expf(ls);
+                            const float u = za[t][r] + sd * ep[t][r], du = u - za[t][r];
+                            lpr += -(du * du) / (2.f * sd * sd) - ls - kLogSqrt2Pi;
+                            lpr -= 2.f * (kLog2 - u - softplus_t(-2.f * u));
+                            an[t][r] = tanhf(u);
+                        } else {
+                            an[t][r] = tanhf(za[t][r]);
+                        }
+                    }
+                }
+            }
+            lpr += lane_xor<16>(lpr);
+            lpr += lane_xor<32>(lpr);
+            if (w == 0) {
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) st4(N.ar + i16 * 32 + 16 * t + 4 * q, an[t]);
+            }
+        }
+        // ---- B: Q(s, a) and dQ/da through the frozen (already stepped) critic
+        const float dqv = sac ? -0.5f * invB : -invB;
+        f32x4 dq[NT3];                                                     // d loss / d a[16 t + 4 q + r] of this lane's row
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const SoloWX Xq{rec + R.obs_off[0], O, vs, (lds_cf)(N.ar + i16 * 32), A};
+            for (int hd = 0; hd < nq; ++hd) {
+                const LayerDesc* L = NC.L + 3 * hd;
+                N.stage_commit(pend);
+                pend = hd + 1 < nq ? N.stage_fetch(thC, NC.L + 3 * (hd + 1), 1, -1, 0) : N.stage_fetch((g_cf)thA, NA.L, NT3, NA.extra_off, NA.extra_n);
+                SoloWNet::DxRegs dxn = dxr;
+                if (hd + 1 < nq) dxn = N.input_bwd_fetch(thC + NC.L[3 * (hd + 1)].w_off, KB1c, ka0, nka);
+                f32x4 h1o[2], h2o[2], d2o[2], d1o[2];
+                N.forward<false>(thC + L[0].w_off, KB1c, Xq, h1o, h2o, h2f);
+                const float z = N.head_q(h2f);
+                if (valid) qrow += z;
+                N.head_bwd_q<false>(nullptr, L, valid ? dqv : 0.f, h2o, d2o);
+                N.hidden_bwd<false>(nullptr, L, KB1c, d2o, h1o, d1o);
+                N.input_bwd(dxr, nka, d1o);
+#pragma unroll
+                for (int t = 0; t < NT3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * t + 4 * q + r;
+                        if (c < A) dq[t][r] += N.dxa[i16 * 48 + (O + c) - 16 * ka0];
+                    }
+                dxr = dxn;
+            }
+        }
+        // ---- C: through a = tanh(.) into the actor; its activations are pass A's (own tiles in registers, h1 / s transposed in LDS)
+        N.stage_commit(pend);
+        f32x4 dz[NT3], gls[NT3];
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            dz[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gls[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * t + 4 * q + r;
+                if (valid && c < A) {
+                    const float av = an[t][r];
+                    if (sac) {                                             // through u = mean + exp(log_std) eps, and alpha log pi
+                        const float d = dq[t][r] * (1.f - av * av) + (alpha * invB) * (2.f * av);
+                        const float ls = fminf(fmaxf(lsv[t][r], -20.f), 2.f);
+                        dz[t][r] = d;
+                        gls[t][r] = d * expf(ls) * ep[t][r] - alpha * invB;
+                    } else {
+                        dz[t][r] = dq[t][r] * (1.f - av * av);
+                    }
+                }
+            }
+        }
+        f32x4 d2o[2], d1o[2];
+        N.head_bwd_a<NT3>(slab, NA.L, dz, ah2, d2o);
+        N.hidden_bwd<true>(slab, NA.L, KB1a, d2o, ah1, d1o);
+        // log_std's gradient of this row tile (zero outside the clamp [-20, 2], SAC.py:77) behind the net's layers
+        if (sac) {
+#pragma unroll
+            for (int t = 0; t < NT3; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * t + 4 * q + r;
+                    const float sgl = SoloNet::rows_sum(gls[t][r]);
+                    if (w == 0 && i16 == 0 && c < A) slab[NA.extra_off + c] = (lsv[t][r] >= -20.f && lsv[t][r] <= 2.f) ? sgl : 0.f;
+                }
+        }
+        lp = valid ? lpr : 0.f;
+        qrow = SoloNet::rows_sum(qrow);
+        lp = SoloNet::rows_sum(lp);
+        if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
+    }
+    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    SoloUpdate u;
+    u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
+    const float total = solow_update(s, a, u, grA, p, b, nb, N.red, s.bar_base + kSoloWG);
+    if (b == 0 && tid == 0) {
+        float qtot = 0.f, lptot = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            qtot += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lptot += __hip_atomic_load(part + k * kSoloPart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        steps[0] = t_new;
+        float* sts = D.stats + (size_t)p * ST_COUNT;
+        sts[ST_ACTOR_LOSS] = sac ? (-(qtot * 0.5f) + alpha * lptot) * invB : -qtot * invB;   // SAC.py:251: (alpha log pi - Q).mean()
+        sts[ST_ACTOR_GNORM] = total;
+        if (sac) {                                                         // alpha step on the batch's entropy (SAC.py:154-169,257-260)
+            float* al = D.alpha + p * 4;
+            const float ent_mean = -lptot * invB;
+            const float mean_term = ent_mean - a.target_entropy;
+            const float gl = alpha * mean_term;                            // d alpha_loss / d log_alpha
+            const int ta = steps[kMaxNets] + 1;
+            float mi = al[1], vi = al[2];
+            mi = mi + (gl - mi) * (1.f - a.beta1);
+            vi = vi * a.beta2 + ((1.f - a.beta2) * gl) * gl;
+            const double b1 = 1.0 - powi_d((double)a.beta1, ta), b2 = 1.0 - powi_d((double)a.beta2, ta);
+            const float denom = sqrtf(vi) / (float)sqrt(b2) + 1e-8f;
+            al[0] = al[0] - (float)((double)a.alpha_lr / b1) * (mi / denom);
+            al[1] = mi;
+            al[2] = vi;
+            al[3] = expf(al[0]);
+            steps[kMaxNets] = ta;
+            sts[ST_ALPHA_LOSS] = alpha * mean_term;
+            sts[ST_ALPHA] = al[3];
+            sts[ST_ENTROPY] = ent_mean;
+        }
+    }
+}
+
+#define FRL_SOLOW_ACTOR(name, nt3)                                                                                                   \
+    __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
+        solow_actor_body<nt3>(*Dp, a, s, smem);                                                                                     \
+    }
+FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1)
+FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2)
+
+}  // namespace frl

@@ -86,6 +86,33 @@ def test_sixteen_workgroups_per_learner_vs_rowchunk_at_population_size(N, case, 
         assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
 
 
+SOLOW_LDS = 4 * (64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + 26 * 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128)
+
+
+@pytest.mark.parametrize("case,P", [("sac_c4", 1), ("td3_wide", 3), ("ddpg_wide", 2), ("sac_100_7", 1), ("td3_201_12", 2), ("sac_380_20_b17", 1),
+                                    ("sac_380_20_b256", 16), ("sac_c4", 5)])
+def test_sixteen_workgroups_wide_first_layer_vs_rowchunk(N, case, P):
+    """kernels_solow.hip (round 6: a handful of learners with a first layer of up to 416 columns and heads of up to 32 outputs on
+    sixteen workgroups each, W1 streamed from the block) against the row-chunk kernels on the same injected indices and noise, own
+    parameters per learner, every array of every learner: config 4's dims at one and five learners, 25 k-tiles with 20 actions at a
+    FULL population of sixteen, one / seven / thirteen k-tiles, single and twin critics, ragged batches (200 rows; 17 rows = two
+    tiles, fourteen workgroups without rows)."""
+    from tests import family_ab as AB
+    calls = 5 if AB.CASES[case]["B"] < 64 else 20
+    a, b = AB.run(case, 0, calls, P), AB.run(case, None, calls, P)
+    assert not a["family"] and b["path"] == (True, SOLOW_LDS, 16), (a["path"], b["path"])
+    d = AB.diff(a, b)
+    st = d.pop("stats")
+    REPORT["solow/%s/P%d" % (case, P)] = dict(calls=calls, P=P, arrays={k: v[0] for k, v in d.items()}, arrays_q99={k: v[3] for k, v in d.items()},
+                                   loss_rel_first5=float(st[:5, :, :, :2].max()), loss_rel_all=float(st[:, :, :, :2].max()))
+    assert st[:5, :, :, :2].max() <= 1e-4, (case, st[:5, :, :, :2].max())
+    assert st[:, :, :, :2].max() <= 5e-3, (case, st[:, :, :, :2].max())
+    for key, (w, at, mx, q99) in d.items():
+        tol = TOL_THETA if key.startswith(("theta", "target", "act")) else TOL_MOMENT
+        assert q99 <= tol, "%s %s: 99th percentile of |diff| / max |x| = %.3e (max %.3e at flat index %d, |x| max %.3g)" % (case, key, q99, w, at, mx)
+        assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
+
+
 @pytest.mark.parametrize("case", ["sac_c4", "maddpg_c5", "td3_h256", "td3_narrow_b100"])
 def test_padding_stays_zero_and_unsampled_nonfinite_rows_are_inert(N, monkeypatch, case):
     """(1) frl_params_pad_max == 0 for theta / target / m / v of every net after 12 updates on the chained families; (2) the same run with
