@@ -8,13 +8,14 @@
 // of every 128-wide layer; partial gradients to per-workgroup slabs in image order, summed in workgroup order behind a flag
 // hand-over — with these differences:
 //   * W1 (up to 26 k-tiles x 8 output tiles = 208 KB) never sits in LDS: a wave's A fragments of the first layer (its two output
-//     tiles x every k-tile) go from the net's block (fragment-image order: one global_load_dwordx4 per lane and tile, L2-resident
-//     after the first workgroup) straight into registers, four k-tiles at a time, the next four in flight under the MFMAs of
-//     these.  The row operand needs no LDS either: lane (row, q) reads columns 16 kb + 4 q .. + 3 of its row from the replay
-//     record (one dwordx4 where the field starts on a 16-byte boundary, four dwords otherwise) or, for a policy's actions, from
-//     a 2 KB table of the tile's action rows in LDS.
-//   * dW1 of the wave's two output tiles = (x^T of the row tile) x (delta tiles): x^T is left in LDS by the forward (26 KB,
-//     written by the wave that holds k-tile kb & 3), 2 x KB1 tiles of four MFMAs each, stored straight to the slab.
+//     tiles x every k-tile) go from the net's block (fragment-image order: one global_load_dwordx4 per lane and tile) straight
+//     into registers, four k-tiles at a time, fetched two batches ahead of their MFMAs (the first two a whole pass ahead).
+//   * the tile's input rows sit in LDS ONCE, as fragment images (26 KB; wave w fetches the k-tiles kb = w mod 4 from the replay
+//     records — a field that starts off a 16-byte boundary as the two aligned dwordx4 around a fragment): read as stored they are
+//     the B operand of a first layer, read transposed (as a weight image is in a backward) the A operand of dW1.  The k-tiles
+//     that hold a policy's action columns are composed next to them ([s | a]: three tiles) for the critic passes on a = pi(s).
+//   * dW1 of the wave's two output tiles = (x^T of the row tile) x (delta tiles): 2 x KB1 tiles of four MFMAs each, stored
+//     straight to the slab.
 //   * actor heads of up to 32 outputs run as MFMA tiles (every wave computes the head of the tile's 16 rows: 64 MFMAs), their
 //     backward (dW3 = h2^T dz, d2 = W3^T dz) on the wave's own tiles with wave-local transposes.
 //   * dQ/da for the policy step: only the k-tiles of W1 that hold action columns (<= 3) are walked backward, one per wave,
@@ -24,17 +25,22 @@
 #pragma once
 #include "solo.hpp"
 
+#ifndef FRL_SOLOW_G
+#define FRL_SOLOW_G 4       // k-tiles of W1 per fetched batch of a first-layer pass (three batches live: 24 G registers)
+#endif
+#ifndef FRL_SOLOW_TOUCH
+#define FRL_SOLOW_TOUCH 0   // 1: warm the XCD's L2 with the first-layer blocks at the top of the kernel (SoloWNet::l2_touch; measured: nothing)
+#endif
+
 namespace frl {
 
 // (kSoloWMaxKB, solow_lds_floats(): frl_desc.h)
 
-// where the B operand of a first layer — this lane's row, input columns 16 kb + 4 q .. + 3 — comes from
+// where the input columns of a row tile come from: columns [0, ng) = the row's record from float `off` on, zero behind them
 struct SoloWX {
-    g_cf base;              // columns [0, ng): base[c] (the row's record + a field offset)
-    int ng;
-    bool vec;               // base is 16-byte aligned: a fragment inside [0, ng) is one dwordx4
-    lds_cf act;             // columns [ng, ng + na): act[c - ng] (this row's 32 floats of the action table)
-    int na;
+    g_cf rec;               // this lane's row: its record in the ring
+    int off, ng;
+    int stride;             // floats per record (a multiple of 4)
 };
 
 struct SoloWNet {
@@ -42,7 +48,10 @@ struct SoloWNet {
     lds_f ea, eb;           // activation / delta exchange, MFMA D layout: tile ft at ft * 256 + 4 * lane
     lds_f th1;              // h1 of the row tile, transposed fragment image (all 8 feature tiles): operand of dW2
     lds_f td;               // a delta's (or h2's) own tiles, transposed (wave-local)
-    lds_f tx;               // the input rows, transposed: k-tile kb at kb * 256 (operand of dW1)
+    lds_f xs;               // the tile's input rows as fragment images (k-tile kb at kb * 256: lane (row, q)'s columns 16 kb + 4 q .. + 3 at fslot):
+                            // B operand of a first layer (one ds_read_b128) AND, read transposed like a weight image, the A operand of dW1
+    lds_f xa;               // ... the k-tiles that hold a policy's action columns, [s | a] composed (<= 3 tiles), for the critic passes on them
+    lds_f zt;               // a tile of zeros: the rows of the k-tiles past a first layer's last one, in the sweeps' padded last batch
     lds_f tz;               // per wave: the head's dz tiles, transposed (operand of dW3)
     lds_f ar;               // [16 rows][32] the tile's policy / target-policy actions
     lds_f dxa;              // [16 rows][48] dQ/d(input columns of the action k-tiles)
@@ -60,11 +69,14 @@ struct SoloWNet {
         eb = p; p += kHT * 256;
         th1 = p; p += kHT * 256;
         td = p; p += kHT * 256;
-        tx = p; p += kSoloWMaxKB * 256;
+        xs = p; p += kSoloWMaxKB * 256;
+        xa = p; p += 3 * 256;
+        zt = p; p += 256;
         tz = p; p += 4 * 2 * 256;
         ar = p; p += 16 * 32;
         dxa = p; p += 16 * 48;
         red = p; p += 128;
+        zt[threadIdx.x] = 0.f;                                         // (visible behind the first stage_commit's barriers)
         C.S.w1 = ea; C.S.ea = ea; C.S.eb = eb; C.S.ab = ea; C.S.yb = ea; C.S.q1 = ea; C.S.lpn = ea; C.S.red = red;
         C.init_lanes();
     }
@@ -77,16 +89,53 @@ struct SoloWNet {
     __device__ __forceinline__ void put_d(lds_f E, int ft, const f32x4& t) const { st4(E + ft * 256 + 4 * C.l, t); }
     __device__ __forceinline__ f32x4 get_d(lds_cf E, int ft) const { return ld4(E + ft * 256 + 4 * C.l); }
 
-    __device__ __forceinline__ f32x4 xfrag(const SoloWX& X, int kb) const {
-        const int c0 = 16 * kb + 4 * C.q;
-        if (X.vec && c0 + 4 <= X.ng) return ld4(X.base + c0);
+    // ---- columns 16 kb + 4 q .. + 3 of this lane's row: every load unconditional (clamped inside the record, selected afterwards —
+    // a conditional load is a branch with its own wait: the first build's per-element conditions put sixteen L2 round trips in a
+    // row per batch of four k-tiles, 12 us per pass).  A field that starts off a 16-byte boundary (next_obs behind [obs | act |
+    // rew | done]) is read as the two aligned dwordx4 around the fragment
+    __device__ __forceinline__ f32x4 xload(const SoloWX& X, int kb) const {
+        const int c0 = 16 * kb + 4 * C.q, mis = X.off & 3;
         f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e;
-            v[e] = c < X.ng ? X.base[c] : (c - X.ng < X.na ? X.act[c - X.ng] : 0.f);
+        if (mis == 0) {
+            v = ld4(X.rec + min(X.off + c0, X.stride - 4));
+        } else {
+            const int fo = X.off - mis + c0;
+            const f32x4 lo = ld4(X.rec + min(fo, X.stride - 4)), hi = ld4(X.rec + min(fo + 4, X.stride - 4));
+            if (mis == 1) v = f32x4{lo[1], lo[2], lo[3], hi[0]};
+            else if (mis == 2) v = f32x4{lo[2], lo[3], hi[0], hi[1]};
+            else v = f32x4{lo[3], hi[0], hi[1], hi[2]};
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = c0 + e < X.ng ? v[e] : 0.f;
         return v;
+    }
+    // the tile's rows -> xs: wave w holds k-tiles kb = w (mod 4) (fetch: up to seven loads in flight; commit: behind a barrier that
+    // says every wave is done with the old rows, and in front of one — the caller's next stage_commit — before anybody reads)
+    struct XRegs { f32x4 v[(kSoloWMaxKB + 3) / 4]; };
+    __device__ __forceinline__ XRegs x_fetch(const SoloWX& X, int KB1) const {
+        XRegs R;
+#pragma unroll
+        for (int j = 0; j < (kSoloWMaxKB + 3) / 4; ++j) { const int kb = C.w + 4 * j; R.v[j] = xload(X, kb < KB1 ? kb : KB1 - 1); }
+        return R;
+    }
+    __device__ __forceinline__ void x_commit(const XRegs& R, int KB1) const {
+#pragma unroll
+        for (int j = 0; j < (kSoloWMaxKB + 3) / 4; ++j) { const int kb = C.w + 4 * j; if (kb < KB1) st4(xs + kb * 256 + C.fslot, R.v[j]); }
+    }
+    // xa <- the k-tiles ka0 .. ka0 + nka - 1 of [columns < O of xs | the A actions of this row in `ar` | 0] (wave j < nka: tile ka0 + j).
+    // xs and ar must be visible (a barrier in front), xa is visible behind the caller's next barrier.
+    __device__ __forceinline__ void xa_compose(int O, int A, int ka0, int nka) const {
+        if (C.w < nka) {
+            const int kb = ka0 + C.w, c0 = 16 * kb + 4 * C.q;
+            f32x4 v = ld4((lds_cf)(xs + kb * 256 + C.fslot));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e, j = c - O;
+                const float av = ar[C.i16 * 32 + (j < 0 ? 0 : (j > 31 ? 31 : j))];
+                v[e] = c < O ? v[e] : (j < A ? av : 0.f);
+            }
+            st4(xa + C.w * 256 + C.fslot, v);
+        }
     }
 
     // ---- layers 2 and 3 of one head -> LDS images (linear copies of the block's image order), the three biases, log_std.
@@ -118,59 +167,107 @@ struct SoloWNet {
         lds_barrier();
     }
 
-    // ---- first layer of the row tile: acc[x] (the bias on entry) += W1[tiles 2w + x] x, K = 16 KB1 columns, W1's fragments from
-    // the block.  KEEP: x is also left transposed in tx (k-tile kb by wave kb & 3)
-    template <bool KEEP>
-    __device__ __forceinline__ void l1(g_cf w1, int KB1, const SoloWX& X, f32x4 (&acc)[2]) const {
+    // ---- warm this XCD's L2 with a first-layer block the passes will stream (FRL_SOLOW_TOUCH: one dword of every 128-byte line, N
+    // per thread in flight at once, at the top of the kernel).  Measured: nothing — the sweeps below are not waiting for memory
+    template <int N>
+    __device__ __forceinline__ float l2_touch(g_cf p, int n_floats) const {
+        float t[N], acc = 0.f;
+        const int nl = n_floats >> 5;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { const int i = C.tid + kWG * k; t[k] = p[32 * (i < nl ? i : nl - 1)]; }
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc += t[k];
+        return acc;
+    }
+
+    // ---- first layer of the row tile: acc[x] (the bias on entry) += W1[tiles 2w + x] x, K = 16 KB1 columns: W1's fragments from
+    // the block, G k-tiles at a time; the rows from xs (k-tiles < ka), xa (the rest) and the zero tile (past the last one).
+    // The first two batches of a sweep are fetched a pass AHEAD (l1_fetch next to the stage_fetch of the same net).
+    // (k-tiles past the last one are NOT clamped: such a fragment is the head of the next tile row, or of the b1 / W2 that follow every
+    // W1 in its block — at most 3 G KB past the layer, finite numbers that meet the zero tile — and one base address per tile row
+    // with the k-tile as an immediate offset is all the address arithmetic a sweep has left)
+    template <int G>
+    struct L1Pre { f32x4 b0[2][G], b1[2][G]; };
+    template <int G>
+    __device__ __forceinline__ L1Pre<G> l1_fetch(g_cf w1, int KB1) const {
+        L1Pre<G> P;
+        g_cf p0 = w1 + ((size_t)(2 * C.w) * KB1 * 256 + C.fslot), p1 = p0 + (size_t)KB1 * 256;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { P.b0[0][g] = ld4(p0 + g * 256); P.b0[1][g] = ld4(p1 + g * 256); }
+        __builtin_amdgcn_sched_barrier(0);                             // (in this order, pinned: vmcnt counts in issue order)
+#pragma unroll
+        for (int g = 0; g < G; ++g) { P.b1[0][g] = ld4(p0 + (G + g) * 256); P.b1[1][g] = ld4(p1 + (G + g) * 256); }
+        __builtin_amdgcn_sched_barrier(0);
+        return P;
+    }
+    template <int G>
+    __device__ __forceinline__ void l1(g_cf w1, int KB1, int ka, f32x4 (&acc)[2], L1Pre<G>& P) const {
         const int w = C.w, fslot = C.fslot;
-        constexpr int G = 4;
-        f32x4 wf[2][G], xf[G], wn[2][G], xn[G];
-        auto load = [&](int kb0, f32x4 (&W)[2][G], f32x4 (&Xf)[G]) {
+        f32x4 (&b0)[2][G] = P.b0, (&b1)[2][G] = P.b1;
+        f32x4 b2[2][G];
+        g_cf nx0 = w1 + ((size_t)(2 * w) * KB1 * 256 + fslot) + G * 256, nx1 = nx0 + (size_t)KB1 * 256;      // (the batch in front of the next one fetched)
+        // One sweep = G k-tiles on the batch W, the batch two sweeps ahead fetched into Wn on the way: two fragment loads in front of
+        // each k-tile's eight MFMAs, so that their issue sits in the MFMAs' shadow (one wave per SIMD: nothing else would fill it).
+        // No branch and no select in here.  Measured on the way (tools/solow_timing.py, a 24-tile sweep, us): fragments fetched right
+        // in front of their MFMAs behind per-tile branches 5.7; one batch ahead 5.9 (the loop header drained everything: batches
+        // issued in the wrong order); two ahead, loads in front of the batch's 32 MFMAs and the padded tiles' rows zeroed by
+        // v_cndmask into ONE register 4.5 — of which the MFMAs alone 3.7 (46 cycles each: the select's write waits for the MFMA in
+        // front to have read the register) and the load phase alone 2.1; this form 3.8 (3.6 without the loads: 44 cycles per
+        // MFMA, the LDS round trip of a sweep's first rows; reading them a sweep ahead: 3.6 with loads, at 40 more registers: not kept).
+        auto sweep = [&](int kb0, const f32x4 (&W)[2][G], f32x4 (&Wn)[2][G]) {
+            f32x4 xf[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int kb = kb0 + g, kbc = kb < KB1 ? kb : KB1 - 1;
-#pragma unroll
-                for (int x = 0; x < 2; ++x) W[x][g] = ld4(w1 + ((size_t)((2 * w + x) * KB1 + kbc) * 256 + fslot));
-                Xf[g] = xfrag(X, kbc);
-                if (kb >= KB1) Xf[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int kb = kb0 + g;
+                xf[g] = ld4((lds_cf)((kb < ka ? xs + kb * 256 : (kb < KB1 ? xa + (kb - ka) * 256 : zt)) + fslot));
             }
-        };
-        load(0, wf, xf);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            xn[g] = xf[g];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) wn[x][g] = wf[x][g];
-        }
-        for (int kb0 = 0; kb0 < KB1; kb0 += G) {
-            if (kb0 + G < KB1) load(kb0 + G, wn, xn);
+            nx0 += G * 256; nx1 += G * 256;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if constexpr (KEEP) { if (g == w && kb0 + g < KB1) put_t(tx, kb0 + g, xf[g]); }
+#if defined(FRL_SOLOW_ABL) && (FRL_SOLOW_ABL & 1)
+                Wn[0][g] = W[0][g]; Wn[1][g] = W[1][g];                // (timing only: no fragment loads behind the first two batches)
+#else
+                Wn[0][g] = ld4(nx0 + g * 256); Wn[1][g] = ld4(nx1 + g * 256);
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x][g][e], xf[g][e], acc[x], 0, 0, 0);
+                    for (int x = 0; x < 2; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[x][g][e], xf[g][e], acc[x], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                     // (a k-tile's loads stay in front of its MFMAs: hipcc sinks them to their uses)
             }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                xf[g] = xn[g];
-#pragma unroll
-                for (int x = 0; x < 2; ++x) wf[x][g] = wn[x][g];
-            }
+        };
+        // three buffers in fixed roles, the loop unrolled by three: a batch is fetched TWO sweeps ahead of its use (a rotation by
+        // register moves made every sweep wait for the batch fetched at its own top: one ahead again)
+#ifdef FRL_SOLO_TIMING
+        if (threadIdx.x == 0) red[121] = (float)(unsigned)(wall_clock64() & 0xFFFFFFull);
+#endif
+        for (int kb0 = 0; kb0 < KB1; kb0 += 3 * G) {
+            sweep(kb0, b0, b2);
+#ifdef FRL_SOLO_TIMING
+            if (threadIdx.x == 0 && kb0 == 0) red[122] = (float)(unsigned)(wall_clock64() & 0xFFFFFFull);
+#endif
+            if (kb0 + G >= KB1) break;
+            sweep(kb0 + G, b1, b0);
+            if (kb0 + 2 * G >= KB1) break;
+            sweep(kb0 + 2 * G, b2, b1);
         }
     }
 
-    // ---- forward of the row tile through the staged head (W2 / W3 images in LDS, W1 from the block w1).  Out: the wave's own tiles
-    // of h1 / h2 (ReLU masks of a backward) and h2 of all tiles (D layout).  KEEP: h1 is also left transposed in th1 and x in tx.
+    // ---- forward of the row tile through the staged head (W2 / W3 images in LDS, W1 from the block w1, rows in xs / xa).  Out: the
+    // wave's own tiles of h1 / h2 (ReLU masks of a backward) and h2 of all tiles (D layout).  KEEP: h1 is also left transposed in th1.
+    typedef L1Pre<FRL_SOLOW_G> Pre;
+    __device__ __forceinline__ Pre pre_fetch(g_cf w1, int KB1) const { return l1_fetch<FRL_SOLOW_G>(w1, KB1); }
     template <bool KEEP>
-    __device__ __forceinline__ void forward(g_cf w1, int KB1, const SoloWX& X, f32x4 (&h1o)[2], f32x4 (&h2o)[2], f32x4 (&h2f)[kHT]) const {
+    __device__ __forceinline__ void forward(g_cf w1, int KB1, int ka, Pre& P, f32x4 (&h1o)[2], f32x4 (&h2o)[2], f32x4 (&h2f)[kHT]) const {
         const ChainLds& S = C.S;
         const int w = C.w, q = C.q, fslot = C.fslot;
         f32x4 acc[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) acc[x] = ld4((lds_cf)(S.b1 + (2 * w + x) * 16 + 4 * q));
-        l1<KEEP>(w1, KB1, X, acc);
+        l1<FRL_SOLOW_G>(w1, KB1, ka, acc, P);
+#ifdef FRL_SOLO_TIMING
+        if (threadIdx.x == 0) red[120] = (float)(unsigned)(wall_clock64() & 0xFFFFFFull);      // (tools/solow_timing.py: end of the last first-layer sweep)
+#endif
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
 #pragma unroll
@@ -294,7 +391,7 @@ struct SoloWNet {
     }
 
     // ---- layers 2 and 1 of a backward from the own tiles' d2o.  WG: dW2 / db2 / dW1 / db1 of the wave's output tiles -> slab
-    // (needs forward<true>: th1, tx).  Returns d1o (own tiles, through the ReLU of h1).
+    // (needs forward<true>: th1; the pass's rows in xs).  Returns d1o (own tiles, through the ReLU of h1).
     template <bool WG>
     __device__ __forceinline__ void hidden_bwd(g_f hs, const LayerDesc* L, int KB1, const f32x4 (&d2o)[2], const f32x4 (&h1o)[2], f32x4 (&d1o)[2]) const {
         const ChainLds& S = C.S;
@@ -346,7 +443,9 @@ struct SoloWNet {
                 if (q == 0) hs[L[0].b_off + ot * 16 + i16] = gb;
             }
             for (int kt = 0; kt < KB1; ++kt) {
-                const f32x4 xt = get_t(tx, kt);
+                f32x4 xt;                                                         // x^T of k-tile kt: rows 4q .. 4q + 3 of column 16 kt + i16
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xt[e] = xs[kt * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
                     st4_slab(hs + L[0].w_off + ((size_t)((2 * w + x) * KB1 + kt) * 256 + fslot), mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af[x]));
@@ -385,9 +484,14 @@ struct SoloWNet {
 // (EngineDesc::grad), partial squared norm; the sixteen partial norms meet through the mailboxes of solo_update; phase 2: clip
 // coefficient, Adam, soft update.  Returns the gradient norm.
 __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int p, int b, int nb, lds_f red,
-                                              unsigned bar2_target) {
+                                              unsigned bar2_target
+#ifdef FRL_SOLO_TIMING
+                                              , unsigned long long solo_t0_
+#endif
+                                              ) {
     constexpr int W = kSoloWG, KM = 3;
     const int tid = threadIdx.x;
+    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const int n4 = u.size >> 2, per = (n4 + W - 1) / W, i0 = b * per, i1 = min(n4, i0 + per);
     g_cf slab = as_global(s.slab + (size_t)p * kSoloWG * s.slab_stride);
     float ss = 0.f;
@@ -425,7 +529,7 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
     sync_stores();                                                         // (phase 2 reads gsum back: the stores are acknowledged)
     if ((tid & 63) == 0) red[64 + (tid >> 6)] = ss;
     __syncthreads();
-    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    SOLO_T(5);
     typedef unsigned long long u64;
     if (tid == 0) {
         const float mine = ((red[64] + red[65]) + red[66]) + red[67];
@@ -443,6 +547,7 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
         red[80 + tid] = __uint_as_float((unsigned)v);
     }
     __syncthreads();
+    SOLO_T(6);
     float tot = 0.f;
 #pragma unroll
     for (int sb = 0; sb < W; ++sb) tot += red[80 + sb];

@@ -1444,7 +1444,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         return;
     }
     if (stage == 0) {
-        if (dev_rng && !(v2 && h.solo)) {                 // (kernels_solo.hip draws inside its critic stage)
+        if (dev_rng && !(v2 && (h.solo || h.solow))) {    // (kernels_solo.hip / kernels_solow.hip draw inside their critic stages)
             prof_begin(e, PK_DRAW);
             hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)2 * ((a.batch + 3) & ~3) * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
             prof_end(e);
@@ -1758,7 +1758,7 @@ extern "C" int frl_learn_work_executed(const frl_engine* e, int batch, int do_ac
 // kernels_solo.hip, their section stamps — [kSoloWG][32] floats of learner 0
 extern "C" int frl_solo_debug_read(frl_engine* e, float* out_host, int n_floats) {
     ENG(e);
-    if (!e->h.solo || !e->d_solo_part || !out_host || n_floats < 0 || n_floats > kSoloWG * kSoloPartHost) return fail(FRL_ERR_STATE, "not a solo engine / bad size");
+    if (!(e->h.solo || e->h.solow) || !e->d_solo_part || !out_host || n_floats < 0 || n_floats > kSoloWG * kSoloPartHost) return fail(FRL_ERR_STATE, "not a solo engine / bad size");
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(out_host, e->d_solo_part, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return FRL_OK;

@@ -52,7 +52,7 @@ constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 12
 
 // ... and its form for wide first layers / heads of up to 32 outputs (device/solo_wide.hpp, kernels_solow.hip): W1 stays in the block
 constexpr int kSoloWMaxKB = 26;          // first layer: <= 416 input columns
-constexpr int solow_lds_floats() { return 64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + kSoloWMaxKB * 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128; }
+constexpr int solow_lds_floats() { return 64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + kSoloWMaxKB * 256 + 3 * 256 + 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128; }
 
 // The K-sliced chained family (device/chain_wide.hpp)
 constexpr int kWideSliceKB = 4;          // k-blocks of W1 per streamed slice (4 x 8 tiles x 1 KB = 32 KB)

@@ -4,12 +4,14 @@
 // The critic stage — TD target with the target nets, critic forward / backward, clip, Adam, soft update: DDPG_simple.py:139-149,
 // TD3.py:193-213,235-244, SAC.py:226-238 — and the actor stage — a = actor(s), Q(s, a) through the updated critic, dQ/da, actor
 // backward, clip, Adam, soft update, SAC's alpha step: DDPG_simple.py:151-154, TD3.py:224-233, SAC.py:244-260 — one launch each,
-// behind draw_kernel (the batch's rows and noise sets in EngineDesc::idx / noise, as for the K-sliced family).  Same arithmetic per
+// the batch's rows drawn inside the critic launch and the noise sets regenerated where they are used (kernels_solo.hip's way; the same
+// bits as draw_kernel's EngineDesc::idx / noise, which are read instead when the caller uploaded them).  Same arithmetic per
 // row as kernels_criticw.hip / kernels_actorw.hip; the decomposition is kernels_solo.hip's.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
 #include "device/solo_wide.hpp"
+#include "device/rng.hpp"
 
 namespace frl {
 
@@ -39,7 +41,9 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
     const float invB = 1.f / (float)B;
     const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
+    const int ka0 = O >> 4, nka = KB1c - ka0;                              // the k-tiles of the critic's first layer that hold action columns (<= 3)
     const int t_new = steps[1] + 1;                    // read by every workgroup before the hand-over; rewritten behind the mailboxes
+    SOLO_T0();
 
     float lossp = 0.f;
     if (b < nb) {
@@ -50,8 +54,29 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
         const int row = 16 * b + i16, rc = row < B ? row : B - 1;
         const bool valid = row < B;
+        // (26 k-tiles x 8 x 256 floats = 1664 lines of 128 B: 7 per thread)
+        float warm = 0.f;
+        if constexpr (FRL_SOLOW_TOUCH) {
+            warm = N.l2_touch<7>(tgA + NA.L[0].w_off, KB1a * kHT * 256);
+#pragma unroll
+            for (int hd = 0; hd < NH; ++hd) warm += N.l2_touch<7>((g_cf)tgC + NC.L[3 * hd].w_off, KB1c * kHT * 256) + N.l2_touch<7>((g_cf)thC + NC.L[3 * hd].w_off, KB1c * kHT * 256);
+        }
         SoloWNet::Stage pend = N.stage_fetch(tgA, NA.L, NT3, NA.extra_off, NA.extra_n);
-        g_cf rec = ring + (size_t)idx[rc] * R.stride;
+        SoloWNet::Pre pre = N.pre_fetch(tgA + NA.L[0].w_off, KB1a), pren;
+        const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
+        int ri;
+        if (a.device_rng) {
+            // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
+            // rejection in its own LDS: ~3 us against a 13 us launch in front of this one) and keeps its tile's; they all write the same
+            // values to D.idx (the actor stage and frl_last_indices read them)
+            FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
+            draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key, false);
+            ri = lidx[rc];
+        } else {
+            ri = idx[rc];
+        }
+        g_cf rec = ring + (size_t)ri * R.stride;
+        SoloWNet::XRegs xr = N.x_fetch(SoloWX{rec, R.nobs_off[0], O, R.stride}, KB1c);     // s' (zero behind its O columns)
         const float rew = rec[R.rew_off], done = rec[R.done_off];
         f32x4 nz[NT3];
 #pragma unroll
@@ -59,17 +84,25 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * t + 4 * q + r;
-                nz[t][r] = (c < A && (sac || a.use_policy_noise)) ? noise0[(size_t)rc * am + c] : 0.f;
+                nz[t][r] = 0.f;
+                if (c < A && (sac || a.use_policy_noise)) {
+                    const unsigned e1 = (unsigned)(rc * am + c);
+                    if (a.device_rng) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, key), n0, n1); nz[t][r] = n0; }      // = draw_kernel's set 0
+                    else nz[t][r] = noise0[e1];
+                }
             }
-        const bool vs = (R.stride & 3) == 0;
+        N.x_commit(xr, KB1c);
         N.stage_commit(pend);
+        if (FRL_SOLOW_TOUCH && warm == 1.2345e38f) N.red[127] = warm;         // (keeps the touches: never true for sums of finite weights)
+        SOLO_T(0);
         pend = N.stage_fetch((g_cf)tgC, NC.L, 1, -1, 0);
+        pren = N.pre_fetch((g_cf)tgC + NC.L[0].w_off, KB1c);
+        xr = N.x_fetch(SoloWX{rec, R.obs_off[0], O + A, R.stride}, KB1c);                  // [s | a]: the record's first O + A columns, for the training passes
         // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
         f32x4 h1o[2], h2o[2], h2f[kHT];
         float lp = 0.f;
         {
-            const SoloWX Xn{rec + R.nobs_off[0], O, vs && (R.nobs_off[0] & 3) == 0, nullptr, 0};
-            N.forward<false>(tgA + NA.L[0].w_off, KB1a, Xn, h1o, h2o, h2f);
+            N.forward<false>(tgA + NA.L[0].w_off, KB1a, KB1a, pre, h1o, h2o, h2f);
             f32x4 z[NT3], an[NT3];
             N.head_tiles<NT3>(h2f, z);
 #pragma unroll
@@ -100,33 +133,40 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
             }
             lp += lane_xor<16>(lp);
             lp += lane_xor<32>(lp);
-            if (w == 0) {                                  // the tile's action rows (every wave holds the same values); read behind the next commit's barriers
+            if (w == 0) {                                  // the tile's action rows (every wave holds the same values)
 #pragma unroll
                 for (int t = 0; t < NT3; ++t) st4(N.ar + i16 * 32 + 16 * t + 4 * q, an[t]);
             }
+            lds_barrier();
+            N.xa_compose(O, A, ka0, nka);                  // [s' | a'] of the action k-tiles; read behind the next commit's barriers
         }
+        SOLO_T(1);
         // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi)
         float qmin = 0.f;
         {
-            const SoloWX Xc{rec + R.nobs_off[0], O, vs && (R.nobs_off[0] & 3) == 0, (lds_cf)(N.ar + i16 * 32), A};
 #pragma unroll
             for (int hd = 0; hd < NH; ++hd) {
                 N.stage_commit(pend);
+                pre = pren;
                 pend = hd + 1 < NH ? N.stage_fetch((g_cf)tgC, NC.L + 3 * (hd + 1), 1, -1, 0) : N.stage_fetch((g_cf)thC, NC.L, 1, -1, 0);
-                N.forward<false>((g_cf)tgC + NC.L[3 * hd].w_off, KB1c, Xc, h1o, h2o, h2f);
+                pren = N.pre_fetch(hd + 1 < NH ? (g_cf)tgC + NC.L[3 * (hd + 1)].w_off : (g_cf)thC + NC.L[0].w_off, KB1c);
+                N.forward<false>((g_cf)tgC + NC.L[3 * hd].w_off, KB1c, ka0, pre, h1o, h2o, h2f);
                 const float qv = N.head_q(h2f);
                 qmin = hd == 0 ? qv : fminf(qmin, qv);
             }
         }
+        SOLO_T(2);
         const float y = sac ? rew + a.gamma * (1.f - done) * (qmin + alpha * (-lp)) : rew + a.gamma * qmin * (1.f - done);
-        // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab.  [s | a] are the record's first O + A columns
-        const SoloWX Xs{rec + R.obs_off[0], O + A, vs && (R.obs_off[0] & 3) == 0, nullptr, 0};
+        // ---- the critic's heads: forward, TD delta, backward -> this workgroup's slab, on [s | a] (every wave is behind the
+        // first-layer reads of the last target pass: its two barriers)
+        N.x_commit(xr, KB1c);
 #pragma unroll
         for (int hd = 0; hd < NH; ++hd) {
             const LayerDesc* L = NC.L + 3 * hd;
             N.stage_commit(pend);
-            if (hd + 1 < NH) pend = N.stage_fetch((g_cf)thC, NC.L + 3 * (hd + 1), 1, -1, 0);
-            N.forward<true>((g_cf)thC + L[0].w_off, KB1c, Xs, h1o, h2o, h2f);
+            pre = pren;
+            if (hd + 1 < NH) { pend = N.stage_fetch((g_cf)thC, NC.L + 3 * (hd + 1), 1, -1, 0); pren = N.pre_fetch((g_cf)thC + NC.L[3 * (hd + 1)].w_off, KB1c); }
+            N.forward<true>((g_cf)thC + L[0].w_off, KB1c, KB1c, pre, h1o, h2o, h2f);
             const float z = N.head_q(h2f);
             float dz = 0.f;
             if (valid) {
@@ -142,12 +182,15 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         lossp = SoloNet::rows_sum(lossp);
         if (tid == 0) part[b * kSoloPart + 0] = lossp;
     }
+    SOLO_T(3);
     solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
     u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
     u.t_new = t_new;
-    const float total = solow_update(s, a, u, grC, p, b, nb, N.red, s.bar_base + kSoloWG);
+    const float total = solow_update(s, a, u, grC, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    SOLO_T(7);
     if (b == 0 && tid == 0) {
         float loss = 0.f;
         for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,7 +240,8 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
     const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
-    const int ka0 = O >> 4, nka = ((O + A - 1) >> 4) - ka0 + 1;            // the k-tiles of the critic's first layer that hold action columns (<= 3)
+    const int ka0 = O >> 4, nka = KB1c - ka0;                              // the k-tiles of the critic's first layer that hold action columns (<= 3)
+    SOLO_T0();
 
     float qrow = 0.f, lp = 0.f;
     if (b < nb) {
@@ -207,28 +251,44 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + b) * s.slab_stride);
         const int row = 16 * b + i16, rc = row < B ? row : B - 1;
         const bool valid = row < B;
+        float warm = 0.f;
+        if constexpr (FRL_SOLOW_TOUCH) {
+            warm = N.l2_touch<7>((g_cf)thA + NA.L[0].w_off, KB1a * kHT * 256);
+            for (int hd = 0; hd < nq; ++hd) warm += N.l2_touch<7>(thC + NC.L[3 * hd].w_off, KB1c * kHT * 256);
+        }
         SoloWNet::Stage pend = N.stage_fetch((g_cf)thA, NA.L, NT3, NA.extra_off, NA.extra_n);
+        SoloWNet::Pre pre = N.pre_fetch((g_cf)thA + NA.L[0].w_off, KB1a), pren;
         g_cf rec = ring + (size_t)idx[rc] * R.stride;
+        const SoloWNet::XRegs xr = N.x_fetch(SoloWX{rec, R.obs_off[0], O, R.stride}, KB1c);       // s (zero behind its O columns)
         f32x4 ep[NT3];
 #pragma unroll
         for (int t = 0; t < NT3; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * t + 4 * q + r;
-                ep[t][r] = (sac && c < A) ? noise1[(size_t)rc * am + c] : 0.f;
+                ep[t][r] = 0.f;
+                if (sac && c < A) {
+                    const unsigned e1 = (unsigned)(rc * am + c);
+                    if (a.device_rng) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, D.seed + 0x9E3779B97F4A7C15ull * (p + 1)), n0, n1); ep[t][r] = n1; }   // = draw_kernel's set 1
+                    else ep[t][r] = noise1[e1];
+                }
             }
-        const bool vs = (R.stride & 3) == 0 && (R.obs_off[0] & 3) == 0;
+        N.x_commit(xr, KB1c);
         N.stage_commit(pend);
+        if (FRL_SOLOW_TOUCH && warm == 1.2345e38f) N.red[127] = warm;         // (keeps the touches: never true for sums of finite weights)
+        SOLO_T(0);
         pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
+        pren = N.pre_fetch(thC + NC.L[0].w_off, KB1c);
         SoloWNet::DxRegs dxr = N.input_bwd_fetch(thC + NC.L[0].w_off, KB1c, ka0, nka);
         // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
         f32x4 ah1[2], ah2[2], h2f[kHT], an[NT3], lsv[NT3];
         float lpr = 0.f;
         {
-            const SoloWX Xo{rec + R.obs_off[0], O, vs, nullptr, 0};
-            N.forward<true>((g_cf)thA + NA.L[0].w_off, KB1a, Xo, ah1, ah2, h2f);   // (th1 / tx keep the actor's h1 and s for pass C: pass B leaves them alone)
+            N.forward<true>((g_cf)thA + NA.L[0].w_off, KB1a, KB1a, pre, ah1, ah2, h2f);   // (th1 / xs keep the actor's h1 and s for pass C: pass B leaves them alone)
+            SOLO_T(9);
             f32x4 za[NT3];
             N.head_tiles<NT3>(h2f, za);
+            SOLO_T(10);
 #pragma unroll
             for (int t = 0; t < NT3; ++t) {
                 an[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -252,26 +312,37 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
             }
             lpr += lane_xor<16>(lpr);
             lpr += lane_xor<32>(lpr);
+            SOLO_T(11);
             if (w == 0) {
 #pragma unroll
                 for (int t = 0; t < NT3; ++t) st4(N.ar + i16 * 32 + 16 * t + 4 * q, an[t]);
             }
+            lds_barrier();
+            N.xa_compose(O, A, ka0, nka);                  // [s | a] of the action k-tiles; read behind the next commit's barriers
         }
+        SOLO_T(1);
+#ifdef FRL_SOLO_TIMING
+        if (tid == 0) {
+            part[b * kSoloPart + 8 + 8] = (float)(((unsigned)N.red[120] - (unsigned)(solo_t0_ & 0xFFFFFFull)) & 0xFFFFFFu);   // pass A: its first layer done
+            part[b * kSoloPart + 8 + 12] = (float)(((unsigned)N.red[121] - (unsigned)(solo_t0_ & 0xFFFFFFull)) & 0xFFFFFFu);  // ... entered
+            part[b * kSoloPart + 8 + 13] = (float)(((unsigned)N.red[122] - (unsigned)(solo_t0_ & 0xFFFFFFull)) & 0xFFFFFFu);  // ... first batch swept
+        }
+#endif
         // ---- B: Q(s, a) and dQ/da through the frozen (already stepped) critic
         const float dqv = sac ? -0.5f * invB : -invB;
         f32x4 dq[NT3];                                                     // d loss / d a[16 t + 4 q + r] of this lane's row
 #pragma unroll
         for (int t = 0; t < NT3; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            const SoloWX Xq{rec + R.obs_off[0], O, vs, (lds_cf)(N.ar + i16 * 32), A};
             for (int hd = 0; hd < nq; ++hd) {
                 const LayerDesc* L = NC.L + 3 * hd;
                 N.stage_commit(pend);
+                pre = pren;
                 pend = hd + 1 < nq ? N.stage_fetch(thC, NC.L + 3 * (hd + 1), 1, -1, 0) : N.stage_fetch((g_cf)thA, NA.L, NT3, NA.extra_off, NA.extra_n);
                 SoloWNet::DxRegs dxn = dxr;
-                if (hd + 1 < nq) dxn = N.input_bwd_fetch(thC + NC.L[3 * (hd + 1)].w_off, KB1c, ka0, nka);
+                if (hd + 1 < nq) { dxn = N.input_bwd_fetch(thC + NC.L[3 * (hd + 1)].w_off, KB1c, ka0, nka); pren = N.pre_fetch(thC + NC.L[3 * (hd + 1)].w_off, KB1c); }
                 f32x4 h1o[2], h2o[2], d2o[2], d1o[2];
-                N.forward<false>(thC + L[0].w_off, KB1c, Xq, h1o, h2o, h2f);
+                N.forward<false>(thC + L[0].w_off, KB1c, ka0, pre, h1o, h2o, h2f);
                 const float z = N.head_q(h2f);
                 if (valid) qrow += z;
                 N.head_bwd_q<false>(nullptr, L, valid ? dqv : 0.f, h2o, d2o);
@@ -287,6 +358,7 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
                 dxr = dxn;
             }
         }
+        SOLO_T(2);
         // ---- C: through a = tanh(.) into the actor; its activations are pass A's (own tiles in registers, h1 / s transposed in LDS)
         N.stage_commit(pend);
         f32x4 dz[NT3], gls[NT3];
@@ -329,10 +401,13 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         lp = SoloNet::rows_sum(lp);
         if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
     }
+    SOLO_T(3);
     solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    SOLO_T(4);
     SoloUpdate u;
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solow_update(s, a, u, grA, p, b, nb, N.red, s.bar_base + kSoloWG);
+    const float total = solow_update(s, a, u, grA, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;
         for (int k = 0; k < nb; ++k) {

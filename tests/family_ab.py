@@ -35,7 +35,7 @@ CASES = {
 }
 
 
-def run(name, family, calls, P=2):
+def run(name, family, calls, P=2, device_rng=False):
     c = CASES[name]
     old = os.environ.get("FRL_CRITIC_V2")
     if family is None:                         # nothing forced: up to sixteen learners of the narrow shape take kernels_solo.hip
@@ -62,7 +62,7 @@ def run(name, family, calls, P=2):
     e.fill_synthetic(3000, seed=5)
     na = e.n_agents
     am = max(c["act"]) if isinstance(c["act"], list) else c["act"]
-    stats = []
+    stats, rows_drawn = [], []
     for k in range(calls):
         idx = np.stack([[g.choice(3000, c["B"], replace=False) for _ in range(na)] for _ in range(P)]).astype(np.int64)
         noise = g.standard_normal((P, na, max(2, na), c["B"], am)).astype(np.float32)
@@ -74,10 +74,16 @@ def run(name, family, calls, P=2):
         if c.get("matd3"):
             kw = dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0, do_actor=(k % 2 == 1))
         need_noise = c["algo"] in (N.ALGO_TD3, N.ALGO_SAC) or c.get("matd3")
-        st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx if na > 1 else idx[:, 0],
-                     noise=noise if need_noise else None, want_stats=True, **kw)
+        if device_rng:              # the engine draws rows and noise itself (Philox): the same bits whatever family runs the update
+            st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, want_stats=True, **kw)
+            rows_drawn.append(e.last_indices(c["B"]).copy())
+        else:
+            st = e.learn(c["B"], gamma=0.99, tau=0.01, actor_lr=1e-3, critic_lr=1e-3, idx=idx if na > 1 else idx[:, 0],
+                         noise=noise if need_noise else None, want_stats=True, **kw)
         stats.append(st.copy())
     out = dict(stats=np.stack(stats), family=e.learn_path(c["B"])[0], path=e.learn_path(c["B"]))
+    if device_rng:
+        out["rows_drawn"] = np.stack(rows_drawn)
     for net in range(e.n_nets):
         for kind, nm in ((N.PARAM_ONLINE, "theta"), (N.PARAM_TARGET, "target"), (N.PARAM_ADAM_M, "m"), (N.PARAM_ADAM_V, "v")):
             out["%s%d" % (nm, net)] = np.stack([e.get_params(net, kind, learner=p) for p in range(P)])
@@ -98,7 +104,7 @@ def diff(a, b):
     are large in BOTH families against the oracle and say nothing (the oracle tests hold each family to it)."""
     out = {}
     for key in sorted(a):
-        if key in ("stats", "family", "layers", "path"):
+        if key in ("stats", "family", "layers", "path", "rows_drawn"):
             continue
         x, y = a[key], b[key]
         rel = np.abs(x - y) / (np.abs(x).max() + 1e-30)

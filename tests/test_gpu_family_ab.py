@@ -86,7 +86,7 @@ def test_sixteen_workgroups_per_learner_vs_rowchunk_at_population_size(N, case, 
         assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
 
 
-SOLOW_LDS = 4 * (64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + 26 * 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128)
+SOLOW_LDS = 4 * (64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + 26 * 256 + 3 * 256 + 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128)
 
 
 @pytest.mark.parametrize("case,P", [("sac_c4", 1), ("td3_wide", 3), ("ddpg_wide", 2), ("sac_100_7", 1), ("td3_201_12", 2), ("sac_380_20_b17", 1),
@@ -111,6 +111,24 @@ def test_sixteen_workgroups_wide_first_layer_vs_rowchunk(N, case, P):
         tol = TOL_THETA if key.startswith(("theta", "target", "act")) else TOL_MOMENT
         assert q99 <= tol, "%s %s: 99th percentile of |diff| / max |x| = %.3e (max %.3e at flat index %d, |x| max %.3g)" % (case, key, q99, w, at, mx)
         assert w <= 5e-2, "%s %s: max |diff| / max |x| = %.3e at flat index %d (|x| max %.3g)" % (case, key, w, at, mx)
+
+
+@pytest.mark.parametrize("case,P", [("sac_c4", 2), ("td3_wide", 1), ("sac_380_20_b17", 3)])
+def test_wide_first_layer_device_draws_are_the_rowchunk_chain_s(N, case, P):
+    """kernels_solow.hip draws the batch's rows inside its critic launch and regenerates the noise sets where they are used; the
+    row-chunk chain has draw_kernel write both to EngineDesc::idx / noise.  Same seed, no injected rows: the rows of every call are
+    identical and the updates agree as in the injected-rows test."""
+    from tests import family_ab as AB
+    calls = 6
+    a, b = AB.run(case, 0, calls, P, device_rng=True), AB.run(case, None, calls, P, device_rng=True)
+    assert not a["family"] and b["path"] == (True, SOLOW_LDS, 16), (a["path"], b["path"])
+    assert np.array_equal(a["rows_drawn"], b["rows_drawn"])
+    d = AB.diff(a, b)
+    st = d.pop("stats")
+    assert st[:5, :, :, :2].max() <= 1e-4, (case, st[:5, :, :, :2].max())
+    for key, (w, at, mx, q99) in d.items():
+        tol = TOL_THETA if key.startswith(("theta", "target", "act")) else TOL_MOMENT
+        assert q99 <= tol and w <= 5e-2, "%s %s: |diff| / max |x|: 99th percentile %.3e, max %.3e at flat index %d" % (case, key, q99, w, at)
 
 
 @pytest.mark.parametrize("case", ["sac_c4", "maddpg_c5", "td3_h256", "td3_narrow_b100"])
