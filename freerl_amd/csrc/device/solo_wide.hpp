@@ -480,19 +480,42 @@ struct SoloWNet {
     }
 };
 
-// ---- behind the slab hand-over: this workgroup's sixteenth of a net of any size — phase 1: slab sum in workgroup order -> gsum
+// ---- "the learner's sixteen slabs are written" (solo.hpp: solo_grid_sync) with HELPER workgroups: b >= kSoloWG has no row tile and
+// publishes nothing — it waits for the sixteen flags like the others and takes its share of the update
+__device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
+    sync_stores();
+    if (threadIdx.x == 0 && b < kSoloWG) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((int)threadIdx.x < kSoloWG) {
+        const unsigned long long t0 = wall_clock64();                      // 100 MHz
+        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
+
+// ---- behind the slab hand-over: this workgroup's share (one Wt-th: the learner's sixteen workgroups and its Wt - 16 helpers — a
+// CU pulls ~65 GB/s of slabs through the fabric, three dependent round trips per workgroup for the twin critic of config 4 on
+// sixteen: 8.4 us, and the other 240 CUs idle) of a net of any size — phase 1: slab sum in workgroup order -> gsum
 // (EngineDesc::grad), partial squared norm; the sixteen partial norms meet through the mailboxes of solo_update; phase 2: clip
 // coefficient, Adam, soft update.  Returns the gradient norm.
-__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int p, int b, int nb, lds_f red,
-                                              unsigned bar2_target
+__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int p, int b, int nb, int Wt, lds_f red,
+                                              lds_f box, unsigned bar2_target
 #ifdef FRL_SOLO_TIMING
                                               , unsigned long long solo_t0_
 #endif
                                               ) {
     constexpr int W = kSoloWG, KM = 3;
     const int tid = threadIdx.x;
-    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
-    const int n4 = u.size >> 2, per = (n4 + W - 1) / W, i0 = b * per, i1 = min(n4, i0 + per);
+    float* part = s.part + ((size_t)p * Wt) * kSoloPart;
+    const int n4 = u.size >> 2, per = (n4 + Wt - 1) / Wt, i0 = b * per, i1 = min(n4, i0 + per);
     g_cf slab = as_global(s.slab + (size_t)p * kSoloWG * s.slab_stride);
     float ss = 0.f;
     for (int c0 = i0; c0 < i1; c0 += kWG * KM) {
@@ -535,22 +558,22 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
         const float mine = ((red[64] + red[65]) + red[66]) + red[67];
         __hip_atomic_store((u64*)(part + b * kSoloPart + 2), ((u64)bar2_target << 32) | (u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < W) {
-        const u64* box = (const u64*)(part + tid * kSoloPart + 2);
+    if (tid < Wt) {
+        const u64* mbox = (const u64*)(part + tid * kSoloPart + 2);
         const unsigned long long t0 = wall_clock64();
-        u64 v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 v = __hip_atomic_load(mbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((unsigned)(v >> 32) != bar2_target) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) { *s.err = 1; break; }
-            v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(mbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        red[80 + tid] = __uint_as_float((unsigned)v);
+        box[tid] = __uint_as_float((unsigned)v);
     }
     __syncthreads();
     SOLO_T(6);
     float tot = 0.f;
 #pragma unroll
-    for (int sb = 0; sb < W; ++sb) tot += red[80 + sb];
+    for (int sb = 0; sb < Wt; ++sb) tot += box[sb];                       // (workgroup order: the same sum in every workgroup)
     const float total = sqrtf(tot);
     const float coef = a.clip_norm > 0.f ? fminf(a.clip_norm / (total + 1e-6f), 1.f) : 1.f;
     const double bc1 = 1.0 - powi_d((double)a.beta1, u.t_new), bc2 = 1.0 - powi_d((double)a.beta2, u.t_new);

@@ -104,6 +104,7 @@ struct frl_engine {
     int* d_solo_ticket = nullptr;         // the rollout tail's learner ticket
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
     int solo_stride = 0;
+    int solow_wgs = 0;                    // kernels_solow.hip: workgroups per learner in its grids (16 + helpers for the update)
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
     float* d_act_out = nullptr;
@@ -561,7 +562,15 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         if (h.solo || h.solow) {
             e->solo_stride = std::max(h.net[0].size, h.net[1].size);
             CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
-            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)kSoloWG * kSoloPartHost, e->stream));
+            // (kernels_solow.hip: helper workgroups on the CUs a small population leaves idle take a share of the slab sum and of Adam —
+            //  FRL_SOLOW_HELPERS=0 switches them off; every workgroup of a launch must be resident)
+            e->solow_wgs = kSoloWG;
+            if (h.solow) {
+                const char* hp = getenv("FRL_SOLOW_HELPERS");
+                const int per = std::min(4, std::max(1, e->n_cus / (kSoloWG * (int)P)));
+                e->solow_wgs = (hp && atoi(hp) == 0) ? kSoloWG : kSoloWG * per;
+            }
+            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)std::max(kSoloWG, e->solow_wgs) * kSoloPartHost, e->stream));
             { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloPre, e->stream)); e->d_solo_pre = (int*)z; }
             float* z = nullptr;
             CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
@@ -1466,11 +1475,11 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {                              // kernels_solow.hip: sixteen workgroups per learner, W1 streamed from the block
             prof_begin(e, PK_GRAD_CRITIC);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel);
-            hipLaunchKernelGGL(k, dim3(pc * kSoloWG), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
+            hipLaunchKernelGGL(k, dim3(pc * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
         }
@@ -1539,9 +1548,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {
             prof_begin(e, PK_GRAD_ACTOR);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
-            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(pc * kSoloWG), blk,
+            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(pc * e->solow_wgs), blk,
                                (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;

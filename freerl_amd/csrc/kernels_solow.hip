@@ -18,8 +18,9 @@ namespace frl {
 // NT3 = head tiles of the actor (act_dim <= 16 -> 1, <= 32 -> 2)
 template <bool TWIN, int NT3>
 __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
-    constexpr int NH = TWIN ? 2 : 1, W = kSoloWG;
-    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
+    constexpr int NH = TWIN ? 2 : 1;
+    const int Wt = s.update_wgs;                       // the learner's sixteen workgroups with row tiles, then its helpers (the update only)
+    const int p = a.p0 + blockIdx.x / Wt, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
@@ -38,7 +39,7 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     g_f vC = as_global(D.v + lbase + D.net_off[1]);
     g_f grC = as_global(D.grad + lbase + D.net_off[1]);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
-    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    float* part = s.part + ((size_t)p * Wt) * kSoloPart;
     const float invB = 1.f / (float)B;
     const int KB1a = NA.L[0].k_pad >> 4, KB1c = NC.L[0].k_pad >> 4;
     const int ka0 = O >> 4, nka = KB1c - ka0;                              // the k-tiles of the critic's first layer that hold action columns (<= 3)
@@ -183,13 +184,13 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         if (tid == 0) part[b * kSoloPart + 0] = lossp;
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    solow_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
     u.soft = a.do_actor != 0 ? 1 : 0;                                     // TD3: the targets move with the delayed policy step (TD3.py:224-233)
     u.t_new = t_new;
-    const float total = solow_update(s, a, u, grC, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solow_update(s, a, u, grC, p, b, nb, Wt, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float loss = 0.f;
@@ -214,8 +215,8 @@ FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2)
 // ------------------------------------------------------------------------------------------------------------- actor stage
 template <int NT3>
 __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
-    constexpr int W = kSoloWG;
-    const int p = a.p0 + blockIdx.x / W, b = blockIdx.x % W;
+    const int Wt = s.update_wgs;
+    const int p = a.p0 + blockIdx.x / Wt, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[0];
     const NetDesc& NC = D.net[1];
@@ -235,7 +236,7 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     g_cf thC = as_global(D.theta + lbase + D.net_off[1]);
     int* steps = D.steps + (size_t)p * (kMaxNets + 1);
     const int t_new = steps[0] + 1;
-    float* part = s.part + ((size_t)p * kSoloWG) * kSoloPart;
+    float* part = s.part + ((size_t)p * Wt) * kSoloPart;
     const float invB = 1.f / (float)B;
     const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
     const int nq = sac ? NC.heads : 1;                                     // SAC.py:250: mean of the twins; TD3.py:227: Q1 only
@@ -402,11 +403,11 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
     }
     SOLO_T(3);
-    solo_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err, W);
+    solow_grid_sync(s.bar + (size_t)p * kSoloWG, b, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solow_update(s, a, u, grA, p, b, nb, N.red, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solow_update(s, a, u, grA, p, b, nb, Wt, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;
