@@ -1477,6 +1477,17 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_begin(e, PK_GRAD_CRITIC);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
+            // the next call's rows drawn by the learners' first helper workgroups (kernels_solo.hip's spare-workgroup scheme: two
+            // alternating slots, a tag the reader checks; FRL_SOLO_PREDRAW=0 switches it off)
+            if (dev_rng && e->d_solo_pre && pc == h.P) {
+                const char* pdf = getenv("FRL_SOLO_PREDRAW");
+                sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * kSoloPre;      // (stale or foreign tags fail the kernel's check)
+                if (e->solow_wgs > kSoloWG && !(pdf && atoi(pdf) == 0)) {
+                    sa.pre_write = e->d_solo_pre + (size_t)((e->solo_pre_seq + 1) & 1) * h.P * kSoloPre;
+                    sa.pre_counter = e->rng_counter;              // what the next frl_learn takes, unless something else draws first
+                }
+                ++e->solo_pre_seq;
+            }
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel);
             hipLaunchKernelGGL(k, dim3(pc * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);

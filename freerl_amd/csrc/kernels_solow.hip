@@ -47,6 +47,13 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     SOLO_T0();
 
     float lossp = 0.f;
+    if (b == kSoloWG && s.pre_write) {
+        // the learner's first helper has nothing to do until the hand-over: the rows of the NEXT call (the Philox counter the next
+        // frl_learn will take, the current ring size), where nobody waits for them — kernels_solo.hip's spare workgroup
+        int* out = s.pre_write + (size_t)(p - a.p0) * kSoloPre;
+        draw_indices((g_i)(out + 8), (FRL_LDS int*)N.ea, B, a.size, s.pre_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (p + 1), true);
+        if (tid == 0) { out[0] = (int)(unsigned)s.pre_counter; out[1] = (int)(unsigned)(s.pre_counter >> 32); out[2] = a.size; out[3] = B; }
+    }
     if (b < nb) {
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         g_ci idx = as_global_i(D.idx + (size_t)p * D.batch_max);
@@ -66,7 +73,14 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         SoloWNet::Pre pre = N.pre_fetch(tgA + NA.L[0].w_off, KB1a), pren;
         const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
         int ri;
-        if (a.device_rng) {
+        // (the next call's rows may have been drawn by the previous launch's first helper workgroup: kernels_solo.hip's tag check)
+        const int* tagp = s.pre_read ? s.pre_read + (size_t)(p - a.p0) * kSoloPre : nullptr;
+        const int ri_pre = tagp ? tagp[8 + rc] : 0;
+        const bool pre_ok = tagp && a.device_rng && tagp[0] == (int)(unsigned)a.rng_counter && tagp[1] == (int)(unsigned)(a.rng_counter >> 32) && tagp[2] == a.size && tagp[3] == B;
+        if (pre_ok) {
+            ri = ri_pre;
+            if (w == 0 && q == 0 && valid) D.idx[(size_t)p * D.batch_max + row] = ri;       // (the actor stage and frl_last_indices read them)
+        } else if (a.device_rng) {
             // draw_kernel's work, here: every workgroup of the learner draws the SAME `batch` distinct rows (same Philox key / counter,
             // rejection in its own LDS: ~3 us against a 13 us launch in front of this one) and keeps its tile's; they all write the same
             // values to D.idx (the actor stage and frl_last_indices read them)

@@ -18,15 +18,16 @@ def N():
     return _native
 
 
-def _run(N, monkeypatch, predraw, algo, P):
+def _run(N, monkeypatch, predraw, algo, P, O=8, A=2):
     from freerl_amd.engine import Engine
     monkeypatch.setenv("FRL_SOLO_PREDRAW", "1" if predraw else "0")
-    for v in ("FRL_CRITIC_V2", "FRL_SOLO"):
+    for v in ("FRL_CRITIC_V2", "FRL_SOLO", "FRL_SOLOW"):
         monkeypatch.delenv(v, raising=False)
-    O, A, B, cap = 8, 2, 256, 4096
+    B, cap = 256, 4096
     twin = algo != N.ALGO_DDPG
     e = Engine(algo, O, A, cap, n_learners=P, twin_critic=twin, batch_max=B, seed=11)
-    assert e.learn_path(B) == (True, 117376, 16), "not the solo kernels"
+    # (narrow shape: kernels_solo.hip, a spare workgroup draws; wide first layer: kernels_solow.hip, the learner's first helper workgroup)
+    assert e.learn_path(B)[0] and e.learn_path(B)[2] == 16 and (e.learn_path(B)[1] == 117376) == (O + A <= 16 and A <= 4), "not the sixteen-workgroup kernels"
     g = np.random.default_rng(5)
     for p in range(P):
         for net in range(2):
@@ -57,11 +58,11 @@ def _run(N, monkeypatch, predraw, algo, P):
     return out, arrays
 
 
-@pytest.mark.parametrize("algo_name,P", [("td3", 1), ("sac", 3), ("ddpg", 15)])
-def test_predrawn_rows_equal_the_in_launch_draw(N, monkeypatch, algo_name, P):
+@pytest.mark.parametrize("algo_name,P,O,A", [("td3", 1, 8, 2), ("sac", 3, 8, 2), ("ddpg", 15, 8, 2), ("sac", 1, 376, 17), ("td3", 5, 17, 6)])
+def test_predrawn_rows_equal_the_in_launch_draw(N, monkeypatch, algo_name, P, O, A):
     algo = {"td3": N.ALGO_TD3, "sac": N.ALGO_SAC, "ddpg": N.ALGO_DDPG}[algo_name]
-    idx1, arr1 = _run(N, monkeypatch, True, algo, P)
-    idx0, arr0 = _run(N, monkeypatch, False, algo, P)
+    idx1, arr1 = _run(N, monkeypatch, True, algo, P, O, A)
+    idx0, arr0 = _run(N, monkeypatch, False, algo, P, O, A)
     for k, (a, b) in enumerate(zip(idx1, idx0)):
         np.testing.assert_array_equal(a, b, err_msg="rows of call %d" % k)
         assert len(np.unique(a.reshape(P, -1)[0])) == a.reshape(P, -1).shape[1], "a batch holds a row twice"
