@@ -1122,7 +1122,9 @@ static int launch_act(frl_engine* e, int net, int mode_flags, int head, int use_
         float* wk = e->d_act_wk + (size_t)slot * e->act_wk_slot;
         if (!e->d_act_wk || slot >= (int)e->act_wk_version.size()) return fail(FRL_ERR_STATE, "wide engine without its act scratch");
         if (e->act_wk_version[slot] != e->param_version) {
-            hipLaunchKernelGGL(frag_to_wk_kernel, dim3(e->h.P), dim3(256), 0, e->stream, e->d, net, use_target, wk);
+            // (enough workgroups per learner for a few thousand elements each, the chip's CUs at most twice over)
+            const int per = std::max(1, std::min((N.size + 2047) / 2048, 2 * e->n_cus / e->h.P));
+            hipLaunchKernelGGL(frag_to_wk_kernel, dim3(e->h.P, per), dim3(256), 0, e->stream, e->d, net, use_target, wk);
             e->act_wk_version[slot] = e->param_version;
         }
         a.theta_alt = wk;

@@ -394,22 +394,25 @@ __global__ __launch_bounds__(256) void relayout_to_wk_kernel(const EngineDesc* _
 }
 
 // One fragment-image net of every learner -> a Wk-layout copy (dst[p][NetDesc::size]; biases / log_std / padding copied as they are):
-// select_action on the engines of the K-sliced chained family reads it through act_kernel (ActArgs::theta_alt).  grid = P
+// select_action on the engines of the K-sliced chained family and of kernels_solow.hip reads it through act_kernel
+// (ActArgs::theta_alt).  grid = (P, any number of workgroups per learner): an element's source is found from its own index, so the
+// workgroups share a net by stride (one workgroup per learner took 260 us for config 4's 67 k-float actor — more than the one
+// learner's whole learn() on kernels_solow.hip, once per env step in its rollout loop)
 __global__ __launch_bounds__(256) void frag_to_wk_kernel(const EngineDesc* __restrict__ Dp, int net, int use_target, float* dst) {
     const EngineDesc& D = *Dp;
     const int p = blockIdx.x;
     const NetDesc& N = D.net[net];
     const float* src = (use_target ? D.target : D.theta) + (size_t)p * D.learner_stride + D.net_off[net];
     float* out = dst + (size_t)p * N.size;
-    for (int i = threadIdx.x; i < N.size; i += kWG) out[i] = src[i];
-    __syncthreads();
-    for (int li = 0; li < N.n_layers + N.n_shadow; ++li) {
-        const LayerDesc& L = N.L[li];
-        const int cnt = L.n_pad * L.k_pad;
-        for (int i = threadIdx.x; i < cnt; i += kWG) {
-            const int k = i / L.n_pad, n = i - k * L.n_pad;
-            out[L.w_off + i] = src[L.w_off + weight_index(N, L, n, k)];
+    const int nl = N.n_layers + N.n_shadow;
+    for (int i = blockIdx.y * kWG + threadIdx.x; i < N.size; i += gridDim.y * kWG) {
+        int from = i;
+        for (int li = 0; li < nl; ++li) {
+            const LayerDesc& L = N.L[li];
+            const int j = i - L.w_off;
+            if (j >= 0 && j < L.n_pad * L.k_pad) { const int k = j / L.n_pad, n = j - k * L.n_pad; from = L.w_off + weight_index(N, L, n, k); }
         }
+        out[i] = src[from];
     }
 }
 
