@@ -442,13 +442,24 @@ struct SoloWNet {
                 gb += lane_xor<16>(gb); gb += lane_xor<32>(gb);
                 if (q == 0) hs[L[0].b_off + ot * 16 + i16] = gb;
             }
-            for (int kt = 0; kt < KB1; ++kt) {
-                f32x4 xt;                                                         // x^T of k-tile kt: rows 4q .. 4q + 3 of column 16 kt + i16
+            // four k-tiles at a time: their sixteen transposed reads in flight before the first MFMA (one tile at a time, every
+            // tile's MFMAs waited out an LDS round trip: 25 of them per head)
+            for (int kt0 = 0; kt0 < KB1; kt0 += 4) {
+                f32x4 xt[4];                                                      // x^T of k-tile kt: rows 4q .. 4q + 3 of column 16 kt + i16
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xt[e] = xs[kt * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                for (int j = 0; j < 4; ++j) {
+                    const int kt = kt0 + j < KB1 ? kt0 + j : KB1 - 1;
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
-                    st4_slab(hs + L[0].w_off + ((size_t)((2 * w + x) * KB1 + kt) * 256 + fslot), mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt, af[x]));
+                    for (int e = 0; e < 4; ++e) xt[j][e] = xs[kt * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kt0 + j < KB1) {
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)
+                            st4_slab(hs + L[0].w_off + ((size_t)((2 * w + x) * KB1 + kt0 + j) * 256 + fslot), mfma4(f32x4{0.f, 0.f, 0.f, 0.f}, xt[j], af[x]));
+                    }
+                }
             }
         }
     }
