@@ -230,7 +230,10 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         const int bt = b + W * t;
         if (bt >= nb) break;
         g_f slab = as_global(s.slab + ((size_t)p * kSoloWG + bt) * s.slab_stride);
-        if (t > 0) pend = C.stage_fetch(tgA, 0, NA.extra_n);
+        if (t > 0) {
+            __builtin_amdgcn_sched_barrier(0);         // (a tile starts where the one in front ends: with the next tile's image and target-head fragments
+            pend = C.stage_fetch(tgA, 0, NA.extra_n);  //  hoisted over the backward in front, the twin kernel was 512 registers and 37 spilled)
+        }
         const int row = 16 * bt + i16;
         const bool valid = row < B;
         const int ri = ri_t[t];
@@ -260,8 +263,10 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
         // the target critics are forward-only: their fragments go straight from the block into registers (SoloNet::forward_g), both
         // heads in one pass — in flight under the target actor's pass
         SoloNet::Frag<1> FC[NH];
+        if constexpr (kT == 1) {
 #pragma unroll
-        for (int hd = 0; hd < NH; ++hd) FC[hd] = N.frag_fetch<1>((g_cf)tgC + hd * kHeadFloats, 1, 0);
+            for (int hd = 0; hd < NH; ++hd) FC[hd] = N.frag_fetch<1>((g_cf)tgC + hd * kHeadFloats, 1, 0);
+        }
         // ---- a' = actor_target(s') [SAC: the tanh-Gaussian sample and its log-prob, SAC.py:70-97,227; TD3: smoothing noise, TD3.py:196-198]
         f32x4 h1o[2], h2o[2], h2f[kHT], z, an = {0.f, 0.f, 0.f, 0.f};
         float lp = 0.f;
@@ -287,6 +292,10 @@ __device__ __forceinline__ void solo_critic_body(const EngineDesc& D, const Lear
             }
         }
         SOLO_T(1);
+        if constexpr (kT > 1) {                            // (two tiles per workgroup: the fragments of two target heads next to the actor's pass, unrolled
+#pragma unroll                                             //  over both tiles, were 512 registers and 37 spilled — fetched behind it here)
+            for (int hd = 0; hd < NH; ++hd) FC[hd] = N.frag_fetch<1>((g_cf)tgC + hd * kHeadFloats, 1, 0);
+        }
         // ---- y = r + gamma (1 - d) min_h Q_target_h(s', a')   (SAC: - alpha log pi): the twin heads in one pass; the online critic's
         // first image travels under it
         pend = C.stage_fetch((g_cf)thC, 0);

@@ -19,7 +19,7 @@ md = s[s.index("amdhsa.kernels:"):]
 # upper bounds on spilled VGPRs (`--check`: exit 1 when a kernel passes its bound — a regression gate for the hot kernels, which must
 # stay spill-free, and a ratchet for the K-sliced / x-stationary / PPO ones, whose spills sit outside their MFMA loops: DESIGN.md 8)
 # (round 6: the lane constants re-derived per phase took the K-sliced kernels from 97-397 spilled VGPRs to 0-51, PPO's from 135-140 to 0)
-BOUNDS = [("ac_critic_v2_", 8), ("ac_actor_v2_", 0), ("solo_", 0), ("dqn_fused_", 0), ("c51_grad_", 0), ("ac_critic_kernel", 0),
+BOUNDS = [("ac_critic_v2_", 8), ("ac_actor_v2_", 0), ("solo_critic_twin_w8_", 8), ("solo_", 0), ("solow_", 0), ("dqn_fused_", 0), ("c51_grad_", 0), ("ac_critic_kernel", 0),
           ("ac_critic_wide_", 60), ("ac_actor_wide_", 16), ("ac_critic_x_", 700), ("ac_actor_x_", 460), ("ppo_update_v2_", 0),
           ("", 20)]
 bad = []

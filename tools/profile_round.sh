@@ -58,6 +58,9 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $(ls $O/stats_cfg/*/*kernel_stats.csv | head -1) $O/kernel_stats_configs.csv
 cd $R && timeout 300 python tools/config_bench.py 1 512 > $O/config_bench.txt 2>&1
 FRL_CRITIC_V2=0 timeout 300 python tools/config_bench.py C4 C5 h256 512 > $O/config_bench_rowchunk.txt 2>&1
+# one learner with a wide first layer (kernels_solow.hip): trace, PMC, section stamps (variant: bash tools/build_unit_variant.sh kernels_solow solowt -DFRL_SOLO_TIMING),
+# the sixteen-workgroup family against the row-chunk chain on the same box, with and without its helper workgroups / pre-draw
+bash $R/tools/profile_solow.sh $O
 # the K-sliced chained families' sections (library variant `widet`: -DFRL_WIDE_TIMING)
 for c in sac_c4 maddpg_c5 td3_h256; do timeout 300 python tools/wide_timing.py $c 256 > $O/wide_timing_$c.txt 2>&1 < /dev/null; done
 timeout 300 python tools/dqn_bench.py 1 512 2048 4096 > $O/dqn_bench.txt 2>&1
