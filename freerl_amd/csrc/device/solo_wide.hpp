@@ -28,9 +28,6 @@
 #ifndef FRL_SOLOW_G
 #define FRL_SOLOW_G 4       // k-tiles of W1 per fetched batch of a first-layer pass (three batches live: 24 G registers)
 #endif
-#ifndef FRL_SOLOW_TOUCH
-#define FRL_SOLOW_TOUCH 0   // 1: warm the XCD's L2 with the first-layer blocks at the top of the kernel (SoloWNet::l2_touch; measured: nothing)
-#endif
 
 namespace frl {
 
@@ -118,21 +115,25 @@ struct SoloWNet {
         for (int j = 0; j < (kSoloWMaxKB + 3) / 4; ++j) { const int kb = C.w + 4 * j; R.v[j] = xload(X, kb < KB1 ? kb : KB1 - 1); }
         return R;
     }
-    __device__ __forceinline__ void x_commit(const XRegs& R, int KB1) const {
+    // (xb: first tile of xs the rows go to — MADDPG's actor stage keeps agent i's observation rows, tiles kSoloWActorBase .., next to
+    // the joint [s | a] rows of its critic passes, tiles 0 ..)
+    __device__ __forceinline__ void x_commit(const XRegs& R, int KB1, int xb = 0) const {
 #pragma unroll
-        for (int j = 0; j < (kSoloWMaxKB + 3) / 4; ++j) { const int kb = C.w + 4 * j; if (kb < KB1) st4(xs + kb * 256 + C.fslot, R.v[j]); }
+        for (int j = 0; j < (kSoloWMaxKB + 3) / 4; ++j) { const int kb = C.w + 4 * j; if (kb < KB1) st4(xs + (xb + kb) * 256 + C.fslot, R.v[j]); }
     }
-    // xa <- the k-tiles ka0 .. ka0 + nka - 1 of [columns < O of xs | the A actions of this row in `ar` | 0] (wave j < nka: tile ka0 + j).
-    // xs and ar must be visible (a barrier in front), xa is visible behind the caller's next barrier.
+    // xa <- the k-tiles ka0 .. ka0 + nka - 1 of xs with columns [O, O + A) replaced by ar[0 .. A) of this row (wave j < nka: tile
+    // ka0 + j; the other columns as they are in xs: zero behind a single agent's observation, the batch's joint actions around
+    // the updating agent's in MADDPG's actor stage).  xs and ar must be visible (a barrier in front), xa is visible behind the
+    // caller's next barrier.
     __device__ __forceinline__ void xa_compose(int O, int A, int ka0, int nka) const {
         if (C.w < nka) {
             const int kb = ka0 + C.w, c0 = 16 * kb + 4 * C.q;
             f32x4 v = ld4((lds_cf)(xs + kb * 256 + C.fslot));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e, j = c - O;
+                const int j = c0 + e - O;
                 const float av = ar[C.i16 * 32 + (j < 0 ? 0 : (j > 31 ? 31 : j))];
-                v[e] = c < O ? v[e] : (j < A ? av : 0.f);
+                v[e] = (j >= 0 && j < A) ? av : v[e];
             }
             st4(xa + C.w * 256 + C.fslot, v);
         }
@@ -167,19 +168,6 @@ struct SoloWNet {
         lds_barrier();
     }
 
-    // ---- warm this XCD's L2 with a first-layer block the passes will stream (FRL_SOLOW_TOUCH: one dword of every 128-byte line, N
-    // per thread in flight at once, at the top of the kernel).  Measured: nothing — the sweeps below are not waiting for memory
-    template <int N>
-    __device__ __forceinline__ float l2_touch(g_cf p, int n_floats) const {
-        float t[N], acc = 0.f;
-        const int nl = n_floats >> 5;
-#pragma unroll
-        for (int k = 0; k < N; ++k) { const int i = C.tid + kWG * k; t[k] = p[32 * (i < nl ? i : nl - 1)]; }
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc += t[k];
-        return acc;
-    }
-
     // ---- first layer of the row tile: acc[x] (the bias on entry) += W1[tiles 2w + x] x, K = 16 KB1 columns: W1's fragments from
     // the block, G k-tiles at a time; the rows from xs (k-tiles < ka), xa (the rest) and the zero tile (past the last one).
     // The first two batches of a sweep are fetched a pass AHEAD (l1_fetch next to the stage_fetch of the same net).
@@ -201,7 +189,7 @@ struct SoloWNet {
         return P;
     }
     template <int G>
-    __device__ __forceinline__ void l1(g_cf w1, int KB1, int ka, f32x4 (&acc)[2], L1Pre<G>& P) const {
+    __device__ __forceinline__ void l1(g_cf w1, int KB1, int ka, int xb, f32x4 (&acc)[2], L1Pre<G>& P) const {
         const int w = C.w, fslot = C.fslot;
         f32x4 (&b0)[2][G] = P.b0, (&b1)[2][G] = P.b1;
         f32x4 b2[2][G];
@@ -219,7 +207,7 @@ struct SoloWNet {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int kb = kb0 + g;
-                xf[g] = ld4((lds_cf)((kb < ka ? xs + kb * 256 : (kb < KB1 ? xa + (kb - ka) * 256 : zt)) + fslot));
+                xf[g] = ld4((lds_cf)((kb < ka ? xs + (xb + kb) * 256 : (kb < KB1 ? xa + (kb - ka) * 256 : zt)) + fslot));
             }
             nx0 += G * 256; nx1 += G * 256;
 #pragma unroll
@@ -258,13 +246,13 @@ struct SoloWNet {
     typedef L1Pre<FRL_SOLOW_G> Pre;
     __device__ __forceinline__ Pre pre_fetch(g_cf w1, int KB1) const { return l1_fetch<FRL_SOLOW_G>(w1, KB1); }
     template <bool KEEP>
-    __device__ __forceinline__ void forward(g_cf w1, int KB1, int ka, Pre& P, f32x4 (&h1o)[2], f32x4 (&h2o)[2], f32x4 (&h2f)[kHT]) const {
+    __device__ __forceinline__ void forward(g_cf w1, int KB1, int ka, Pre& P, f32x4 (&h1o)[2], f32x4 (&h2o)[2], f32x4 (&h2f)[kHT], int xb = 0) const {
         const ChainLds& S = C.S;
         const int w = C.w, q = C.q, fslot = C.fslot;
         f32x4 acc[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) acc[x] = ld4((lds_cf)(S.b1 + (2 * w + x) * 16 + 4 * q));
-        l1<FRL_SOLOW_G>(w1, KB1, ka, acc, P);
+        l1<FRL_SOLOW_G>(w1, KB1, ka, xb, acc, P);
 #ifdef FRL_SOLO_TIMING
         if (threadIdx.x == 0) red[120] = (float)(unsigned)(wall_clock64() & 0xFFFFFFull);      // (tools/solow_timing.py: end of the last first-layer sweep)
 #endif
@@ -393,7 +381,7 @@ struct SoloWNet {
     // ---- layers 2 and 1 of a backward from the own tiles' d2o.  WG: dW2 / db2 / dW1 / db1 of the wave's output tiles -> slab
     // (needs forward<true>: th1; the pass's rows in xs).  Returns d1o (own tiles, through the ReLU of h1).
     template <bool WG>
-    __device__ __forceinline__ void hidden_bwd(g_f hs, const LayerDesc* L, int KB1, const f32x4 (&d2o)[2], const f32x4 (&h1o)[2], f32x4 (&d1o)[2]) const {
+    __device__ __forceinline__ void hidden_bwd(g_f hs, const LayerDesc* L, int KB1, const f32x4 (&d2o)[2], const f32x4 (&h1o)[2], f32x4 (&d1o)[2], int xb = 0) const {
         const ChainLds& S = C.S;
         const int w = C.w, q = C.q, i16 = C.i16, fslot = C.fslot, tslot = C.tslot;
 #pragma unroll
@@ -450,7 +438,7 @@ struct SoloWNet {
                 for (int j = 0; j < 4; ++j) {
                     const int kt = kt0 + j < KB1 ? kt0 + j : KB1 - 1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xt[j][e] = xs[kt * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
+                    for (int e = 0; e < 4; ++e) xt[j][e] = xs[(xb + kt) * 256 + tslot + (((4 * q + e) ^ (i16 >> 2)) << 2)];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -491,16 +479,17 @@ struct SoloWNet {
     }
 };
 
-// ---- "the learner's sixteen slabs are written" (solo.hpp: solo_grid_sync) with HELPER workgroups: b >= kSoloWG has no row tile and
-// publishes nothing — it waits for the sixteen flags like the others and takes its share of the update
-__device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, unsigned epoch, int* err) {
+// ---- "the unit's NT slabs are written" (solo.hpp: solo_grid_sync; NT = 16 row tiles of a batch of up to 256 rows, 64 of MADDPG's
+// 1024) with HELPER workgroups: b >= NT has no row tile and publishes nothing — it waits for the NT flags like the others and takes
+// its share of the update
+__device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, int NT, unsigned epoch, int* err) {
     sync_stores();
-    if (threadIdx.x == 0 && b < kSoloWG) {
+    if (threadIdx.x == 0 && b < NT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if ((int)threadIdx.x < kSoloWG) {
+    if ((int)threadIdx.x < NT) {
         const unsigned long long t0 = wall_clock64();                      // 100 MHz
         while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
             __builtin_amdgcn_s_sleep(1);
@@ -517,7 +506,7 @@ __device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, unsigned
 // sixteen: 8.4 us, and the other 240 CUs idle) of a net of any size — phase 1: slab sum in workgroup order -> gsum
 // (EngineDesc::grad), partial squared norm; the sixteen partial norms meet through the mailboxes of solo_update; phase 2: clip
 // coefficient, Adam, soft update.  Returns the gradient norm.
-__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int p, int b, int nb, int Wt, lds_f red,
+__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int unit, int b, int nb, int NT, int Wt, lds_f red,
                                               lds_f box, unsigned bar2_target
 #ifdef FRL_SOLO_TIMING
                                               , unsigned long long solo_t0_
@@ -525,29 +514,32 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
                                               ) {
     constexpr int W = kSoloWG, KM = 3;
     const int tid = threadIdx.x;
-    float* part = s.part + ((size_t)p * Wt) * kSoloPart;
+    float* part = s.part + ((size_t)unit * Wt) * kSoloPart;
     const int n4 = u.size >> 2, per = (n4 + Wt - 1) / Wt, i0 = b * per, i1 = min(n4, i0 + per);
-    g_cf slab = as_global(s.slab + (size_t)p * kSoloWG * s.slab_stride);
+    g_cf slab = as_global(s.slab + (size_t)unit * NT * s.slab_stride);
     float ss = 0.f;
     for (int c0 = i0; c0 < i1; c0 += kWG * KM) {
-        f32x4 sl[W][KM], g[KM];
-#pragma unroll
-        for (int sb = 0; sb < W; ++sb) {
-            const int sc = sb < nb ? sb : nb - 1;                          // (slabs past the batch's tiles: a harmless re-read, dropped below)
-#pragma unroll
-            for (int k = 0; k < KM; ++k) {
-                const int i = c0 + tid + kWG * k, ic = i < i1 ? i : i1 - 1;
-                sl[sb][k] = ld4(slab + (size_t)sc * s.slab_stride + 4 * (size_t)ic);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        f32x4 g[KM];
 #pragma unroll
         for (int k = 0; k < KM; ++k) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < nb; s0 += W) {                               // sixteen slabs in flight at a time, summed in tile order
+            f32x4 sl[W][KM];
 #pragma unroll
-        for (int sb = 0; sb < W; ++sb) {
-            if (sb < nb) {
+            for (int sb = 0; sb < W; ++sb) {
+                const int sc = s0 + sb < nb ? s0 + sb : nb - 1;            // (slabs past the batch's tiles: a harmless re-read, dropped below)
 #pragma unroll
-                for (int k = 0; k < KM; ++k) g[k] += sl[sb][k];
+                for (int k = 0; k < KM; ++k) {
+                    const int i = c0 + tid + kWG * k, ic = i < i1 ? i : i1 - 1;
+                    sl[sb][k] = ld4(slab + (size_t)sc * s.slab_stride + 4 * (size_t)ic);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sb = 0; sb < W; ++sb) {
+                if (s0 + sb < nb) {
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) g[k] += sl[sb][k];
+                }
             }
         }
 #pragma unroll

@@ -428,13 +428,17 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         // FRL_SOLOW=0/1 overrides, FRL_CRITIC_V2 set means the caller asked for one of the other two families by name).  Every one of
         // the P x 16 workgroups has to be resident, as for kernels_solo.hip.  [s | a] must be the record's first columns, 16-byte aligned
         const char* sw = getenv("FRL_SOLOW");
-        const bool solow_shape = h.n_agents == 1 && h.algo != ALGO_MADDPG && h.hidden == 128 && h.batch_max <= 256 && h.rec.stride % 4 == 0 &&
-                                 h.rec.obs_off[0] % 4 == 0 && h.rec.act_off[0] == h.rec.obs_off[0] + h.rec.obs_dim[0] &&
-                                 h.net[0].L[0].k_pad <= 16 * kSoloWMaxKB && h.net[1].L[0].k_pad <= 16 * kSoloWMaxKB;
-        const bool solow_fits = h.P <= kSoloMaxP && (long long)h.P * kSoloWG <= e->n_cus && e->lds_per_cu >= (int)(solow_lds_floats() * sizeof(float));
+        // ... MADDPG / MATD3 (config 5: three agents, batches of 1024): a unit = (learner, agent), 64 row tiles = 64 workgroups per unit; the
+        // updating agent's own observation rows sit behind the joint rows in LDS, so both first layers have at most kSoloWActorBase k-tiles
+        bool solow_shape = h.hidden == 128 && h.batch_max <= (h.n_agents == 1 ? 256 : 1024) && h.rec.stride % 4 == 0 && h.rec.obs_off[0] % 4 == 0 &&
+                           h.rec.act_off[0] == h.rec.obs_off[0] + h.rec.obs_total;
+        for (int i = 0; i < h.n_nets; ++i) solow_shape = solow_shape && h.net[i].L[0].k_pad <= 16 * (h.n_agents == 1 ? kSoloWMaxKB : kSoloWActorBase);
+        const int solow_tiles = h.batch_max <= 256 ? kSoloWG : 4 * kSoloWG;
+        const long long solow_units = (long long)h.P * h.n_agents;
+        const bool solow_fits = solow_units <= kSoloMaxP && solow_units * solow_tiles <= e->n_cus && e->lds_per_cu >= (int)(solow_lds_floats() * sizeof(float) + 256);
         if ((sw ? atoi(sw) != 0 : !force) && solow_shape && solow_fits) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
-            h.solow = kSoloWG;
+            h.solow = solow_tiles;
         } else
         // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
         // kernels' 46.2, MADDPG simple_spread 77.2 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 71.1 / 56.9
@@ -560,22 +564,24 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         CREATE_TRY(dalloc_zero(&h.ticket, P + 1, e->stream));
         CREATE_TRY(dalloc_zero(&h.alpha, P * 4, e->stream));
         if (h.solo || h.solow) {
-            e->solo_stride = std::max(h.net[0].size, h.net[1].size);
-            CREATE_TRY(dalloc_zero(&e->d_solo_slab, P * (size_t)kSoloWG * e->solo_stride, e->stream));
+            e->solo_stride = 0;
+            for (int i = 0; i < h.n_nets; ++i) e->solo_stride = std::max(e->solo_stride, h.net[i].size);
+            const size_t U = P * (size_t)h.n_agents, NT = h.solow ? (size_t)h.solow : (size_t)kSoloWG;      // (kernels_solow.hip: units, row tiles per unit)
+            CREATE_TRY(dalloc_zero(&e->d_solo_slab, U * NT * e->solo_stride, e->stream));
             // (kernels_solow.hip: helper workgroups on the CUs a small population leaves idle take a share of the slab sum and of Adam —
             //  FRL_SOLOW_HELPERS=0 switches them off; every workgroup of a launch must be resident)
-            e->solow_wgs = kSoloWG;
+            e->solow_wgs = (int)NT;
             if (h.solow) {
                 const char* hp = getenv("FRL_SOLOW_HELPERS");
-                const int per = std::min(4, std::max(1, e->n_cus / (kSoloWG * (int)P)));
-                e->solow_wgs = (hp && atoi(hp) == 0) ? kSoloWG : kSoloWG * per;
+                const int per = std::min(64 / (int)NT > 0 ? 64 / (int)NT : 1, std::max(1, e->n_cus / ((int)NT * (int)U)));      // (at most 64 workgroups per unit: the mailboxes are polled by one wave)
+                e->solow_wgs = (hp && atoi(hp) == 0) ? (int)NT : (int)NT * per;
             }
-            CREATE_TRY(dalloc_zero(&e->d_solo_part, P * (size_t)std::max(kSoloWG, e->solow_wgs) * kSoloPartHost, e->stream));
+            CREATE_TRY(dalloc_zero(&e->d_solo_part, U * (size_t)std::max((int)NT, e->solow_wgs) * kSoloPartHost, e->stream));
             { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloPre, e->stream)); e->d_solo_pre = (int*)z; }
             float* z = nullptr;
-            CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloWG + 2, e->stream));
-            e->d_solo_bar = (unsigned*)z;                                  // [P][16] slab flags, then [P][16] "actor slice stepped" flags,
-            e->d_solo_ticket = (int*)(z + 2 * P * (size_t)kSoloWG);        // ... and the rollout tail's learner ticket
+            CREATE_TRY(dalloc_zero(&z, 2 * U * NT + 2, e->stream));
+            e->d_solo_bar = (unsigned*)z;                                  // [units][tiles] slab flags, then as many "actor slice stepped" flags (kernels_solo.hip: offset P * 16),
+            e->d_solo_ticket = (int*)(z + 2 * U * NT);                     // ... and the rollout tail's learner ticket
         }
         if (h.solo || h.solow || h.algo == ALGO_DQN) {                     // the pinned give-up word of the spinning launches (solo hand-overs, pre-armed DQN steps)
             CREATE_TRY(hipHostMalloc((void**)&e->h_solo_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1391,6 +1397,7 @@ static bool chained_shape(const EngineDesc& h) {
 static bool chained_path(const EngineDesc& h, int batch, int pc) {
     (void)pc;
     if (h.wide) return !h.obs_norm_on;          // any batch <= batch_max: super-chunks of 256 rows
+    if (h.solow) return !h.obs_norm_on;         // any batch <= batch_max: a 16-row tile per workgroup, h.solow of them per unit
     return h.net[0].frag && h.net[1].frag && batch <= 256 && !h.obs_norm_on;
 }
 // The K-sliced chained family (device/chain_wide.hpp): the reference's hidden-128 ReLU actor-critic nets with first layers of up
@@ -1455,7 +1462,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         return;
     }
     if (stage == 0) {
-        if (dev_rng && !(v2 && (h.solo || h.solow))) {    // (kernels_solo.hip / kernels_solow.hip draw inside their critic stages)
+        if (dev_rng && !(v2 && (h.solo || (h.solow && h.n_agents == 1)))) {    // (kernels_solo.hip / single-agent kernels_solow.hip draw inside their critic stages)
             prof_begin(e, PK_DRAW);
             hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)2 * ((a.batch + 3) & ~3) * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
             prof_end(e);
@@ -1477,14 +1484,14 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {                              // kernels_solow.hip: sixteen workgroups per learner, W1 streamed from the block
             prof_begin(e, PK_GRAD_CRITIC);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             // the next call's rows drawn by the learners' first helper workgroups (kernels_solo.hip's spare-workgroup scheme: two
             // alternating slots, a tag the reader checks; FRL_SOLO_PREDRAW=0 switches it off)
-            if (dev_rng && e->d_solo_pre && pc == h.P) {
+            if (dev_rng && e->d_solo_pre && pc == h.P && h.n_agents == 1) {
                 const char* pdf = getenv("FRL_SOLO_PREDRAW");
                 sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * kSoloPre;      // (stale or foreign tags fail the kernel's check)
-                if (e->solow_wgs > kSoloWG && !(pdf && atoi(pdf) == 0)) {
+                if (e->solow_wgs > h.solow && !(pdf && atoi(pdf) == 0)) {
                     sa.pre_write = e->d_solo_pre + (size_t)((e->solo_pre_seq + 1) & 1) * h.P * kSoloPre;
                     sa.pre_counter = e->rng_counter;              // what the next frl_learn takes, unless something else draws first
                 }
@@ -1492,7 +1499,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             }
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel);
-            hipLaunchKernelGGL(k, dim3(pc * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
+            hipLaunchKernelGGL(k, dim3(units * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
         }
@@ -1561,9 +1568,9 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {
             prof_begin(e, PK_GRAD_ACTOR);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
-            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(pc * e->solow_wgs), blk,
+            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(units * e->solow_wgs), blk,
                                (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;

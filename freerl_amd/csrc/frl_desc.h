@@ -52,6 +52,8 @@ constexpr int solo_lds_floats() { return 8 * 256 + 64 * 256 + 8 * 256 + 128 + 12
 
 // ... and its form for wide first layers / heads of up to 32 outputs (device/solo_wide.hpp, kernels_solow.hip): W1 stays in the block
 constexpr int kSoloWMaxKB = 26;          // first layer: <= 416 input columns
+constexpr int kSoloWActorBase = 13;      // multi-agent engines: tile of the LDS row images where the updating agent's own observation rows start (the joint rows: tile 0);
+                                         // both first layers then have at most 13 k-tiles
 constexpr int solow_lds_floats() { return 64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + kSoloWMaxKB * 256 + 3 * 256 + 256 + 4 * 2 * 256 + 16 * 32 + 16 * 48 + 128; }
 
 // The K-sliced chained family (device/chain_wide.hpp)

@@ -20,6 +20,8 @@ CASES = {
     "td3_h256": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True, hidden=256),
     "sac_h256": dict(algo=N.ALGO_SAC, obs=40, act=17, B=200, twin=True, hidden=256),
     "ddpg_h256": dict(algo=N.ALGO_DDPG, obs=11, act=3, B=96, twin=False, hidden=256),
+    "td3_8_6": dict(algo=N.ALGO_TD3, obs=8, act=6, B=256, twin=True),                 # one first-layer k-tile, six actions: past the narrow kernels' four
+    "ddpg_30_20": dict(algo=N.ALGO_DDPG, obs=30, act=20, B=128, twin=False),          # a single critic head with two actor head tiles
     "td3_syn": dict(algo=N.ALGO_TD3, obs=8, act=2, B=256, twin=True),                 # the bench shape
     "td3_narrow_b100": dict(algo=N.ALGO_TD3, obs=8, act=2, B=100, twin=True),        # the narrow register-chained kernels, ragged batches
     "sac_narrow_b200": dict(algo=N.ALGO_SAC, obs=11, act=3, B=200, twin=True),

@@ -90,23 +90,31 @@ SOLOW_LDS = 4 * (64 * 256 + 2 * 8 * 256 + 128 + 128 + 32 + 32 + 4 * 8 * 256 + 26
 
 
 @pytest.mark.parametrize("case,P", [("sac_c4", 1), ("td3_wide", 3), ("ddpg_wide", 2), ("sac_100_7", 1), ("td3_201_12", 2), ("sac_380_20_b17", 1),
-                                    ("sac_380_20_b256", 16), ("sac_c4", 5)])
+                                    ("sac_380_20_b256", 16), ("sac_c4", 5), ("td3_8_6", 2), ("ddpg_30_20", 1),
+                                    ("maddpg_c5", 1), ("maddpg_het", 2), ("matd3_het", 5), ("matd3_c5", 1)])
 def test_sixteen_workgroups_wide_first_layer_vs_rowchunk(N, case, P):
     """kernels_solow.hip (round 6: a handful of learners with a first layer of up to 416 columns and heads of up to 32 outputs on
     sixteen workgroups each, W1 streamed from the block) against the row-chunk kernels on the same injected indices and noise, own
     parameters per learner, every array of every learner: config 4's dims at one and five learners, 25 k-tiles with 20 actions at a
     FULL population of sixteen, one / seven / thirteen k-tiles, single and twin critics, ragged batches (200 rows; 17 rows = two
-    tiles, fourteen workgroups without rows)."""
+    tiles, fourteen workgroups without rows); MADDPG / MATD3 with a unit = (learner, agent): config 5's three agents at batch 1024 (64
+    row tiles per unit), heterogeneous agents (own rows behind the joint rows in LDS, action columns off every boundary) at two and five learners."""
     from tests import family_ab as AB
-    calls = 5 if AB.CASES[case]["B"] < 64 else 20
+    calls = 5 if AB.CASES[case]["B"] < 64 else (20 if AB.CASES[case]["B"] <= 256 else 10)
     a, b = AB.run(case, 0, calls, P), AB.run(case, None, calls, P)
     assert not a["family"] and b["path"] == (True, SOLOW_LDS, 16), (a["path"], b["path"])
     d = AB.diff(a, b)
     st = d.pop("stats")
     REPORT["solow/%s/P%d" % (case, P)] = dict(calls=calls, P=P, arrays={k: v[0] for k, v in d.items()}, arrays_q99={k: v[3] for k, v in d.items()},
                                    loss_rel_first5=float(st[:5, :, :, :2].max()), loss_rel_all=float(st[:, :, :, :2].max()))
-    assert st[:5, :, :, :2].max() <= 1e-4, (case, st[:5, :, :, :2].max())
-    assert st[:, :, :, :2].max() <= 5e-3, (case, st[:, :, :, :2].max())
+    # critic losses by their own size; actor losses (-Q mean: they cross zero — maddpg_c5's agent 1 passes -0.0005 in its tenth call,
+    # where 4e-6 of absolute difference reads as 0.9 relative) by the critic-loss scale, as tests/test_gpu_longrun.py reports them
+    sa, sb = a["stats"], b["stats"]
+    scale = float(np.abs(sa[..., 0]).mean())
+    act_err = np.abs(sa[..., 1] - sb[..., 1]) / max(scale, 1e-6)
+    REPORT["solow/%s/P%d" % (case, P)]["actor_abs_err_over_critic_scale"] = [float(act_err[:5].max()), float(act_err.max())]
+    assert st[:5, :, :, 0].max() <= 1e-4 and act_err[:5].max() <= 1e-4, (case, st[:5, :, :, 0].max(), act_err[:5].max())
+    assert st[:, :, :, 0].max() <= 5e-3 and act_err.max() <= 5e-3, (case, st[:, :, :, 0].max(), act_err.max())
     for key, (w, at, mx, q99) in d.items():
         tol = TOL_THETA if key.startswith(("theta", "target", "act")) else TOL_MOMENT
         assert q99 <= tol, "%s %s: 99th percentile of |diff| / max |x| = %.3e (max %.3e at flat index %d, |x| max %.3g)" % (case, key, q99, w, at, mx)
