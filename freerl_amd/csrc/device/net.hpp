@@ -671,9 +671,57 @@ __device__ __forceinline__ void soft_update_net(int size, g_f target, g_cf theta
 // masks kept as scalars (ballot, s_and / s_or: ~35 cycles per entry behind the VALU -> SGPR -> SALU hazards) 8 us.
 // drain = false (batch <= 256 only): return without the closing __syncthreads — lidx is final behind the last round's LDS barrier; the
 // caller does not need its earlier global stores (or the idx store) performed before it goes on (kernels_solo.hip: 1.7 us)
+//
+// batch > 256 with a hash table (MADDPG's 1024; `table`: 2 x kDrawTable ints of LDS behind lidx's, batch <= kDrawTable / 4): a round
+// inserts every entry under its row — linear probing, the slot keeps the SMALLEST position that holds the row (ds_cmpst + ds_min) —
+// and an entry whose slot names another position has an earlier equal: O(batch) per round.  The scan of every entry's predecessors
+// (the path below, still there for larger batches) took 92 us for draw_kernel's 3 x 1024 rows of config 5 — more than either update
+// launch behind it.  Same rule, same Philox streams: the same rows.
+constexpr int kDrawTable = 8192;
 __device__ __forceinline__ void draw_indices(g_i idx, FRL_LDS int* lidx, int batch, int size, unsigned long long counter,
-                                             unsigned stream, unsigned long long key, bool drain = true) {
+                                             unsigned stream, unsigned long long key, bool drain = true, FRL_LDS int* table = nullptr) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+    if (batch > kWG && table && 4 * batch <= kDrawTable) {
+        const int tid = threadIdx.x;
+        int T = 1024;
+        while (T < 4 * batch) T <<= 1;
+        FRL_LDS int* tkey = table;                                      // the row a slot belongs to (-1: free)
+        FRL_LDS int* tpos = table + kDrawTable;                         // the smallest position holding it
+        FRL_LDS int* lslot = lidx + ((batch + 3) & ~3);                 // second half of the caller's 2 x batch ints: an entry's slot; then "somebody redraws"
+        for (int i = tid; i < batch; i += kWG) lidx[i] = (int)uniform_index(philox4x32_10(counter, stream, (unsigned)i, key), (unsigned)size);
+        for (unsigned round = 1; round < 64; ++round) {
+            for (int t = tid; t < T; t += kWG) { tkey[t] = -1; tpos[t] = 0x7fffffff; }
+            __syncthreads();
+            for (int i = tid; i < batch; i += kWG) {
+                const int v = lidx[i];
+                int h = (int)((unsigned)v * 2654435761u >> 7) & (T - 1);
+                for (;;) {
+                    int expect = -1;
+                    const bool got = __hip_atomic_compare_exchange_strong(tkey + h, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (got || expect == v) break;
+                    h = (h + 1) & (T - 1);
+                }
+                __hip_atomic_fetch_min(tpos + h, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lslot[i] = h;
+            }
+            __syncthreads();
+            int dup = 0;
+            for (int i = tid; i < batch; i += kWG) {
+                const int d = tpos[lslot[i]] != i ? 1 : 0;              // an earlier position holds the same row
+                lslot[i] = d;
+                dup |= d;
+            }
+            // redraw AFTER everyone has finished comparing against the old values
+            const int any = __syncthreads_or(dup);
+            if (!any) break;
+            for (int i = tid; i < batch; i += kWG)
+                if (lslot[i]) lidx[i] = (int)uniform_index(philox4x32_10(counter, stream + round * 0x10000u, (unsigned)i, key), (unsigned)size);
+            __syncthreads();
+        }
+        if (idx) for (int i = tid; i < batch; i += kWG) idx[i] = lidx[i];
+        __syncthreads();
+        return;
+    }
     if (batch <= kWG) {
         const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int nq = (batch + 3) >> 2;                                // quads of entries (the last one padded)

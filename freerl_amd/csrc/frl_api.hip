@@ -620,6 +620,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     { const char* cw = getenv("FRL_CHAIN_WAVES"); e->chain_waves = (cw && atoi(cw) == 4) ? 4 : 8; }
     if (h.algo == ALGO_DQN)
         CREATE_TRY(hipFuncSetAttribute((const void*)dqn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dqn2_lds_floats() * (int)sizeof(float)));
+    if (h.batch_max > 256 && 4 * h.batch_max <= kDrawTableHost)     // draw_kernel's duplicate table for batches of 257 .. 2048 rows (device/net.hpp)
+        CREATE_TRY(hipFuncSetAttribute((const void*)draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 2048 + 2 * kDrawTableHost) * (int)sizeof(int)));
     if (h.wide == 2) {
         const int lb = wide16_lds_floats_host() * (int)sizeof(float);
         for (auto k : {ac_critic_x_h1a1_kernel, ac_critic_x_h1a2_kernel, ac_critic_x_h2a1_kernel, ac_critic_x_h2a2_kernel, ac_actor_x_a1_kernel, ac_actor_x_a2_kernel})
@@ -631,7 +633,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solow) {
         const int lb = solow_lds_floats() * (int)sizeof(float);
-        for (auto k : {solow_critic_h1a1_kernel, solow_critic_h1a2_kernel, solow_critic_h2a1_kernel, solow_critic_h2a2_kernel, solow_actor_a1_kernel, solow_actor_a2_kernel})
+        for (auto k : {solow_critic_h1a1_kernel, solow_critic_h1a2_kernel, solow_critic_h2a1_kernel, solow_critic_h2a2_kernel, solow_actor_a1_kernel, solow_actor_a2_kernel,
+                       solow_critic_ma_h1a1_kernel, solow_critic_ma_h1a2_kernel, solow_critic_ma_h2a1_kernel, solow_critic_ma_h2a2_kernel, solow_actor_ma_a1_kernel, solow_actor_ma_a2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solo) {
         const int lb = std::max(solo_lds_floats(), critic2_lds_floats()) * (int)sizeof(float);      // (critic2: the rollout tail's act_frag_body)
@@ -1464,7 +1467,10 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
     if (stage == 0) {
         if (dev_rng && !(v2 && (h.solo || (h.solow && h.n_agents == 1)))) {    // (kernels_solo.hip / single-agent kernels_solow.hip draw inside their critic stages)
             prof_begin(e, PK_DRAW);
-            hipLaunchKernelGGL(draw_kernel, grid_units, blk, (size_t)2 * ((a.batch + 3) & ~3) * sizeof(int), st, e->d, a, needs_noise ? 1 : 0);
+            const char* scan = getenv("FRL_DRAW_SCAN");                        // developer / test knob: no duplicate table
+            const bool table = a.batch > 256 && 4 * a.batch <= kDrawTableHost && !(scan && atoi(scan) != 0);
+            const size_t draw_lds = ((size_t)2 * ((a.batch + 3) & ~3) + (table ? 2 * kDrawTableHost : 0)) * sizeof(int);
+            hipLaunchKernelGGL(draw_kernel, grid_units, blk, draw_lds, st, e->d, a, (needs_noise ? 1 : 0) | (table ? 0 : 2));
             prof_end(e);
         }
         if (h.obs_norm_on && h.algo != ALGO_DQN)                         // sample(): norm(obs) updates the statistics first
@@ -1498,7 +1504,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
                 ++e->solo_pre_seq;
             }
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
-            auto k = twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel);
+            auto k = h.n_agents > 1 ? (twin ? (a2 ? solow_critic_ma_h2a2_kernel : solow_critic_ma_h2a1_kernel) : (a2 ? solow_critic_ma_h1a2_kernel : solow_critic_ma_h1a1_kernel))
+                                    : (twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel));
             hipLaunchKernelGGL(k, dim3(units * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
@@ -1570,7 +1577,8 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             prof_begin(e, PK_GRAD_ACTOR);
             SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
-            hipLaunchKernelGGL(h.net[0].L[2].n_pad > 16 ? solow_actor_a2_kernel : solow_actor_a1_kernel, dim3(units * e->solow_wgs), blk,
+            const bool a2 = h.net[0].L[2].n_pad > 16;
+            hipLaunchKernelGGL(h.n_agents > 1 ? (a2 ? solow_actor_ma_a2_kernel : solow_actor_ma_a1_kernel) : (a2 ? solow_actor_a2_kernel : solow_actor_a1_kernel), dim3(units * e->solow_wgs), blk,
                                (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;

@@ -43,6 +43,8 @@ struct NetDesc {
 constexpr int kL1w = 0, kL1b = kL1w + 128 * 16, kL2w = kL1b + 128, kL2b = kL2w + 128 * 128, kL3w = kL2b + 128,
               kL3b = kL3w + 16 * 128, kHeadFloats = kL3b + 16;
 
+constexpr int kDrawTableHost = 8192;     // ints per half of draw_indices' duplicate table (device/net.hpp: kDrawTable), batches of 257 .. 2048 rows
+
 // One learner on sixteen workgroups (device/solo.hpp, kernels_solo.hip): the single-learner latency path
 constexpr int kSoloWG = 16;              // workgroups per learner = 16-row tiles of a 256-row batch
 constexpr int kSoloPartHost = 32;        // floats per workgroup of SoloArgs::part (device/solo.hpp: kSoloPart)

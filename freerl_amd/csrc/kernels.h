@@ -257,6 +257,13 @@ __global__ void solow_critic_h2a1_kernel(const EngineDesc* __restrict__ Dp, Lear
 __global__ void solow_critic_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 __global__ void solow_actor_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 __global__ void solow_actor_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+// ... MADDPG / MATD3: a unit = (learner, agent)
+__global__ void solow_critic_ma_h1a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_ma_h1a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_ma_h2a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_critic_ma_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_actor_ma_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_actor_ma_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }

@@ -65,11 +65,12 @@ __device__ __forceinline__ float policy_rows(const SoloWNet& N, const LearnArgs&
 }  // namespace
 
 // NT3 = head tiles of the actors (act_dim <= 16 -> 1, <= 32 -> 2)
-template <bool TWIN, int NT3>
+// MULTI: MADDPG / MATD3 (a compile-time 1 for the single-agent kernels: their loop over the agents' target actors is straight-line code)
+template <bool TWIN, int NT3, bool MULTI>
 __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
     const int Wt = s.update_wgs, NT = s.tiles;         // the unit's NT workgroups with a row tile each, then its helpers (the update only)
-    const int nag = D.n_agents;
+    const int nag = MULTI ? D.n_agents : 1;
     const int unit = a.p0 * nag + blockIdx.x / Wt, p = unit / nag, ag = unit - p * nag, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
     const NetDesc& NC = D.net[2 * ag + 1];
@@ -258,21 +259,25 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     }
 }
 
-#define FRL_SOLOW_CRITIC(name, twin, nt3)                                                                                          \
+#define FRL_SOLOW_CRITIC(name, twin, nt3, multi)                                                                                   \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_critic_body<twin, nt3>(*Dp, a, s, smem);                                                                              \
+        solow_critic_body<twin, nt3, multi>(*Dp, a, s, smem);                                                                       \
     }
-FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1)
-FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2)
-FRL_SOLOW_CRITIC(solow_critic_h2a1_kernel, true, 1)
-FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2)
+FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1, false)
+FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2, false)
+FRL_SOLOW_CRITIC(solow_critic_h2a1_kernel, true, 1, false)
+FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2, false)
+FRL_SOLOW_CRITIC(solow_critic_ma_h1a1_kernel, false, 1, true)
+FRL_SOLOW_CRITIC(solow_critic_ma_h1a2_kernel, false, 2, true)
+FRL_SOLOW_CRITIC(solow_critic_ma_h2a1_kernel, true, 1, true)
+FRL_SOLOW_CRITIC(solow_critic_ma_h2a2_kernel, true, 2, true)
 
 // ------------------------------------------------------------------------------------------------------------- actor stage
-template <int NT3>
+template <int NT3, bool MULTI>
 __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
     const int Wt = s.update_wgs, NT = s.tiles;
-    const int nag = D.n_agents;
+    const int nag = MULTI ? D.n_agents : 1;
     const int unit = a.p0 * nag + blockIdx.x / Wt, p = unit / nag, ag = unit - p * nag, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
     const NetDesc& NA = D.net[2 * ag];
@@ -480,12 +485,14 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     }
 }
 
-#define FRL_SOLOW_ACTOR(name, nt3)                                                                                                   \
+#define FRL_SOLOW_ACTOR(name, nt3, multi)                                                                                            \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_actor_body<nt3>(*Dp, a, s, smem);                                                                                     \
+        solow_actor_body<nt3, multi>(*Dp, a, s, smem);                                                                              \
     }
-FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1)
-FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2)
+FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1, false)
+FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2, false)
+FRL_SOLOW_ACTOR(solow_actor_ma_a1_kernel, 1, true)
+FRL_SOLOW_ACTOR(solow_actor_ma_a2_kernel, 2, true)
 
 }  // namespace frl

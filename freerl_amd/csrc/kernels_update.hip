@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256) void draw_kernel(const EngineDesc* __restrict_
     const int n = D.n_agents, p = a.p0 + blockIdx.x / n, ag = blockIdx.x % n, B = a.batch;
     g_i idx = (g_i)(D.idx + ((size_t)p * n + ag) * D.batch_max);
     const unsigned long long key = D.seed + 0x9E3779B97F4A7C15ull * (p + 1);
-    draw_indices(idx, (FRL_LDS int*)smem, B, a.size, a.rng_counter, (unsigned)ag, key);
-    if (want_noise) {
+    // (batches of 257 .. 2048 rows: the hash-table duplicate check; the launch carries its 2 x kDrawTable ints behind the row buffers)
+    FRL_LDS int* lb = (FRL_LDS int*)smem;
+    // (want_noise bit 1, FRL_DRAW_SCAN=1: the scan of every entry's predecessors whatever the batch — tests hold the two to the same rows)
+    draw_indices(idx, lb, B, a.size, a.rng_counter, (unsigned)ag, key, true, (B > kWG && 4 * B <= kDrawTable && !(want_noise & 2)) ? lb + 2 * ((B + 3) & ~3) : nullptr);
+    if (want_noise & 1) {
         const int am = D.act_max, NS = D.noise_sets;
         for (int s2 = 0; s2 < NS; s2 += 2) {          // two sets per Philox draw
             g_f noise0 = as_global(D.noise + (((size_t)p * n + ag) * NS + s2) * D.batch_max * am);

@@ -14,12 +14,16 @@ from freerl_amd.engine import Engine  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "sac"
 obs, act = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (376, 17)
-algo = dict(td3=N.ALGO_TD3, ddpg=N.ALGO_DDPG, sac=N.ALGO_SAC)[which]
-kw = dict(td3=dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0), ddpg={}, sac=dict(alpha_lr=1e-4, target_entropy=-float(act)))[which]
-e = Engine(algo, obs, act, 20_000, n_learners=1, twin_critic=algo != N.ALGO_DDPG, batch_max=256, seed=1)
-assert e.learn_path(256)[2] == 16 and e.learn_path(256)[0], e.learn_path(256)
+algo = dict(td3=N.ALGO_TD3, ddpg=N.ALGO_DDPG, sac=N.ALGO_SAC, maddpg=N.ALGO_MADDPG)[which]
+kw = dict(td3=dict(use_policy_noise=True, policy_noise=0.2, noise_clip=0.5, max_action=1.0), ddpg={}, sac=dict(alpha_lr=1e-4, target_entropy=-float(act)), maddpg={})[which]
+BATCH = 1024 if which == "maddpg" else 256          # (maddpg: config 5 — three agents of 18 / 5, batch 1024; the stamps are agent 0's first sixteen workgroups)
+if which == "maddpg":
+    e = Engine(algo, [18] * 3, [5] * 3, 20_000, n_learners=1, twin_critic=False, batch_max=BATCH, seed=1)
+else:
+    e = Engine(algo, obs, act, 20_000, n_learners=1, twin_critic=algo != N.ALGO_DDPG, batch_max=256, seed=1)
+assert e.learn_path(BATCH)[2] == 16 and e.learn_path(BATCH)[0], e.learn_path(BATCH)
 rng = np.random.default_rng(0)
-for net in range(2):
+for net in range(e.n_nets):
     flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
     e.set_params(net, flat, N.PARAM_ONLINE); e.set_params(net, flat, N.PARAM_TARGET)
 if algo == N.ALGO_SAC:
@@ -29,7 +33,7 @@ e.fill_synthetic(20_000, seed=5)
 
 def stamps(do_actor):
     for k in range(6):
-        e.learn(256, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=do_actor, **kw)
+        e.learn(BATCH, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=do_actor, **kw)
     buf = np.zeros((16, 32), np.float32)
     N.check(N.lib().frl_solo_debug_read(e._h, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size))
     if do_actor and buf[0, 16]:
@@ -56,7 +60,7 @@ for title, names, do_actor in (("critic stage (last launch of a critic-only call
         print("   %-40s %6.2f | %6.2f | %6.2f" % (n, d[0, i], d[:, i].mean(), d[:, i].max()))
 e.profile(True)
 for k in range(200):
-    e.learn(256, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(algo != N.ALGO_TD3 or k % 2 == 1), **kw)
+    e.learn(BATCH, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, do_actor=(algo != N.ALGO_TD3 or k % 2 == 1), **kw)
 pr = e.profile_read()
 print("HIP-event time per launch (us):", {k: round(1e3 * v[0] / v[1], 2) for k, v in pr.items()})
 e.close()
