@@ -1613,7 +1613,10 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         prof_end(e);
     } else {                                          // MATD3_simple.py:245-246: targets move with the delayed policy step
         prof_begin(e, PK_SOFT);
-        hipLaunchKernelGGL(soft_update_kernel, dim3(pc * h.n_nets), blk, 0, st, e->d, a.tau, p0);
+        int biggest = 0;
+        for (int i = 0; i < h.n_nets; ++i) biggest = std::max(biggest, h.net[i].size);
+        const int per = std::max(1, std::min((biggest + 4095) / 4096, 4 * e->n_cus / std::max(1, pc * h.n_nets)));
+        hipLaunchKernelGGL(soft_update_kernel, dim3(pc * h.n_nets, per), blk, 0, st, e->d, a.tau, p0);
         prof_end(e);
     }
 }
@@ -1676,7 +1679,8 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
     // streams so that one half's HBM-bound reduce/Adam runs under the other half's MFMA-bound gradient kernel — unchained
     // +2.7 %, with the gradient kernels chained across the streams -8 %: the Adam workgroups do not get co-resident with
     // the gradient kernel's (2 x 80 KB of LDS and 448 of 512 VGPRs per SIMD are taken).
-    const bool actor_stage = (h.algo != ALGO_DQN && a.do_actor), soft_stage = (h.algo == ALGO_MADDPG && a.do_actor);
+    // (kernels_solow.hip moves MADDPG's targets at the end of its actor launch)
+    const bool actor_stage = (h.algo != ALGO_DQN && a.do_actor), soft_stage = (h.algo == ALGO_MADDPG && a.do_actor && !(h.solow && chained_path(h, a.batch, h.P)));
     if (h.noisy) {
         // the reference draws noise per forward in program order: [online(s') if Double,] target(s'), online(s)
         const int first = a.double_dqn ? 0 : 1;

@@ -449,8 +449,18 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     solow_grid_sync(s.bar + (size_t)unit * NT, b, NT, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
-    u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = nag == 1 ? 1 : 0; u.t_new = t_new;
+    // (the actor's target moves here also for MADDPG: nothing in this launch reads a target net)
+    u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
     const float total = solow_update(s, a, u, grA, unit, b, nb, NT, Wt, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
+    if (MULTI) {
+        // MADDPG_simple.py:188-190 / MATD3_simple.py:245-246: every target follows its net once all agents are updated — the critic's here,
+        // a share per workgroup of the unit (soft_update_kernel's arithmetic; its launch, one workgroup per net, was 34 us of config 5's learn())
+        g_cf thCw = as_global(D.theta + lbase + D.net_off[2 * ag + 1]);
+        g_f tgCw = as_global(D.target + lbase + D.net_off[2 * ag + 1]);
+        const int n4 = NC.size >> 2, per = (n4 + Wt - 1) / Wt, i1 = min(n4, (b + 1) * per);
+        const float tk = 1.f - a.tau;
+        for (int i = b * per + tid; i < i1; i += kWG) st4(tgCw + 4 * (size_t)i, ld4((g_cf)(tgCw + 4 * (size_t)i)) * tk + ld4(thCw + 4 * (size_t)i) * a.tau);
+    }
     SOLO_T(7);
     if (b == 0 && tid == 0) {
         float qtot = 0.f, lptot = 0.f;

@@ -365,7 +365,11 @@ __global__ __launch_bounds__(256) void soft_update_kernel(const EngineDesc* __re
     const EngineDesc& D = *Dp;
     const int p = p0 + blockIdx.x / D.n_nets, net = blockIdx.x % D.n_nets;
     const size_t off = (size_t)p * D.learner_stride + D.net_off[net];
-    soft_update_net(D.net[net].size, as_global(D.target + off), as_global(D.theta + off), tau);
+    // (grid.y workgroups share a net by stride: one per net streamed config 5's 29 k-float critics at one load in flight per thread, 34 us)
+    g_f target = as_global(D.target + off);
+    g_cf theta = as_global(D.theta + off);
+    const float tk = 1.f - tau;
+    for (int i = blockIdx.y * kWG + threadIdx.x; i < D.net[net].size; i += gridDim.y * kWG) target[i] = target[i] * tk + theta[i] * tau;
 }
 
 // Fragment-image order -> Wk[k][n] for every weight block of the frag nets of all learners, in all four parameter arrays: what
