@@ -518,7 +518,30 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
     const int n4 = u.size >> 2, per = (n4 + Wt - 1) / Wt, i0 = b * per, i1 = min(n4, i0 + per);
     g_cf slab = as_global(s.slab + (size_t)unit * NT * s.slab_stride);
     float ss = 0.f;
-    for (int c0 = i0; c0 < i1; c0 += kWG * KM) {
+    const bool many_slabs = NT > W && per <= kWG / 2;
+    if (many_slabs) {
+        // MADDPG's 64 slabs of a 7-29 k-float net: a workgroup's share is ~100 float4 — one per thread of a HALF of the workgroup,
+        // the halves take slabs [0, 32) and [32, 64), all 32 loads of a thread in flight at once, the two partial sums meet in LDS
+        // (four dependent rounds of sixteen slabs with 113 of 256 threads busy were 15 us of a 53 us launch)
+        const int half = tid >> 7, t = tid & 127, i = i0 + t, ic = i < i1 ? i : (i1 > i0 ? i1 - 1 : 0);
+        f32x4 sl[32], acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sb = 0; sb < 32; ++sb) {
+            const int sx = 32 * half + sb, sc = sx < nb ? sx : nb - 1;
+            sl[sb] = ld4(slab + (size_t)sc * s.slab_stride + 4 * (size_t)ic);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sb = 0; sb < 32; ++sb) if (32 * half + sb < nb) acc += sl[sb];
+        st4(box + 256 + 4 * tid, acc);
+        __syncthreads();
+        if (tid < kWG / 2 && i < i1) {
+            const f32x4 g = ld4((lds_cf)(box + 256 + 4 * tid)) + ld4((lds_cf)(box + 256 + 4 * (tid + 128)));
+            st4(gsum + 4 * (size_t)i, g);
+            ss += (g[0] * g[0] + g[1] * g[1]) + (g[2] * g[2] + g[3] * g[3]);
+        }
+    }
+    for (int c0 = i0; c0 < i1 && !many_slabs; c0 += kWG * KM) {
         f32x4 g[KM];
 #pragma unroll
         for (int k = 0; k < KM; ++k) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
