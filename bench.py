@@ -234,6 +234,43 @@ def dqn_single_learner_loop(P=512):
                            "updates_per_sec": r["updates"] / r["seconds"]}}
 
 
+def baseline_configs_one_learner(device_id=0):
+    """BASELINE.json's configs 4 and 5 as the reference runs them — ONE learner per GPU, one learn() per vector step: SAC at Humanoid-v4's
+    376 + 17 columns (batch 256), MADDPG_simple on simple_spread's 3 x (18, 5) (batch 1024).  us per learn() with device-drawn rows,
+    the kernel family that served it (round 6: kernels_solow.hip, sixteen workgroups per (learner, agent) unit with the first layer
+    streamed from its block; 64 per unit at batch 1024), random weights, synthetic ring.  Not bench lines: a detail of the report."""
+    from freerl_amd import _native as N
+    from freerl_amd.engine import Engine
+    out = {}
+    for name, algo, obs, act, B, kw in (("config4_sac_humanoid_dims", N.ALGO_SAC, 376, 17, 256, dict(alpha_lr=1e-4, target_entropy=-17.0)),
+                                        ("config5_maddpg_simple_spread_dims", N.ALGO_MADDPG, [18] * 3, [5] * 3, 1024, {})):
+        try:
+            e = Engine(algo, obs, act, 20_000, n_learners=1, twin_critic=(algo == N.ALGO_SAC), batch_max=B, seed=1, device_id=device_id)
+            rng = np.random.default_rng(0)
+            for net in range(e.n_nets):
+                flat = (rng.standard_normal(e.num_params(net)) * 0.05).astype(np.float32)
+                e.set_params(net, flat, N.PARAM_ONLINE); e.set_params(net, flat, N.PARAM_TARGET)
+            if algo == N.ALGO_SAC:
+                e.set_alpha_state([np.log(0.01), 0, 0, 0.01])
+            e.fill_synthetic(20_000, seed=5)
+            for k in range(10):
+                e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, **kw)
+            e.sync()
+            t0 = time.perf_counter()
+            n = 300
+            for k in range(n):
+                e.learn(B, gamma=0.99, tau=0.005, actor_lr=1e-3, critic_lr=1e-3, **kw)
+            e.sync()
+            dt = (time.perf_counter() - t0) / n
+            path = e.learn_path(B)
+            out[name] = {"us_per_learn": dt * 1e6, "updates_per_sec": 1.0 / dt, "batch": B,
+                         "kernel_family": "sixteen workgroups per unit, first layer streamed (kernels_solow.hip)" if path[0] and path[2] == 16 else ("chained" if path[0] else "row-chunk")}
+            e.close()
+        except Exception as ex:                       # a detail of the report, never the reason a bench line is missing
+            out[name] = {"error": str(ex)[:200]}
+    return out
+
+
 def dqn_roofline(device_id=0):
     """The DQN update (north_star's own target algorithm: DQN_file/DQN.py:104-118) against BOTH rooflines.  One launch of
     dqn_fused_kernel (kernels_dqn2.hip) is the whole learn() of every resident learner — index draw, target + online forward,
@@ -539,6 +576,7 @@ def main():
                          "step_ms_avg": step_s * 1e3,
                          "step_tflops": (fl_a * n_act + fl_c * (args.steps - n_act)) / args.steps / step_s / 1e12,
                          "kernels": kern},
+            "baseline_configs_one_learner": None if args.headline_only else baseline_configs_one_learner(local_rank),
             "roofline_dqn": None if args.headline_only else dqn_roofline(local_rank),
             "dropin_classes": None if args.headline_only else dropin_classes(),
             "dqn_single_learner_loop": None if args.headline_only else dqn_single_learner_loop(args.learners),
