@@ -21,10 +21,16 @@ def N():
     return _native
 
 
-@pytest.fixture(params=["rowchunk", "chained"])
+@pytest.fixture(params=["rowchunk", "chained", "unforced"])
 def family(request, monkeypatch):
-    """Both kernel families on the same inputs: the row-chunk kernels (what a single learner runs) and the K-sliced chained
-    ones (kernels_criticw / _actorw: what populations of these shapes run), forced at engine creation."""
+    """The kernel families on the same inputs: the row-chunk kernels and the K-sliced chained ones (kernels_criticw / _actorw: what
+    populations of these shapes run), forced at engine creation — and, nothing forced, what ONE learner of these shapes gets since
+    round 6: kernels_solow.hip (sixteen workgroups per (learner, agent) unit; hidden 256 stays with the row-chunk kernels).
+    Returns what frl_learn_path must report as `chained`, or None where the test decides."""
+    if request.param == "unforced":
+        for v in ("FRL_CRITIC_V2", "FRL_SOLOW"):
+            monkeypatch.delenv(v, raising=False)
+        return None
     monkeypatch.setenv("FRL_CRITIC_V2", "1" if request.param == "chained" else "0")
     return request.param == "chained"
 
@@ -41,7 +47,11 @@ def test_c4_sac_humanoid_shape(N, family):
     e = Engine(N.ALGO_SAC, O, A, 2000, twin_critic=True, batch_max=B)
     lds, rc = e.lds_bytes()
     assert lds <= 160 * 1024 and rc in (16, 32, 64)
-    assert e.learn_path(B)[0] == family and e.learn_path(B)[1] <= 160 * 1024
+    if family is None:
+        assert e.learn_path(B)[0] and e.learn_path(B)[2] == 16, e.learn_path(B)      # kernels_solow.hip
+    else:
+        assert e.learn_path(B)[0] == family
+    assert e.learn_path(B)[1] <= 160 * 1024
     for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
         e.set_params(0, flat_params(actor, an, "log_std"), kind)
         e.set_params(1, flat_params(critic, TWIN), kind)
@@ -83,7 +93,13 @@ def test_c5_maddpg_spread_shape(N, family, hidden):
     params = {a: dict(actor=synth.mlp_params(90 + 2 * j, cases.actor_layers(O, A, hidden=hidden)),
                       critic=synth.mlp_params(91 + 2 * j, cases.critic_layers(n * (O + A), hidden=hidden))) for j, a in enumerate(ids)}
     e = Engine(N.ALGO_MADDPG, [O] * n, [A] * n, 2048, batch_max=B, hidden=hidden)
-    assert e.learn_path(B)[0] == family
+    if family is None:
+        if hidden != 128:
+            e.close()
+            pytest.skip("hidden 256: the unforced single learner is the row-chunk family, already run")
+        assert e.learn_path(B)[0] and e.learn_path(B)[2] == 16, e.learn_path(B)      # kernels_solow.hip: 3 units x 64 row tiles
+    else:
+        assert e.learn_path(B)[0] == family
     for j, a in enumerate(ids):
         for kind in (N.PARAM_ONLINE, N.PARAM_TARGET):
             e.set_params(2 * j, flat_params(params[a]["actor"], AC), kind)
@@ -307,6 +323,31 @@ def test_learn_path_reports_the_kernel_family(N, monkeypatch):
     few = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=100, twin_critic=True, batch_max=256)      # ... from 129 (learner, agent) units up
     assert not few.learn_path(256)[0]
     few.close()
+    # round 6: up to sixteen (learner, agent) units with a wide first layer at hidden 128 — kernels_solow.hip (160 512 B of LDS, a 16-row
+    # tile per workgroup), while every workgroup of a launch fits the chip: 64 row tiles per unit at MADDPG's batch of 1024
+    SOLOW = (True, 160512, 16)
+    for args, kw, B, want in (((N.ALGO_SAC, 376, 17, 512), dict(twin_critic=True, batch_max=256), 256, SOLOW),
+                              ((N.ALGO_TD3, 17, 6, 512), dict(n_learners=16, twin_critic=True, batch_max=256), 256, SOLOW),
+                              ((N.ALGO_TD3, 17, 6, 512), dict(n_learners=17, twin_critic=True, batch_max=256), 256, None),
+                              ((N.ALGO_DDPG, 8, 6, 512), dict(batch_max=100), 100, SOLOW),                  # act > 4: past the narrow kernels
+                              ((N.ALGO_MADDPG, [18] * 3, [5] * 3, 2048), dict(batch_max=1024), 1024, SOLOW),       # config 5: 3 x 64 workgroups
+                              ((N.ALGO_MADDPG, [18] * 3, [5] * 3, 2048), dict(n_learners=2, batch_max=1024), 1024, None),  # 6 x 64 do not fit
+                              ((N.ALGO_MADDPG, [18] * 3, [5] * 3, 512), dict(n_learners=5, batch_max=128), 128, SOLOW),    # 15 units x 16
+                              ((N.ALGO_MADDPG, [18] * 3, [5] * 3, 512), dict(n_learners=6, batch_max=128), 128, None),
+                              ((N.ALGO_SAC, 376, 17, 512), dict(twin_critic=True, batch_max=256, hidden=256), 256, None)):
+        e1 = Engine(*args, **kw)
+        assert (e1.learn_path(B) == want) if want else (not e1.learn_path(B)[0]), (args, kw, e1.learn_path(B))
+        e1.close()
+    monkeypatch.setenv("FRL_SOLOW", "0")
+    off = Engine(N.ALGO_SAC, 376, 17, 512, twin_critic=True, batch_max=256)
+    assert not off.learn_path(256)[0]
+    off.close()
+    monkeypatch.delenv("FRL_SOLOW")
+    monkeypatch.setenv("FRL_ASSUME_CUS", "40")                         # a device (or partition) that cannot hold 3 x 16 workgroups resident
+    part = Engine(N.ALGO_TD3, 17, 6, 512, n_learners=3, twin_critic=True, batch_max=256)
+    assert not part.learn_path(256)[0]
+    part.close()
+    monkeypatch.delenv("FRL_ASSUME_CUS")
     spread = Engine(N.ALGO_MADDPG, [18] * 3, [5] * 3, 512, n_learners=64, batch_max=128)       # 192 units
     assert spread.learn_path(128)[0]
     spread.close()
