@@ -155,20 +155,31 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
             // MATD3's per-agent smoothing noise is set j of the updating agent; single agent: set 0 (TD3 policy noise / SAC eps')
             g_cf noise0 = noise_u + (size_t)(nag > 1 ? j : 0) * D.batch_max * am;
             f32x4 nz[NT3];
+            const bool want_nz = sac || a.use_policy_noise;
 #pragma unroll
-            for (int t = 0; t < NT3; ++t)
+            for (int t = 0; t < NT3; ++t) {
+                nz[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (inline_draw) {
+                    // wave w regenerates component 16 t + 4 q + w of its lanes' rows (Philox + Box-Muller: ~250 instructions each, and every
+                    // wave holds the same rows); the other three come through LDS behind the image's barriers
+                    const int c = 16 * t + 4 * q + w;
+                    float v = 0.f;
+                    if (c < Aj && want_nz) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, (unsigned)(rc * am + c), key), n0, n1); v = n0; }      // = draw_kernel's set 0
+                    N.tz[i16 * 32 + c] = v;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * t + 4 * q + r;
-                    nz[t][r] = 0.f;
-                    if (c < Aj && (sac || a.use_policy_noise)) {
-                        const unsigned e1 = (unsigned)(rc * am + c);
-                        if (inline_draw) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, key), n0, n1); nz[t][r] = n0; }      // = draw_kernel's set 0
-                        else nz[t][r] = noise0[e1];
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * t + 4 * q + r;
+                        if (c < Aj && want_nz) nz[t][r] = noise0[(unsigned)(rc * am + c)];
                     }
                 }
+            }
             N.x_commit(xr, nag == 1 ? KB1c : KB1a);    // (every wave is behind the first-layer reads of the pass in front: its two barriers)
             N.stage_commit(pend);
+            if (inline_draw) {
+#pragma unroll
+                for (int t = 0; t < NT3; ++t) nz[t] = ld4((lds_cf)(N.tz + i16 * 32 + 16 * t + 4 * q));
+            }
             if (j == 0) SOLO_T(0);
             if (j == nag - 1) {
                 pend = N.stage_fetch((g_cf)tgC, NC.L, 1, -1, 0);
@@ -328,20 +339,28 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         if (nag > 1) xj = N.x_fetch(SoloWX{rec, R.obs_off[0], OT + AT, R.stride}, KB1c);
         f32x4 ep[NT3];
 #pragma unroll
-        for (int t = 0; t < NT3; ++t)
+        for (int t = 0; t < NT3; ++t) {
+            ep[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inline_draw) {                             // (one component per wave, the rest through LDS: the critic stage's nz)
+                const int c = 16 * t + 4 * q + w;
+                float v = 0.f;
+                if (sac && c < Ai) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, (unsigned)(rc * am + c), D.seed + 0x9E3779B97F4A7C15ull * (p + 1)), n0, n1); v = n1; }   // = draw_kernel's set 1
+                N.tz[i16 * 32 + c] = v;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * t + 4 * q + r;
-                ep[t][r] = 0.f;
-                if (sac && c < Ai) {
-                    const unsigned e1 = (unsigned)(rc * am + c);
-                    if (inline_draw) { float n0, n1; normal2(philox4x32_10(a.rng_counter, 0x4000u, e1, D.seed + 0x9E3779B97F4A7C15ull * (p + 1)), n0, n1); ep[t][r] = n1; }   // = draw_kernel's set 1
-                    else ep[t][r] = noise1[e1];
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * t + 4 * q + r;
+                    if (sac && c < Ai) ep[t][r] = noise1[(unsigned)(rc * am + c)];
                 }
             }
+        }
         N.x_commit(xr, nag == 1 ? KB1c : KB1a, xb);
         if (nag > 1) N.x_commit(xj, KB1c);
         N.stage_commit(pend);
+        if (inline_draw) {
+#pragma unroll
+            for (int t = 0; t < NT3; ++t) ep[t] = ld4((lds_cf)(N.tz + i16 * 32 + 16 * t + 4 * q));
+        }
         SOLO_T(0);
         pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
         pren = N.pre_fetch(thC + NC.L[0].w_off, KB1c);
