@@ -479,9 +479,9 @@ struct SoloWNet {
     }
 };
 
-// ---- "the unit's NT slabs are written" (solo.hpp: solo_grid_sync; NT = 16 row tiles of a batch of up to 256 rows, 64 of MADDPG's
-// 1024) with HELPER workgroups: b >= NT has no row tile and publishes nothing — it waits for the NT flags like the others and takes
-// its share of the update
+// ---- "the unit's slabs are written" (solo.hpp: solo_grid_sync) by its NT workgroups with row tiles (16 for batches of up to 256 rows
+// — 8, with two tiles each, for populations of 17 .. 32 units —, 64 for MADDPG's 1024) with HELPER workgroups: b >= NT has no row
+// tile and publishes nothing — it waits for the NT flags like the others and takes its share of the update
 __device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, int NT, unsigned epoch, int* err) {
     sync_stores();
     if (threadIdx.x == 0 && b < NT) {

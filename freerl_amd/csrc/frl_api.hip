@@ -104,7 +104,8 @@ struct frl_engine {
     int* d_solo_ticket = nullptr;         // the rollout tail's learner ticket
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
     int solo_stride = 0;
-    int solow_wgs = 0;                    // kernels_solow.hip: workgroups per learner in its grids (16 + helpers for the update)
+    int solow_wgs = 0;                    // kernels_solow.hip: workgroups per unit in its grids (row-tile workgroups + helpers for the update)
+    int solow_row_wgs = 0;                // ... of which own row tiles (16: one tile each; 8: two each, populations of 17 .. 32 units; 64: MADDPG's batches of 1024)
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
     float* d_act_out = nullptr;
@@ -435,10 +436,13 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         for (int i = 0; i < h.n_nets; ++i) solow_shape = solow_shape && h.net[i].L[0].k_pad <= 16 * (h.n_agents == 1 ? kSoloWMaxKB : kSoloWActorBase);
         const int solow_tiles = h.batch_max <= 256 ? kSoloWG : 4 * kSoloWG;
         const long long solow_units = (long long)h.P * h.n_agents;
-        const bool solow_fits = solow_units <= kSoloMaxP && solow_units * solow_tiles <= e->n_cus && e->lds_per_cu >= (int)(solow_lds_floats() * sizeof(float) + 256);
+        // (two row tiles per workgroup for 17 .. 32 units: measured level with the row-chunk chain — kernels_solow.hip — and not built)
+        const int solow_rw = solow_tiles;
+        const bool solow_fits = solow_units <= kSoloMaxP && solow_units * solow_rw <= e->n_cus && e->lds_per_cu >= (int)(solow_lds_floats() * sizeof(float) + 256);
         if ((sw ? atoi(sw) != 0 : !force) && solow_shape && solow_fits) {
             for (int i = 0; i < h.n_nets; ++i) h.net[i].frag = 1;
             h.solow = solow_tiles;
+            e->solow_row_wgs = solow_rw;
         } else
         // from 129 (learner, agent) units up: hidden 128 (chain_wide.hpp) SAC at Humanoid dims 85.5 TFLOP/s against the row-chunk
         // kernels' 46.2, MADDPG simple_spread 77.2 / 55.5; hidden 256 (chain_wide16.hpp: x-stationary sweeps) 71.1 / 56.9
@@ -573,8 +577,9 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             e->solow_wgs = (int)NT;
             if (h.solow) {
                 const char* hp = getenv("FRL_SOLOW_HELPERS");
-                const int per = std::min(64 / (int)NT > 0 ? 64 / (int)NT : 1, std::max(1, e->n_cus / ((int)NT * (int)U)));      // (at most 64 workgroups per unit: the mailboxes are polled by one wave)
-                e->solow_wgs = (hp && atoi(hp) == 0) ? (int)NT : (int)NT * per;
+                const int rw = e->solow_row_wgs;
+                const int per = std::min(64 / rw > 0 ? 64 / rw : 1, std::max(1, e->n_cus / (rw * (int)U)));      // (at most 64 workgroups per unit: the mailboxes are polled by one wave)
+                e->solow_wgs = (hp && atoi(hp) == 0) ? rw : rw * per;
             }
             CREATE_TRY(dalloc_zero(&e->d_solo_part, U * (size_t)std::max((int)NT, e->solow_wgs) * kSoloPartHost, e->stream));
             { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloPre, e->stream)); e->d_solo_pre = (int*)z; }
@@ -737,7 +742,7 @@ extern "C" int frl_learn_path(const frl_engine* e, int batch, int* chained_out, 
     if (v2 && e->h.solow) {                                 // kernels_solow.hip: one 16-row tile per workgroup
         if (chained_out) *chained_out = 1;
         if (bytes_out) *bytes_out = solow_lds_floats() * (int)sizeof(float);
-        if (rows_out) *rows_out = 16;
+        if (rows_out) *rows_out = 16 * (e->h.solow / std::max(1, e->solow_row_wgs));
         return FRL_OK;
     }
     if (chained_out) *chained_out = v2 ? 1 : 0;
@@ -1490,14 +1495,14 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {                              // kernels_solow.hip: sixteen workgroups per learner, W1 streamed from the block
             prof_begin(e, PK_GRAD_CRITIC);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_row_wgs, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             // the next call's rows drawn by the learners' first helper workgroups (kernels_solo.hip's spare-workgroup scheme: two
             // alternating slots, a tag the reader checks; FRL_SOLO_PREDRAW=0 switches it off)
             if (dev_rng && e->d_solo_pre && pc == h.P && h.n_agents == 1) {
                 const char* pdf = getenv("FRL_SOLO_PREDRAW");
                 sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * kSoloPre;      // (stale or foreign tags fail the kernel's check)
-                if (e->solow_wgs > h.solow && !(pdf && atoi(pdf) == 0)) {
+                if (e->solow_wgs > e->solow_row_wgs && !(pdf && atoi(pdf) == 0)) {
                     sa.pre_write = e->d_solo_pre + (size_t)((e->solo_pre_seq + 1) & 1) * h.P * kSoloPre;
                     sa.pre_counter = e->rng_counter;              // what the next frl_learn takes, unless something else draws first
                 }
@@ -1575,7 +1580,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {
             prof_begin(e, PK_GRAD_ACTOR);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_row_wgs, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             const bool a2 = h.net[0].L[2].n_pad > 16;
             hipLaunchKernelGGL(h.n_agents > 1 ? (a2 ? solow_actor_ma_a2_kernel : solow_actor_ma_a1_kernel) : (a2 ? solow_actor_a2_kernel : solow_actor_a1_kernel), dim3(units * e->solow_wgs), blk,

@@ -221,6 +221,7 @@ struct SoloArgs {
     int* pre_write;         // [P][kSoloPre] or NULL: the grid carries p_count extra workgroups behind the learners'
     unsigned long long pre_counter;   // the counter the next frl_learn call will take if nothing else draws in between
     int tiles;              // kernels_solow.hip: row tiles = slabs = flags per unit (16: batches of up to 256 rows; 64: MADDPG's 1024); slab / bar are [units][tiles]
+    int row_wgs;            // kernels_solow.hip: workgroups per unit that own row tiles (tiles / row_wgs each; flags are polled for these)
     int update_wgs;         // kernels_solow.hip: workgroups per learner in the grid (16 with row tiles + helpers that only take a share of the update); `part` is [P][update_wgs][..]
 };
 constexpr int kSoloPre = 8 + 256;

@@ -66,10 +66,15 @@ __device__ __forceinline__ float policy_rows(const SoloWNet& N, const LearnArgs&
 
 // NT3 = head tiles of the actors (act_dim <= 16 -> 1, <= 32 -> 2)
 // MULTI: MADDPG / MATD3 (a compile-time 1 for the single-agent kernels: their loop over the agents' target actors is straight-line code)
-template <bool TWIN, int NT3, bool MULTI>
+// T: row tiles per workgroup — 1.  T = 2 (populations of 17 .. 32 single-agent units on eight workgroups each, kernels_solo.hip's _w8
+// form) was built and measured, SAC at 376 / 17, us per learn(): 17 / 24 / 32 learners 384 / 457 / 536 against the row-chunk chain's
+// 435 / ~480 / 530 — every CU holds a workgroup that streams W1 five times per tile and writes two 560 KB slabs, and the chip's
+// memory side is what the 256 of them share — so it is not instantiated (as a RUNTIME tile loop hipcc hoisted the tile-invariant
+// address arithmetic of the whole body in front of it: 512 registers, 250-410 spilled; unrolled: 20-56 spilled)
+template <bool TWIN, int NT3, bool MULTI, int T>
 __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
-    const int Wt = s.update_wgs, NT = s.tiles;         // the unit's NT workgroups with a row tile each, then its helpers (the update only)
+    const int Wt = s.update_wgs, NT = s.tiles, Wc = s.row_wgs;   // the unit's Wc workgroups with row tiles (NT / Wc each, walked one after the other), then its helpers (the update only)
     const int nag = MULTI ? D.n_agents : 1;
     const int unit = a.p0 * nag + blockIdx.x / Wt, p = unit / nag, ag = unit - p * nag, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
@@ -96,21 +101,26 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     const int t_new = steps[2 * ag + 1] + 1;           // read by every workgroup before the hand-over; rewritten behind the mailboxes
     SOLO_T0();
 
-    float lossp = 0.f;
-    if (b == NT && s.pre_write && inline_draw) {
+    if (b == Wc && s.pre_write && inline_draw) {
         // the learner's first helper has nothing to do until the hand-over: the rows of the NEXT call (the Philox counter the next
         // frl_learn will take, the current ring size), where nobody waits for them — kernels_solo.hip's spare workgroup
         int* out = s.pre_write + (size_t)(p - a.p0) * kSoloPre;
         draw_indices((g_i)(out + 8), (FRL_LDS int*)N.ea, B, a.size, s.pre_counter, 0u, D.seed + 0x9E3779B97F4A7C15ull * (p + 1), true);
         if (tid == 0) { out[0] = (int)(unsigned)s.pre_counter; out[1] = (int)(unsigned)(s.pre_counter >> 32); out[2] = a.size; out[3] = B; }
     }
-    if (b < nb) {
+    // this workgroup's row tiles b, b + Wc, ..: one after the other, a slab per TILE
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+        const int bt = b + Wc * tt;
+        if (bt >= nb || b >= Wc) break;
+        if (tt > 0) { lds_barrier(); __builtin_amdgcn_sched_barrier(0); }      // (every wave is done with the tile in front: its rows, action table and exchanges)
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         g_ci idx = as_global_i(D.idx + (size_t)unit * D.batch_max);
         g_cf noise_u = as_global(D.noise + (size_t)unit * D.noise_sets * D.batch_max * am);      // this unit's sets
-        g_f slab = as_global(s.slab + ((size_t)unit * NT + b) * s.slab_stride);
+        g_f slab = as_global(s.slab + ((size_t)unit * NT + bt) * s.slab_stride);
         const float alpha = sac ? D.alpha[p * 4 + 3] : 0.f;
-        const int row = 16 * b + i16, rc = row < B ? row : B - 1;
+        const int row = 16 * bt + i16, rc = row < B ? row : B - 1;
+        float lossp = 0.f;
         const bool valid = row < B;
         const NetDesc& NA0 = D.net[0];
         g_cf tgA0 = as_global(D.target + lbase + D.net_off[0]);
@@ -247,10 +257,10 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
             N.hidden_bwd<true>(slab, L, KB1c, d2o, h1o, d1o);
         }
         lossp = SoloNet::rows_sum(lossp);
-        if (tid == 0) part[b * kSoloPart + 0] = lossp;
+        if (tid == 0) part[bt * kSoloPart + 0] = lossp;
     }
     SOLO_T(3);
-    solow_grid_sync(s.bar + (size_t)unit * NT, b, NT, s.bar_base + kSoloWG, s.err);
+    solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
@@ -270,24 +280,25 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     }
 }
 
-#define FRL_SOLOW_CRITIC(name, twin, nt3, multi)                                                                                   \
+#define FRL_SOLOW_CRITIC(name, twin, nt3, multi, tiles)                                                                            \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_critic_body<twin, nt3, multi>(*Dp, a, s, smem);                                                                       \
+        solow_critic_body<twin, nt3, multi, tiles>(*Dp, a, s, smem);                                                                \
     }
-FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1, false)
-FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2, false)
-FRL_SOLOW_CRITIC(solow_critic_h2a1_kernel, true, 1, false)
-FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2, false)
-FRL_SOLOW_CRITIC(solow_critic_ma_h1a1_kernel, false, 1, true)
-FRL_SOLOW_CRITIC(solow_critic_ma_h1a2_kernel, false, 2, true)
-FRL_SOLOW_CRITIC(solow_critic_ma_h2a1_kernel, true, 1, true)
-FRL_SOLOW_CRITIC(solow_critic_ma_h2a2_kernel, true, 2, true)
+FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1, false, 1)
+FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2, false, 1)
+FRL_SOLOW_CRITIC(solow_critic_h2a1_kernel, true, 1, false, 1)
+FRL_SOLOW_CRITIC(solow_critic_h2a2_kernel, true, 2, false, 1)
+FRL_SOLOW_CRITIC(solow_critic_ma_h1a1_kernel, false, 1, true, 1)
+FRL_SOLOW_CRITIC(solow_critic_ma_h1a2_kernel, false, 2, true, 1)
+FRL_SOLOW_CRITIC(solow_critic_ma_h2a1_kernel, true, 1, true, 1)
+FRL_SOLOW_CRITIC(solow_critic_ma_h2a2_kernel, true, 2, true, 1)
+
 
 // ------------------------------------------------------------------------------------------------------------- actor stage
-template <int NT3, bool MULTI>
+template <int NT3, bool MULTI, int T>
 __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
-    const int Wt = s.update_wgs, NT = s.tiles;
+    const int Wt = s.update_wgs, NT = s.tiles, Wc = s.row_wgs;
     const int nag = MULTI ? D.n_agents : 1;
     const int unit = a.p0 * nag + blockIdx.x / Wt, p = unit / nag, ag = unit - p * nag, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
@@ -322,13 +333,17 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     const int xb = nag == 1 ? 0 : kSoloWActorBase;
     SOLO_T0();
 
-    float qrow = 0.f, lp = 0.f;
-    if (b < nb) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {                       // this workgroup's row tiles, one after the other; a slab per TILE
+        const int bt = b + Wc * tt;
+        if (bt >= nb || b >= Wc) break;
+        if (tt > 0) { lds_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        float qrow = 0.f, lp = 0.f;
         g_cf ring = as_global(D.replay + (size_t)p * D.capacity * R.stride);
         g_ci idx = as_global_i(D.idx + (size_t)unit * D.batch_max);
         g_cf noise1 = as_global(D.noise + ((size_t)unit * D.noise_sets + 1) * D.batch_max * am);      // the actor stage's eps (set 1; SAC)
-        g_f slab = as_global(s.slab + ((size_t)unit * NT + b) * s.slab_stride);
-        const int row = 16 * b + i16, rc = row < B ? row : B - 1;
+        g_f slab = as_global(s.slab + ((size_t)unit * NT + bt) * s.slab_stride);
+        const int row = 16 * bt + i16, rc = row < B ? row : B - 1;
         const bool valid = row < B;
         SoloWNet::Stage pend = N.stage_fetch((g_cf)thA, NA.L, NT3, NA.extra_off, NA.extra_n);
         SoloWNet::Pre pre = N.pre_fetch((g_cf)thA + NA.L[0].w_off, KB1a), pren;
@@ -462,10 +477,10 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         lp = valid ? lpr : 0.f;
         qrow = SoloNet::rows_sum(qrow);
         lp = SoloNet::rows_sum(lp);
-        if (tid == 0) { part[b * kSoloPart + 0] = qrow; part[b * kSoloPart + 1] = lp; }
+        if (tid == 0) { part[bt * kSoloPart + 0] = qrow; part[bt * kSoloPart + 1] = lp; }
     }
     SOLO_T(3);
-    solow_grid_sync(s.bar + (size_t)unit * NT, b, NT, s.bar_base + kSoloWG, s.err);
+    solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, s.bar_base + kSoloWG, s.err);
     SOLO_T(4);
     SoloUpdate u;
     // (the actor's target moves here also for MADDPG: nothing in this launch reads a target net)
@@ -514,14 +529,15 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
     }
 }
 
-#define FRL_SOLOW_ACTOR(name, nt3, multi)                                                                                            \
+#define FRL_SOLOW_ACTOR(name, nt3, multi, tiles)                                                                                     \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_actor_body<nt3, multi>(*Dp, a, s, smem);                                                                              \
+        solow_actor_body<nt3, multi, tiles>(*Dp, a, s, smem);                                                                       \
     }
-FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1, false)
-FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2, false)
-FRL_SOLOW_ACTOR(solow_actor_ma_a1_kernel, 1, true)
-FRL_SOLOW_ACTOR(solow_actor_ma_a2_kernel, 2, true)
+FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1, false, 1)
+FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2, false, 1)
+FRL_SOLOW_ACTOR(solow_actor_ma_a1_kernel, 1, true, 1)
+FRL_SOLOW_ACTOR(solow_actor_ma_a2_kernel, 2, true, 1)
+
 
 }  // namespace frl
