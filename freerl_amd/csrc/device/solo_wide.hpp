@@ -491,7 +491,9 @@ __device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, int NT, 
     }
     if ((int)threadIdx.x < NT) {
         const unsigned long long t0 = wall_clock64();                      // 100 MHz
-        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        // ("has reached", not "equals": in the fused step a workgroup without rows flags its empty slab, walks through the actor half and
+        //  flags the NEXT epoch before a slow helper has looked — epochs only grow)
+        while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
         }
@@ -501,12 +503,37 @@ __device__ __forceinline__ void solow_grid_sync(unsigned* flags, int b, int NT, 
     __syncthreads();
 }
 
+// ---- the fused policy step: the workgroups with row tiles wait here — behind the policy's forward, which needs nothing of it — until
+// the unit's H helpers have stepped the critic (flags2[h] = epoch, published like the slab flags)
+__device__ __forceinline__ void solow_wait_flags(const unsigned* flags2, int H, unsigned epoch, int* err) {
+    if ((int)threadIdx.x < H) {
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(flags2 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull) { *err = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
+__device__ __forceinline__ void solow_publish(unsigned* flag, unsigned epoch) {
+    sync_stores();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- behind the slab hand-over: this workgroup's share (one Wt-th: the learner's sixteen workgroups and its Wt - 16 helpers — a
 // CU pulls ~65 GB/s of slabs through the fabric, three dependent round trips per workgroup for the twin critic of config 4 on
 // sixteen: 8.4 us, and the other 240 CUs idle) of a net of any size — phase 1: slab sum in workgroup order -> gsum
 // (EngineDesc::grad), partial squared norm; the sixteen partial norms meet through the mailboxes of solo_update; phase 2: clip
 // coefficient, Adam, soft update.  Returns the gradient norm.
-__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int unit, int b, int nb, int NT, int Wt, lds_f red,
+// (b of Wt: this workgroup's place among the ones that share the update — all of the unit's, or, in the fused policy step, its helpers
+// alone; part: the unit's rows of SoloArgs::part, whose mailboxes are read by place)
+__device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs& a, const SoloUpdate& u, g_f gsum, int unit, float* part, int b, int nb, int NT, int Wt, lds_f red,
                                               lds_f box, unsigned bar2_target
 #ifdef FRL_SOLO_TIMING
                                               , unsigned long long solo_t0_
@@ -514,7 +541,6 @@ __device__ __forceinline__ float solow_update(const SoloArgs& s, const LearnArgs
                                               ) {
     constexpr int W = kSoloWG, KM = 3;
     const int tid = threadIdx.x;
-    float* part = s.part + ((size_t)unit * Wt) * kSoloPart;
     const int n4 = u.size >> 2, per = (n4 + Wt - 1) / Wt, i0 = b * per, i1 = min(n4, i0 + per);
     g_cf slab = as_global(s.slab + (size_t)unit * NT * s.slab_stride);
     float ss = 0.f;

@@ -105,6 +105,7 @@ struct frl_engine {
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
     int solo_stride = 0;
     int solow_wgs = 0;                    // kernels_solow.hip: workgroups per unit in its grids (row-tile workgroups + helpers for the update)
+    unsigned* d_solow_bar2 = nullptr;     // [units][64] "critic stepped" flags of the helper workgroups (the fused policy step)
     int solow_row_wgs = 0;                // ... of which own row tiles (16: one tile each; 8: two each, populations of 17 .. 32 units; 64: MADDPG's batches of 1024)
     float* d_act_in = nullptr;
     float* d_act_eps = nullptr;
@@ -271,6 +272,7 @@ extern "C" int frl_destroy(frl_engine* e) {
     if (e->d_solo_part) hipFree(e->d_solo_part);
     if (e->d_solo_pre) hipFree(e->d_solo_pre);
     if (e->d_solo_bar) hipFree(e->d_solo_bar);
+    if (e->d_solow_bar2) hipFree(e->d_solow_bar2);
     if (e->h_solo_err) hipHostFree(e->h_solo_err);
     float* dev[] = {e->h.act_spill, e->h.theta_eff, e->h.noisy_eps, e->h.isw, e->h.td_err, e->h.theta, e->h.target, e->h.m, e->h.v, e->h.grad, e->h.replay, e->h.noise, e->h.stats, e->h.alpha,
                     e->d_stage_rows, e->d_act_in, e->d_act_eps, e->d_act_out, e->d_act_logp, e->d_ppo, e->d_act_wk, e->h.wide_scr};
@@ -587,6 +589,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
             CREATE_TRY(dalloc_zero(&z, 2 * U * NT + 2, e->stream));
             e->d_solo_bar = (unsigned*)z;                                  // [units][tiles] slab flags, then as many "actor slice stepped" flags (kernels_solo.hip: offset P * 16),
             e->d_solo_ticket = (int*)(z + 2 * U * NT);                     // ... and the rollout tail's learner ticket
+            if (h.solow) { float* z2 = nullptr; CREATE_TRY(dalloc_zero(&z2, U * 64, e->stream)); e->d_solow_bar2 = (unsigned*)z2; }
         }
         if (h.solo || h.solow || h.algo == ALGO_DQN) {                     // the pinned give-up word of the spinning launches (solo hand-overs, pre-armed DQN steps)
             CREATE_TRY(hipHostMalloc((void**)&e->h_solo_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -639,7 +642,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
     } else if (h.solow) {
         const int lb = solow_lds_floats() * (int)sizeof(float);
         for (auto k : {solow_critic_h1a1_kernel, solow_critic_h1a2_kernel, solow_critic_h2a1_kernel, solow_critic_h2a2_kernel, solow_actor_a1_kernel, solow_actor_a2_kernel,
-                       solow_critic_ma_h1a1_kernel, solow_critic_ma_h1a2_kernel, solow_critic_ma_h2a1_kernel, solow_critic_ma_h2a2_kernel, solow_actor_ma_a1_kernel, solow_actor_ma_a2_kernel})
+                       solow_critic_ma_h1a1_kernel, solow_critic_ma_h1a2_kernel, solow_critic_ma_h2a1_kernel, solow_critic_ma_h2a2_kernel, solow_actor_ma_a1_kernel, solow_actor_ma_a2_kernel,
+                       solow_step_h1a1_kernel, solow_step_h1a2_kernel, solow_step_h2a1_kernel, solow_step_h2a2_kernel})
             CREATE_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     } else if (h.solo) {
         const int lb = std::max(solo_lds_floats(), critic2_lds_floats()) * (int)sizeof(float);      // (critic2: the rollout tail's act_frag_body)
@@ -1495,7 +1499,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {                              // kernels_solow.hip: sixteen workgroups per learner, W1 streamed from the block
             prof_begin(e, PK_GRAD_CRITIC);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_row_wgs, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->d_solow_bar2, e->solow_row_wgs, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             // the next call's rows drawn by the learners' first helper workgroups (kernels_solo.hip's spare-workgroup scheme: two
             // alternating slots, a tag the reader checks; FRL_SOLO_PREDRAW=0 switches it off)
@@ -1511,6 +1515,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             const bool twin = h.net[1].heads == 2, a2 = h.net[0].L[2].n_pad > 16;
             auto k = h.n_agents > 1 ? (twin ? (a2 ? solow_critic_ma_h2a2_kernel : solow_critic_ma_h2a1_kernel) : (a2 ? solow_critic_ma_h1a2_kernel : solow_critic_ma_h1a1_kernel))
                                     : (twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel));
+            if (a.fuse_actor) k = twin ? (a2 ? solow_step_h2a2_kernel : solow_step_h2a1_kernel) : (a2 ? solow_step_h1a2_kernel : solow_step_h1a1_kernel);
             hipLaunchKernelGGL(k, dim3(units * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
@@ -1580,7 +1585,7 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         }
         if (v2 && h.solow) {
             prof_begin(e, PK_GRAD_ACTOR);
-            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->solow_row_wgs, e->solow_wgs};
+            SoloArgs sa{e->d_solo_slab, e->d_solo_part, e->d_solo_bar, e->d_solo_err, e->solo_bar_base, e->solo_stride, nullptr, nullptr, 0ull, h.solow, e->d_solow_bar2, e->solow_row_wgs, e->solow_wgs};
             e->solo_bar_base += kSoloWG;
             const bool a2 = h.net[0].L[2].n_pad > 16;
             hipLaunchKernelGGL(h.n_agents > 1 ? (a2 ? solow_actor_ma_a2_kernel : solow_actor_ma_a1_kernel) : (a2 ? solow_actor_a2_kernel : solow_actor_a1_kernel), dim3(units * e->solow_wgs), blk,
@@ -1692,6 +1697,12 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         if (args->noisy_eps) { rc = noisy_upload(e, args->noisy_eps, first, 3 - first); if (rc) return rc; }
         else hipLaunchKernelGGL(noisy_draw_kernel, dim3(h.P, 3), dim3(256), 0, e->stream, e->d, 0, 3, e->rng_counter++);
     }
+    // kernels_solow.hip, single agent, helper workgroups present: a policy step is ONE launch — the critic's update runs on the helpers
+    // under the policy's forward (FRL_SOLOW_FUSE=0: two launches)
+    if (actor_stage && h.solow && h.n_agents == 1 && e->solow_wgs > e->solow_row_wgs && chained_path(h, a.batch, h.P)) {
+        const char* fz = getenv("FRL_SOLOW_FUSE");
+        a.fuse_actor = (fz && atoi(fz) == 0) ? 0 : 1;
+    }
     hipStream_t lst = stream_override ? stream_override : e->stream;      // (frl_rollout's pre-armed launches: the pool's second stream)
     if (sstep) {
         // frl_rollout on a solo engine: the step's add() rides at the head of the critic launch, its tail (obs advance + the next
@@ -1706,7 +1717,7 @@ static int learn_impl(frl_engine* e, const frl_learn_args* args, const DqnStepAr
         return FRL_OK;
     }
     launch_learn_stage(e, lst, a, 0, 0, h.P, dev_rng, needs_noise, step);
-    if (actor_stage) launch_learn_stage(e, lst, a, 1, 0, h.P, dev_rng, needs_noise);
+    if (actor_stage && !a.fuse_actor) launch_learn_stage(e, lst, a, 1, 0, h.P, dev_rng, needs_noise);
     if (soft_stage) launch_learn_stage(e, lst, a, 2, 0, h.P, dev_rng, needs_noise);
     HIP_TRY(hipGetLastError());
     if (args->stats_out) return frl_stats_get(e, args->stats_out);

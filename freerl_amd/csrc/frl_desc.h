@@ -201,6 +201,7 @@ struct LearnArgs {
     int stagger;          // kernels_critic2: s_sleep(32) units (2 k cycles) between the start phases of the first round's workgroups (0: none)
     int stagger_groups;   // ... how many start phases (a power of two), and how many workgroups make the first round (the device's CUs)
     int stagger_wgs;
+    int fuse_actor;       // kernels_solow.hip: this call's critic AND actor stage run in one launch (solow_step_*); frl_learn skips the actor launch
     int huber;            // TD loss: 0 F.mse_loss (every hot-path loss of the reference), 1 Huber with `huber_delta`
     float huber_delta;    // (the reference's huber_loss, MAPPO_file/MAPPO.py:273-276: e^2/2 if |e| <= d else d(|e| - d/2), mean)
 };

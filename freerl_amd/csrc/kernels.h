@@ -221,6 +221,7 @@ struct SoloArgs {
     int* pre_write;         // [P][kSoloPre] or NULL: the grid carries p_count extra workgroups behind the learners'
     unsigned long long pre_counter;   // the counter the next frl_learn call will take if nothing else draws in between
     int tiles;              // kernels_solow.hip: row tiles = slabs = flags per unit (16: batches of up to 256 rows; 64: MADDPG's 1024); slab / bar are [units][tiles]
+    unsigned* bar2;         // kernels_solow.hip, fused policy step: [units][64] "critic stepped" flags of the unit's helper workgroups (or NULL)
     int row_wgs;            // kernels_solow.hip: workgroups per unit that own row tiles (tiles / row_wgs each; flags are polled for these)
     int update_wgs;         // kernels_solow.hip: workgroups per learner in the grid (16 with row tiles + helpers that only take a share of the update); `part` is [P][update_wgs][..]
 };
@@ -265,6 +266,11 @@ __global__ void solow_critic_ma_h2a1_kernel(const EngineDesc* __restrict__ Dp, L
 __global__ void solow_critic_ma_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 __global__ void solow_actor_ma_a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 __global__ void solow_actor_ma_a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+// ... a policy step (critic + actor stage) of single-agent engines with helper workgroups in one launch
+__global__ void solow_step_h1a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_step_h1a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_step_h2a1_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
+__global__ void solow_step_h2a2_kernel(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s);
 // kernels_dqn2.hip: draw + DQN / Double-DQN update + Adam + soft update of one learner in one launch
 constexpr int kDqn2Batch = 256;
 constexpr int dqn2_lds_floats() { return 4 * 8 * 256 + 8 * 4 * 256 + 4 * 256 + 2 * (128 + 16) + 64 + 64 * 16 + 2 * kDqn2Batch; }

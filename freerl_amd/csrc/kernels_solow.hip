@@ -71,7 +71,9 @@ __device__ __forceinline__ float policy_rows(const SoloWNet& N, const LearnArgs&
 // 435 / ~480 / 530 — every CU holds a workgroup that streams W1 five times per tile and writes two 560 KB slabs, and the chip's
 // memory side is what the 256 of them share — so it is not instantiated (as a RUNTIME tile loop hipcc hoisted the tile-invariant
 // address arithmetic of the whole body in front of it: 512 registers, 250-410 spilled; unrolled: 20-56 spilled)
-template <bool TWIN, int NT3, bool MULTI, int T>
+// FUSED: the critic half of a policy step in ONE launch (solow_step_*): a workgroup with a row tile flags its slab and goes on to the
+// policy's forward, which needs nothing of the update; the unit's HELPERS alone sum the slabs and step the critic meanwhile
+template <bool TWIN, int NT3, bool MULTI, int T, bool FUSED>
 __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
     constexpr int NH = TWIN ? 2 : 1;
     const int Wt = s.update_wgs, NT = s.tiles, Wc = s.row_wgs;   // the unit's Wc workgroups with row tiles (NT / Wc each, walked one after the other), then its helpers (the update only)
@@ -260,7 +262,14 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         if (tid == 0) part[bt * kSoloPart + 0] = lossp;
     }
     SOLO_T(3);
-    solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, s.bar_base + kSoloWG, s.err);
+    int ub = b, uw = Wt;                               // this workgroup's place among the ones that share the update
+    if constexpr (FUSED) {
+        if (b < Wc) { solow_publish(s.bar + (size_t)unit * NT + b, s.bar_base + kSoloWG); return; }
+        solow_wait_flags(s.bar + (size_t)unit * NT, Wc, s.bar_base + kSoloWG, s.err);
+        ub = b - Wc; uw = Wt - Wc;
+    } else {
+        solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, s.bar_base + kSoloWG, s.err);
+    }
     SOLO_T(4);
     SoloUpdate u;
     u.th = thC; u.mm = mC; u.vv = vC; u.tg = tgC; u.size = NC.size; u.lr = a.critic_lr; u.wd = a.critic_wd;
@@ -268,9 +277,9 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     // (every agent's workgroups read every target actor)
     u.soft = (nag == 1 && a.do_actor != 0) ? 1 : 0;
     u.t_new = t_new;
-    const float total = solow_update(s, a, u, grC, unit, b, nb, NT, Wt, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solow_update(s, a, u, grC, unit, part, ub, nb, NT, uw, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
     SOLO_T(7);
-    if (b == 0 && tid == 0) {
+    if (ub == 0 && tid == 0) {
         float loss = 0.f;
         for (int k = 0; k < nb; ++k) loss += __hip_atomic_load(part + k * kSoloPart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         steps[2 * ag + 1] = t_new;
@@ -278,12 +287,14 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
         sts[ST_CRITIC_LOSS] = loss * invB;
         sts[ST_CRITIC_GNORM] = total;
     }
+    // (the loss partials are read: the row-tile workgroups may overwrite them with the actor stage's once they see this flag)
+    if constexpr (FUSED) solow_publish(s.bar2 + (size_t)unit * 64 + ub, s.bar_base + kSoloWG);
 }
 
 #define FRL_SOLOW_CRITIC(name, twin, nt3, multi, tiles)                                                                            \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_critic_body<twin, nt3, multi, tiles>(*Dp, a, s, smem);                                                                \
+        solow_critic_body<twin, nt3, multi, tiles, false>(*Dp, a, s, smem);                                                                \
     }
 FRL_SOLOW_CRITIC(solow_critic_h1a1_kernel, false, 1, false, 1)
 FRL_SOLOW_CRITIC(solow_critic_h1a2_kernel, false, 2, false, 1)
@@ -296,7 +307,7 @@ FRL_SOLOW_CRITIC(solow_critic_ma_h2a2_kernel, true, 2, true, 1)
 
 
 // ------------------------------------------------------------------------------------------------------------- actor stage
-template <int NT3, bool MULTI, int T>
+template <int NT3, bool MULTI, int T, bool FUSED>
 __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const LearnArgs& a, const SoloArgs& s, float* smem) {
     const int Wt = s.update_wgs, NT = s.tiles, Wc = s.row_wgs;
     const int nag = MULTI ? D.n_agents : 1;
@@ -377,9 +388,12 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
             for (int t = 0; t < NT3; ++t) ep[t] = ld4((lds_cf)(N.tz + i16 * 32 + 16 * t + 4 * q));
         }
         SOLO_T(0);
-        pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
-        pren = N.pre_fetch(thC + NC.L[0].w_off, KB1c);
-        SoloWNet::DxRegs dxr = N.input_bwd_fetch(thC + NC.L[0].w_off, KB1c, ka0, nkd);
+        SoloWNet::DxRegs dxr;
+        if constexpr (!FUSED) {                            // (a pass ahead: the critic is final when this launch starts)
+            pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
+            pren = N.pre_fetch(thC + NC.L[0].w_off, KB1c);
+            dxr = N.input_bwd_fetch(thC + NC.L[0].w_off, KB1c, ka0, nkd);
+        }
         // ---- A: a = tanh(actor(s))   (SAC: a = tanh(mean + std eps) and the row's log pi, SAC.py:70-97)
         f32x4 ah1[2], ah2[2], h2f[kHT], an[NT3], lsv[NT3];
         float lpr = 0.f;
@@ -397,6 +411,13 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
             }
             lds_barrier();
             N.xa_compose(ca, Ai, ka0, nkx);                // the action k-tiles with a_i in them; read behind the next commit's barriers
+        }
+        if constexpr (FUSED) {
+            // the unit's helpers have stepped the critic meanwhile (its slab sum, clip, Adam, soft update): nothing of it is read before here
+            solow_wait_flags(s.bar2 + (size_t)unit * 64, Wt - Wc, s.bar_base + kSoloWG, s.err);
+            pend = N.stage_fetch(thC, NC.L, 1, -1, 0);
+            pren = N.pre_fetch(thC + NC.L[0].w_off, KB1c);
+            dxr = N.input_bwd_fetch(thC + NC.L[0].w_off, KB1c, ka0, nkd);
         }
         SOLO_T(1);
 #ifdef FRL_SOLO_TIMING
@@ -480,12 +501,13 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
         if (tid == 0) { part[bt * kSoloPart + 0] = qrow; part[bt * kSoloPart + 1] = lp; }
     }
     SOLO_T(3);
-    solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, s.bar_base + kSoloWG, s.err);
+    const unsigned epoch = s.bar_base + kSoloWG + (FUSED ? 1u : 0u);      // (the fused step's second hand-over: its own epoch for flags and mailboxes)
+    solow_grid_sync(s.bar + (size_t)unit * NT, b, Wc, epoch, s.err);
     SOLO_T(4);
     SoloUpdate u;
     // (the actor's target moves here also for MADDPG: nothing in this launch reads a target net)
     u.th = thA; u.mm = mA; u.vv = vA; u.tg = tgA; u.size = NA.size; u.lr = a.actor_lr; u.wd = 0.f; u.soft = 1; u.t_new = t_new;
-    const float total = solow_update(s, a, u, grA, unit, b, nb, NT, Wt, N.red, N.ea, s.bar_base + kSoloWG SOLO_TARG);
+    const float total = solow_update(s, a, u, grA, unit, part, b, nb, NT, Wt, N.red, N.ea, epoch SOLO_TARG);
     if (MULTI) {
         // MADDPG_simple.py:188-190 / MATD3_simple.py:245-246: every target follows its net once all agents are updated — the critic's here,
         // a share per workgroup of the unit (soft_update_kernel's arithmetic; its launch, one workgroup per net, was 34 us of config 5's learn())
@@ -532,12 +554,27 @@ __device__ __forceinline__ void solow_actor_body(const EngineDesc& D, const Lear
 #define FRL_SOLOW_ACTOR(name, nt3, multi, tiles)                                                                                     \
     __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
         extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
-        solow_actor_body<nt3, multi, tiles>(*Dp, a, s, smem);                                                                       \
+        solow_actor_body<nt3, multi, tiles, false>(*Dp, a, s, smem);                                                                \
     }
 FRL_SOLOW_ACTOR(solow_actor_a1_kernel, 1, false, 1)
 FRL_SOLOW_ACTOR(solow_actor_a2_kernel, 2, false, 1)
 FRL_SOLOW_ACTOR(solow_actor_ma_a1_kernel, 1, true, 1)
 FRL_SOLOW_ACTOR(solow_actor_ma_a2_kernel, 2, true, 1)
 
+
+// ------------------------------------------------------------------------------------------------------------- a policy step in one launch
+// Single-agent engines with helper workgroups (up to eight learners): critic stage and actor stage in ONE launch, the critic's update
+// (slab sum, clip, Adam, soft update — on the unit's helpers alone) under the policy's forward on the workgroups with row tiles.
+#define FRL_SOLOW_STEP(name, twin, nt3)                                                                                            \
+    __global__ __launch_bounds__(256) void name(const EngineDesc* __restrict__ Dp, LearnArgs a, SoloArgs s) {                        \
+        extern __shared__ __attribute__((aligned(16))) float smem[];                                                                \
+        solow_critic_body<twin, nt3, false, 1, true>(*Dp, a, s, smem);                                                              \
+        __syncthreads();                                                                                                            \
+        solow_actor_body<nt3, false, 1, true>(*Dp, a, s, smem);                                                                     \
+    }
+FRL_SOLOW_STEP(solow_step_h1a1_kernel, false, 1)
+FRL_SOLOW_STEP(solow_step_h1a2_kernel, false, 2)
+FRL_SOLOW_STEP(solow_step_h2a1_kernel, true, 1)
+FRL_SOLOW_STEP(solow_step_h2a2_kernel, true, 2)
 
 }  // namespace frl

@@ -139,6 +139,30 @@ def test_wide_first_layer_device_draws_are_the_rowchunk_chain_s(N, case, P):
         assert q99 <= tol and w <= 5e-2, "%s %s: |diff| / max |x|: 99th percentile %.3e, max %.3e at flat index %d" % (case, key, q99, w, at)
 
 
+@pytest.mark.parametrize("case,P", [("sac_c4", 1), ("td3_wide", 4), ("sac_380_20_b17", 8), ("ddpg_wide", 5)])
+def test_policy_step_in_one_launch_matches_two_launches(N, monkeypatch, case, P):
+    """kernels_solow.hip with helper workgroups runs a policy step as ONE launch (solow_step_*): a workgroup with a row tile flags its
+    critic slab and goes on to the policy's forward while the helpers alone step the critic; FRL_SOLOW_FUSE=0 keeps the two launches.
+    Same arithmetic per element — only the gradient norm's partial sums are grouped by other workgroups — so 20 calls agree to
+    rounding; ragged batches (200 rows, 17 rows: workgroups without rows walk through both halves at once), TD3's alternation of
+    critic-only launches and fused steps, 1 .. 8 learners (48 / 32 / 16 helpers per learner)."""
+    from tests import family_ab as AB
+    calls = 5 if AB.CASES[case]["B"] < 64 else 20
+    monkeypatch.setenv("FRL_SOLOW_FUSE", "0")
+    a = AB.run(case, None, calls, P, device_rng=True)
+    monkeypatch.delenv("FRL_SOLOW_FUSE")
+    b = AB.run(case, None, calls, P, device_rng=True)
+    assert a["path"] == b["path"] == (True, SOLOW_LDS, 16)
+    assert np.array_equal(a["rows_drawn"], b["rows_drawn"])
+    d = AB.diff(a, b)
+    st = d.pop("stats")
+    scale = float(np.abs(a["stats"][..., 0]).mean())
+    act_err = np.abs(a["stats"][..., 1] - b["stats"][..., 1]) / max(scale, 1e-6)
+    assert st[:, :, :, 0].max() <= 1e-4 and act_err.max() <= 1e-4, (case, st[:, :, :, 0].max(), act_err.max())
+    for key, (w, at, mx, q99) in d.items():
+        assert q99 <= 1e-4 and w <= 5e-2, "%s %s: |diff| / max |x|: 99th percentile %.3e, max %.3e at flat index %d" % (case, key, q99, w, at)
+
+
 @pytest.mark.parametrize("case", ["sac_c4", "maddpg_c5", "td3_h256", "td3_narrow_b100"])
 def test_padding_stays_zero_and_unsampled_nonfinite_rows_are_inert(N, monkeypatch, case):
     """(1) frl_params_pad_max == 0 for theta / target / m / v of every net after 12 updates on the chained families; (2) the same run with
