@@ -18,9 +18,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_
 done
 rm -rf $O/stats_solow $O/pmc_solow[0-9]
 cd $R
-{ for a in "sac 376 17" "td3 376 17" "td3 17 6" "maddpg"; do echo "== $a"; FRL_HIP_VARIANT=solowt timeout 120 python tools/solow_timing.py $a; done; } 2>&1 < /dev/null | grep -v amdgpu.ids > $O/solow_timing.txt
+# (the stamps: the two-launch form — in the fused policy step the actor half's stamps overwrite the critic half's)
+{ for a in "sac 376 17" "td3 376 17" "td3 17 6" "maddpg"; do echo "== $a"; FRL_SOLOW_FUSE=0 FRL_HIP_VARIANT=solowt timeout 120 python tools/solow_timing.py $a; done; } 2>&1 < /dev/null | grep -v amdgpu.ids > $O/solow_timing.txt
 { echo "== default (kernels_solow.hip)"; timeout 300 python tools/config_bench.py 1 2 4 5 8 16 17 C4
-  echo "== FRL_SOLOW_HELPERS=0 (sixteen workgroups per learner only: no helpers, no pre-draw)"; FRL_SOLOW_HELPERS=0 timeout 300 python tools/config_bench.py 1 4 C4
+  echo "== FRL_SOLOW_FUSE=0 (critic and actor stage as two launches)"; FRL_SOLOW_FUSE=0 timeout 300 python tools/config_bench.py 1 2 4 8 C4
+  echo "== FRL_SOLOW_HELPERS=0 (sixteen workgroups per learner only: no helpers, no pre-draw, two launches)"; FRL_SOLOW_HELPERS=0 timeout 300 python tools/config_bench.py 1 4 C4
   echo "== FRL_SOLO_PREDRAW=0"; FRL_SOLO_PREDRAW=0 timeout 300 python tools/config_bench.py 1 C4
   echo "== FRL_SOLOW=0 (the row-chunk chain)"; FRL_SOLOW=0 timeout 300 python tools/config_bench.py 1 2 4 8 16 C4
   echo "== FRL_CRITIC_V2=1 (the K-sliced chained family: one workgroup per learner)"; FRL_CRITIC_V2=1 timeout 300 python tools/config_bench.py 1 16 C4
