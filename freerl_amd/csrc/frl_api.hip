@@ -404,7 +404,8 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
         }
     }
     h.learner_stride = pad32(off);
-    if (e->has_nets && chained_shape(h)) {       // kernel family (and with it the parameter layout in HBM), fixed for the engine's life
+    if (e->has_nets && chained_shape(h) && !(getenv("FRL_SOLOW_NARROW") && atoi(getenv("FRL_SOLOW_NARROW")) != 0)) {       // kernel family (and with it the parameter layout in HBM), fixed for the engine's life
+        // (FRL_SOLOW_NARROW=1, developer knob: the narrow standard shape on kernels_solow.hip — one first-layer k-tile — for A/Bs against kernels_solo.hip)
         const char* force = getenv("FRL_CRITIC_V2");
         // measured (bench workload, updates/s): 128 learners are exactly one round of the row-chunk kernels' 512 resident
         // workgroups — 484 k against 373 k for 128 one-learner workgroups on half the CUs; from 129 up the chained kernels win
