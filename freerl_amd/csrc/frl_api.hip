@@ -100,6 +100,10 @@ struct frl_engine {
     int* d_solo_err = nullptr;            // device address of h_solo_err
     int* d_solo_pre = nullptr;            // [2][P][kSoloPre]: the next call's rows, drawn a launch ahead (SoloArgs::pre_read / pre_write)
     unsigned solo_pre_seq = 0;            // critic-stage launches so far: which of the two slots is read / written
+    // kernels_solow.hip, multi-agent: what the rows in the slot the next launch reads were drawn for (the HOST decides whether draw_kernel runs)
+    bool ma_pre_valid = false;
+    unsigned long long ma_pre_counter = 0;
+    int ma_pre_size = 0, ma_pre_batch = 0;
     int* h_solo_err = nullptr;            // pinned: a solo workgroup that waited 2 s for its learner's others sets it (checked after syncs: solo_err_check)
     int* d_solo_ticket = nullptr;         // the rollout tail's learner ticket
     unsigned solo_bar_base = 0;           // arrivals every counter has seen (one counting barrier per launch: kSoloWG)
@@ -585,7 +589,7 @@ extern "C" int frl_create(const frl_config* cfg, frl_engine** out) {
                 e->solow_wgs = (hp && atoi(hp) == 0) ? rw : rw * per;
             }
             CREATE_TRY(dalloc_zero(&e->d_solo_part, U * (size_t)std::max((int)NT, e->solow_wgs) * kSoloPartHost, e->stream));
-            { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * P * (size_t)kSoloPre, e->stream)); e->d_solo_pre = (int*)z; }
+            { float* z = nullptr; CREATE_TRY(dalloc_zero(&z, 2 * U * (size_t)std::max(kSoloPre, 8 + h.batch_max), e->stream)); e->d_solo_pre = (int*)z; }
             float* z = nullptr;
             CREATE_TRY(dalloc_zero(&z, 2 * U * NT + 2, e->stream));
             e->d_solo_bar = (unsigned*)z;                                  // [units][tiles] slab flags, then as many "actor slice stepped" flags (kernels_solo.hip: offset P * 16),
@@ -1474,8 +1478,13 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
         prof_end(e);
         return;
     }
+    // kernels_solow.hip, MADDPG without smoothing noise: the rows may have been drawn by the previous launch's spare workgroups (one per
+    // unit, the duplicate table in their own LDS) — for exactly this counter, ring size and batch, or draw_kernel runs as ever
+    const int ma_pre_stride = 8 + h.batch_max;
+    const bool ma_solow = v2 && h.solow && h.n_agents > 1 && stage == 0 && dev_rng && !needs_noise && pc == h.P;
+    const bool ma_use_pre = ma_solow && e->ma_pre_valid && e->ma_pre_counter == a.rng_counter && e->ma_pre_size == a.size && e->ma_pre_batch == a.batch;
     if (stage == 0) {
-        if (dev_rng && !(v2 && (h.solo || (h.solow && h.n_agents == 1)))) {    // (kernels_solo.hip / single-agent kernels_solow.hip draw inside their critic stages)
+        if (dev_rng && !ma_use_pre && !(v2 && (h.solo || (h.solow && h.n_agents == 1)))) {    // (kernels_solo.hip / single-agent kernels_solow.hip draw inside their critic stages)
             prof_begin(e, PK_DRAW);
             const char* scan = getenv("FRL_DRAW_SCAN");                        // developer / test knob: no duplicate table
             const bool table = a.batch > 256 && 4 * a.batch <= kDrawTableHost && !(scan && atoi(scan) != 0);
@@ -1517,7 +1526,20 @@ static void launch_learn_stage(frl_engine* e, hipStream_t st, LearnArgs a, int s
             auto k = h.n_agents > 1 ? (twin ? (a2 ? solow_critic_ma_h2a2_kernel : solow_critic_ma_h2a1_kernel) : (a2 ? solow_critic_ma_h1a2_kernel : solow_critic_ma_h1a1_kernel))
                                     : (twin ? (a2 ? solow_critic_h2a2_kernel : solow_critic_h2a1_kernel) : (a2 ? solow_critic_h1a2_kernel : solow_critic_h1a1_kernel));
             if (a.fuse_actor) k = twin ? (a2 ? solow_step_h2a2_kernel : solow_step_h2a1_kernel) : (a2 ? solow_step_h1a2_kernel : solow_step_h1a1_kernel);
-            hipLaunchKernelGGL(k, dim3(units * e->solow_wgs), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
+            int extra = 0;
+            if (h.n_agents > 1) {
+                const char* pdf = getenv("FRL_SOLO_PREDRAW");
+                if (ma_use_pre) sa.pre_read = e->d_solo_pre + (size_t)(e->solo_pre_seq & 1) * h.P * h.n_agents * ma_pre_stride;
+                e->ma_pre_valid = false;
+                if (ma_solow && units * (e->solow_wgs + 1) <= e->n_cus && !(pdf && atoi(pdf) == 0)) {
+                    sa.pre_write = e->d_solo_pre + (size_t)((e->solo_pre_seq + 1) & 1) * h.P * h.n_agents * ma_pre_stride;
+                    sa.pre_counter = e->rng_counter;              // what the next frl_learn takes, unless something else draws first
+                    extra = units;
+                    e->ma_pre_valid = true; e->ma_pre_counter = e->rng_counter; e->ma_pre_size = a.size; e->ma_pre_batch = a.batch;
+                }
+                ++e->solo_pre_seq;
+            }
+            hipLaunchKernelGGL(k, dim3(units * e->solow_wgs + extra), blk, (size_t)solow_lds_floats() * sizeof(float), st, e->d, a, sa);
             prof_end(e);
             return;
         }

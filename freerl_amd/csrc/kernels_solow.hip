@@ -78,6 +78,17 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
     constexpr int NH = TWIN ? 2 : 1;
     const int Wt = s.update_wgs, NT = s.tiles, Wc = s.row_wgs;   // the unit's Wc workgroups with row tiles (NT / Wc each, walked one after the other), then its helpers (the update only)
     const int nag = MULTI ? D.n_agents : 1;
+    if (MULTI && (int)blockIdx.x >= a.p_count * nag * Wt) {
+        // a spare workgroup per unit behind the units' own in the grid (MADDPG without smoothing noise): the rows agent `ag` of learner `p`
+        // samples in the NEXT call — draw_kernel's draw (stream = the agent, the duplicate table in this workgroup's LDS), a launch
+        // ahead; the host remembers what they were drawn for and skips draw_kernel when the next call asks for exactly that
+        const int us = a.p0 * nag + (int)blockIdx.x - a.p_count * nag * Wt, ps = us / nag, as_ = us - ps * nag;
+        int* out = s.pre_write + (size_t)(us - a.p0 * nag) * (8 + D.batch_max);
+        FRL_LDS int* lb = (FRL_LDS int*)smem;
+        draw_indices((g_i)(out + 8), lb, a.batch, a.size, s.pre_counter, (unsigned)as_, D.seed + 0x9E3779B97F4A7C15ull * (ps + 1), true,
+                     (a.batch > kWG && 4 * a.batch <= kDrawTable) ? lb + 2 * ((a.batch + 3) & ~3) : nullptr);
+        return;
+    }
     const int unit = a.p0 * nag + blockIdx.x / Wt, p = unit / nag, ag = unit - p * nag, b = blockIdx.x % Wt;
     const RecordDesc& R = D.rec;
     const NetDesc& NC = D.net[2 * ag + 1];
@@ -144,6 +155,9 @@ __device__ __forceinline__ void solow_critic_body(const EngineDesc& D, const Lea
             FRL_LDS int* lidx = (FRL_LDS int*)N.ea;
             draw_indices((g_i)(D.idx + (size_t)p * D.batch_max), lidx, B, a.size, a.rng_counter, 0u, key, false);
             ri = lidx[rc];
+        } else if (MULTI && s.pre_read) {                  // the previous launch's spare workgroup drew this unit's rows (the host checked what for)
+            ri = s.pre_read[(size_t)(unit - a.p0 * nag) * (8 + D.batch_max) + 8 + rc];
+            if (w == 0 && q == 0 && valid) D.idx[(size_t)unit * D.batch_max + row] = ri;     // (the actor stage and frl_last_indices read them)
         } else {
             ri = idx[rc];
         }

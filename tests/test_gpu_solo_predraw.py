@@ -68,3 +68,36 @@ def test_predrawn_rows_equal_the_in_launch_draw(N, monkeypatch, algo_name, P, O,
         assert len(np.unique(a.reshape(P, -1)[0])) == a.reshape(P, -1).shape[1], "a batch holds a row twice"
     for i, (a, b) in enumerate(zip(arr1, arr0)):
         np.testing.assert_array_equal(a, b, err_msg="array %d" % i)
+
+
+def _run_maddpg(N, monkeypatch, predraw, B, P):
+    """MADDPG on kernels_solow.hip: a spare workgroup per (learner, agent) unit of a critic launch draws the unit's rows for the next call;
+    the host skips draw_kernel when the next call asks for exactly that counter / ring size / batch."""
+    from freerl_amd.engine import Engine
+    monkeypatch.setenv("FRL_SOLO_PREDRAW", "1" if predraw else "0")
+    for v in ("FRL_CRITIC_V2", "FRL_SOLOW"):
+        monkeypatch.delenv(v, raising=False)
+    e = Engine(N.ALGO_MADDPG, [6, 5, 7], [2, 3, 2], 4096, n_learners=P, batch_max=B, seed=17)
+    assert e.learn_path(B)[0] and e.learn_path(B)[2] == 16, "not kernels_solow.hip"
+    e.fill_synthetic(3000, seed=4)
+    out = []
+    for k in range(12):
+        batch = B // 2 if k in (7, 8) else B                         # a changed batch: the pre-drawn rows are for another one
+        if k in (3, 4):                                                # the rings grow between two calls: drawn for a stale size
+            e.fill_synthetic(3000 + 200 * (k - 2), seed=4)
+        e.learn(batch, gamma=0.95, tau=0.01, actor_lr=1e-3, critic_lr=1e-3)
+        out.append(np.array(e.last_indices(batch)))
+    arrays = [e.get_params(net, kind, learner=p) for p in range(P) for net in range(6)
+              for kind in (N.PARAM_ONLINE, N.PARAM_TARGET, N.PARAM_ADAM_M, N.PARAM_ADAM_V)]
+    e.close()
+    return out, arrays
+
+
+@pytest.mark.parametrize("B,P", [(1024, 1), (128, 4)])
+def test_maddpg_predrawn_rows_equal_draw_kernel_s(N, monkeypatch, B, P):
+    idx1, arr1 = _run_maddpg(N, monkeypatch, True, B, P)
+    idx0, arr0 = _run_maddpg(N, monkeypatch, False, B, P)
+    for k, (a, b) in enumerate(zip(idx1, idx0)):
+        np.testing.assert_array_equal(a, b, err_msg="rows of call %d" % k)
+    for i, (a, b) in enumerate(zip(arr1, arr0)):
+        np.testing.assert_array_equal(a, b, err_msg="array %d" % i)
