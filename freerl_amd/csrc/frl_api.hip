@@ -703,7 +703,7 @@ static int solo_err_check(frl_engine* e) {
     if (what == 2)
         return fail(FRL_ERR_STATE, "dqn_fused_kernel: a pre-armed rollout launch waited 2 s for the previous launch or for the host's doorbell and gave up; "
                                    "its update and the actions it was to select were dropped");
-    return fail(FRL_ERR_STATE, "kernels_solo.hip: a workgroup waited 2 s for the other workgroups of its learner (is something else holding this GPU's "
+    return fail(FRL_ERR_STATE, "kernels_solo.hip / kernels_solow.hip: a workgroup waited 2 s for the other workgroups of its learner (is something else holding this GPU's "
                                "CUs?); the updates since the last synchronising call are not valid");
 }
 
