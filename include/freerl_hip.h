@@ -158,7 +158,9 @@ int frl_sync(frl_engine* e);               /* wait for the engine's stream */
 int frl_lds_bytes(const frl_engine* e, int* bytes_out, int* row_chunk_out);
 /* Which kernel family frl_learn() launches for this engine at `batch` rows: chained = 1 when the critic and actor stages run
  * as one workgroup per learner with the weights in LDS images (kernels_critic2.hip / kernels_actor2.hip), 0 for the row-chunk
- * kernels + reduce / Adam launches; the dynamic LDS bytes and the batch rows of one workgroup of that family. */
+ * kernels + reduce / Adam launches; the dynamic LDS bytes and the batch rows of one workgroup of that family.  16 (or 32) rows with
+ * chained = 1: the sixteen-workgroups-per-learner families of small populations (kernels_solo.hip; kernels_solow.hip for wide first
+ * layers and MADDPG: 160512 bytes of LDS). */
 int frl_learn_path(const frl_engine* e, int batch, int* chained_out, int* lds_bytes_out, int* rows_per_workgroup_out);
 
 /* ---------------------------------------------------------------- replay ring (Buffer.py)
